@@ -1,0 +1,206 @@
+/*
+ * is3d_amd.h -- C ABI of the MI355X-native smooth Cooper-Frye spectra path.
+ *
+ * The reference (derekeverett/iS3D) has no FFI layer; the boundary this library is a drop-in for
+ * is the C++ method
+ *
+ *   void EmissionFunctionArray::calculate_dN_pTdpTdphidy(double *Mass, double *Sign,
+ *        double *Degeneracy, double *Baryon, double *T_fo, double *P_fo, double *E_fo,
+ *        double *tau_fo, double *eta_fo, double *ux_fo, double *uy_fo, double *un_fo,
+ *        double *dat_fo, double *dax_fo, double *day_fo, double *dan_fo, double *pixx_fo,
+ *        double *pixy_fo, double *pixn_fo, double *piyy_fo, double *piyn_fo, double *bulkPi_fo,
+ *        double *muB_fo, double *nB_fo, double *Vx_fo, double *Vy_fo, double *Vn_fo,
+ *        Deltaf_Data *df_data)
+ *   declared  src/cpp/emissionfunction.h:179, defined src/cpp/emissionfunction_smooth_kernels.cpp:28-393,
+ *   called    src/cpp/emissionfunction.cpp:1519,
+ *
+ * whose implicit inputs are members of the object (FO_length, number_of_chosen_particles, the
+ * pT/phi/y/eta Tables, DIMENSION, DF_MODE, OUTFLOW, REGULATE_DELTAF, INCLUDE_* --
+ * src/cpp/emissionfunction.h:73-90, :139-142) and whose output is the member array
+ * dN_pTdpTdphidy (emissionfunction.h:142), index
+ *   iS3D = ipart + npart * (ipT + npT * (iphip + nphi * iy))      (smooth_kernels.cpp:363)
+ * Every implicit input is an explicit argument here.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - all functions return IS3D_OK (0) or a negative IS3D_E* code; nothing calls exit()/abort()
+ *     (reference: printf + exit(-1), GSL abort);  is3d_last_error() has the text;
+ *   - the caller owns every buffer; the library never frees or keeps caller memory past a call
+ *     (a plan keeps its own device copies of species/grid/tables);
+ *   - pointers for disabled corrections (muB, nB, Vx, Vy, Vn; eta in 2+1D) may be NULL and are
+ *     never dereferenced (reference passes uninitialised pointers there, emissionfunction.cpp:1357-1378);
+ *   - dN_out has n_species * n_pT * n_phi * n_y_eff doubles, n_y_eff = (dimension == 2) ? 1 : n_y,
+ *     species fastest; it is OVERWRITTEN unless opts->accumulate (reference semantics: +=, :375);
+ *   - thread-safe for distinct plans; one plan serves one call at a time;
+ *   - there is NO CPU fallback: without a HIP device every compute entry returns IS3D_ENODEVICE.
+ */
+#ifndef IS3D_AMD_H
+#define IS3D_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IS3D_OK 0
+#define IS3D_EINVAL (-1)     /* bad argument / unsupported option combination            */
+#define IS3D_ENODEVICE (-2)  /* no HIP device, or a HIP runtime error (see last_error)    */
+#define IS3D_EDOMAIN (-3)    /* a non-skipped cell's T is outside the coefficient table  */
+                             /* (reference: GSL domain error -> abort, deltafReader.cpp:339) */
+#define IS3D_ENOMEM (-4)
+#define IS3D_EIO (-5)        /* host reader/writer failure                               */
+
+/* Freezeout cells, structure of arrays, fp64, length n_cells each.  Replaces the *_fo pointer
+ * arguments of calculate_dN_pTdpTdphidy (emissionfunction.h:179).  Units as after the reader's
+ * hbar*c conversion (GeV, GeV/fm^3; readindata.cpp:367-410). */
+typedef struct {
+    int64_t n_cells;                    /* FO_length (emissionfunction.h:139) */
+    const double *tau, *eta;            /* eta unused (may be NULL) when dimension == 2 */
+    const double *dat, *dax, *day, *dan; /* covariant dsigma_mu */
+    const double *ux, *uy, *un;         /* contravariant u^mu; u^tau recomputed (:133) */
+    const double *T, *P, *E;
+    const double *pixx, *pixy, *pixn, *piyy, *piyn; /* other components reconstructed (:166-170) */
+    const double *bulkPi;
+    const double *muB, *nB, *Vx, *Vy, *Vn; /* only read if include_baryon && include_baryondiff_deltaf */
+} is3d_cells;
+
+/* Replaces Mass, Sign, Degeneracy, Baryon (emissionfunction.cpp:1293-1307) */
+typedef struct {
+    int32_t n;                          /* number_of_chosen_particles */
+    const double *mass, *sign, *degeneracy, *baryon;
+} is3d_species;
+
+/* Replaces pT_tab, phi_tab, y_tab, eta_tab column 1 (and eta weights, column 2)
+ * (smooth_kernels.cpp:40-92).  cos/sin(phi) are formed inside, as the reference does. */
+typedef struct {
+    int32_t n_pT;  const double *pT;
+    int32_t n_phi; const double *phi;
+    int32_t n_y;   const double *y;     /* used when dimension == 3 */
+    int32_t n_eta; const double *eta, *eta_w; /* used when dimension == 2 */
+} is3d_grid;
+
+/* Replaces Deltaf_Data for the include_baryon = 0 branch: the mu_B = 0 rows of the coefficient
+ * tables as loaded by load_df_coefficient_data (deltafReader.cpp:120-197), still carrying their
+ * temperature scaling (c0*T^4, c2*T^4, F/T, betabulk/T^4, betapi/T^4).  The natural cubic splines
+ * of construct_cubic_splines (deltafReader.cpp:300-322) are built inside. */
+typedef struct {
+    int32_t n_T;
+    const double *T;                    /* GeV, ascending */
+    const double *c0, *c2;              /* df_mode 1 */
+    const double *F, *betabulk, *betapi; /* df_mode 2 */
+} is3d_df_tables;
+
+typedef struct {
+    int32_t dimension;                  /* 2 | 3                      DIMENSION  */
+    int32_t df_mode;                    /* 1 14-moment | 2 Chapman-Enskog  DF_MODE */
+    int32_t include_baryon;             /* must be 0 (bilinear branch: not yet) */
+    int32_t include_bulk_deltaf;
+    int32_t include_shear_deltaf;
+    int32_t include_baryondiff_deltaf;  /* ignored unless include_baryon */
+    int32_t regulate_deltaf;
+    int32_t outflow;
+    int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
+    int32_t device;                     /* HIP device ordinal; -1 = current device */
+    /* tuning; 0 = library default */
+    int32_t kernel_variant;             /* 0 default | 1 direct-exp kernel | 2 factorised-exp kernel */
+    int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
+    int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
+    int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per
+                                           distinct (mass, sign) and scale by degeneracy */
+    int32_t reserved[7];
+} is3d_options;
+
+typedef struct {
+    int32_t code;                       /* same as the return value */
+    int32_t n_classes;                  /* distinct (mass, sign) classes actually evaluated */
+    int64_t n_cells_skipped;            /* cells with u.dsigma <= 0 (contribute 0, :137) */
+    int64_t bad_cell;                   /* first cell index with T outside the table, or -1 */
+    int32_t n_passes;                   /* workspace passes over the cell axis */
+    int32_t kernel_variant;             /* variant that ran */
+    double ms_prep, ms_main, ms_finalize; /* device time of the three kernels (HIP events), summed over passes;
+                                             filled by is3d_plan_timings / the host entry, else 0 */
+    double ms_h2d, ms_d2h;              /* host entry only */
+} is3d_status;
+
+typedef struct is3d_plan is3d_plan;
+
+const char *is3d_last_error(void);
+const char *is3d_version(void);
+/* number of visible HIP devices (>= 0), never fails */
+int is3d_device_count(void);
+
+/*
+ * One-shot host entry: what a maintainer calls from calculate_dN_pTdpTdphidy.  All pointers are
+ * HOST memory.  Uploads the cell arrays, runs prep -> main -> finalize on the device, downloads
+ * the spectrum.
+ */
+int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                        const is3d_df_tables *df, const is3d_options *opts, double *dN_out,
+                        is3d_status *status);
+
+/*
+ * Device-resident API.  A plan holds the species classes, grids and spline tables on the device and
+ * the workspaces sized for up to max_cells cells per execute.
+ */
+int is3d_plan_create(is3d_plan **plan, const is3d_species *species, const is3d_grid *grid,
+                     const is3d_df_tables *df, const is3d_options *opts, int64_t max_cells);
+/* length of dN_out in doubles */
+int64_t is3d_plan_output_size(const is3d_plan *plan);
+/* cells->* and dN_out are DEVICE pointers on the plan's device; hip_stream is a hipStream_t (NULL =
+ * default stream).  Asynchronous with respect to the host except for the final status read-back
+ * when status != NULL (then the stream is synchronised). */
+int is3d_plan_execute(is3d_plan *plan, const is3d_cells *cells, double *dN_out, void *hip_stream,
+                      is3d_status *status);
+/* Enable (1) / disable (0) HIP-event timing of the three kernels on subsequent executes. */
+int is3d_plan_set_timing(is3d_plan *plan, int32_t enable);
+/* Synchronises the recorded events of the last execute and fills status->ms_*. */
+int is3d_plan_timings(is3d_plan *plan, is3d_status *status);
+/* Name of the dominant kernel as it appears in rocprofv3 traces, for the variant in use. */
+const char *is3d_plan_main_kernel_name(const is3d_plan *plan);
+/* bytes of device workspace the plan holds */
+int64_t is3d_plan_workspace_bytes(const is3d_plan *plan);
+void is3d_plan_destroy(is3d_plan *plan);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host I/O in the reference's file formats (C++ implementation, C ABI so that tests and other
+ * hosts can reach it).  All paths are explicit; the CLI driver passes the reference's hard-coded
+ * CWD-relative names.
+ * --------------------------------------------------------------------------------------------- */
+
+/* ParameterReader::readFromFile + getVal (src/cpp/ParameterReader.cpp:38-155): `name = value # comment`.
+ * Returns IS3D_EIO if the file cannot be read, IS3D_EINVAL if `name` is absent (reference: exit). */
+int is3d_param_get(const char *path, const char *name, double *value);
+
+/* Table(filename) (src/cpp/Table.cpp:179-195, arsenal.cpp:406-453): n-column numeric text.  Two-call
+ * pattern: data == NULL returns the shape; otherwise fills data[row * n_cols + col] (capacity in
+ * doubles).  A last line without a trailing newline is dropped, as in the reference. */
+int is3d_table_read(const char *path, int64_t *n_rows, int32_t *n_cols, double *data, int64_t capacity);
+
+/* FO_data_reader::read_surf_VH (mode 1; src/cpp/readindata.cpp:320-468).  Two-call pattern as above
+ * (cells == NULL -> only *n_cells).  Fills caller-allocated arrays named in `cells` (non-NULL
+ * members of at least n_cells doubles; x,y positions are not kept).  Also returns the
+ * surface-volume-weighted averages {T, E, P, muB, nB} (readindata.cpp:422-466) in avg5 if non-NULL. */
+int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                         int32_t dimension, int64_t *n_cells, double *const *cell_arrays23, double *avg5);
+
+/* PDG_Data::read_resonances_conventional (src/cpp/readindata.cpp:1440-1568), reduced to what the
+ * smooth path uses.  Two-call pattern (mc_id == NULL -> only *n).  Arrays of capacity entries. */
+int is3d_pdg_read(const char *path, int32_t *n, int64_t *mc_id, double *mass, double *gspin,
+                  double *baryon, double *sign, int32_t capacity);
+
+/* Deltaf_Data::load_df_coefficient_data (src/cpp/deltafReader.cpp:65-219) for one file, mu_B = 0 row.
+ * Two-call pattern (T == NULL -> only *n_T). */
+int is3d_df_table_read(const char *path, int32_t *n_T, double *T, double *value, int32_t capacity);
+
+/* Writers (src/cpp/emissionfunction.cpp:381-450, :729-772, :1053-1136): append to
+ * <dir>/dN_pTdpTdphidy.dat, <dir>/dN_pTdpTdphidy_<mcid>.dat, <dir>/dN_dy_<mcid>.dat,
+ * <dir>/vn_continuous/vn_<mcid>.dat in the reference's formatting.  pT/phi/y carry nodes and
+ * weights (w may be NULL for write_spectra only). */
+int is3d_write_results(const char *results_dir, int32_t dimension, int32_t n_species, const int64_t *mc_id,
+                       int32_t n_pT, const double *pT, const double *pT_w, int32_t n_phi, const double *phi,
+                       const double *phi_w, int32_t n_y, const double *y, const double *dN);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IS3D_AMD_H */

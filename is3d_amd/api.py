@@ -1,0 +1,284 @@
+"""ctypes binding of include/is3d_amd.h (lib/libis3d_amd.so) -- plumbing, not the product.
+
+The compute entry points run HIP kernels only; there is no CPU fallback here or in the library:
+without the built extension `load()` raises, without a GPU the library returns IS3D_ENODEVICE.
+PyTorch is used by callers for device memory and streams; this module itself needs only ctypes+numpy.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libis3d_amd.so")
+CLI_PATH = os.path.join(_HERE, "bin", "iS3D_amd")
+
+IS3D_OK, IS3D_EINVAL, IS3D_ENODEVICE, IS3D_EDOMAIN, IS3D_ENOMEM, IS3D_EIO = 0, -1, -2, -3, -4, -5
+
+_dp = C.POINTER(C.c_double)
+
+CELL_FIELDS = ["tau", "eta", "dat", "dax", "day", "dan", "ux", "uy", "un", "T", "P", "E",
+               "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi", "muB", "nB", "Vx", "Vy", "Vn"]
+# order of the cell_arrays23 argument of is3d_surface_read_vh
+SURFACE_READ_ORDER = ["T", "P", "E", "tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan",
+                      "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi", "muB", "nB", "Vx", "Vy", "Vn"]
+
+
+class Cells(C.Structure):
+    _fields_ = [("n_cells", C.c_int64)] + [(n, C.c_void_p) for n in CELL_FIELDS]
+
+
+class Species(C.Structure):
+    _fields_ = [("n", C.c_int32), ("mass", _dp), ("sign", _dp), ("degeneracy", _dp), ("baryon", _dp)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("n_pT", C.c_int32), ("pT", _dp), ("n_phi", C.c_int32), ("phi", _dp), ("n_y", C.c_int32), ("y", _dp),
+                ("n_eta", C.c_int32), ("eta", _dp), ("eta_w", _dp)]
+
+
+class DfTables(C.Structure):
+    _fields_ = [("n_T", C.c_int32), ("T", _dp), ("c0", _dp), ("c2", _dp), ("F", _dp), ("betabulk", _dp), ("betapi", _dp)]
+
+
+class Options(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
+                                         "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
+                                         "accumulate", "device", "kernel_variant", "cell_chunks"]] + \
+               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class Status(C.Structure):
+    _fields_ = [("code", C.c_int32), ("n_classes", C.c_int32), ("n_cells_skipped", C.c_int64), ("bad_cell", C.c_int64),
+                ("n_passes", C.c_int32), ("kernel_variant", C.c_int32), ("ms_prep", C.c_double), ("ms_main", C.c_double),
+                ("ms_finalize", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_plan_create",
+           "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings",
+           "is3d_plan_main_kernel_name", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
+           "is3d_table_read", "is3d_surface_read_vh", "is3d_pdg_read", "is3d_df_table_read", "is3d_write_results"]
+
+
+class Is3dError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("is3d_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile the HIP library and the CLI in-tree (hipcc --offload-arch=gfx950)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=out)
+    return LIB_PATH
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C is3d_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.is3d_last_error.restype = C.c_char_p
+    L.is3d_version.restype = C.c_char_p
+    L.is3d_plan_main_kernel_name.restype = C.c_char_p
+    L.is3d_plan_main_kernel_name.argtypes = [C.c_void_p]
+    L.is3d_smooth_spectra.argtypes = [C.POINTER(Cells), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
+                                      C.POINTER(Options), _dp, C.POINTER(Status)]
+    L.is3d_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
+                                   C.POINTER(Options), C.c_int64]
+    L.is3d_plan_output_size.restype = C.c_int64
+    L.is3d_plan_output_size.argtypes = [C.c_void_p]
+    L.is3d_plan_workspace_bytes.restype = C.c_int64
+    L.is3d_plan_workspace_bytes.argtypes = [C.c_void_p]
+    L.is3d_plan_execute.argtypes = [C.c_void_p, C.POINTER(Cells), C.c_void_p, C.c_void_p, C.POINTER(Status)]
+    L.is3d_plan_set_timing.argtypes = [C.c_void_p, C.c_int32]
+    L.is3d_plan_timings.argtypes = [C.c_void_p, C.POINTER(Status)]
+    L.is3d_plan_destroy.argtypes = [C.c_void_p]
+    L.is3d_plan_destroy.restype = None
+    L.is3d_param_get.argtypes = [C.c_char_p, C.c_char_p, _dp]
+    L.is3d_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp, C.c_int64]
+    L.is3d_surface_read_vh.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                       C.POINTER(_dp), _dp]
+    L.is3d_pdg_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _dp, _dp, _dp, _dp, C.c_int32]
+    L.is3d_df_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), _dp, _dp, C.c_int32]
+    L.is3d_write_results.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, _dp, _dp,
+                                     C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise Is3dError(rc, load().is3d_last_error().decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
+                    include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1, accumulate=0, device=-1,
+                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0)
+
+
+def _pack_common(species, grid, df, opts):
+    o = dict(DEFAULT_OPTS)
+    o.update(opts or {})
+    keep = {}
+    sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy", "baryon"]}
+    g = {k: _f64(grid[k]) for k in ["pT", "phi", "y", "eta", "eta_w"]}
+    d = {k: _f64(df[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]}
+    keep.update(sp=sp, g=g, d=d)
+    sps = Species(len(sp["mass"]), _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), _p(sp["baryon"]))
+    gs = Grid(len(g["pT"]), _p(g["pT"]), len(g["phi"]), _p(g["phi"]), len(g["y"]), _p(g["y"]), len(g["eta"]),
+              _p(g["eta"]), _p(g["eta_w"]))
+    ds = DfTables(len(d["T"]), _p(d["T"]), _p(d["c0"]), _p(d["c2"]), _p(d["F"]), _p(d["betabulk"]), _p(d["betapi"]))
+    os_ = Options()
+    for k, v in o.items():
+        setattr(os_, k, int(v))
+    ny_eff = 1 if o["dimension"] == 2 else len(g["y"])
+    nout = len(sp["mass"]) * len(g["pT"]) * len(g["phi"]) * ny_eff
+    return sps, gs, ds, os_, nout, keep
+
+
+def smooth_spectra(cells, species, grid, df, opts=None, out=None):
+    """Host-pointer entry is3d_smooth_spectra (the drop-in for calculate_dN_pTdpTdphidy).
+    cells: dict of numpy arrays (host).  Returns (dN flat numpy array, status dict)."""
+    L = load()
+    sps, gs, ds, os_, nout, keep = _pack_common(species, grid, df, opts)
+    n = len(cells["tau"])
+    cs = Cells()
+    cs.n_cells = n
+    held = []
+    for f in CELL_FIELDS:
+        a = cells.get(f)
+        if a is not None:
+            a = _f64(a)
+            assert a.shape == (n,), f
+            held.append(a)
+            setattr(cs, f, a.ctypes.data)
+    if out is None:
+        out = np.zeros(nout)
+    assert out.dtype == np.float64 and out.size == nout and out.flags.c_contiguous
+    st = Status()
+    rc = L.is3d_smooth_spectra(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), _p(out), C.byref(st))
+    _check(rc)
+    return out, st.as_dict()
+
+
+class Plan:
+    """Device-resident plan (is3d_plan_*).  Cell arrays and the output are device pointers (ints),
+    e.g. torch tensors' data_ptr(); `stream` is a hipStream_t handle (torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, species, grid, df, opts=None, max_cells=1):
+        L = load()
+        sps, gs, ds, os_, nout, keep = _pack_common(species, grid, df, opts)
+        self._h = C.c_void_p()
+        _check(L.is3d_plan_create(C.byref(self._h), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), int(max_cells)))
+        self.output_size = int(L.is3d_plan_output_size(self._h))
+        assert self.output_size == nout
+        self.workspace_bytes = int(L.is3d_plan_workspace_bytes(self._h))
+        self.main_kernel_name = L.is3d_plan_main_kernel_name(self._h).decode()
+
+    def set_timing(self, enable=True):
+        _check(load().is3d_plan_set_timing(self._h, 1 if enable else 0))
+
+    def execute(self, n_cells, cell_ptrs, out_ptr, stream=0, want_status=True):
+        """cell_ptrs: dict field -> device pointer (int)."""
+        cs = Cells()
+        cs.n_cells = int(n_cells)
+        for f in CELL_FIELDS:
+            p = cell_ptrs.get(f)
+            if p:
+                setattr(cs, f, int(p))
+        st = Status()
+        rc = load().is3d_plan_execute(self._h, C.byref(cs), C.c_void_p(int(out_ptr)), C.c_void_p(int(stream or 0)),
+                                      C.byref(st) if want_status else None)
+        _check(rc)
+        return st.as_dict() if want_status else None
+
+    def timings(self):
+        st = Status()
+        _check(load().is3d_plan_timings(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            load().is3d_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host I/O wrappers -------------------------------------------------------------------------
+def param_get(path, name):
+    v = C.c_double()
+    _check(load().is3d_param_get(path.encode(), name.encode(), C.byref(v)))
+    return v.value
+
+
+def table_read(path):
+    L = load()
+    rows, cols = C.c_int64(), C.c_int32()
+    _check(L.is3d_table_read(path.encode(), C.byref(rows), C.byref(cols), None, 0))
+    data = np.zeros((rows.value, cols.value))
+    _check(L.is3d_table_read(path.encode(), C.byref(rows), C.byref(cols), _p(data), data.size))
+    return data
+
+
+def surface_read_vh(path, include_baryon=0, include_baryondiff_deltaf=0, dimension=3):
+    L = load()
+    n = C.c_int64(0)
+    _check(L.is3d_surface_read_vh(path.encode(), include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), None, None))
+    arrs = {f: np.zeros(n.value) for f in SURFACE_READ_ORDER}
+    ptrs = (_dp * 23)(*[_p(arrs[f]) for f in SURFACE_READ_ORDER])
+    avg = np.zeros(5)
+    if n.value > 0:
+        _check(L.is3d_surface_read_vh(path.encode(), include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), ptrs, _p(avg)))
+    return arrs, avg
+
+
+def pdg_read(path):
+    L = load()
+    n = C.c_int32(0)
+    _check(L.is3d_pdg_read(path.encode(), C.byref(n), None, None, None, None, None, 0))
+    ids = np.zeros(n.value, dtype=np.int64)
+    mass, gspin, baryon, sign = (np.zeros(n.value) for _ in range(4))
+    _check(L.is3d_pdg_read(path.encode(), C.byref(n), ids.ctypes.data_as(C.POINTER(C.c_int64)), _p(mass), _p(gspin),
+                           _p(baryon), _p(sign), n.value))
+    return dict(mc_id=ids, mass=mass, gspin=gspin, baryon=baryon, sign=sign)
+
+
+def df_table_read(path):
+    L = load()
+    n = C.c_int32(0)
+    _check(L.is3d_df_table_read(path.encode(), C.byref(n), None, None, 0))
+    T, v = np.zeros(n.value), np.zeros(n.value)
+    _check(L.is3d_df_table_read(path.encode(), C.byref(n), _p(T), _p(v), n.value))
+    return T, v
+
+
+def write_results(results_dir, dimension, mc_id, pT, pT_w, phi, phi_w, y, dN):
+    L = load()
+    mc = np.ascontiguousarray(mc_id, dtype=np.int64)
+    pT, pT_w, phi, phi_w, y, dN = (_f64(a) for a in (pT, pT_w, phi, phi_w, y, dN))
+    _check(L.is3d_write_results(results_dir.encode(), dimension, len(mc), mc.ctypes.data_as(C.POINTER(C.c_int64)), len(pT),
+                                _p(pT), _p(pT_w), len(phi), _p(phi), _p(phi_w), len(y), _p(y), _p(dN)))

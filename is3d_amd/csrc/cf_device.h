@@ -1,0 +1,68 @@
+// cf_device.h -- shared definitions between the HIP kernels (cf_kernels.hip) and the plan/host code.
+#pragma once
+#include <stdint.h>
+
+namespace is3d {
+
+constexpr double kHbarC = 0.197327053;  // src/cpp/iS3D.h:9
+
+// ---- derived per-cell coefficient streams written by cf_prep, read (wave-uniform) by cf_main ----
+// S1[cell][k]   : {A_k, Cp_k, alpha_k, W_k}      k = y index (3+1D) or eta quadrature index (2+1D)
+// S2[cell][j]   : {B_j, Dp_j, gamma_j, kappa}    j = phi index
+// S3[cell][j][k]: beta_jk
+// so that for a momentum (mT, pT, phi_j, y_k):
+//   p.dsigma            = mT*A_k + W_k*pT*B_j                        (W_k = 1 in 3+1D)
+//   p.u / T  (=: x)     = mT*Cp_k - pT*Dp_j
+//   14-moment  df/feqbar = mT^2*alpha_k + mT*pT*beta_jk + pT^2*gamma_j
+//   Chapman-E. df/feqbar = (mT^2*alpha_k + mT*pT*beta_jk + pT^2*gamma_j)/x + kappa*x
+constexpr int kS1Rec = 4;
+constexpr int kS2Rec = 4;
+
+struct SplineDev {       // natural cubic spline, device copy: knots x, values y, second-derivative c
+    int n;
+    const double *x;
+    const double *y[3];  // df_mode 1: {c0, c2, -}; df_mode 2: {F, betabulk, betapi}
+    const double *c[3];
+    int nspl;
+};
+
+struct CellPtrs {        // device pointers to the caller's SoA (is3d_cells), may be null when unused
+    const double *tau, *eta, *dat, *dax, *day, *dan, *ux, *uy, *un, *T, *P, *E;
+    const double *pixx, *pixy, *pixn, *piyy, *piyn, *bulkPi;
+};
+
+struct PrepParams {
+    CellPtrs cells;
+    int64_t cell0;       // first cell of this pass in the caller's arrays
+    int32_t n_cells;     // cells in this pass
+    int32_t J, K;
+    int32_t dim3;        // 1: 3+1D (k = y), 0: 2+1D (k = eta quadrature)
+    int32_t ce;          // 1: Chapman-Enskog, 0: 14-moment
+    int32_t include_bulk, include_shear;
+    const double *cosphi, *sinphi;  // [J]
+    const double *kgrid;            // [K] y values (3+1D) or eta nodes (2+1D)
+    const double *kweight;          // [K] eta weights (2+1D), unused in 3+1D
+    SplineDev spl;
+    double *S1, *S2, *S3;
+    unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count
+};
+
+// ---- main kernel geometry ----
+struct MainGeom {
+    int32_t n_cells;   // cells in this pass
+    int32_t J, K;
+    int32_t Lpad;      // padded lane-slot count (multiple of 64)
+    int32_t G;         // workgroups per stream = ceil(Lpad/64 / 4)
+    int32_t jtiles, ktiles, nch;
+    int32_t NT;        // streams = jtiles*ktiles*nch
+    int32_t Kacc;      // accumulator slots along k: K (3+1D) or 1 (2+1D)
+    int32_t first_pass;  // 1: store partials, 0: add to them
+};
+
+struct MainArgs {
+    const double *S1, *S2, *S3, *lane_mT, *lane_pT, *lane_sign;
+    double *partial;
+    MainGeom g;
+};
+
+}  // namespace is3d

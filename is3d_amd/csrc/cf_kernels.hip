@@ -1,0 +1,588 @@
+// cf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the smooth Cooper-Frye path.
+//
+// Replaces the two hot loops of EmissionFunctionArray::calculate_dN_pTdpTdphidy
+// (/root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:106-349 compute, :354-383 reduce).
+//
+// Design:
+//   cf_prep      lanes <-> cells.  Coalesced SoA reads of the 18 cell arrays, delta-f splines staged
+//                in LDS, writes the per-cell *derived coefficient streams* S1/S2/S3 (cf_device.h):
+//                everything in the integrand that does not depend on the species/pT of a lane is
+//                folded into ~4 numbers per (cell, phi, y) so the hot loop is ~20 fp64 VALU ops/eval.
+//   cf_main_*    lanes <-> (species class, pT) bins, loop over cells.  Cell coefficients are
+//                wave-uniform: they arrive through scalar loads (SGPR operands of v_fma_f64), so no
+//                cross-lane reduction and no LDS traffic exists in the hot loop; accumulators stay in
+//                VGPRs for a whole cell chunk.  fp64 VALU bound (no MFMA: nothing to contract).
+//   cf_finalize  fixed-order sum over cell chunks (bitwise reproducible), x prefactor x degeneracy,
+//                scatter from class layout to the reference's species-fastest layout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cf_launch.h"
+
+namespace is3d {
+
+// ------------------------------------------------------------------------------------------------
+// fp64 building blocks (gfx950 has no v_exp_f64; v_rcp_f64 is an approximation)
+// ------------------------------------------------------------------------------------------------
+#define IS3D_LOG2E 1.44269504088896338700e+00
+#define IS3D_LN2_HI 6.93147180369123816490e-01 /* 0x3fe62e42fee00000: n*LN2_HI exact for |n| < 2^21 */
+#define IS3D_LN2_LO 1.90821492927058770002e-10 /* 0x3dea39ef35793c76 */
+
+// e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-12 Taylor of e^r, |r| <= ln2/2
+// (truncation 0.3466^13/13! = 1.7e-16).  Splitting mantissa and exponent lets two exponentials be
+// multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
+__device__ __forceinline__ void exp_core(double v, double &f, int &n)
+{
+    double dn = __builtin_rint(v * IS3D_LOG2E);
+    double r = __builtin_fma(-dn, IS3D_LN2_HI, v);
+    r = __builtin_fma(-dn, IS3D_LN2_LO, r);
+    double p = 2.08767569878680989792e-09;             // 1/12!
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);  // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);  // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);  // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);  // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);  // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);  // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);  // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);  // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);  // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    f = __builtin_fma(p, r, 1.0);
+    n = (int)dn;
+}
+
+__device__ __forceinline__ double ldexp_fast(double f, int n) { return __builtin_amdgcn_ldexp(f, n); }  // v_ldexp_f64
+
+// 1/d: v_rcp_f64 seed + two Newton steps (each squares the relative error)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+// Tail of one integrand evaluation, shared by both main kernels.
+//   z = exp(-p.u/T), x = p.u/T, br = mT^2 alpha + mT pT beta + pT^2 gamma, pds = p.dsigma (weighted)
+// reference lines (smooth_kernels.cpp): feq :289 = z/(1 + sign z); feqbar :290 = 1/(1 + sign z);
+// df :303-321; regulate :328; f :330; outflow :285.
+template <bool CE, bool OUTFLOW, bool REG>
+__device__ __forceinline__ double eval_tail(double z, double x, double br, double kappa, double sign, double pds)
+{
+    double d = __builtin_fma(sign, z, 1.0);
+    double r, df;
+    if (CE) {
+        // one reciprocal for both 1/(1 + sign z) and 1/x
+        double R = rcp_nr(d * x);
+        r = R * x;
+        double invx = R * d;
+        df = r * __builtin_fma(br, invx, kappa * x);
+    } else {
+        r = rcp_nr(d);
+        df = r * br;
+    }
+    if (REG) df = __builtin_fmax(-1.0, __builtin_fmin(df, 1.0));
+    double feq = z * r;
+    double f = __builtin_fma(feq, df, feq);
+    if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
+    return pds * f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cf_prep
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrepCB = 4;          // cells per workgroup batch
+constexpr int kPrepThreads = 256;
+
+struct CellScal {
+    double dat, dax, day, dan_tau, ut, ux, uy, tau_un, invT, eta;
+    double pitt, pitx, pity, tpitn, pixx, pixy, tpixn, piyy, tpiyn, t2pinn;
+    double shear, Pb0, Pb2, kappa;
+    double wvalid;  // 1.0 valid, 0.0 neutralised (skipped or out-of-table)
+};
+
+// gsl_interp_cspline evaluation (deltafReader.cpp:339-358 call sites) on LDS-resident tables.
+__device__ __forceinline__ double spline_eval_lds(int n, const double *x, const double *y, const double *c, double xq)
+{
+    int lo = 0, hi = n - 1;
+    while (hi > lo + 1) {
+        int i = (hi + lo) >> 1;
+        if (x[i] > xq) hi = i; else lo = i;
+    }
+    double x_lo = x[lo], dx = x[lo + 1] - x_lo;
+    double y_lo = y[lo], dy = y[lo + 1] - y_lo;
+    double delx = xq - x_lo;
+    double c_i = c[lo], c_ip1 = c[lo + 1];
+    double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
+    double d_i = (c_ip1 - c_i) / (3.0 * dx);
+    return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
+}
+
+__global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
+{
+    extern __shared__ double lds[];
+    const int nT = p.spl.n, nspl = p.spl.nspl, J = p.J, K = p.K;
+    double *sx = lds;                         // [nT]
+    double *sy = sx + nT;                     // [nspl][nT]
+    double *sc = sy + nspl * nT;              // [nspl][nT]
+    CellScal *cs = (CellScal *)(sc + nspl * nT);  // [CB]
+    double *l_ch = (double *)(cs + kPrepCB);  // [CB][K]
+    double *l_sh = l_ch + kPrepCB * K;
+    double *l_C = l_sh + kPrepCB * K;
+    double *l_D = l_C + kPrepCB * K;          // [CB][J]
+    double *l_E = l_D + kPrepCB * J;
+    double *l_F = l_E + kPrepCB * J;
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nT; i += kPrepThreads) {
+        sx[i] = p.spl.x[i];
+        for (int s = 0; s < nspl; s++) {
+            sy[s * nT + i] = p.spl.y[s][i];
+            sc[s * nT + i] = p.spl.c[s][i];
+        }
+    }
+    __syncthreads();
+
+    const int nbatch = (p.n_cells + kPrepCB - 1) / kPrepCB;
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int cbase = batch * kPrepCB;
+        const int ncb = min(kPrepCB, p.n_cells - cbase);
+
+        // ---- phase 1: per-cell scalars (smooth_kernels.cpp:118-242) ----
+        if (tid < ncb) {
+            const int64_t gi = p.cell0 + cbase + tid;
+            CellScal s;
+            double tau = p.cells.tau[gi], tau2 = tau * tau;
+            double dat = p.cells.dat[gi], dax = p.cells.dax[gi], day = p.cells.day[gi], dan = p.cells.dan[gi];
+            double ux = p.cells.ux[gi], uy = p.cells.uy[gi], un = p.cells.un[gi];
+            double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);          // :133
+            double udsigma = ut * dat + ux * dax + uy * day + un * dan;           // :135
+            bool valid = udsigma > 0.0;                                           // :137
+            if (!valid) atomicAdd(&p.status[1], 1ULL);
+            double T = p.cells.T[gi];
+            if (valid && !(T >= sx[0] && T <= sx[nT - 1])) {                      // GSL domain error
+                atomicMin(&p.status[0], (unsigned long long)gi);
+                valid = false;
+            }
+            if (valid) {
+                double P = p.cells.P[gi], E = p.cells.E[gi];
+                double ux2 = ux * ux, uy2 = uy * uy, ut2 = ut * ut;
+                double utperp2 = 1.0 + ux * ux + uy * uy;                         // utperp^2, :142
+                double pixx = 0, pixy = 0, pixn = 0, piyy = 0, piyn = 0, pinn = 0, pitn = 0, pity = 0, pitx = 0, pitt = 0;
+                if (p.include_shear) {                                            // :159-171
+                    pixx = p.cells.pixx[gi]; pixy = p.cells.pixy[gi]; pixn = p.cells.pixn[gi];
+                    piyy = p.cells.piyy[gi]; piyn = p.cells.piyn[gi];
+                    pinn = (pixx * (ux2 - ut2) + piyy * (uy2 - ut2) + 2.0 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp2);
+                    pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut;
+                    pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut;
+                    pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut;
+                    pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
+                }
+                double bulkPi = p.include_bulk ? p.cells.bulkPi[gi] : 0.0;       // :173-175
+                double T2 = T * T, T4 = T2 * T2;
+                double shear, b0, b2, kappa = 0.0;
+                if (!p.ce) {                                                      // :222-229, deltafReader.cpp:337-344
+                    double c0 = spline_eval_lds(nT, sx, sy, sc, T) / T4;
+                    double c2 = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) / T4;
+                    shear = 0.5 / (T2 * (E + P));
+                    b0 = c0 - c2;
+                    b2 = 4.0 * c2 - c0;
+                } else {                                                          // :230-237, deltafReader.cpp:352-358
+                    double F = spline_eval_lds(nT, sx, sy, sc, T) * T;
+                    double betabulk = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) * T4;
+                    double betapi = spline_eval_lds(nT, sx, sy + 2 * nT, sc + 2 * nT, T) * T4;
+                    shear = 0.5 / (betapi * T);
+                    b0 = F / (T2 * betabulk);
+                    b2 = 1.0 / (3.0 * T * betabulk);
+                    kappa = (b0 + b2) * bulkPi * T;
+                }
+                s.dat = dat; s.dax = dax; s.day = day; s.dan_tau = dan / tau;
+                s.ut = ut; s.ux = ux; s.uy = uy; s.tau_un = tau * un; s.invT = 1.0 / T;
+                s.eta = p.dim3 ? p.cells.eta[gi] : 0.0;
+                s.pitt = pitt; s.pitx = pitx; s.pity = pity; s.tpitn = tau * pitn;
+                s.pixx = pixx; s.pixy = pixy; s.tpixn = tau * pixn; s.piyy = piyy; s.tpiyn = tau * piyn;
+                s.t2pinn = tau2 * pinn;
+                s.shear = shear; s.Pb0 = bulkPi * b0; s.Pb2 = bulkPi * b2; s.kappa = kappa;
+                s.wvalid = 1.0;
+            } else {
+                // neutral cell: p.dsigma == 0 for every momentum, finite distribution -> contributes 0
+                s.dat = s.dax = s.day = s.dan_tau = 0.0;
+                s.ut = 1.0; s.ux = s.uy = s.tau_un = 0.0; s.invT = 1.0; s.eta = 0.0;
+                s.pitt = s.pitx = s.pity = s.tpitn = s.pixx = s.pixy = s.tpixn = s.piyy = s.tpiyn = s.t2pinn = 0.0;
+                s.shear = s.Pb0 = s.Pb2 = s.kappa = 0.0;
+                s.wvalid = 0.0;
+            }
+            cs[tid] = s;
+        }
+        __syncthreads();
+
+        // ---- phase 2: (cell, k) -> S1 ----
+        for (int idx = tid; idx < ncb * K; idx += kPrepThreads) {
+            const int c = idx / K, k = idx - c * K;
+            const CellScal &s = cs[c];
+            double dlt, w;
+            if (p.dim3) { dlt = p.kgrid[k] - s.eta; w = s.wvalid; }      // y - eta_cell, :279
+            else { dlt = 0.0 - p.kgrid[k]; w = p.kweight[k] * s.wvalid; }   // y = 0, eta = table node, :75-80
+            double ch = cosh(dlt), sh = sinh(dlt);
+            double A = w * (ch * s.dat + sh * s.dan_tau);
+            double C = ch * s.ut - sh * s.tau_un;
+            double Q0 = s.pitt * ch * ch + s.t2pinn * sh * sh - 2.0 * s.tpitn * ch * sh;
+            double alpha = p.ce ? (s.shear * Q0 - s.Pb2) * s.invT : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
+            double *o = p.S1 + ((int64_t)(cbase + c) * K + k) * kS1Rec;
+            o[0] = A; o[1] = C * s.invT; o[2] = alpha; o[3] = w;
+            l_ch[c * K + k] = ch; l_sh[c * K + k] = sh; l_C[c * K + k] = C;
+        }
+        // ---- phase 2b: (cell, j) -> S2 ----
+        for (int idx = tid; idx < ncb * J; idx += kPrepThreads) {
+            const int c = idx / J, j = idx - c * J;
+            const CellScal &s = cs[c];
+            double cp = p.cosphi[j], sp = p.sinphi[j];
+            double B = cp * s.dax + sp * s.day;
+            double D = cp * s.ux + sp * s.uy;
+            double Q2 = s.pixx * cp * cp + s.piyy * sp * sp + 2.0 * s.pixy * cp * sp;
+            double gamma = p.ce ? (s.shear * Q2 + s.Pb2) * s.invT : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
+            double *o = p.S2 + ((int64_t)(cbase + c) * J + j) * kS2Rec;
+            o[0] = B; o[1] = D * s.invT; o[2] = gamma; o[3] = s.kappa;
+            l_D[c * J + j] = D;
+            l_E[c * J + j] = -2.0 * (s.pitx * cp + s.pity * sp);
+            l_F[c * J + j] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
+        }
+        __syncthreads();
+        // ---- phase 3: (cell, j, k) -> S3 ----
+        const int JK = J * K;
+        for (int idx = tid; idx < ncb * JK; idx += kPrepThreads) {
+            const int c = idx / JK, r = idx - c * JK, j = r / K, k = r - j * K;
+            const CellScal &s = cs[c];
+            double X = l_E[c * J + j] * l_ch[c * K + k] + l_F[c * J + j] * l_sh[c * K + k];
+            double beta = p.ce ? s.shear * X * s.invT : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
+            p.S3[(int64_t)(cbase + c) * JK + r] = beta;
+        }
+        __syncthreads();
+    }
+}
+
+size_t prep_lds_bytes(int nT, int nspl, int J, int K)
+{
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)kPrepCB * (3 * K + 3 * J)) + sizeof(CellScal) * kPrepCB;
+}
+
+hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
+{
+    if (p.n_cells <= 0) return hipSuccess;
+    int nbatch = (p.n_cells + kPrepCB - 1) / kPrepCB;
+    int grid = nbatch < 4096 ? nbatch : 4096;
+    size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K);
+    hipLaunchKernelGGL(cf_prep, dim3(grid), dim3(kPrepThreads), lds, stream, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// cf_main: shared task decode.  Workgroup = 4 waves = 4 consecutive lane-waves of the same
+// (j tile, k tile, cell chunk) "stream"; the workgroups of one stream are placed on one XCD (blocks
+// b and b+8 share an XCD under round-robin dispatch; speed only) so the stream is fetched into one L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWPB = kWavesPerBlock;
+
+struct Task {
+    int l;            // lane slot
+    int jt, kt, chunk;
+    bool active;
+};
+
+__device__ __forceinline__ Task decode_task(const MainGeom &g)
+{
+    Task t;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int stream = (q / g.G) * 8 + xcd;
+    const int wave = threadIdx.x >> 6;
+    const int lw = grp * kWPB + wave;
+    t.l = lw * 64 + (threadIdx.x & 63);
+    t.active = (stream < g.NT) && (lw * 64 < g.Lpad);
+    int s = stream;
+    t.jt = s % g.jtiles; s /= g.jtiles;
+    t.kt = s % g.ktiles; s /= g.ktiles;
+    t.chunk = s;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cf_main_direct (variant 1): one phi per wave-task, one exp per evaluation.  Simple reference kernel.
+// 3+1D: KT accumulators (a tile of the y axis).  2+1D: one accumulator, loop over the eta table.
+// ------------------------------------------------------------------------------------------------
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int KT>
+__global__ void __launch_bounds__(256)
+cf_main_direct(const double *__restrict__ S1, const double *__restrict__ S2, const double *__restrict__ S3,
+               const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
+               const double *__restrict__ lane_sign, double *__restrict__ partial, MainGeom g)
+{
+    const Task t = decode_task(g);
+    if (!t.active) return;
+    const int J = g.J, K = g.K;
+    const int j = t.jt;
+    const double mT = lane_mT[t.l], pT = lane_pT[t.l], sign = lane_sign[t.l];
+    const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
+    const int c0 = (int)(((int64_t)t.chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(t.chunk + 1) * g.n_cells) / g.nch);
+    const int k0 = DIM3 ? t.kt * KT : 0;
+
+    double acc[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; kk++) acc[kk] = 0.0;
+
+    for (int c = c0; c < c1; c++) {
+        const double *r2 = S2 + ((int64_t)c * J + j) * kS2Rec;
+        const double B = r2[0], Dp = r2[1], gamma = r2[2], kappa = r2[3];
+        const double pTB = pT * B, pTD = pT * Dp, pT2g = pT2 * gamma;
+        const double *r1 = S1 + (int64_t)c * K * kS1Rec;
+        const double *r3 = S3 + ((int64_t)c * J + j) * K;
+        if (DIM3) {
+#pragma unroll
+            for (int kk = 0; kk < KT; kk++) {
+                const int k = k0 + kk;
+                if (k < K) {
+                    const double A = r1[k * kS1Rec + 0], Cp = r1[k * kS1Rec + 1], alpha = r1[k * kS1Rec + 2];
+                    const double beta = r3[k];
+                    double pds = __builtin_fma(mT, A, pTB);
+                    double x = __builtin_fma(mT, Cp, -pTD);
+                    double f; int n;
+                    exp_core(-x, f, n);
+                    double z = ldexp_fast(f, n);
+                    double br = __builtin_fma(mT2, alpha, __builtin_fma(mTpT, beta, pT2g));
+                    acc[kk] += eval_tail<CE, OUTFLOW, REG>(z, x, br, kappa, sign, pds);
+                }
+            }
+        } else {
+            // eta quadrature: KT independent partial sums for ILP
+            for (int kb = 0; kb < K; kb += KT) {
+#pragma unroll
+                for (int kk = 0; kk < KT; kk++) {
+                    const int k = kb + kk;
+                    if (k < K) {
+                        const double A = r1[k * kS1Rec + 0], Cp = r1[k * kS1Rec + 1], alpha = r1[k * kS1Rec + 2], W = r1[k * kS1Rec + 3];
+                        const double beta = r3[k];
+                        double pds = __builtin_fma(mT, A, pTB * W);
+                        double x = __builtin_fma(mT, Cp, -pTD);
+                        double f; int n;
+                        exp_core(-x, f, n);
+                        double z = ldexp_fast(f, n);
+                        double br = __builtin_fma(mT2, alpha, __builtin_fma(mTpT, beta, pT2g));
+                        acc[kk] += eval_tail<CE, OUTFLOW, REG>(z, x, br, kappa, sign, pds);
+                    }
+                }
+            }
+        }
+    }
+
+    const int64_t JKacc = (int64_t)J * g.Kacc;
+    double *pp = partial + (int64_t)t.chunk * JKacc * g.Lpad;
+    if (DIM3) {
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++) {
+            const int k = k0 + kk;
+            if (k < K) {
+                double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + t.l;
+                *o = g.first_pass ? acc[kk] : (*o + acc[kk]);
+            }
+        }
+    } else {
+        double s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++) s += acc[kk];
+        double *o = pp + (int64_t)j * g.Lpad + t.l;
+        *o = g.first_pass ? s : (*o + s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cf_main_fact (variant 2): factorised exponential.
+//   exp(-p.u/T) = exp(-mT Cp_k) * exp(+pT Dp_j): one exp_core per (cell, k) and one per (cell, j)
+// instead of one per (cell, j, k); the JT x KT evaluations of a tile cost a multiply, an integer add
+// and a v_ldexp_f64 each.  Mantissa/exponent are kept apart so neither factor can overflow.
+// 3+1D: tile JT x KT, JT*KT accumulators.  2+1D: JT accumulators, loop over the whole eta table.
+// ------------------------------------------------------------------------------------------------
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int KT>
+__global__ void __launch_bounds__(256)
+cf_main_fact(const double *__restrict__ S1, const double *__restrict__ S2, const double *__restrict__ S3,
+             const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
+             const double *__restrict__ lane_sign, double *__restrict__ partial, MainGeom g)
+{
+    const Task t = decode_task(g);
+    if (!t.active) return;
+    const int J = g.J, K = g.K;
+    const int j0 = t.jt * JT;
+    const double mT = lane_mT[t.l], pT = lane_pT[t.l], sign = lane_sign[t.l];
+    const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
+    const int c0 = (int)(((int64_t)t.chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(t.chunk + 1) * g.n_cells) / g.nch);
+    const int k0 = DIM3 ? t.kt * KT : 0;
+    constexpr int NACC = DIM3 ? JT * KT : JT;
+
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+
+    for (int c = c0; c < c1; c++) {
+        double pTB[JT], pTD[JT], pT2g[JT], f2[JT], kappa = 0.0;
+        int n2[JT];
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) {
+            const int j = min(j0 + jj, J - 1);
+            const double *r2 = S2 + ((int64_t)c * J + j) * kS2Rec;
+            pTB[jj] = pT * r2[0];
+            pTD[jj] = pT * r2[1];
+            pT2g[jj] = pT2 * r2[2];
+            kappa = r2[3];
+            exp_core(pTD[jj], f2[jj], n2[jj]);
+        }
+        const double *r1 = S1 + (int64_t)c * K * kS1Rec;
+        const double *r3 = S3 + (int64_t)c * J * K;
+
+        auto do_k = [&](int k, int kk) {
+            const double A = r1[k * kS1Rec + 0], Cp = r1[k * kS1Rec + 1], alpha = r1[k * kS1Rec + 2], W = r1[k * kS1Rec + 3];
+            const double mTA = mT * A, mTC = mT * Cp, mT2a = mT2 * alpha;
+            double f1; int n1;
+            exp_core(-mTC, f1, n1);
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) {
+                const int j = min(j0 + jj, J - 1);
+                const double beta = r3[(int64_t)j * K + k];
+                double pds = mTA + (DIM3 ? pTB[jj] : pTB[jj] * W);
+                double z = ldexp_fast(f1 * f2[jj], n1 + n2[jj]);
+                double x = mTC - pTD[jj];
+                double br = __builtin_fma(mTpT, beta, mT2a + pT2g[jj]);
+                double v = eval_tail<CE, OUTFLOW, REG>(z, x, br, kappa, sign, pds);
+                if (DIM3) acc[jj * KT + kk] += v; else acc[jj] += v;
+            }
+        };
+        if (DIM3) {
+#pragma unroll
+            for (int kk = 0; kk < KT; kk++) {
+                const int k = k0 + kk;
+                if (k < K) do_k(k, kk);
+            }
+        } else {
+            for (int k = 0; k < K; k++) do_k(k, 0);
+        }
+    }
+
+    const int64_t JKacc = (int64_t)J * g.Kacc;
+    double *pp = partial + (int64_t)t.chunk * JKacc * g.Lpad;
+#pragma unroll
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = j0 + jj;
+        if (j < J) {
+            if (DIM3) {
+#pragma unroll
+                for (int kk = 0; kk < KT; kk++) {
+                    const int k = k0 + kk;
+                    if (k < K) {
+                        double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + t.l;
+                        *o = g.first_pass ? acc[jj * KT + kk] : (*o + acc[jj * KT + kk]);
+                    }
+                }
+            } else {
+                double *o = pp + (int64_t)j * g.Lpad + t.l;
+                *o = g.first_pass ? acc[jj] : (*o + acc[jj]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cf_finalize: out[sp + npart*(ipT + npT*(j + J*k))] (smooth_kernels.cpp:363)
+//              (+)= prefactor * degeneracy[sp] * sum_chunks partial[chunk][j*Kacc + k][class(sp)*npT + ipT]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, const double *__restrict__ degeneracy,
+            double *__restrict__ out, int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch,
+            double prefactor, int accumulate)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nout) return;
+    const int sp = (int)(idx % npart);
+    int64_t r = idx / npart;
+    const int ipT = (int)(r % npT);
+    r /= npT;
+    const int j = (int)(r % J);
+    const int k = (int)(r / J);
+    const int l = cls[sp] * npT + ipT;
+    const int64_t stride = (int64_t)J * Kacc * Lpad;
+    const double *p = partial + ((int64_t)j * Kacc + k) * Lpad + l;
+    double s = 0.0;
+    for (int ch = 0; ch < nch; ch++) s += p[ch * stride];
+    const double v = (prefactor * degeneracy[sp]) * s;
+    out[idx] = accumulate ? (out[idx] + v) : v;
+}
+
+hipError_t launch_finalize(const double *partial, const int *cls, const double *degeneracy, double *out,
+                           int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
+                           int accumulate, hipStream_t stream)
+{
+    if (nout <= 0) return hipSuccess;
+    int grid = (int)((nout + 255) / 256);
+    hipLaunchKernelGGL(cf_finalize, dim3(grid), dim3(256), 0, stream, partial, cls, degeneracy, out, nout, npart,
+                       npT, J, Kacc, Lpad, nch, prefactor, accumulate);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// main-kernel dispatch
+// ------------------------------------------------------------------------------------------------
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int KT>
+static void launch_direct_t(const MainArgs &a, hipStream_t st)
+{
+    int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    hipLaunchKernelGGL((cf_main_direct<CE, DIM3, OUTFLOW, REG, KT>), dim3(grid), dim3(kWPB * 64), 0, st, a.S1, a.S2,
+                       a.S3, a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
+}
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int KT>
+static void launch_fact_t(const MainArgs &a, hipStream_t st)
+{
+    int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    hipLaunchKernelGGL((cf_main_fact<CE, DIM3, OUTFLOW, REG, JT, KT>), dim3(grid), dim3(kWPB * 64), 0, st, a.S1, a.S2,
+                       a.S3, a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
+}
+
+// tile shapes: (variant 1) KT; (variant 2) JT x KT.  Must match main_tile_shape().
+constexpr int kV1KT3 = 7, kV1KT2 = 4;
+constexpr int kV2JT3 = 4, kV2KT3 = 7, kV2JT2 = 12;
+
+void main_tile_shape(int variant, int dim3, int *JT, int *KT)
+{
+    if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; }
+    else { *JT = dim3 ? kV2JT3 : kV2JT2; *KT = dim3 ? kV2KT3 : 1; }
+}
+
+template <bool CE, bool DIM3>
+static void launch_flags(int variant, bool outflow, bool reg, const MainArgs &a, hipStream_t st)
+{
+#define IS3D_LAUNCH(OF, RG)                                                                        \
+    do {                                                                                           \
+        if (variant == 1) launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st);      \
+        else launch_fact_t<CE, DIM3, OF, RG, (DIM3 ? kV2JT3 : kV2JT2), (DIM3 ? kV2KT3 : 1)>(a, st); \
+    } while (0)
+    if (outflow && reg) IS3D_LAUNCH(true, true);
+    else if (outflow && !reg) IS3D_LAUNCH(true, false);
+    else if (!outflow && reg) IS3D_LAUNCH(false, true);
+    else IS3D_LAUNCH(false, false);
+#undef IS3D_LAUNCH
+}
+
+hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st)
+{
+    if (a.g.n_cells <= 0) return hipSuccess;
+    if (ce && dim3) launch_flags<true, true>(variant, outflow, reg, a, st);
+    else if (ce && !dim3) launch_flags<true, false>(variant, outflow, reg, a, st);
+    else if (!ce && dim3) launch_flags<false, true>(variant, outflow, reg, a, st);
+    else launch_flags<false, false>(variant, outflow, reg, a, st);
+    return hipGetLastError();
+}
+
+const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : "cf_main_fact"; }
+
+}  // namespace is3d

@@ -1,0 +1,446 @@
+// cf_plan.cpp -- plan object and C ABI of the device path (include/is3d_amd.h).
+//
+// Host-side counterpart of EmissionFunctionArray's packing/dispatch for the smooth path
+// (/root/reference/src/cpp/emissionfunction.cpp:1282-1307 species scalars, :1503-1521 dispatch):
+// groups species into (mass, sign) classes, builds the lane table, the natural cubic splines of
+// Deltaf_Data::construct_cubic_splines (deltafReader.cpp:300-322) and drives prep -> main -> finalize.
+// There is no CPU compute path in this file: without a HIP device every entry fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/is3d_amd.h"
+#include "cf_launch.h"
+#include "errors.h"
+#include "spline.h"
+
+#define fail is3d::set_error
+
+namespace {
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(IS3D_ENODEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct is3d_plan {
+    is3d_options opts{};
+    int device = 0;
+    int npart = 0, ncls = 0, npT = 0, J = 0, K = 0, Kacc = 0, ny_eff = 0;
+    int L = 0, Lpad = 0;
+    int variant = 2, JT = 1, KT = 1, jtiles = 1, ktiles = 1;
+    bool dim3 = true, ce = false;
+    int64_t max_cells = 0, pass_cells = 0, nout = 0;
+    int nch_max = 1;
+    size_t bytes_per_cell = 0;
+    double prefactor = 0;
+
+    DevBuf<double> d_mT, d_pT, d_sign, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
+    DevBuf<int> d_cls;
+    DevBuf<double> d_splx, d_sply[3], d_splc[3];
+    DevBuf<double> d_S1, d_S2, d_S3, d_partial;
+    DevBuf<unsigned long long> d_status;
+    is3d::SplineDev spl{};
+
+    bool timing = false;
+    std::vector<hipEvent_t> ev_list;  // [pass][0..3]: start, after prep, after main; last: after finalize
+    int last_passes = 0;
+    int64_t workspace = 0;
+
+    ~is3d_plan()
+    {
+        for (hipEvent_t e : ev_list)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df, const is3d_options *o)
+{
+    if (!sp || !g || !df || !o) return fail(IS3D_EINVAL, "null argument");
+    if (o->dimension != 2 && o->dimension != 3) return fail(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", o->dimension);
+    if (o->df_mode != 1 && o->df_mode != 2)
+        return fail(IS3D_EINVAL, "df_mode must be 1 (14-moment) or 2 (Chapman-Enskog) on this path (got %d)", o->df_mode);
+    if (o->include_baryon)
+        return fail(IS3D_EINVAL, "include_baryon = 1 (bilinear (T, muB) coefficients, baryon diffusion) is not implemented yet");
+    if (sp->n < 1 || !sp->mass || !sp->sign || !sp->degeneracy) return fail(IS3D_EINVAL, "empty species list");
+    if (g->n_pT < 1 || g->n_phi < 1 || !g->pT || !g->phi) return fail(IS3D_EINVAL, "empty pT/phi grid");
+    if (o->dimension == 3 && (g->n_y < 1 || !g->y)) return fail(IS3D_EINVAL, "dimension 3 needs a y grid");
+    if (o->dimension == 2 && (g->n_eta < 1 || !g->eta || !g->eta_w)) return fail(IS3D_EINVAL, "dimension 2 needs an eta table");
+    if (df->n_T < 3 || !df->T) return fail(IS3D_EINVAL, "coefficient table needs >= 3 temperatures");
+    if (o->df_mode == 1 && (!df->c0 || !df->c2)) return fail(IS3D_EINVAL, "df_mode 1 needs c0 and c2 tables");
+    if (o->df_mode == 2 && (!df->F || !df->betabulk || !df->betapi)) return fail(IS3D_EINVAL, "df_mode 2 needs F, betabulk, betapi tables");
+    for (int i = 1; i < df->n_T; i++)
+        if (!(df->T[i] > df->T[i - 1])) return fail(IS3D_EINVAL, "coefficient table temperatures must ascend");
+    return IS3D_OK;
+}
+
+extern "C" const char *is3d_version(void) { return "is3d_amd 0.1 (gfx950)"; }
+extern "C" int is3d_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df,
+                                const is3d_options *o, int64_t max_cells)
+{
+    if (!out) return fail(IS3D_EINVAL, "null plan pointer");
+    *out = nullptr;
+    int rc = validate(sp, g, df, o);
+    if (rc) return rc;
+    if (max_cells < 1) max_cells = 1;
+    if (max_cells > (int64_t)1 << 40) return fail(IS3D_EINVAL, "max_cells too large");
+    if (is3d_device_count() < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+
+    std::unique_ptr<is3d_plan> P(new is3d_plan);
+    P->opts = *o;
+    if (o->device >= 0) HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipGetDevice(&P->device));
+    P->dim3 = (o->dimension == 3);
+    P->ce = (o->df_mode == 2);
+    P->npart = sp->n;
+    P->npT = g->n_pT;
+    P->J = g->n_phi;
+    P->K = P->dim3 ? g->n_y : g->n_eta;
+    P->Kacc = P->dim3 ? P->K : 1;
+    P->ny_eff = P->Kacc;
+    P->nout = (int64_t)P->npart * P->npT * P->J * P->ny_eff;
+    P->prefactor = std::pow(2.0 * M_PI * is3d::kHbarC, -3);  // smooth_kernels.cpp:36
+    P->variant = (o->kernel_variant == 1) ? 1 : 2;
+
+    // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
+    std::vector<int> cls(P->npart);
+    std::vector<double> cmass, csign;
+    const bool collapse = (o->collapse_species != 2);
+    for (int s = 0; s < P->npart; s++) {
+        int found = -1;
+        if (collapse)
+            for (size_t c = 0; c < cmass.size(); c++)
+                if (cmass[c] == sp->mass[s] && csign[c] == sp->sign[s]) { found = (int)c; break; }
+        if (found < 0) { found = (int)cmass.size(); cmass.push_back(sp->mass[s]); csign.push_back(sp->sign[s]); }
+        cls[s] = found;
+    }
+    P->ncls = (int)cmass.size();
+    P->L = P->ncls * P->npT;
+    P->Lpad = ((P->L + 63) / 64) * 64;
+    std::vector<double> mT(P->Lpad, 1.0), pT(P->Lpad, 0.0), sg(P->Lpad, 1.0);
+    for (int c = 0; c < P->ncls; c++)
+        for (int i = 0; i < P->npT; i++) {
+            double m = cmass[c], p = g->pT[i];
+            mT[c * P->npT + i] = std::sqrt(m * m + p * p);  // :259
+            pT[c * P->npT + i] = p;
+            sg[c * P->npT + i] = csign[c];
+        }
+    std::vector<double> deg(sp->degeneracy, sp->degeneracy + P->npart);
+    std::vector<double> cosphi(P->J), sinphi(P->J);
+    for (int j = 0; j < P->J; j++) { cosphi[j] = std::cos(g->phi[j]); sinphi[j] = std::sin(g->phi[j]); }  // :43-48
+    std::vector<double> kgrid(P->K), kweight(P->K, 1.0);
+    for (int k = 0; k < P->K; k++) {
+        kgrid[k] = P->dim3 ? g->y[k] : g->eta[k];
+        if (!P->dim3) kweight[k] = g->eta_w[k];
+    }
+    HIP_TRY(P->d_mT.upload(mT));
+    HIP_TRY(P->d_pT.upload(pT));
+    HIP_TRY(P->d_sign.upload(sg));
+    HIP_TRY(P->d_degeneracy.upload(deg));
+    HIP_TRY(P->d_cls.upload(cls));
+    HIP_TRY(P->d_cosphi.upload(cosphi));
+    HIP_TRY(P->d_sinphi.upload(sinphi));
+    HIP_TRY(P->d_kgrid.upload(kgrid));
+    HIP_TRY(P->d_kweight.upload(kweight));
+
+    // ---- splines (deltafReader.cpp:300-322) ----
+    const double *tabs[3] = {nullptr, nullptr, nullptr};
+    int nspl;
+    if (!P->ce) { tabs[0] = df->c0; tabs[1] = df->c2; nspl = 2; }
+    else { tabs[0] = df->F; tabs[1] = df->betabulk; tabs[2] = df->betapi; nspl = 3; }
+    std::vector<double> xs(df->T, df->T + df->n_T);
+    HIP_TRY(P->d_splx.upload(xs));
+    P->spl.n = df->n_T;
+    P->spl.x = P->d_splx.p;
+    P->spl.nspl = nspl;
+    for (int s = 0; s < 3; s++) { P->spl.y[s] = nullptr; P->spl.c[s] = nullptr; }
+    for (int s = 0; s < nspl; s++) {
+        std::vector<double> ys(tabs[s], tabs[s] + df->n_T), cs;
+        if (!is3d::natural_cspline_init(xs, ys, cs)) return fail(IS3D_EINVAL, "spline construction failed");
+        HIP_TRY(P->d_sply[s].upload(ys));
+        HIP_TRY(P->d_splc[s].upload(cs));
+        P->spl.y[s] = P->d_sply[s].p;
+        P->spl.c[s] = P->d_splc[s].p;
+    }
+    if (is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K) > 160 * 1024)
+        return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
+
+    // ---- tiling / workspace ----
+    is3d::main_tile_shape(P->variant, P->dim3 ? 1 : 0, &P->JT, &P->KT);
+    P->jtiles = (P->J + P->JT - 1) / P->JT;
+    P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;
+    P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
+    int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
+    int64_t pc = ws / (int64_t)P->bytes_per_cell;
+    if (pc < 1) pc = 1;
+    if (pc > max_cells) pc = max_cells;
+    if (pc > 0x7fff0000LL) pc = 0x7fff0000LL;
+    P->pass_cells = pc;
+    P->max_cells = max_cells;
+
+    // cell chunks: enough wave-tasks for >= ~24 rounds of the chip, chunks of >= 64 cells,
+    // partial buffer <= 2 GiB
+    {
+        const int lane_waves = P->Lpad / 64;
+        const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
+        const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves
+        int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24 * capacity + tasks_per_chunk - 1) / tasks_per_chunk;
+        int64_t by_cells = std::max<int64_t>(1, pc / 64);
+        nch = std::min(nch, by_cells);
+        int64_t part_bytes_per_chunk = (int64_t)P->J * P->Kacc * P->Lpad * (int64_t)sizeof(double);
+        int64_t by_mem = std::max<int64_t>(1, ((int64_t)2 << 30) / part_bytes_per_chunk);
+        nch = std::max<int64_t>(1, std::min(nch, by_mem));
+        P->nch_max = (int)nch;
+    }
+    HIP_TRY(P->d_S1.alloc((size_t)pc * P->K * is3d::kS1Rec));
+    HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
+    HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
+    HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
+    HIP_TRY(P->d_status.alloc(2));
+    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_partial.n) * (int64_t)sizeof(double);
+    *out = P.release();
+    return IS3D_OK;
+}
+
+extern "C" int64_t is3d_plan_output_size(const is3d_plan *P) { return P ? P->nout : 0; }
+extern "C" int64_t is3d_plan_workspace_bytes(const is3d_plan *P) { return P ? P->workspace : 0; }
+extern "C" const char *is3d_plan_main_kernel_name(const is3d_plan *P) { return is3d::main_kernel_name(P ? P->variant : 2); }
+extern "C" int is3d_plan_set_timing(is3d_plan *P, int32_t enable)
+{
+    if (!P) return fail(IS3D_EINVAL, "null plan");
+    P->timing = enable != 0;
+    return IS3D_OK;
+}
+extern "C" void is3d_plan_destroy(is3d_plan *P)
+{
+    if (!P) return;
+    (void)hipSetDevice(P->device);
+    delete P;
+}
+
+static int chunks_for(const is3d_plan *P, int64_t n)
+{
+    int64_t by_cells = std::max<int64_t>(1, n / 64);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(P->nch_max, by_cells));
+}
+
+extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *dN_out, void *hip_stream, is3d_status *status)
+{
+    if (!P || !cells || !dN_out) return fail(IS3D_EINVAL, "null argument");
+    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
+    const int64_t n = cells->n_cells;
+    if (n < 0 || n > P->max_cells) return fail(IS3D_EINVAL, "n_cells = %lld exceeds the plan's max_cells = %lld", (long long)n, (long long)P->max_cells);
+    const is3d_options &o = P->opts;
+    const bool need_eta = P->dim3;
+    if (n > 0) {
+        if (!cells->tau || !cells->dat || !cells->dax || !cells->day || !cells->dan || !cells->ux || !cells->uy || !cells->un ||
+            !cells->T || !cells->P || !cells->E || (need_eta && !cells->eta))
+            return fail(IS3D_EINVAL, "a required cell array is NULL");
+        if (o.include_shear_deltaf && (!cells->pixx || !cells->pixy || !cells->pixn || !cells->piyy || !cells->piyn))
+            return fail(IS3D_EINVAL, "include_shear_deltaf needs pixx, pixy, pixn, piyy, piyn");
+        if (o.include_bulk_deltaf && !cells->bulkPi) return fail(IS3D_EINVAL, "include_bulk_deltaf needs bulkPi");
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(P->device));
+
+    const int npasses = n == 0 ? 0 : (int)((n + P->pass_cells - 1) / P->pass_cells);
+    if (P->timing) {
+        size_t need = (size_t)npasses * 3 + 1;
+        while (P->ev_list.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            P->ev_list.push_back(e);
+        }
+    }
+    P->last_passes = npasses;
+    unsigned long long init[2] = {~0ULL, 0ULL};
+    HIP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, st));
+
+    int nch_used = 1;
+    if (n == 0) {
+        // empty surface: spectrum is zero (reference: loops do not execute)
+        if (!o.accumulate) HIP_TRY(hipMemsetAsync(dN_out, 0, (size_t)P->nout * sizeof(double), st));
+    } else {
+        // all passes use the chunk count of the first (largest) pass so that partial slots line up
+        nch_used = chunks_for(P, std::min<int64_t>(n, P->pass_cells));
+        for (int pass = 0; pass < npasses; pass++) {
+            const int64_t c0 = (int64_t)pass * P->pass_cells;
+            const int32_t nc = (int32_t)std::min<int64_t>(P->pass_cells, n - c0);
+            is3d::PrepParams pp{};
+            pp.cells = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                        cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
+            pp.cell0 = c0;
+            pp.n_cells = nc;
+            pp.J = P->J; pp.K = P->K;
+            pp.dim3 = P->dim3; pp.ce = P->ce;
+            pp.include_bulk = o.include_bulk_deltaf != 0;
+            pp.include_shear = o.include_shear_deltaf != 0;
+            pp.cosphi = P->d_cosphi.p; pp.sinphi = P->d_sinphi.p;
+            pp.kgrid = P->d_kgrid.p; pp.kweight = P->d_kweight.p;
+            pp.spl = P->spl;
+            pp.S1 = P->d_S1.p; pp.S2 = P->d_S2.p; pp.S3 = P->d_S3.p;
+            pp.status = P->d_status.p;
+            if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
+            HIP_TRY(is3d::launch_prep(pp, st));
+            if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 1], st));
+
+            is3d::MainArgs a{};
+            a.S1 = P->d_S1.p; a.S2 = P->d_S2.p; a.S3 = P->d_S3.p;
+            a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
+            a.partial = P->d_partial.p;
+            a.g.n_cells = nc;
+            a.g.J = P->J; a.g.K = P->K;
+            a.g.Lpad = P->Lpad;
+            a.g.G = (P->Lpad / 64 + is3d::kWavesPerBlock - 1) / is3d::kWavesPerBlock;
+            a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles;
+            a.g.nch = nch_used;
+            a.g.NT = P->jtiles * P->ktiles * nch_used;
+            a.g.Kacc = P->Kacc;
+            a.g.first_pass = (pass == 0);
+            HIP_TRY(is3d::launch_main(P->variant, P->ce, P->dim3, o.outflow != 0, o.regulate_deltaf != 0, a, st));
+            if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 2], st));
+        }
+        HIP_TRY(is3d::launch_finalize(P->d_partial.p, P->d_cls.p, P->d_degeneracy.p, dN_out, P->nout, P->npart, P->npT, P->J,
+                                      P->Kacc, P->Lpad, nch_used, P->prefactor, o.accumulate != 0, st));
+        if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[npasses * 3], st));
+    }
+
+    if (status) {
+        unsigned long long h[2];
+        HIP_TRY(hipMemcpyAsync(h, P->d_status.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        status->n_classes = P->ncls;
+        status->n_passes = npasses;
+        status->kernel_variant = P->variant;
+        status->n_cells_skipped = (int64_t)h[1];
+        status->bad_cell = (h[0] == ~0ULL) ? -1 : (int64_t)h[0];
+        if (status->bad_cell >= 0) {
+            status->code = IS3D_EDOMAIN;
+            return fail(IS3D_EDOMAIN, "cell %lld: T outside the delta-f coefficient table (the reference aborts in gsl_spline_eval here)",
+                        (long long)status->bad_cell);
+        }
+    }
+    return IS3D_OK;
+}
+
+extern "C" int is3d_plan_timings(is3d_plan *P, is3d_status *status)
+{
+    if (!P || !status) return fail(IS3D_EINVAL, "null argument");
+    status->ms_prep = status->ms_main = status->ms_finalize = 0.0;
+    if (!P->timing || P->last_passes == 0) return IS3D_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipEventSynchronize(P->ev_list[P->last_passes * 3]));
+    for (int pass = 0; pass < P->last_passes; pass++) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, P->ev_list[pass * 3 + 0], P->ev_list[pass * 3 + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, P->ev_list[pass * 3 + 1], P->ev_list[pass * 3 + 2]));
+        status->ms_prep += a;
+        status->ms_main += b;
+    }
+    float c = 0;
+    HIP_TRY(hipEventElapsedTime(&c, P->ev_list[(P->last_passes - 1) * 3 + 2], P->ev_list[P->last_passes * 3]));
+    status->ms_finalize = c;
+    status->n_passes = P->last_passes;
+    status->kernel_variant = P->variant;
+    status->n_classes = P->ncls;
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-shot host entry
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                                   const is3d_df_tables *df, const is3d_options *opts, double *dN_out, is3d_status *status)
+{
+    if (!cells || !dN_out) return fail(IS3D_EINVAL, "null argument");
+    is3d_plan *P = nullptr;
+    int rc = is3d_plan_create(&P, species, grid, df, opts, std::max<int64_t>(cells->n_cells, 1));
+    if (rc) { if (status) { memset(status, 0, sizeof *status); status->code = rc; status->bad_cell = -1; } return rc; }
+    struct Guard { is3d_plan *p; ~Guard() { is3d_plan_destroy(p); } } guard{P};
+    (void)is3d_plan_set_timing(P, 1);
+
+    const int64_t n = cells->n_cells;
+    const double *src[18] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
+    DevBuf<double> dcell, dout;
+    HIP_TRY(dcell.alloc((size_t)std::max<int64_t>(n, 1) * 18));
+    HIP_TRY(dout.alloc((size_t)P->nout));
+    hipEvent_t e0, e1, e2, e3;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2)); HIP_TRY(hipEventCreate(&e3));
+    struct EvGuard { hipEvent_t e[4]; ~EvGuard() { for (auto x : e) (void)hipEventDestroy(x); } } evg{{e0, e1, e2, e3}};
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    const double *dptr[18];
+    for (int a = 0; a < 18; a++) {
+        dptr[a] = nullptr;
+        if (src[a] && n > 0) {
+            HIP_TRY(hipMemcpyAsync(dcell.p + (size_t)a * n, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+            dptr[a] = dcell.p + (size_t)a * n;
+        }
+    }
+    if (opts->accumulate) HIP_TRY(hipMemcpyAsync(dout.p, dN_out, (size_t)P->nout * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    is3d_cells dc{};
+    dc.n_cells = n;
+    dc.tau = dptr[0]; dc.eta = dptr[1]; dc.dat = dptr[2]; dc.dax = dptr[3]; dc.day = dptr[4]; dc.dan = dptr[5];
+    dc.ux = dptr[6]; dc.uy = dptr[7]; dc.un = dptr[8]; dc.T = dptr[9]; dc.P = dptr[10]; dc.E = dptr[11];
+    dc.pixx = dptr[12]; dc.pixy = dptr[13]; dc.pixn = dptr[14]; dc.piyy = dptr[15]; dc.piyn = dptr[16]; dc.bulkPi = dptr[17];
+    is3d_status st{};
+    rc = is3d_plan_execute(P, &dc, dout.p, nullptr, &st);
+    if (rc) { if (status) *status = st; return rc; }
+    HIP_TRY(hipEventRecord(e2, nullptr));
+    HIP_TRY(hipMemcpyAsync(dN_out, dout.p, (size_t)P->nout * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipEventRecord(e3, nullptr));
+    HIP_TRY(hipEventSynchronize(e3));
+    (void)is3d_plan_timings(P, &st);
+    float h2d = 0, d2h = 0;
+    HIP_TRY(hipEventElapsedTime(&h2d, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&d2h, e2, e3));
+    st.ms_h2d = h2d;
+    st.ms_d2h = d2h;
+    st.code = IS3D_OK;
+    if (status) *status = st;
+    return IS3D_OK;
+}

@@ -1,0 +1,416 @@
+// host_io.cpp -- readers and writers in the reference's text formats (host side, plain C++17).
+//
+// Each function states the reference routine whose observable behaviour it reproduces
+// (paths relative to /root/reference).  Nothing here calls exit(): errors become IS3D_E* codes.
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/is3d_amd.h"
+#include "errors.h"
+
+namespace {
+
+const double kHbarC = 0.197327053;  // src/cpp/iS3D.h:9
+
+bool slurp(const char *path, std::string &out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    std::string s;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    out.swap(s);
+    return true;
+}
+
+// arsenal.cpp:552-565: trim() removes EVERY blank and tab, not only the ends
+std::string strip_blanks(const std::string &s)
+{
+    std::string t;
+    for (char ch : s)
+        if (ch != ' ' && ch != '\t') t.push_back(ch);
+    return t;
+}
+std::string lower(std::string s)
+{
+    for (char &ch : s) ch = (char)tolower((unsigned char)ch);
+    return s;
+}
+
+// arsenal.cpp:378-393 stringToDoubles: numbers until the first token that does not parse
+void line_to_doubles(const char *b, const char *e, std::vector<double> &v)
+{
+    v.clear();
+    std::string tmp(b, e);
+    const char *p = tmp.c_str();
+    for (;;) {
+        char *q;
+        double x = strtod(p, &q);
+        if (q == p) break;
+        v.push_back(x);
+        p = q;
+    }
+}
+
+}  // namespace
+
+namespace is3d {
+static thread_local std::string g_last_error;
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+}  // namespace is3d
+#define io_fail is3d::set_error
+
+extern "C" const char *is3d_last_error(void) { return is3d::g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// ParameterReader::readFromFile / getVal  (src/cpp/ParameterReader.cpp:38-155)
+//   per line: drop everything from '#', remove all blanks/tabs, split at the first '=',
+//   name lower-cased, value = leading double of the right-hand side; later lines overwrite.
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_param_get(const char *path, const char *name, double *value)
+{
+    if (!path || !name || !value) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "parameter file %s does not exist", path);
+    const std::string want = lower(strip_blanks(name));
+    bool found = false;
+    size_t pos = 0;
+    while (pos <= text.size()) {
+        size_t nl = text.find('\n', pos);
+        std::string line = text.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+        pos = (nl == std::string::npos) ? text.size() + 1 : nl + 1;
+        if (strip_blanks(line).empty()) continue;
+        line = line.substr(0, line.find('#'));
+        if (strip_blanks(line).empty()) continue;
+        size_t eq = line.find('=');
+        if (eq == std::string::npos)
+            return io_fail(IS3D_EINVAL, "%s: \"=\" symbol not found in assignment \"%s\"", path, line.c_str());
+        std::string lhs = lower(strip_blanks(line.substr(0, eq)));
+        std::string rhs = strip_blanks(line.substr(eq + 1));
+        if (lhs == want) {
+            *value = strtod(rhs.c_str(), nullptr);
+            found = true;
+        }
+    }
+    if (!found) return io_fail(IS3D_EINVAL, "parameter with name %s not found in %s", name, path);
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Table::loadTableFromFile -> readBlockData  (src/cpp/Table.cpp:179-195, src/cpp/arsenal.cpp:406-453)
+//   column count = numbers on the first line; every '\n'-terminated line is a row; whatever follows
+//   the last '\n' is never stored.
+// ---------------------------------------------------------------------------------------------
+static int parse_table(const std::string &text, const char *path, int64_t *n_rows, int32_t *n_cols,
+                       std::vector<double> *store)
+{
+    std::vector<double> v;
+    size_t pos = 0, nl = text.find('\n');
+    const char *base = text.data();
+    line_to_doubles(base, base + (nl == std::string::npos ? text.size() : nl), v);
+    if (v.empty()) return io_fail(IS3D_EIO, "%s: empty first row; no data read", path);
+    const int32_t ncol = (int32_t)v.size();
+    int64_t rows = 0;
+    while (nl != std::string::npos) {
+        // the line [pos, nl) is complete -> it is a row
+        if (rows > 0) line_to_doubles(base + pos, base + nl, v);
+        if ((int32_t)v.size() < ncol)
+            return io_fail(IS3D_EIO, "%s: row %lld has %d numbers, expected %d", path, (long long)rows + 1, (int)v.size(), ncol);
+        if (store) store->insert(store->end(), v.begin(), v.begin() + ncol);
+        rows++;
+        pos = nl + 1;
+        nl = text.find('\n', pos);
+    }
+    *n_rows = rows;
+    *n_cols = ncol;
+    return IS3D_OK;
+}
+
+extern "C" int is3d_table_read(const char *path, int64_t *n_rows, int32_t *n_cols, double *data, int64_t capacity)
+{
+    if (!path || !n_rows || !n_cols) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    std::vector<double> store;
+    int rc = parse_table(text, path, n_rows, n_cols, data ? &store : nullptr);
+    if (rc) return rc;
+    if (data) {
+        if ((int64_t)store.size() > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %lld < %zu", path, (long long)capacity, store.size());
+        memcpy(data, store.data(), store.size() * sizeof(double));
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FO_data_reader::get_number_cells + read_surf_VH  (src/cpp/readindata.cpp:122-131, :320-468)
+//   cell count = Table rows of the file; values = whitespace token stream, 20 (+1 muB, +4 nB,Vx,Vy,Vn)
+//   numbers per cell; E, T, P, pi**, bulkPi, muB multiplied by hbar*c.
+//   cell_arrays23 order: T P E tau eta ux uy un dat dax day dan pixx pixy pixn piyy piyn bulkPi muB nB Vx Vy Vn
+//   (argument order of calculate_dN_pTdpTdphidy after the species arrays, emissionfunction.h:179).
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                                    int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
+{
+    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    int64_t rows;
+    int32_t cols;
+    int rc = parse_table(text, path, &rows, &cols, nullptr);
+    if (rc) return rc;
+    if (!A) { *n_cells = rows; return IS3D_OK; }
+    if (*n_cells < rows) return io_fail(IS3D_EINVAL, "%s: arrays hold %lld cells, file has %lld", path, (long long)*n_cells, (long long)rows);
+    *n_cells = rows;
+    enum { iT, iP, iE, itau, ieta, iux, iuy, iun, idat, idax, iday, idan, ipixx, ipixy, ipixn, ipiyy, ipiyn, ibulk, imuB, inB, iVx, iVy, iVn };
+    for (int a = 0; a <= ibulk; a++)
+        if (!A[a]) return io_fail(IS3D_EINVAL, "cell array %d is NULL", a);
+    if (include_baryon && !A[imuB]) return io_fail(IS3D_EINVAL, "include_baryon needs the muB array");
+    if (include_baryondiff_deltaf && (!A[inB] || !A[iVx] || !A[iVy] || !A[iVn])) return io_fail(IS3D_EINVAL, "baryon diffusion needs nB, Vx, Vy, Vn arrays");
+
+    const char *p = text.c_str();
+    bool short_read = false;
+    auto next = [&]() -> double {
+        char *q;
+        double x = strtod(p, &q);
+        if (q == p) { short_read = true; return 0.0; }
+        p = q;
+        return x;
+    };
+    double Tavg = 0, Eavg = 0, Pavg = 0, muBavg = 0, nBavg = 0, vol = 0;
+    for (int64_t i = 0; i < rows; i++) {
+        double tau = next();
+        (void)next();  // x
+        (void)next();  // y
+        double eta = next();
+        double dat = next(), dax = next(), day = next(), dan = next();
+        double ux = next(), uy = next(), un = next();
+        double E = next() * kHbarC, T = next() * kHbarC, P = next() * kHbarC;
+        double pixx = next() * kHbarC, pixy = next() * kHbarC, pixn = next() * kHbarC;
+        double piyy = next() * kHbarC, piyn = next() * kHbarC, bulkPi = next() * kHbarC;
+        double muB = 0.0, nB = 0.0;
+        if (include_baryon) { muB = next() * kHbarC; A[imuB][i] = muB; }
+        if (include_baryondiff_deltaf) {
+            nB = next();
+            A[inB][i] = nB;
+            A[iVx][i] = next();
+            A[iVy][i] = next();
+            A[iVn][i] = next();
+        }
+        if (short_read) return io_fail(IS3D_EIO, "%s: ran out of numbers at cell %lld", path, (long long)i);
+        (void)dimension;  // the reference only prints a warning for dan != 0 in 2+1D (readindata.cpp:355-359)
+        A[itau][i] = tau; A[ieta][i] = eta;
+        A[idat][i] = dat; A[idax][i] = dax; A[iday][i] = day; A[idan][i] = dan;
+        A[iux][i] = ux; A[iuy][i] = uy; A[iun][i] = un;
+        A[iE][i] = E; A[iT][i] = T; A[iP][i] = P;
+        A[ipixx][i] = pixx; A[ipixy][i] = pixy; A[ipixn][i] = pixn; A[ipiyy][i] = piyy; A[ipiyn][i] = piyn;
+        A[ibulk][i] = bulkPi;
+        // surface-volume weighted averages, readindata.cpp:422-450
+        double ut = sqrt(1.0 + ux * ux + uy * uy + tau * tau * un * un);
+        double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+        double dsigma_dsigma = dat * dat - dax * dax - day * day - dan * dan / (tau * tau);
+        double mag = fabs(udsigma) + sqrt(fabs(udsigma * udsigma - dsigma_dsigma));
+        vol += mag;
+        Eavg += E * mag; Tavg += T * mag; Pavg += P * mag; muBavg += muB * mag; nBavg += nB * mag;
+    }
+    if (avg5) {
+        avg5[0] = Tavg / vol; avg5[1] = Eavg / vol; avg5[2] = Pavg / vol; avg5[3] = muBavg / vol; avg5[4] = nBavg / vol;
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PDG_Data::read_resonances_conventional  (src/cpp/readindata.cpp:1440-1568)
+//   token stream: 12 header fields + decays x 8 fields; an antiparticle entry follows each
+//   baryon > 0; the entry produced by the read attempt that hits EOF is dropped (Nparticle =
+//   count - 1, :1540), which for a file WITHOUT trailing whitespace drops the last real entry;
+//   sign = (baryon % 2 == 0) ? -1 : +1  (:1544-1545).
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_pdg_read(const char *path, int32_t *n, int64_t *mc_id, double *mass, double *gspin, double *baryon,
+                             double *sign, int32_t capacity)
+{
+    if (!path || !n) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "cannot open %s", path);
+    struct Ent { long id; double m; int g, b; };
+    std::vector<Ent> v;
+    std::vector<std::string> tok;
+    {
+        std::istringstream ss(text);
+        std::string t;
+        while (ss >> t) tok.push_back(t);
+    }
+    const bool trailing_ws = !text.empty() && isspace((unsigned char)text.back());
+    size_t i = 0;
+    while (i < tok.size()) {
+        if (i + 12 > tok.size()) return io_fail(IS3D_EIO, "%s: truncated particle record", path);
+        Ent e;
+        e.id = strtol(tok[i].c_str(), nullptr, 10);
+        e.m = strtod(tok[i + 2].c_str(), nullptr);
+        e.g = (int)strtol(tok[i + 4].c_str(), nullptr, 10);
+        e.b = (int)strtol(tok[i + 5].c_str(), nullptr, 10);
+        int decays = (int)strtol(tok[i + 11].c_str(), nullptr, 10);
+        if (decays < 0 || decays > 50) return io_fail(IS3D_EIO, "%s: particle %ld has %d decay channels (max 50)", path, e.id, decays);
+        i += 12 + 8 * (size_t)decays;
+        if (i > tok.size()) return io_fail(IS3D_EIO, "%s: truncated decay table of particle %ld", path, e.id);
+        v.push_back(e);
+        if (e.b > 0) v.push_back(Ent{-e.id, e.m, e.g, -e.b});
+    }
+    if (!trailing_ws && !v.empty()) v.pop_back();
+    *n = (int32_t)v.size();
+    if (!mc_id) return IS3D_OK;
+    if ((int32_t)v.size() > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %d < %zu particles", path, capacity, v.size());
+    for (size_t k = 0; k < v.size(); k++) {
+        mc_id[k] = v[k].id;
+        if (mass) mass[k] = v[k].m;
+        if (gspin) gspin[k] = v[k].g;
+        if (baryon) baryon[k] = v[k].b;
+        if (sign) sign[k] = (v[k].b % 2 == 0) ? -1.0 : 1.0;
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deltaf_Data::load_df_coefficient_data, one file, include_baryon = 0  (src/cpp/deltafReader.cpp:120-197)
+//   line 1: points_T, line 2: points_muB, line 3: labels, then rows "T muB value" with T fastest;
+//   only the first points_T rows (muB = 0) are kept.
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_df_table_read(const char *path, int32_t *n_T, double *T, double *value, int32_t capacity)
+{
+    if (!path || !n_T) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "couldn't open coefficient file %s", path);
+    const char *p = text.c_str();
+    char *q;
+    long nT = strtol(p, &q, 10);
+    if (q == p || nT < 1) return io_fail(IS3D_EIO, "%s: bad T dimension", path);
+    p = q;
+    long nB = strtol(p, &q, 10);
+    if (q == p || nB < 1) return io_fail(IS3D_EIO, "%s: bad muB dimension", path);
+    p = q;
+    while (*p && isspace((unsigned char)*p)) p++;  // fscanf("%d\n%d\n") eats the white space
+    while (*p && *p != '\n') p++;                  // fgets: label line
+    *n_T = (int32_t)nT;
+    if (!T) return IS3D_OK;
+    if (nT > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %d < %ld", path, capacity, nT);
+    for (long i = 0; i < nT; i++) {
+        double t = strtod(p, &q);
+        if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, i);
+        p = q;
+        (void)strtod(p, &q);
+        if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, i);
+        p = q;
+        double v = strtod(p, &q);
+        if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, i);
+        p = q;
+        T[i] = t;
+        if (value) value[i] = v;
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// write_dN_pTdpTdphidy_toFile (src/cpp/emissionfunction.cpp:381-450), write_continuous_vn_toFile
+// (:1053-1136), write_dN_dy_toFile (:729-772); same order as calculate_spectra calls them (:1678-1686).
+// All files are opened in append mode, as in the reference.
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_write_results(const char *dir, int32_t dimension, int32_t npart, const int64_t *mc_id, int32_t npT,
+                                  const double *pT, const double *pT_w, int32_t nphi, const double *phi, const double *phi_w,
+                                  int32_t ny, const double *y, const double *dN)
+{
+    if (!dir || !mc_id || !pT || !phi || !dN) return io_fail(IS3D_EINVAL, "null argument");
+    if (dimension == 3 && !y) return io_fail(IS3D_EINVAL, "3+1D output needs the y grid");
+    const int y_pts = (dimension == 2) ? 1 : ny;
+    auto idx = [&](int ipart, int ipT, int iphip, int iy) {
+        return (long long)ipart + (long long)npart * ((long long)ipT + (long long)npT * ((long long)iphip + (long long)nphi * (long long)iy));
+    };
+    auto yval = [&](int iy) { return (dimension == 2) ? 0.0 : y[iy]; };
+    const std::string base(dir);
+    auto block = [&](std::ofstream &f, int ipart) {
+        for (int iy = 0; iy < y_pts; iy++)
+            for (int iphip = 0; iphip < nphi; iphip++) {
+                for (int ipT = 0; ipT < npT; ipT++)
+                    f << std::scientific << std::setw(5) << std::setprecision(8) << yval(iy) << "\t" << phi[iphip] << "\t" << pT[ipT]
+                      << "\t" << dN[idx(ipart, ipT, iphip, iy)] << "\n";
+                f << "\n";
+            }
+    };
+    {
+        std::ofstream f(base + "/dN_pTdpTdphidy.dat", std::ios_base::app);
+        if (!f) return io_fail(IS3D_EIO, "cannot open %s/dN_pTdpTdphidy.dat (the results directory must exist)", dir);
+        for (int ipart = 0; ipart < npart; ipart++) block(f, ipart);
+    }
+    for (int ipart = 0; ipart < npart; ipart++) {
+        char name[64];
+        snprintf(name, sizeof name, "/dN_pTdpTdphidy_%d.dat", (int)mc_id[ipart]);
+        std::ofstream f(base + name, std::ios_base::app);
+        if (!f) return io_fail(IS3D_EIO, "cannot open %s%s", dir, name);
+        f << "y" << "\t" << "phip" << "\t" << "pT" << "\t" << "dN_pTdpTdphidy" << "\n";
+        block(f, ipart);
+    }
+    if (phi_w) {  // vn_continuous
+        const std::complex<double> I(0.0, 1.0);
+        const int k_max = 7;
+        for (int ipart = 0; ipart < npart; ipart++) {
+            char name[64];
+            snprintf(name, sizeof name, "/vn_continuous/vn_%d.dat", (int)mc_id[ipart]);
+            std::ofstream f(base + name, std::ios_base::app);
+            if (!f) return io_fail(IS3D_EIO, "cannot open %s%s (results/vn_continuous must exist)", dir, name);
+            for (int iy = 0; iy < y_pts; iy++) {
+                for (int ipT = 0; ipT < npT; ipT++) {
+                    double re[k_max] = {0}, im[k_max] = {0}, den = 0.0;
+                    for (int iphip = 0; iphip < nphi; iphip++) {
+                        double v = dN[idx(ipart, ipT, iphip, iy)];
+                        for (int k = 0; k < k_max; k++) {
+                            re[k] += cos(((double)k + 1.0) * phi[iphip]) * phi_w[iphip] * v;
+                            im[k] += sin(((double)k + 1.0) * phi[iphip]) * phi_w[iphip] * v;
+                        }
+                        den += phi_w[iphip] * v;
+                    }
+                    f << std::scientific << std::setw(5) << std::setprecision(8) << yval(iy) << "\t" << pT[ipT];
+                    for (int k = 0; k < k_max; k++) {
+                        double vn = std::abs(re[k] + I * im[k]) / den;
+                        if (den < 1.e-15) vn = 0.0;
+                        f << "\t" << vn;
+                    }
+                    f << "\n";
+                }
+                f << "\n";
+            }
+        }
+    }
+    if (phi_w && pT_w) {  // dN_dy
+        for (int ipart = 0; ipart < npart; ipart++) {
+            char name[64];
+            snprintf(name, sizeof name, "/dN_dy_%d.dat", (int)mc_id[ipart]);
+            std::ofstream f(base + name, std::ios_base::app);
+            if (!f) return io_fail(IS3D_EIO, "cannot open %s%s", dir, name);
+            for (int iy = 0; iy < y_pts; iy++) {
+                double dN_dy = 0.0;
+                for (int iphip = 0; iphip < nphi; iphip++)
+                    for (int ipT = 0; ipT < npT; ipT++) dN_dy += phi_w[iphip] * pT_w[ipT] * dN[idx(ipart, ipT, iphip, iy)];
+                f << std::setw(5) << std::setprecision(8) << yval(iy) << "\t" << dN_dy << "\n";
+            }
+        }
+    }
+    return IS3D_OK;
+}

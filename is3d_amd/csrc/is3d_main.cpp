@@ -1,0 +1,189 @@
+// is3d_main.cpp -- `iS3D`-compatible command line driver for the smooth-spectra path.
+//
+// Run it in a directory laid out like the reference's run directory; it reads the same hard-coded
+// CWD-relative files IS3D::run_particlization reads (/root/reference/src/cpp/iS3D.cpp:74-192):
+//   iS3D_parameters.dat, input/surface.dat, PDG/pdg-urqmd_v3.3+.dat | PDG/pdg_smash.dat,
+//   PDG/chosen_particles.dat, deltaf_coefficients/vh/<eos>/{c0,c2,F,betabulk,betapi}.dat,
+//   tables/pT_gauss_legendre_table.dat, tables/phi_gauss_legendre_table.dat,
+//   tables/y_trapezoid_table_21pt.dat, tables/eta/eta_trapezoid_table_241pt.dat
+// and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
+// (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
+// average_thermodynamic_quantities.dat (readindata.cpp:464-466).
+// Scope: operation = 1, mode = 1, df_mode in {1, 2}, include_baryon = 0.  Anything else is refused
+// with a message instead of silently doing something different from the reference.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <iomanip>
+#include <string>
+#include <vector>
+
+#include "../../include/is3d_amd.h"
+
+static double now_s()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+#define DIE(...)                        \
+    do {                                \
+        fprintf(stderr, "iS3D-amd: ");  \
+        fprintf(stderr, __VA_ARGS__);   \
+        fprintf(stderr, "\n");          \
+        return 1;                       \
+    } while (0)
+
+static int get_param(const char *name, double *v, bool required = true)
+{
+    int rc = is3d_param_get("iS3D_parameters.dat", name, v);
+    if (rc && required) fprintf(stderr, "iS3D-amd: %s\n", is3d_last_error());
+    return rc;
+}
+
+static int read_table(const char *path, std::vector<double> &col1, std::vector<double> &col2)
+{
+    int64_t rows;
+    int32_t cols;
+    if (is3d_table_read(path, &rows, &cols, nullptr, 0)) return 1;
+    std::vector<double> d((size_t)rows * cols);
+    if (is3d_table_read(path, &rows, &cols, d.data(), (int64_t)d.size())) return 1;
+    col1.resize(rows);
+    col2.assign(rows, 0.0);
+    for (int64_t r = 0; r < rows; r++) {
+        col1[r] = d[r * cols];
+        if (cols > 1) col2[r] = d[r * cols + 1];
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int variant = 0;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--variant") && i + 1 < argc) variant = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--help")) {
+            printf("usage: %s [--variant 1|2]   (run inside an iS3D run directory)\n", argv[0]);
+            return 0;
+        }
+    }
+    printf("iS3D-amd: MI355X-native smooth Cooper-Frye spectra (%s)\n", is3d_version());
+    double v;
+    int operation, mode, hrg_eos, dimension, df_mode, include_baryon, include_bulk, include_shear, include_diff, regulate, outflow;
+#define GET(var, name)                 \
+    if (get_param(name, &v)) return 1; \
+    var = (int)v;
+    GET(operation, "operation");
+    GET(mode, "mode");
+    GET(hrg_eos, "hrg_eos");
+    GET(dimension, "dimension");
+    GET(df_mode, "df_mode");
+    GET(include_baryon, "include_baryon");
+    GET(include_bulk, "include_bulk_deltaf");
+    GET(include_shear, "include_shear_deltaf");
+    GET(include_diff, "include_baryondiff_deltaf");
+    GET(regulate, "regulate_deltaf");
+    GET(outflow, "outflow");
+#undef GET
+    if (operation != 1) DIE("operation = %d: only operation = 1 (smooth momentum spectra) is on this path", operation);
+    if (mode != 1) DIE("mode = %d: only the mode-1 (gpu-vh) surface format is read so far", mode);
+    if (df_mode != 1 && df_mode != 2) DIE("df_mode = %d: only 1 (14-moment) and 2 (Chapman-Enskog)", df_mode);
+    if (include_baryon) DIE("include_baryon = 1 is not implemented yet");
+    const char *pdg_path, *df_dir;
+    if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
+    else if (hrg_eos == 2) { pdg_path = "PDG/pdg_smash.dat"; df_dir = "deltaf_coefficients/vh/smash/"; }
+    else DIE("hrg_eos = %d: choose 1 (urqmd) or 2 (smash)", hrg_eos);
+
+    double t0 = now_s();
+    // ---- surface (iS3D.cpp:90-98) ----
+    int64_t n_cells = 0;
+    if (is3d_surface_read_vh("input/surface.dat", 0, 0, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
+    std::vector<std::vector<double>> arr(23);
+    double *ptr[23];
+    for (int a = 0; a < 23; a++) {
+        arr[a].assign(a < 18 ? (size_t)n_cells : 0, 0.0);
+        ptr[a] = a < 18 ? arr[a].data() : nullptr;
+    }
+    double avg[5] = {0, 0, 0, 0, 0};
+    if (n_cells > 0 && is3d_surface_read_vh("input/surface.dat", 0, 0, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
+    {
+        std::ofstream f("average_thermodynamic_quantities.dat", std::ios_base::out);
+        f << std::setprecision(15) << avg[0] << "\n" << avg[1] << "\n" << avg[2] << "\n" << avg[3] << "\n" << avg[4];
+    }
+    // ---- species (iS3D.cpp:138-140, 156; emissionfunction.cpp:336-351, 1293-1307) ----
+    int32_t npdg = 0;
+    if (is3d_pdg_read(pdg_path, &npdg, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+    std::vector<int64_t> pid(npdg);
+    std::vector<double> pmass(npdg), pg(npdg), pb(npdg), ps(npdg);
+    if (is3d_pdg_read(pdg_path, &npdg, pid.data(), pmass.data(), pg.data(), pb.data(), ps.data(), npdg)) DIE("%s", is3d_last_error());
+    std::vector<double> chosen, dummy;
+    if (read_table("PDG/chosen_particles.dat", chosen, dummy)) DIE("%s", is3d_last_error());
+    std::vector<int64_t> mcid;
+    std::vector<double> mass, sign, deg, bar;
+    for (double c : chosen) {
+        int id = (int)c;
+        bool found = false;
+        for (int n = 0; n < npdg; n++)
+            if (pid[n] == id) {
+                mcid.push_back(pid[n]); mass.push_back(pmass[n]); sign.push_back(ps[n]); deg.push_back(pg[n]); bar.push_back(pb[n]);
+                found = true;
+                break;
+            }
+        if (!found) DIE("chosen particle %d is not in %s", id, pdg_path);
+    }
+    // ---- grids (iS3D.cpp:161-167) ----
+    std::vector<double> pT, pTw, phi, phiw, y, yw, eta, etaw;
+    if (read_table("tables/pT_gauss_legendre_table.dat", pT, pTw) || read_table("tables/phi_gauss_legendre_table.dat", phi, phiw) ||
+        read_table("tables/y_trapezoid_table_21pt.dat", y, yw) || read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
+        DIE("%s", is3d_last_error());
+    // ---- delta-f coefficient tables (iS3D.cpp:144-145) ----
+    const char *names[5] = {"c0.dat", "c2.dat", "F.dat", "betabulk.dat", "betapi.dat"};
+    std::vector<double> Tk, tab[5];
+    for (int t = 0; t < 5; t++) {
+        std::string p = std::string(df_dir) + names[t];
+        int32_t nT = 0;
+        if (is3d_df_table_read(p.c_str(), &nT, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        Tk.resize(nT);
+        tab[t].resize(nT);
+        if (is3d_df_table_read(p.c_str(), &nT, Tk.data(), tab[t].data(), nT)) DIE("%s", is3d_last_error());
+    }
+    double t1 = now_s();
+    printf("Total number of freezeout cells: %lld\nNumber of chosen particles: %zu\n", (long long)n_cells, mcid.size());
+
+    is3d_cells cells{};
+    cells.n_cells = n_cells;
+    cells.T = ptr[0]; cells.P = ptr[1]; cells.E = ptr[2]; cells.tau = ptr[3]; cells.eta = ptr[4];
+    cells.ux = ptr[5]; cells.uy = ptr[6]; cells.un = ptr[7];
+    cells.dat = ptr[8]; cells.dax = ptr[9]; cells.day = ptr[10]; cells.dan = ptr[11];
+    cells.pixx = ptr[12]; cells.pixy = ptr[13]; cells.pixn = ptr[14]; cells.piyy = ptr[15]; cells.piyn = ptr[16];
+    cells.bulkPi = ptr[17];
+    is3d_species sp{(int32_t)mcid.size(), mass.data(), sign.data(), deg.data(), bar.data()};
+    is3d_grid grid{(int32_t)pT.size(), pT.data(), (int32_t)phi.size(), phi.data(), (int32_t)y.size(), y.data(),
+                   (int32_t)eta.size(), eta.data(), etaw.data()};
+    is3d_df_tables df{(int32_t)Tk.size(), Tk.data(), tab[0].data(), tab[1].data(), tab[2].data(), tab[3].data(), tab[4].data()};
+    is3d_options opts{};
+    opts.dimension = dimension; opts.df_mode = df_mode; opts.include_baryon = 0;
+    opts.include_bulk_deltaf = include_bulk; opts.include_shear_deltaf = include_shear; opts.include_baryondiff_deltaf = include_diff;
+    opts.regulate_deltaf = regulate; opts.outflow = outflow;
+    opts.accumulate = 0; opts.device = -1; opts.kernel_variant = variant;
+    const int ny_eff = (dimension == 2) ? 1 : (int)y.size();
+    std::vector<double> dN(mcid.size() * pT.size() * phi.size() * (size_t)ny_eff, 0.0);
+    is3d_status st{};
+    printf("computing thermal spectra from vhydro with df...\n");
+    int rc = is3d_smooth_spectra(&cells, &sp, &grid, &df, &opts, dN.data(), &st);
+    if (rc) DIE("is3d_smooth_spectra failed (%d): %s", rc, is3d_last_error());
+    double t2 = now_s();
+    if (is3d_write_results("results", dimension, sp.n, mcid.data(), grid.n_pT, pT.data(), pTw.data(), grid.n_phi, phi.data(),
+                           phiw.data(), grid.n_y, y.data(), dN.data()))
+        DIE("%s", is3d_last_error());
+    double t3 = now_s();
+    printf("species classes evaluated: %d of %d; cells skipped (u.dsigma <= 0): %lld\n", st.n_classes, sp.n, (long long)st.n_cells_skipped);
+    printf("device time: prep %.3f ms, main %.3f ms (kernel variant %d), finalize %.3f ms; h2d %.3f ms, d2h %.3f ms\n", st.ms_prep,
+           st.ms_main, st.kernel_variant, st.ms_finalize, st.ms_h2d, st.ms_d2h);
+    printf("wall: read %.3f s, spectra %.3f s, write %.3f s\n", t1 - t0, t2 - t1, t3 - t2);
+    printf("Done calculating particle spectra. Output stored in results folder. Goodbye!\n");
+    return 0;
+}

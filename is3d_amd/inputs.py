@@ -1,0 +1,44 @@
+"""Input bundles for tests/bench on boxes without the reference tree: grids, the mu_B = 0 rows of the
+urqmd delta-f coefficient tables and the hadron list, from tests/golden/inputs_urqmd.json (built by
+tests/golden/make_inputs.py from the reference's data files)."""
+import json
+import os
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(_ROOT, "tests", "golden", "inputs_urqmd.json")
+_CACHE = None
+
+
+def load_fixture():
+    global _CACHE
+    if _CACHE is None:
+        with open(FIXTURE) as f:
+            _CACHE = json.load(f)
+    return _CACHE
+
+
+def grid():
+    """pT/phi/y/eta nodes (+ weights) of iS3D.cpp:161-167's tables."""
+    g = load_fixture()["grids"]
+    return dict(pT=np.array(g["pT"]["x"]), pT_w=np.array(g["pT"]["w"]), phi=np.array(g["phi"]["x"]),
+                phi_w=np.array(g["phi"]["w"]), y=np.array(g["y"]["x"]), y_w=np.array(g["y"]["w"]),
+                eta=np.array(g["eta"]["x"]), eta_w=np.array(g["eta"]["w"]))
+
+
+def df_tables():
+    d = load_fixture()["df_urqmd_muB0"]
+    return {k: np.array(d[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]}
+
+
+def species(which="pikp"):
+    """which: 'pikp' (chosen_particles_pikp.dat) | 'urqmd' (chosen_particles_urqmd_v3.3+.dat, 305) |
+    list of mc_ids.  Order = order of the chosen list (emissionfunction.cpp:336-351)."""
+    fx = load_fixture()
+    pdg = {int(r[0]): r for r in fx["pdg_urqmd"]}
+    ids = fx["chosen_pikp"] if which == "pikp" else fx["chosen_urqmd"] if which == "urqmd" else list(which)
+    rows = [pdg[int(i)] for i in ids]
+    return dict(mc_id=np.array([r[0] for r in rows], dtype=np.int64), mass=np.array([r[1] for r in rows], dtype=np.float64),
+                degeneracy=np.array([r[2] for r in rows], dtype=np.float64), baryon=np.array([r[3] for r in rows], dtype=np.float64),
+                sign=np.array([r[4] for r in rows], dtype=np.float64))

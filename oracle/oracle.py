@@ -1,0 +1,144 @@
+"""ctypes front end of oracle/libcf_oracle.so -- TEST INFRASTRUCTURE ONLY (see cf_oracle.c header).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+package is3d_amd never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+CELL_FIELDS = ["T", "P", "E", "tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan",
+               "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi", "muB", "nB", "Vx", "Vy", "Vn"]
+_dp = C.POINTER(C.c_double)
+
+
+class _CellArrays(C.Structure):
+    _fields_ = [(n, _dp) for n in CELL_FIELDS]
+
+
+class _DfTables(C.Structure):
+    _fields_ = [("n_T", C.c_int), ("T", _dp), ("c0", _dp), ("c2", _dp), ("F", _dp), ("betabulk", _dp), ("betapi", _dp)]
+
+
+class _Opts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
+                                       "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow"]]
+
+
+class _Grid(C.Structure):
+    _fields_ = [("pT_tab_length", C.c_int), ("pT", _dp), ("phi_tab_length", C.c_int), ("phi", _dp),
+                ("y_tab_length", C.c_int), ("y", _dp), ("eta_tab_length", C.c_int), ("eta", _dp), ("eta_w", _dp)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libcf_oracle.so")
+    src = os.path.join(_HERE, "cf_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcf_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oracle_cspline_init.argtypes = [C.c_int, _dp, _dp, _dp]
+        _LIB.oracle_cspline_eval.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, _dp]
+        _LIB.oracle_df_coefficients.argtypes = [C.POINTER(_DfTables), C.c_int, C.c_double, _dp]
+        sig = [C.c_long, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_CellArrays), C.POINTER(_DfTables),
+               C.POINTER(_Grid), C.POINTER(_Opts)]
+        _LIB.oracle_dN_pTdpTdphidy.argtypes = sig + [_dp]
+        _LIB.oracle_dN_pTdpTdphidy_chunked.argtypes = sig + [C.c_long, _dp]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def cspline_init(x, y):
+    x, y = _f64(x), _f64(y)
+    c = np.zeros_like(x)
+    rc = lib().oracle_cspline_init(len(x), _p(x), _p(y), _p(c))
+    assert rc == 0
+    return c
+
+
+def cspline_eval(x, y, c, xq):
+    x, y, c = _f64(x), _f64(y), _f64(c)
+    out = C.c_double()
+    rc = lib().oracle_cspline_eval(len(x), _p(x), _p(y), _p(c), float(xq), C.byref(out))
+    if rc:
+        raise ValueError("oracle_cspline_eval: x outside the table (GSL would abort)")
+    return out.value
+
+
+def _df_struct(df):
+    keep = {k: _f64(df[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]}
+    st = _DfTables(len(keep["T"]), *[_p(keep[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]])
+    return st, keep
+
+
+def df_coefficients(df, df_mode, T):
+    """-> dict(c0, c2, F, betabulk, betapi) with the temperature scaling undone (deltafReader.cpp:337-358)."""
+    st, keep = _df_struct(df)
+    out = np.zeros(5)
+    rc = lib().oracle_df_coefficients(C.byref(st), int(df_mode), float(T), _p(out))
+    if rc:
+        raise ValueError("T outside the coefficient table")
+    return dict(zip(["c0", "c2", "F", "betabulk", "betapi"], out))
+
+
+DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
+                    include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1)
+
+
+def dN_pTdpTdphidy(cells, species, grid, df, opts, chunked=False, FO_chunk=10000, out=None):
+    """cells: dict of 1-D arrays (CELL_FIELDS; missing ones = unused);
+    species: dict(mass, sign, degeneracy, baryon); grid: dict(pT, phi, y, eta, eta_w);
+    df: dict(T, c0, c2, F, betabulk, betapi); opts: dict like DEFAULT_OPTS.
+    Returns the spectrum, flat, length npart*npT*nphi*ny_eff with ny_eff = 1 in 2+1D; species fastest."""
+    o = dict(DEFAULT_OPTS)
+    o.update(opts)
+    n = len(cells["tau"])
+    keep = {}
+    ca = _CellArrays()
+    for f in CELL_FIELDS:
+        if f in cells and cells[f] is not None:
+            keep[f] = _f64(cells[f])
+            assert keep[f].shape == (n,), f
+            setattr(ca, f, _p(keep[f]))
+    sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy", "baryon"]}
+    npart = len(sp["mass"])
+    g = {k: _f64(grid[k]) for k in ["pT", "phi", "y", "eta", "eta_w"]}
+    gs = _Grid(len(g["pT"]), _p(g["pT"]), len(g["phi"]), _p(g["phi"]), len(g["y"]), _p(g["y"]),
+               len(g["eta"]), _p(g["eta"]), _p(g["eta_w"]))
+    st, keep_df = _df_struct(df)
+    os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
+    ny = 1 if o["dimension"] == 2 else len(g["y"])
+    size = npart * len(g["pT"]) * len(g["phi"]) * ny
+    if out is None:
+        out = np.zeros(size)
+    assert out.dtype == np.float64 and out.size == size
+    args = [n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), _p(sp["baryon"]),
+            C.byref(ca), C.byref(st), C.byref(gs), C.byref(os_)]
+    if chunked:
+        rc = lib().oracle_dN_pTdpTdphidy_chunked(*args, int(FO_chunk), _p(out))
+    else:
+        rc = lib().oracle_dN_pTdpTdphidy(*args, _p(out))
+    if rc:
+        raise RuntimeError("oracle_dN_pTdpTdphidy failed rc=%d" % rc)
+    return out
+
+
+def num_threads():
+    return lib().oracle_num_threads()

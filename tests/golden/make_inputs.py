@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Build tests/golden/inputs_urqmd.json -- the INPUT DATA the hot path needs on a box that has no
+/root/reference (GPU box, bench.py, smoke()).
+
+It is data only: quadrature nodes/weights, the mu_B = 0 rows of the delta-f coefficient tables and
+(mc_id, mass, gspin, baryon) of the hadron list, parsed from the reference's shipped data files
+with small independent Python parsers that follow the reference readers' semantics:
+
+  tables/*.dat, PDG/chosen_particles*.dat   readBlockData  (src/cpp/arsenal.cpp:406-453): a row counts
+                                            only if its line is newline-terminated
+  deltaf_coefficients/vh/urqmd/*.dat        Deltaf_Data::load_df_coefficient_data (src/cpp/deltafReader.cpp:120-197)
+  PDG/pdg-urqmd_v3.3+.dat                   PDG_Data::read_resonances_conventional (src/cpp/readindata.cpp:1440-1568)
+
+Run here (container) only:  python tests/golden/make_inputs.py
+"""
+import json
+import os
+import sys
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "inputs_urqmd.json")
+
+
+def read_block(path):
+    """readBlockData semantics: the last fragment (no trailing newline) is dropped."""
+    with open(path, "r", newline="") as f:
+        text = f.read()
+    lines = text.split("\n")
+    lines = lines[:-1]  # what follows the last '\n' is never pushed (arsenal.cpp:441-449)
+    rows = [[float(tok) for tok in ln.split()] for ln in lines]
+    ncol = len(rows[0])
+    return [r[:ncol] for r in rows]
+
+
+def read_df_table(path, n_keep_muB=1):
+    with open(path) as f:
+        nT = int(f.readline())
+        nB = int(f.readline())
+        f.readline()  # label line
+        T, val = [], []
+        for iB in range(n_keep_muB):
+            for iT in range(nT):
+                t, mub, v = (float(x) for x in f.readline().split())
+                if iB == 0:
+                    T.append(t)
+                    val.append(v)
+    assert nB >= 1
+    return T, val
+
+
+def read_pdg(path):
+    """Token stream; antibaryon appended after each baryon; sign from baryon parity."""
+    with open(path) as f:
+        toks = f.read().split()
+    out, i = [], 0
+    while i < len(toks):
+        mc_id, name, mass, width, gspin, baryon, strange, charm, bottom, gisospin, charge, decays = toks[i:i + 12]
+        i += 12 + 8 * int(decays)
+        p = dict(mc_id=int(mc_id), name=name, mass=float(mass), gspin=int(gspin), baryon=int(baryon))
+        out.append(p)
+        if p["baryon"] > 0:
+            out.append(dict(mc_id=-p["mc_id"], name="Anti-baryon-" + name, mass=p["mass"], gspin=p["gspin"], baryon=-p["baryon"]))
+    for p in out:
+        p["sign"] = -1 if p["baryon"] % 2 == 0 else 1  # readindata.cpp:1544-1545
+    return out
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (run in the build container)")
+    d = {"source": "derekeverett/iS3D data files (MIT), parsed by tests/golden/make_inputs.py", "hbarC": 0.197327053}
+    grids = {}
+    for key, rel in [("pT", "tables/pT_gauss_legendre_table.dat"), ("phi", "tables/phi_gauss_legendre_table.dat"),
+                     ("y", "tables/y_trapezoid_table_21pt.dat"), ("eta", "tables/eta/eta_trapezoid_table_241pt.dat")]:
+        rows = read_block(os.path.join(REF, rel))
+        grids[key] = {"file": rel, "x": [r[0] for r in rows], "w": [r[1] for r in rows]}
+    d["grids"] = grids
+    df = {}
+    for name in ["c0", "c2", "F", "betabulk", "betapi"]:
+        T, v = read_df_table(os.path.join(REF, "deltaf_coefficients/vh/urqmd", name + ".dat"))
+        df["T"] = T
+        df[name] = v
+    d["df_urqmd_muB0"] = df
+    pdg = read_pdg(os.path.join(REF, "PDG/pdg-urqmd_v3.3+.dat"))
+    d["pdg_urqmd"] = [[p["mc_id"], p["mass"], p["gspin"], p["baryon"], p["sign"]] for p in pdg]
+    d["pdg_urqmd_columns"] = ["mc_id", "mass", "gspin", "baryon", "sign"]
+    for key, rel in [("chosen_pikp", "PDG/chosen_particles_pikp.dat"), ("chosen_urqmd", "PDG/chosen_particles_urqmd_v3.3+.dat")]:
+        d[key] = [int(r[0]) for r in read_block(os.path.join(REF, rel))]
+    with open(OUT, "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+        f.write("\n")
+    print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(pdg), "pdg entries;",
+          {k: len(v["x"]) for k, v in grids.items()}, len(d["chosen_urqmd"]), "chosen")
+
+
+if __name__ == "__main__":
+    main()
