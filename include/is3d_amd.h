@@ -102,7 +102,7 @@ typedef struct {
     int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
     int32_t device;                     /* HIP device ordinal; -1 = current device */
     /* tuning; 0 = library default */
-    int32_t kernel_variant;             /* 0 default | 1 direct-exp kernel | 2 factorised-exp kernel */
+    int32_t kernel_variant;             /* 0 default (2) | 1 direct-exp kernel | 2,3,4 tile kernel, tile shapes 8x7 / 4x7 / 6x7 (2+1D: 12 / 8 / 24) */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
     int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per

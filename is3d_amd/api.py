@@ -87,6 +87,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C is3d_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    try:
+        # torch bundles its own libamdhip64.so.7; if our library pulled in /opt/rocm's copy first, the
+        # process would hold two HIP runtimes and the second one finds no GPU.  Importing torch first
+        # makes the loader resolve our DT_NEEDED libamdhip64.so.7 to the copy that is already mapped.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.is3d_last_error.restype = C.c_char_p
     L.is3d_version.restype = C.c_char_p

@@ -43,9 +43,23 @@ struct PrepParams {
     const double *kgrid;            // [K] y values (3+1D) or eta nodes (2+1D)
     const double *kweight;          // [K] eta weights (2+1D), unused in 3+1D
     SplineDev spl;
-    double *S1, *S2, *S3;
+    double *S1, *S2, *S3;           // flat streams (variant 1); unused when tiled
+    // tiled stream (variants >= 2), see "unit record" below
+    int32_t tiled;                  // 1: write TS, 0: write S1/S2/S3
+    int32_t JT, R;                  // tile: JT phi's x R rows (rows = y's in 3+1D, eta nodes in 2+1D)
+    int32_t jtiles, rblocks;        // ceil(J/JT), ceil(K/R)
+    double *TS;
     unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count
 };
+
+// ---- tiled stream TS (variants >= 2): what one workgroup of the main kernel streams through LDS ----
+// unit record (REC = 4*JT + R*(4+JT) doubles) for tile (jt, rb) of one cell:
+//   header  jj < JT : {B_j, Dp_j, gamma_j, kappa}                 j = jt*JT + jj (clamped to J-1)
+//   row     r  < R  : {A_k, Cp_k, alpha_k, W_k, beta_{j0..j0+JT-1,k}}   k = rb*R + r; rows past K are
+//                     neutral padding (A = W = 0, Cp copied from row K-1, alpha = beta = 0)
+// 3+1D: stream s = jt*rblocks + rb, one unit per cell:        TS[(s*n_cells + cell)*REC]
+// 2+1D: stream s = jt, rblocks units per cell (eta blocks):   TS[((s*n_cells + cell)*rblocks + rb)*REC]
+inline int unit_rec_doubles(int JT, int R) { return 4 * JT + R * (4 + JT); }
 
 // ---- main kernel geometry ----
 struct MainGeom {
@@ -57,10 +71,11 @@ struct MainGeom {
     int32_t NT;        // streams = jtiles*ktiles*nch
     int32_t Kacc;      // accumulator slots along k: K (3+1D) or 1 (2+1D)
     int32_t first_pass;  // 1: store partials, 0: add to them
+    int32_t upc;       // tiled stream: units per cell within a stream (1 in 3+1D, rblocks in 2+1D)
 };
 
 struct MainArgs {
-    const double *S1, *S2, *S3, *lane_mT, *lane_pT, *lane_sign;
+    const double *S1, *S2, *S3, *TS, *lane_mT, *lane_pT, *lane_sign;
     double *partial;
     MainGeom g;
 };

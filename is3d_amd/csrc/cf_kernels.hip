@@ -129,12 +129,12 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *sy = sx + nT;                     // [nspl][nT]
     double *sc = sy + nspl * nT;              // [nspl][nT]
     CellScal *cs = (CellScal *)(sc + nspl * nT);  // [CB]
-    double *l_ch = (double *)(cs + kPrepCB);  // [CB][K]
-    double *l_sh = l_ch + kPrepCB * K;
-    double *l_C = l_sh + kPrepCB * K;
-    double *l_D = l_C + kPrepCB * K;          // [CB][J]
-    double *l_E = l_D + kPrepCB * J;
-    double *l_F = l_E + kPrepCB * J;
+    // per (cell, k): A, Cp, alpha, W, ch, sh, C ; per (cell, j): B, Dp, gamma, D, E, F
+    double *lk = (double *)(cs + kPrepCB);    // [7][CB][K]
+    double *lj = lk + 7 * kPrepCB * K;        // [6][CB][J]
+    const int CK = kPrepCB * K, CJ = kPrepCB * J;
+    double *l_A = lk, *l_Cp = lk + CK, *l_al = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK, *l_C = lk + 6 * CK;
+    double *l_B = lj, *l_Dp = lj + CJ, *l_ga = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_E = lj + 4 * CJ, *l_F = lj + 5 * CJ;
 
     const int tid = threadIdx.x;
     for (int i = tid; i < nT; i += kPrepThreads) {
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
         }
         __syncthreads();
 
-        // ---- phase 2: (cell, k) -> S1 ----
+        // ---- phase 2: (cell, k) quantities ----
         for (int idx = tid; idx < ncb * K; idx += kPrepThreads) {
             const int c = idx / K, k = idx - c * K;
             const CellScal &s = cs[c];
@@ -227,38 +227,81 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             if (p.dim3) { dlt = p.kgrid[k] - s.eta; w = s.wvalid; }      // y - eta_cell, :279
             else { dlt = 0.0 - p.kgrid[k]; w = p.kweight[k] * s.wvalid; }   // y = 0, eta = table node, :75-80
             double ch = cosh(dlt), sh = sinh(dlt);
-            double A = w * (ch * s.dat + sh * s.dan_tau);
             double C = ch * s.ut - sh * s.tau_un;
             double Q0 = s.pitt * ch * ch + s.t2pinn * sh * sh - 2.0 * s.tpitn * ch * sh;
-            double alpha = p.ce ? (s.shear * Q0 - s.Pb2) * s.invT : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
-            double *o = p.S1 + ((int64_t)(cbase + c) * K + k) * kS1Rec;
-            o[0] = A; o[1] = C * s.invT; o[2] = alpha; o[3] = w;
+            l_A[c * K + k] = w * (ch * s.dat + sh * s.dan_tau);
+            l_Cp[c * K + k] = C * s.invT;
+            l_al[c * K + k] = p.ce ? (s.shear * Q0 - s.Pb2) * s.invT : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
+            l_W[c * K + k] = w;
             l_ch[c * K + k] = ch; l_sh[c * K + k] = sh; l_C[c * K + k] = C;
         }
-        // ---- phase 2b: (cell, j) -> S2 ----
+        // ---- phase 2b: (cell, j) quantities ----
         for (int idx = tid; idx < ncb * J; idx += kPrepThreads) {
             const int c = idx / J, j = idx - c * J;
             const CellScal &s = cs[c];
             double cp = p.cosphi[j], sp = p.sinphi[j];
-            double B = cp * s.dax + sp * s.day;
             double D = cp * s.ux + sp * s.uy;
             double Q2 = s.pixx * cp * cp + s.piyy * sp * sp + 2.0 * s.pixy * cp * sp;
-            double gamma = p.ce ? (s.shear * Q2 + s.Pb2) * s.invT : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
-            double *o = p.S2 + ((int64_t)(cbase + c) * J + j) * kS2Rec;
-            o[0] = B; o[1] = D * s.invT; o[2] = gamma; o[3] = s.kappa;
+            l_B[c * J + j] = cp * s.dax + sp * s.day;
+            l_Dp[c * J + j] = D * s.invT;
+            l_ga[c * J + j] = p.ce ? (s.shear * Q2 + s.Pb2) * s.invT : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
             l_D[c * J + j] = D;
             l_E[c * J + j] = -2.0 * (s.pitx * cp + s.pity * sp);
             l_F[c * J + j] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
         }
         __syncthreads();
-        // ---- phase 3: (cell, j, k) -> S3 ----
-        const int JK = J * K;
-        for (int idx = tid; idx < ncb * JK; idx += kPrepThreads) {
-            const int c = idx / JK, r = idx - c * JK, j = r / K, k = r - j * K;
+        // beta_jk = shear X_jk - 2 Pi b2 C_k D_j (14-moment) | shear X_jk / T (Chapman-Enskog)
+        auto beta_of = [&](int c, int j, int k) {
             const CellScal &s = cs[c];
             double X = l_E[c * J + j] * l_ch[c * K + k] + l_F[c * J + j] * l_sh[c * K + k];
-            double beta = p.ce ? s.shear * X * s.invT : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
-            p.S3[(int64_t)(cbase + c) * JK + r] = beta;
+            return p.ce ? s.shear * X * s.invT : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
+        };
+        if (!p.tiled) {
+            // ---- phase 3 (flat): S1[cell][k][4], S2[cell][j][4], S3[cell][j][k] ----
+            for (int idx = tid; idx < ncb * K; idx += kPrepThreads) {
+                double *o = p.S1 + ((int64_t)cbase * K + idx) * kS1Rec;
+                o[0] = l_A[idx]; o[1] = l_Cp[idx]; o[2] = l_al[idx]; o[3] = l_W[idx];
+            }
+            for (int idx = tid; idx < ncb * J; idx += kPrepThreads) {
+                double *o = p.S2 + ((int64_t)cbase * J + idx) * kS2Rec;
+                o[0] = l_B[idx]; o[1] = l_Dp[idx]; o[2] = l_ga[idx]; o[3] = cs[idx / J].kappa;
+            }
+            const int JK = J * K;
+            for (int idx = tid; idx < ncb * JK; idx += kPrepThreads) {
+                const int c = idx / JK, r = idx - c * JK, j = r / K, k = r - j * K;
+                p.S3[(int64_t)(cbase + c) * JK + r] = beta_of(c, j, k);
+            }
+        } else {
+            // ---- phase 3 (tiled): unit records, consecutive threads -> consecutive doubles ----
+            const int JT = p.JT, R = p.R, REC = 4 * JT + R * (4 + JT);
+            const int units_per_cell = p.jtiles * p.rblocks;
+            const int per_cell = units_per_cell * REC;
+            for (int idx = tid; idx < ncb * per_cell; idx += kPrepThreads) {
+                const int c = idx / per_cell;
+                int rem = idx - c * per_cell;
+                const int ut = rem / REC, e = rem - ut * REC;
+                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
+                double v;
+                if (e < 4 * JT) {
+                    const int jj = e >> 2, f = e & 3;
+                    const int j = min(jt * JT + jj, J - 1);
+                    v = f == 0 ? l_B[c * J + j] : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : cs[c].kappa;
+                } else {
+                    const int q = e - 4 * JT, r = q / (4 + JT), f = q - r * (4 + JT);
+                    const int k = rb * R + r;
+                    if (k < K) {
+                        if (f < 4) v = f == 0 ? l_A[c * K + k] : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
+                        else v = beta_of(c, min(jt * JT + (f - 4), J - 1), k);
+                    } else {
+                        v = (f == 1) ? l_Cp[c * K + K - 1] : 0.0;   // neutral padding row
+                    }
+                }
+                const int64_t cell = cbase + c;
+                int64_t unit;
+                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;                         // s = jt*rblocks + rb
+                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;              // s = jt
+                p.TS[unit * REC + e] = v;
+            }
         }
         __syncthreads();
     }
@@ -266,7 +309,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 
 size_t prep_lds_bytes(int nT, int nspl, int J, int K)
 {
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)kPrepCB * (3 * K + 3 * J)) + sizeof(CellScal) * kPrepCB;
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)kPrepCB * (7 * K + 6 * J)) + sizeof(CellScal) * kPrepCB;
 }
 
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
@@ -399,95 +442,198 @@ cf_main_direct(const double *__restrict__ S1, const double *__restrict__ S2, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// cf_main_fact (variant 2): factorised exponential.
-//   exp(-p.u/T) = exp(-mT Cp_k) * exp(+pT Dp_j): one exp_core per (cell, k) and one per (cell, j)
-// instead of one per (cell, j, k); the JT x KT evaluations of a tile cost a multiply, an integer add
-// and a v_ldexp_f64 each.  Mantissa/exponent are kept apart so neither factor can overflow.
-// 3+1D: tile JT x KT, JT*KT accumulators.  2+1D: JT accumulators, loop over the whole eta table.
+// cf_main_tile (variant 2, default): factorised exponential on a JT x KT tile of (phi, y) bins.
+//
+//   exp(-p.u/T) = exp(-(mT Cp_k - bmax)) * exp(pT Dp_j - bmax),   bmax = max_j pT Dp_j  (per lane, cell)
+// One exponential per (cell, k) and one per (cell, j) instead of one per (cell, j, k); an evaluation
+// costs a single multiply for z.  Both factors lie in (0, 1]: since p.u >= 0 for every j of the tile,
+// mT Cp_k >= bmax, and a factor can only underflow when z itself is below 1e-307 (negligible).
+//
+// Per evaluation (14-moment): 12 fp64 VALU ops + v_rcp_f64:
+//   z = E1*E2; d = fma(sign,z,1); r = rcp+1 Newton (2e-15); br = fma(mTpT,beta, a_k + g_j);
+//   u = clamp01(fma(r, br/2, 1/2))  -- regulate_deltaf folded into the VOP3 clamp modifier: (1+df)/2 in [0,1];
+//   acc += max(pds,0) * (z*r) * u    (the factor 2 is restored once, when the accumulators are stored).
+// 3+1D: JT*KT accumulators.  2+1D: JT accumulators, loop over the whole eta table.
 // ------------------------------------------------------------------------------------------------
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int KT>
+__device__ __forceinline__ double exp_full(double v)
+{
+    double f; int n;
+    exp_core(v, f, n);
+    return ldexp_fast(f, n);
+}
+
+__device__ __forceinline__ double rcp_nr1(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);      // 4.5e-8 relative (measured, tools/ubench_fp64.hip)
+    double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);           // 2e-15
+}
+
+// fma with the VOP3 clamp modifier: result clamped to [0, 1] (NaN -> 0 under DX10_CLAMP)
+__device__ __forceinline__ double fma_clamp01_half(double a, double b)
+{
+    double u;
+    asm("v_fma_f64 %0, %1, %2, 0.5 clamp" : "=v"(u) : "v"(a), "v"(b));
+    return u;
+}
+
+// The tile's coefficients are staged through LDS: the 4 waves of a workgroup (4 different lane-waves,
+// same tile and cell chunk) stream ONE contiguous run of unit records (cf_device.h) with coalesced
+// 16-byte loads, double-buffered (global -> registers while the previous batch is being consumed ->
+// LDS), one barrier per batch.  Operands then come from wave-uniform ds_read_b128 broadcasts that the
+// compiler can hoist far ahead of their use, so no evaluation waits on memory.  (The first version
+// used scalar loads; each s_load sat 4 instructions in front of its s_waitcnt and the kernel ran at
+// ~60 % of its issue bound.)
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
 __global__ void __launch_bounds__(256)
-cf_main_fact(const double *__restrict__ S1, const double *__restrict__ S2, const double *__restrict__ S3,
-             const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
+cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, double *__restrict__ partial, MainGeom g)
 {
-    const Task t = decode_task(g);
-    if (!t.active) return;
-    const int J = g.J, K = g.K;
-    const int j0 = t.jt * JT;
-    const double mT = lane_mT[t.l], pT = lane_pT[t.l], sign = lane_sign[t.l];
-    const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
-    const int c0 = (int)(((int64_t)t.chunk * g.n_cells) / g.nch);
-    const int c1 = (int)(((int64_t)(t.chunk + 1) * g.n_cells) / g.nch);
-    const int k0 = DIM3 ? t.kt * KT : 0;
-    constexpr int NACC = DIM3 ? JT * KT : JT;
+    constexpr int REC = 4 * JT + R * (4 + JT);
+    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;  // units per batch (about 12 KB)
+    constexpr int BUF2 = UB * REC / 2;                       // double2 per buffer
+    constexpr int NLD = (BUF2 + 255) / 256;
+    static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
+    __shared__ double2 lbuf[2][BUF2];
 
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int stream = (q / g.G) * 8 + xcd;
+    if (stream >= g.NT) return;  // uniform for the whole workgroup
+    int sidx = stream;
+    const int jt = sidx % g.jtiles; sidx /= g.jtiles;
+    const int kt = sidx % g.ktiles; sidx /= g.ktiles;
+    const int chunk = sidx;
+    const int lw = grp * kWPB + (tid >> 6);
+    const bool wave_active = lw * 64 < g.Lpad;
+    const int l = wave_active ? lw * 64 + (tid & 63) : 0;
+
+    const int J = g.J, K = g.K;
+    const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    const double hs = REG ? 0.5 : 1.0;  // u = (1 + df) * hs
+    const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
+    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    const int n_units = (c1 - c0) * g.upc;
+    const int s_tile = DIM3 ? (jt * g.ktiles + kt) : jt;
+    const double2 *src = (const double2 *)(TS + (((int64_t)s_tile * g.n_cells + c0) * g.upc) * REC);
+    const int nb = (n_units + UB - 1) / UB;
+
+    constexpr int NACC = DIM3 ? JT * R : JT;
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
-    for (int c = c0; c < c1; c++) {
-        double pTB[JT], pTD[JT], pT2g[JT], f2[JT], kappa = 0.0;
-        int n2[JT];
+    auto process_unit = [&](const double *U) {
+        double pTB[JT], pTD[JT], pT2g[JT], E2[JT], kap = 0.0;
+        double bmax = -1.0e300;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
-            const int j = min(j0 + jj, J - 1);
-            const double *r2 = S2 + ((int64_t)c * J + j) * kS2Rec;
-            pTB[jj] = pT * r2[0];
-            pTD[jj] = pT * r2[1];
-            pT2g[jj] = pT2 * r2[2];
-            kappa = r2[3];
-            exp_core(pTD[jj], f2[jj], n2[jj]);
+            pTB[jj] = pT * U[4 * jj + 0];
+            pTD[jj] = pT * U[4 * jj + 1];
+            pT2g[jj] = pT2s * U[4 * jj + 2];
+            if (CE) kap = hs * U[4 * jj + 3];
+            bmax = __builtin_fmax(bmax, pTD[jj]);
         }
-        const double *r1 = S1 + (int64_t)c * K * kS1Rec;
-        const double *r3 = S3 + (int64_t)c * J * K;
-
-        auto do_k = [&](int k, int kk) {
-            const double A = r1[k * kS1Rec + 0], Cp = r1[k * kS1Rec + 1], alpha = r1[k * kS1Rec + 2], W = r1[k * kS1Rec + 3];
-            const double mTA = mT * A, mTC = mT * Cp, mT2a = mT2 * alpha;
-            double f1; int n1;
-            exp_core(-mTC, f1, n1);
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) E2[jj] = exp_full(pTD[jj] - bmax);
+        auto do_row = [&](const double *row, int r) {
+            const double mTA = mT * row[0], mTC = mT * row[1], mT2a = mT2s * row[2];
+            const double W = row[3];
+            const double E1 = exp_full(bmax - mTC);
 #pragma unroll
             for (int jj = 0; jj < JT; jj++) {
-                const int j = min(j0 + jj, J - 1);
-                const double beta = r3[(int64_t)j * K + k];
-                double pds = mTA + (DIM3 ? pTB[jj] : pTB[jj] * W);
-                double z = ldexp_fast(f1 * f2[jj], n1 + n2[jj]);
-                double x = mTC - pTD[jj];
-                double br = __builtin_fma(mTpT, beta, mT2a + pT2g[jj]);
-                double v = eval_tail<CE, OUTFLOW, REG>(z, x, br, kappa, sign, pds);
-                if (DIM3) acc[jj * KT + kk] += v; else acc[jj] += v;
+                const double beta = row[4 + jj];
+                double pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
+                const double z = E1 * E2[jj];
+                const double d = __builtin_fma(sign, z, 1.0);
+                const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
+                double rr, inner;
+                if (CE) {
+                    const double x = mTC - pTD[jj];
+                    const double Rc = rcp_nr1(d * x);  // one reciprocal for 1/(1 + sign z) and 1/x
+                    rr = Rc * x;
+                    inner = __builtin_fma(br, Rc * d, kap * x);
+                } else {
+                    rr = rcp_nr1(d);
+                    inner = br;
+                }
+                const double u = REG ? fma_clamp01_half(rr, inner) : __builtin_fma(rr, inner, 1.0);
+                const double w = (z * rr) * u;
+                if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
+                if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                else acc[jj] = __builtin_fma(pds, w, acc[jj]);
             }
         };
         if (DIM3) {
 #pragma unroll
-            for (int kk = 0; kk < KT; kk++) {
-                const int k = k0 + kk;
-                if (k < K) do_k(k, kk);
-            }
+            for (int r = 0; r < R; r++) do_row(U + 4 * JT + r * (4 + JT), r);
         } else {
-            for (int k = 0; k < K; k++) do_k(k, 0);
+            // eta quadrature rows all feed the same JT accumulators: keep the loop rolled (code size)
+#pragma unroll 2
+            for (int r = 0; r < R; r++) do_row(U + 4 * JT + r * (4 + JT), 0);
+        }
+    };
+
+    // double-buffered staging: batch ib+1 travels global -> registers while batch ib is consumed
+    double2 pre[NLD];
+    if (nb > 0) {
+        {
+            const int n2 = min(UB, n_units) * (REC / 2);
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * 256;
+                if (i < n2) lbuf[0][i] = src[i];
+            }
+        }
+        __syncthreads();
+        for (int ib = 0; ib < nb; ib++) {
+            const bool more = ib + 1 < nb;
+            const int n2next = more ? min(UB, n_units - (ib + 1) * UB) * (REC / 2) : 0;
+            const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * 256;
+                pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
+            }
+            if (wave_active) {
+                const int nu = min(UB, n_units - ib * UB);
+                const double *base = (const double *)lbuf[ib & 1];
+                for (int u = 0; u < nu; u++) process_unit(base + u * REC);
+            }
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * 256;
+                if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
+            }
+            __syncthreads();
         }
     }
+    if (!wave_active) return;
 
+    const double unscale = REG ? 2.0 : 1.0;
     const int64_t JKacc = (int64_t)J * g.Kacc;
-    double *pp = partial + (int64_t)t.chunk * JKacc * g.Lpad;
+    double *pp = partial + (int64_t)chunk * JKacc * g.Lpad;
 #pragma unroll
     for (int jj = 0; jj < JT; jj++) {
-        const int j = j0 + jj;
+        const int j = jt * JT + jj;
         if (j < J) {
             if (DIM3) {
 #pragma unroll
-                for (int kk = 0; kk < KT; kk++) {
-                    const int k = k0 + kk;
+                for (int r = 0; r < R; r++) {
+                    const int k = kt * R + r;
                     if (k < K) {
-                        double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + t.l;
-                        *o = g.first_pass ? acc[jj * KT + kk] : (*o + acc[jj * KT + kk]);
+                        double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + l;
+                        const double v = unscale * acc[jj * R + r];
+                        *o = g.first_pass ? v : (*o + v);
                     }
                 }
             } else {
-                double *o = pp + (int64_t)j * g.Lpad + t.l;
-                *o = g.first_pass ? acc[jj] : (*o + acc[jj]);
+                double *o = pp + (int64_t)j * g.Lpad + l;
+                const double v = unscale * acc[jj];
+                *o = g.first_pass ? v : (*o + v);
             }
         }
     }
@@ -540,37 +686,46 @@ static void launch_direct_t(const MainArgs &a, hipStream_t st)
     hipLaunchKernelGGL((cf_main_direct<CE, DIM3, OUTFLOW, REG, KT>), dim3(grid), dim3(kWPB * 64), 0, st, a.S1, a.S2,
                        a.S3, a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
 }
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int KT>
-static void launch_fact_t(const MainArgs &a, hipStream_t st)
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
+static void launch_tile_t(const MainArgs &a, hipStream_t st)
 {
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
-    hipLaunchKernelGGL((cf_main_fact<CE, DIM3, OUTFLOW, REG, JT, KT>), dim3(grid), dim3(kWPB * 64), 0, st, a.S1, a.S2,
-                       a.S3, a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
+    hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, JT, R>), dim3(grid), dim3(kWPB * 64), 0, st, a.TS,
+                       a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
 }
 
-// tile shapes: (variant 1) KT; (variant 2) JT x KT.  Must match main_tile_shape().
+// Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.
+//   variant : 3+1D (JT x R rows of y) / 2+1D (JT x R rows of the eta table per unit)
 constexpr int kV1KT3 = 7, kV1KT2 = 4;
-constexpr int kV2JT3 = 4, kV2KT3 = 7, kV2JT2 = 12;
+constexpr int kTileJT3[3] = {4, 8, 6}, kTileR3[3] = {7, 7, 7};
+constexpr int kTileJT2[3] = {8, 12, 4}, kTileR2[3] = {61, 61, 61};
 
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
-    if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; }
-    else { *JT = dim3 ? kV2JT3 : kV2JT2; *KT = dim3 ? kV2KT3 : 1; }
+    if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
+    int i = (variant >= 2 && variant <= 4) ? variant - 2 : 0;
+    *JT = dim3 ? kTileJT3[i] : kTileJT2[i];
+    *KT = dim3 ? kTileR3[i] : kTileR2[i];
+}
+
+template <bool CE, bool DIM3, bool OF, bool RG>
+static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
+{
+    switch (variant) {
+    case 1: launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st); break;
+    case 3: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[1] : kTileJT2[1]), (DIM3 ? kTileR3[1] : kTileR2[1])>(a, st); break;
+    case 4: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[2] : kTileJT2[2]), (DIM3 ? kTileR3[2] : kTileR2[2])>(a, st); break;
+    default: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[0] : kTileJT2[0]), (DIM3 ? kTileR3[0] : kTileR2[0])>(a, st); break;
+    }
 }
 
 template <bool CE, bool DIM3>
 static void launch_flags(int variant, bool outflow, bool reg, const MainArgs &a, hipStream_t st)
 {
-#define IS3D_LAUNCH(OF, RG)                                                                        \
-    do {                                                                                           \
-        if (variant == 1) launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st);      \
-        else launch_fact_t<CE, DIM3, OF, RG, (DIM3 ? kV2JT3 : kV2JT2), (DIM3 ? kV2KT3 : 1)>(a, st); \
-    } while (0)
-    if (outflow && reg) IS3D_LAUNCH(true, true);
-    else if (outflow && !reg) IS3D_LAUNCH(true, false);
-    else if (!outflow && reg) IS3D_LAUNCH(false, true);
-    else IS3D_LAUNCH(false, false);
-#undef IS3D_LAUNCH
+    if (outflow && reg) launch_variant<CE, DIM3, true, true>(variant, a, st);
+    else if (outflow && !reg) launch_variant<CE, DIM3, true, false>(variant, a, st);
+    else if (!outflow && reg) launch_variant<CE, DIM3, false, true>(variant, a, st);
+    else launch_variant<CE, DIM3, false, false>(variant, a, st);
 }
 
 hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st)
@@ -583,6 +738,6 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
     return hipGetLastError();
 }
 
-const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : "cf_main_fact"; }
+const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : "cf_main_tile"; }
 
 }  // namespace is3d

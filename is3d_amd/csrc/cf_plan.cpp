@@ -74,7 +74,8 @@ struct is3d_plan {
     DevBuf<double> d_mT, d_pT, d_sign, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
     DevBuf<int> d_cls;
     DevBuf<double> d_splx, d_sply[3], d_splc[3];
-    DevBuf<double> d_S1, d_S2, d_S3, d_partial;
+    DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
+    int rblocks = 1, upc = 1;   // row blocks of the tiled stream; units per cell within a stream
     DevBuf<unsigned long long> d_status;
     is3d::SplineDev spl{};
 
@@ -143,7 +144,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     P->ny_eff = P->Kacc;
     P->nout = (int64_t)P->npart * P->npT * P->J * P->ny_eff;
     P->prefactor = std::pow(2.0 * M_PI * is3d::kHbarC, -3);  // smooth_kernels.cpp:36
-    P->variant = (o->kernel_variant == 1) ? 1 : 2;
+    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 4) ? o->kernel_variant : 2;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
@@ -211,8 +212,14 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     // ---- tiling / workspace ----
     is3d::main_tile_shape(P->variant, P->dim3 ? 1 : 0, &P->JT, &P->KT);
     P->jtiles = (P->J + P->JT - 1) / P->JT;
-    P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;
-    P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
+    const bool tiled = P->variant != 1;
+    P->rblocks = tiled ? (P->K + P->KT - 1) / P->KT : 1;
+    P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;   // k tiles are separate tasks only in 3+1D
+    P->upc = (tiled && !P->dim3) ? P->rblocks : 1;            // 2+1D: eta blocks are consecutive units of one stream
+    if (tiled)
+        P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT);
+    else
+        P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
     int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
     int64_t pc = ws / (int64_t)P->bytes_per_cell;
     if (pc < 1) pc = 1;
@@ -235,12 +242,16 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
         nch = std::max<int64_t>(1, std::min(nch, by_mem));
         P->nch_max = (int)nch;
     }
-    HIP_TRY(P->d_S1.alloc((size_t)pc * P->K * is3d::kS1Rec));
-    HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
-    HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
+    if (tiled) {
+        HIP_TRY(P->d_TS.alloc((size_t)pc * (P->bytes_per_cell / sizeof(double))));
+    } else {
+        HIP_TRY(P->d_S1.alloc((size_t)pc * P->K * is3d::kS1Rec));
+        HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
+        HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
+    }
     HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
     HIP_TRY(P->d_status.alloc(2));
-    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_partial.n) * (int64_t)sizeof(double);
+    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_TS.n + P->d_partial.n) * (int64_t)sizeof(double);
     *out = P.release();
     return IS3D_OK;
 }
@@ -322,13 +333,17 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             pp.kgrid = P->d_kgrid.p; pp.kweight = P->d_kweight.p;
             pp.spl = P->spl;
             pp.S1 = P->d_S1.p; pp.S2 = P->d_S2.p; pp.S3 = P->d_S3.p;
+            pp.tiled = (P->variant != 1);
+            pp.JT = P->JT; pp.R = P->KT; pp.jtiles = P->jtiles; pp.rblocks = P->rblocks;
+            pp.TS = P->d_TS.p;
             pp.status = P->d_status.p;
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
             HIP_TRY(is3d::launch_prep(pp, st));
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 1], st));
 
             is3d::MainArgs a{};
-            a.S1 = P->d_S1.p; a.S2 = P->d_S2.p; a.S3 = P->d_S3.p;
+            a.S1 = P->d_S1.p; a.S2 = P->d_S2.p; a.S3 = P->d_S3.p; a.TS = P->d_TS.p;
+            a.g.upc = P->upc;
             a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
             a.partial = P->d_partial.p;
             a.g.n_cells = nc;
