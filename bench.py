@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the smooth Cooper-Frye spectra path on N GPUs of one node.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Metric (BASELINE.json): FO-cell x momentum-bin x species evals/sec.  A "step" is one pass of the hot path
+(prep -> main -> finalize, plus the spectrum all-reduce when N > 1) over one synthetic surface whose cell
+arrays are already resident in HBM.  Default workload = BASELINE config 3 (the configuration north_star
+quotes its target on): 1e6-cell seeded 3+1D surface, Chapman-Enskog delta-f, the 305-species urqmd list,
+32 x 24 x 21 momentum bins = 4.919e12 evals per GPU per step.  N > 1: the cell axis is sharded, every rank
+takes its own 1e6-cell slice of the (infinite, counter-based) seeded surface -- weak scaling -- and one RCCL
+all-reduce of the 39 MB spectrum ends the step.  `--workload config2` gives the 1e5-cell 2+1D case.
+
+One JSON line on stdout (rank 0).  Besides the contract's fields it carries
+  roofline        the contract's object for the dominant kernel, HBM view: algorithmic bytes / kernel time
+  roofline_valu   the roofline that actually binds this kernel: fp64 VALU
+  cpu_baseline    the CPU oracle (a port of the reference loop) timed on this host, bounded sample
+evals are counted as the reference would execute them (every species); the kernel evaluates one
+representative per distinct (mass, sign) class (75 of 305) -- both counts are in `config`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def workload(name):
+    if name == "config3":
+        return dict(name="config3", dimension=3, df_mode=2, species="urqmd", cells=1000000,
+                    text="BASELINE config 3: 1e6-cell synthetic 3+1D surface (seed 20260002), Chapman-Enskog delta-f, "
+                         "305-species pdg-urqmd_v3.3+ list, 32x24x21 (pT,phi,y) bins")
+    if name == "config2":
+        return dict(name="config2", dimension=2, df_mode=1, species="pikp", cells=100000,
+                    text="BASELINE config 2: 1e5-cell synthetic 2+1D boost-invariant surface (seed 20260001), 14-moment "
+                         "delta-f, pi/K/p, 32x24 (pT,phi) bins x 241-point eta quadrature")
+    raise SystemExit("unknown workload %s" % name)
+
+
+def isa_counts(kernel_name, wl, JT_R):
+    p = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
+    if not os.path.exists(p):
+        return None
+    d = json.load(open(p))
+    ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
+    if kernel_name == "cf_main_tile":
+        key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
+    else:
+        key = "cf_main_direct:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,KT=%d" % (ce, d3, JT_R[1])
+    return d.get(key)
+
+
+def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0):
+    """The oracle (variant B, a scratch-free port of smooth_kernels.cpp:106-349; OpenMP over cells) on the first
+    cells of the same surface, all host cores.  Also the reference-shaped variant A (chunk + scratch + reduce)."""
+    from is3d_amd import synth
+    from oracle import oracle  # checker doubling as the reported CPU baseline
+    nbins = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if wl["dimension"] == 3 else 1)
+    per_cell = nbins * len(sp["mass"])
+    opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"])
+    # a 1-GPU box owns a 16-core share of the host (and the oracle keeps one 39 MB partial spectrum per thread)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = oracle.set_num_threads(min(16, avail))
+    probe = synth.synth_surface(2 * threads, wl["dimension"])
+    t0 = time.time()
+    oracle.dN_pTdpTdphidy(probe, sp, grid, df, opts)
+    t_probe = max(time.time() - t0, 1e-3)
+    n = int(max(2 * threads, min(8192, 2 * threads * (0.5 * seconds_budget / t_probe))))
+    n -= n % threads
+    cells = synth.synth_surface(n, wl["dimension"])
+    t0 = time.time()
+    oracle.dN_pTdpTdphidy(cells, sp, grid, df, opts)
+    tb = time.time() - t0
+    res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, kind="port",
+               sample="first %d cells of the workload surface x all %d species x %d bins, oracle variant B (no scratch), %.1f s" % (
+                   n, len(sp["mass"]), nbins, tb))
+    # variant A: the reference's own structure; scratch = npart*chunk*bins*8 B must fit
+    na = n
+    while na * per_cell * 8 > 6e9 and na > threads:
+        na //= 2
+    ca = {k: v[:na] for k, v in cells.items()}
+    t0 = time.time()
+    oracle.dN_pTdpTdphidy(ca, sp, grid, df, opts, chunked=True, FO_chunk=na)
+    ta = time.time() - t0
+    res["reference_shaped"] = dict(value=na * per_cell / ta, unit="evals/s", cores=threads,
+                                   sample="%d cells, oracle variant A (10000-cell-chunk scratch + collapse(4) reduction as in the reference), %.1f s" % (na, ta))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--cells", type=int, default=0, help="override cells per GPU (parity/dev runs)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from is3d_amd import api, inputs, synth
+    from is3d_amd import dist as idist
+
+    rank, world, local = idist.env_rank_world()
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        idist.init_process_group("nccl")
+        import torch.distributed as dist
+
+    wl = workload(a.workload)
+    g = inputs.grid()
+    grid = dict(pT=g["pT"], phi=g["phi"], y=g["y"], eta=g["eta"], eta_w=g["eta_w"])
+    df = inputs.df_tables()
+    sp = inputs.species(wl["species"])
+    n_total = a.cells * world if (a.cells and a.scaling == "weak") else (a.cells or wl["cells"] * (world if a.scaling == "weak" else 1))
+    lo, hi = idist.shard_bounds(n_total, rank, world)
+    n_loc = hi - lo
+    cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}   # resident in HBM before timing
+    opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local)
+    plan = api.Plan(sp, grid, df, opts, max_cells=max(n_loc, 1))
+    plan.set_timing(True)
+    out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    ms = dict(prep=[], main=[], finalize=[])
+
+    def step(record):
+        plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
+        if world > 1:
+            idist.allreduce_spectrum(out)
+        if record:
+            t = plan.timings()   # HIP events recorded on `stream` around each kernel of this step
+            ms["prep"].append(t["ms_prep"])
+            ms["main"].append(t["ms_main"])
+            ms["finalize"].append(t["ms_finalize"])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
+    torch.cuda.synchronize()
+    spectrum_ok = bool(torch.isfinite(out).all().item())
+
+    if rank == 0:
+        nbins = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if wl["dimension"] == 3 else 1)
+        nsp = len(sp["mass"])
+        evals_step = float(n_total) * nbins * nsp
+        value = evals_step * a.steps / elapsed
+        ms_main = float(np.mean(ms["main"]))
+        # ---- roofline (contract form, HBM): algorithmic bytes of the launch = cell arrays read once + spectrum written once
+        ncell_arrays = 18 if wl["dimension"] == 3 else 17
+        b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            tj = json.load(open(tp)).get(wl["name"])
+            if tj and tj.get("cells") == n_loc:
+                traffic = tj["hbm_bytes_per_launch"]
+        roofline = dict(bound="hbm", achieved=b_alg / (ms_main * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=b_alg / (ms_main * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, kernel=plan.main_kernel_name,
+                        kernel_ms=ms_main, algorithmic_bytes=b_alg,
+                        note="not the binding roofline: 1e6 flop/byte; see roofline_valu and DESIGN.md section 5")
+        # ---- the binding roofline: fp64 VALU
+        jt_r = plan.tile_shape
+        ic = isa_counts(plan.main_kernel_name, wl, jt_r)
+        unique_evals = float(n_loc) * nbins * st["n_classes"] * (len(grid["eta"]) if wl["dimension"] == 2 else 1)
+        rv = None
+        if ic:
+            tf = unique_evals * ic["flop_per_eval"] / (ms_main * 1e-3) / 1e12
+            rv = dict(bound="fp64_valu", achieved=tf, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_VALU_PEAK_TF,
+                      executed_flop_per_eval=ic["flop_per_eval"], fp64_valu_instr_per_eval=ic["valu_f64_instr_per_eval"],
+                      issue_cycles_per_eval=ic["issue_cycles_per_eval"],
+                      issue_bound_frac_at_2p4GHz=unique_evals / 64.0 * ic["issue_cycles_per_eval"] / (1024 * 2.4e9 * ms_main * 1e-3),
+                      evaluated_integrands_per_launch=unique_evals)
+        res = dict(metric="FO-cell x momentum-bin x species evals/sec", value=value, unit="evals/s", n_gpus=world, steps=a.steps,
+                   warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling, vs_baseline=None,
+                   dtype="f64", data="synthetic",
+                   config=dict(workload=wl["text"], cells_total=n_total, cells_per_gpu=n_loc, species=nsp, species_classes_evaluated=st["n_classes"],
+                               bins=nbins, evals_per_step=evals_step, kernel=plan.main_kernel_name, kernel_variant=st["kernel_variant"],
+                               parallelism="cell-axis shards x%d, one all-reduce of the spectrum" % world if world > 1 else "1 GPU",
+                               workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok),
+                   kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"]))),
+                   roofline=roofline, roofline_valu=rv)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df)
+            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,9 @@ typedef struct {
     int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
     int32_t device;                     /* HIP device ordinal; -1 = current device */
     /* tuning; 0 = library default */
-    int32_t kernel_variant;             /* 0 default (2) | 1 direct-exp kernel | 2,3,4 tile kernel, tile shapes 8x7 / 4x7 / 6x7 (2+1D: 12 / 8 / 24) */
+    int32_t kernel_variant;             /* 0 default (2) | 1 direct kernel (flat streams, one exp per evaluation) |
+                                           2,3,4 LDS-staged tile kernel, (phi x rows) tiles 8x7 / 4x7 / 6x7 in 3+1D,
+                                           8x61 / 12x61 / 4x61 in 2+1D */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
     int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per
@@ -157,6 +159,8 @@ int is3d_plan_set_timing(is3d_plan *plan, int32_t enable);
 int is3d_plan_timings(is3d_plan *plan, is3d_status *status);
 /* Name of the dominant kernel as it appears in rocprofv3 traces, for the variant in use. */
 const char *is3d_plan_main_kernel_name(const is3d_plan *plan);
+/* tile of the main kernel: *JT phi's x *R rows (y's in 3+1D, eta nodes in 2+1D) */
+int is3d_plan_tile_shape(const is3d_plan *plan, int32_t *JT, int32_t *R);
 /* bytes of device workspace the plan holds */
 int64_t is3d_plan_workspace_bytes(const is3d_plan *plan);
 void is3d_plan_destroy(is3d_plan *plan);

@@ -60,7 +60,7 @@ class Status(C.Structure):
 
 EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_plan_create",
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings",
-           "is3d_plan_main_kernel_name", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
+           "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_pdg_read", "is3d_df_table_read", "is3d_write_results"]
 
 
@@ -107,6 +107,7 @@ def load():
     L.is3d_plan_output_size.argtypes = [C.c_void_p]
     L.is3d_plan_workspace_bytes.restype = C.c_int64
     L.is3d_plan_workspace_bytes.argtypes = [C.c_void_p]
+    L.is3d_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.is3d_plan_execute.argtypes = [C.c_void_p, C.POINTER(Cells), C.c_void_p, C.c_void_p, C.POINTER(Status)]
     L.is3d_plan_set_timing.argtypes = [C.c_void_p, C.c_int32]
     L.is3d_plan_timings.argtypes = [C.c_void_p, C.POINTER(Status)]
@@ -200,6 +201,9 @@ class Plan:
         assert self.output_size == nout
         self.workspace_bytes = int(L.is3d_plan_workspace_bytes(self._h))
         self.main_kernel_name = L.is3d_plan_main_kernel_name(self._h).decode()
+        jt, r = C.c_int32(), C.c_int32()
+        _check(L.is3d_plan_tile_shape(self._h, C.byref(jt), C.byref(r)))
+        self.tile_shape = (jt.value, r.value)
 
     def set_timing(self, enable=True):
         _check(load().is3d_plan_set_timing(self._h, 1 if enable else 0))

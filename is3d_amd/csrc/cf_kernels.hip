@@ -697,7 +697,7 @@ static void launch_tile_t(const MainArgs &a, hipStream_t st)
 // Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.
 //   variant : 3+1D (JT x R rows of y) / 2+1D (JT x R rows of the eta table per unit)
 constexpr int kV1KT3 = 7, kV1KT2 = 4;
-constexpr int kTileJT3[3] = {4, 8, 6}, kTileR3[3] = {7, 7, 7};
+constexpr int kTileJT3[3] = {8, 4, 6}, kTileR3[3] = {7, 7, 7};
 constexpr int kTileJT2[3] = {8, 12, 4}, kTileR2[3] = {61, 61, 61};
 
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)

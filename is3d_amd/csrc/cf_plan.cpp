@@ -259,6 +259,13 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
 extern "C" int64_t is3d_plan_output_size(const is3d_plan *P) { return P ? P->nout : 0; }
 extern "C" int64_t is3d_plan_workspace_bytes(const is3d_plan *P) { return P ? P->workspace : 0; }
 extern "C" const char *is3d_plan_main_kernel_name(const is3d_plan *P) { return is3d::main_kernel_name(P ? P->variant : 2); }
+extern "C" int is3d_plan_tile_shape(const is3d_plan *P, int32_t *JT, int32_t *R)
+{
+    if (!P || !JT || !R) return fail(IS3D_EINVAL, "null argument");
+    *JT = P->JT;
+    *R = P->KT;
+    return IS3D_OK;
+}
 extern "C" int is3d_plan_set_timing(is3d_plan *P, int32_t enable)
 {
     if (!P) return fail(IS3D_EINVAL, "null plan");

@@ -1,0 +1,46 @@
+"""Multi-GPU plumbing for the smooth-spectra path: one process per GPU, the freezeout-cell axis in
+contiguous shards, no data-path collective, one all-reduce (RCCL over xGMI; gloo on CPU in tests) of
+the per-bin spectrum at the end.  The reference has no distributed code."""
+import os
+
+
+def shard_bounds(n_cells, rank, world_size):
+    """Contiguous shard [lo, hi) of rank; sizes differ by at most one cell."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, rem = divmod(int(n_cells), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend=None):
+    """Join the job torchrun started (MASTER_ADDR/PORT, RANK, WORLD_SIZE in the env).  backend defaults to
+    nccl (= RCCL on ROCm) when a GPU is visible, else gloo."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world == 1 or dist.is_initialized():
+        return rank, world, local
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allreduce_spectrum(spectrum):
+    """In-place sum of the flat fp64 spectrum over all ranks (a no-op for a single process).
+    All terms are >= 0 when outflow = 1, so the reduction order only moves the last bits."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(spectrum, op=dist.ReduceOp.SUM)
+    return spectrum

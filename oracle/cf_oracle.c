@@ -11,7 +11,7 @@
  * vendored) is absent from this image, and executing the reference binary was denied by the
  * environment.  The restatement is therefore anchored on
  *   (a) the reference source text cited line by line below,
- *   (b) closed-form known answers for the 1-cell toy surface (tests/test_oracle_kat.py),
+ *   (b) closed-form known answers for the 1-cell toy surface (tests/test_oracle.py),
  *   (c) an independent extended-precision numpy restatement (tests/golden/make_golden.py),
  *   (d) scipy's independent natural cubic spline for the GSL replacement.
  *
@@ -514,6 +514,15 @@ int oracle_dN_pTdpTdphidy_chunked(long FO_length, int npart, const double *Mass,
     }
     free(all); free(s); free(yValues); free(cosphi); free(sinphi);
     return err;
+}
+
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int oracle_num_threads(void)

@@ -142,3 +142,8 @@ def dN_pTdpTdphidy(cells, species, grid, df, opts, chunked=False, FO_chunk=10000
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(int(n))
+    return num_threads()

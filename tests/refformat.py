@@ -1,0 +1,92 @@
+"""Test helper: write input files in the reference's on-disk formats from the JSON
+fixture, so that reader / CLI tests run on boxes that have no /root/reference.  The quirks of the shipped
+files are reproduced on purpose: CRLF PDG records with decay lines, leading tabs, a phi table that ends
+in "\\n\\t" (a fragment readBlockData drops), coefficient tables with the three header lines."""
+import os
+
+import numpy as np
+
+from is3d_amd import inputs, synth
+
+PARAMS_TEMPLATE = """operation	                = {operation}	 # operation
+mode       		      	= {mode} 	 # mode for reading in freeze out information
+hrg_eos				= 1	 # HRG equation of state
+set_FO_temperature		= 1      # ignored by the smooth path
+T_switch			= 0.151
+dimension  		     	= {dimension}      # 2: boost invariant, 3: full 3+1D
+df_mode		                = {df_mode}     # 1: 14-moment, 2: Chapman-Enskog
+include_baryon            	= 0
+Include_Bulk_Deltaf       	= {include_bulk_deltaf}     # names are case-insensitive
+include_shear_deltaf      	= {include_shear_deltaf}
+include_baryondiff_deltaf 	= 0
+regulate_deltaf           	= {regulate_deltaf}
+outflow 			= {outflow}	             # Theta(p.dsigma)
+
+deta_min 			= 1.e-5
+group_particles                 = 0
+"""
+
+
+def write_table(path, x, w, leading_tab=False, dangling_fragment=False):
+    with open(path, "w") as f:
+        for a, b in zip(x, w):
+            f.write(("\t" if leading_tab else "") + repr(float(a)) + "\t" + repr(float(b)) + "\n")
+        if dangling_fragment:
+            f.write("\t")
+
+
+def write_pdg(path, rows, trailing_blank=True):
+    """rows: [mc_id, mass, gspin, baryon, sign] for PARTICLES only (baryon >= 0); antibaryons are synthesised by the reader."""
+    with open(path, "w", newline="") as f:
+        for mc_id, mass, gspin, baryon, _ in rows:
+            f.write("%8d  %-20s %9.5f %9.5f %2d %2d  0  0  0  1  0  2\r\n" % (mc_id, "P%d" % mc_id, mass, 0.0, gspin, baryon))
+            f.write("%8d  2  0.600 %13d %7d       0       0       0\r\n" % (mc_id, 211, -211))
+            f.write("%8d  1  0.400 %13d       0       0       0       0\r\n" % (mc_id, mc_id))
+        if trailing_blank:
+            f.write("\r\n")
+
+
+def write_df_table(path, T, values, label, n_muB=2):
+    with open(path, "w") as f:
+        f.write("%d\n%d\n" % (len(T), n_muB))
+        f.write("T [GeV]\t\tmuB [GeV]\t\t%s\n" % label)
+        for ib in range(n_muB):
+            for t, v in zip(T, values):
+                f.write("%.6f\t\t%.6f\t\t%s\n" % (t, 0.01 * ib, repr(float(v) * (1.0 + 0.5 * ib))))
+
+
+def make_run_dir(root, cells, species_ids, params):
+    """An iS3D-style run directory: iS3D_parameters.dat, input/, PDG/, tables/, deltaf_coefficients/, results/."""
+    fx = inputs.load_fixture()
+    g = inputs.grid()
+    df = inputs.df_tables()
+    for d in ("input", "PDG", "tables/eta", "deltaf_coefficients/vh/urqmd", "results/vn_continuous"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    p = dict(operation=1, mode=1, dimension=3, df_mode=1, include_bulk_deltaf=1, include_shear_deltaf=1, regulate_deltaf=1, outflow=1)
+    p.update(params)
+    with open(os.path.join(root, "iS3D_parameters.dat"), "w") as f:
+        f.write(PARAMS_TEMPLATE.format(**p))
+    synth.write_surface_dat(os.path.join(root, "input", "surface.dat"), cells)
+    write_table(os.path.join(root, "tables", "pT_gauss_legendre_table.dat"), g["pT"], g["pT_w"])
+    write_table(os.path.join(root, "tables", "phi_gauss_legendre_table.dat"), g["phi"], g["phi_w"], leading_tab=True, dangling_fragment=True)
+    write_table(os.path.join(root, "tables", "y_trapezoid_table_21pt.dat"), g["y"], g["y_w"])
+    write_table(os.path.join(root, "tables", "eta", "eta_trapezoid_table_241pt.dat"), g["eta"], g["eta_w"])
+    for name in ("c0", "c2", "F", "betabulk", "betapi"):
+        write_df_table(os.path.join(root, "deltaf_coefficients", "vh", "urqmd", name + ".dat"), df["T"], df[name], name)
+    particles = [r for r in fx["pdg_urqmd"] if r[3] >= 0]
+    write_pdg(os.path.join(root, "PDG", "pdg-urqmd_v3.3+.dat"), particles)
+    with open(os.path.join(root, "PDG", "chosen_particles.dat"), "w") as f:
+        for i in species_ids:
+            f.write("\t%d\n" % i)
+    return root
+
+
+def read_surface_like_reference(path):
+    """What read_surf_VH does to a mode-1 file (readindata.cpp:343-410), in numpy: -> dict of the 18 arrays."""
+    a = np.loadtxt(path, ndmin=2)
+    h = synth.HBARC
+    names = ["tau", "x", "y", "eta", "dat", "dax", "day", "dan", "ux", "uy", "un", "E", "T", "P", "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi"]
+    s = {n: a[:, i].copy() for i, n in enumerate(names)}
+    for n in ("E", "T", "P", "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi"):
+        s[n] = s[n] * h
+    return s

@@ -1,0 +1,70 @@
+"""GPU (-m gpu): the iS3D-compatible command line driver end to end -- reference file formats in, reference
+file formats out -- against the oracle run on the same parsed inputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import refformat
+from conftest import relerr
+from is3d_amd import api, inputs, synth
+from oracle import oracle  # the checker
+
+pytestmark = pytest.mark.gpu
+
+
+def read_spectra_file(path, header=False):
+    rows = []
+    with open(path) as f:
+        if header:
+            assert f.readline() == "y\tphip\tpT\tdN_pTdpTdphidy\n"
+        for ln in f:
+            if ln.strip():
+                rows.append([float(x) for x in ln.split("\t")])
+    return np.array(rows)
+
+
+@pytest.mark.parametrize("dim,df_mode", [(3, 1), (3, 2), (2, 1)])
+def test_cli_run_directory(tmp_path, fx, dim, df_mode):
+    ids = [211, -2212, 3122, 321]          # antibaryon ids exist only because the reader synthesises them
+    cells = synth.synth_surface(23 if dim == 3 else 7, dim, seed=40 + dim)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(dimension=dim, df_mode=df_mode))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Number of chosen particles: 4" in r.stdout and "Total number of freezeout cells: %d" % len(cells["tau"]) in r.stdout
+
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    sp = inputs.species(ids)
+    g = fx["grid_w"]
+    ref = oracle.dN_pTdpTdphidy(parsed, sp, fx["grid"], fx["df"], dict(dimension=dim, df_mode=df_mode))
+    ny = 21 if dim == 3 else 1
+    ref4 = ref.reshape(ny, 24, 32, 4)
+    allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
+    assert allsp.shape == (4 * ny * 24 * 32, 4)
+    want = np.transpose(ref4, (3, 0, 1, 2)).reshape(-1)             # file order: species, y, phi, pT
+    assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8           # files carry 9 significant digits
+    yv = g["y"] if dim == 3 else np.zeros(1)
+    assert np.allclose(allsp[: 32, 2], g["pT"], rtol=1e-8) and np.allclose(allsp[:ny * 24 * 32:24 * 32, 0], yv, atol=1e-12)
+    one = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy_-2212.dat"), header=True)
+    assert relerr(one[:, 3], ref4[:, :, :, 1].reshape(-1), floor=1e-250) < 2e-8
+    dndy = np.loadtxt(os.path.join(root, "results", "dN_dy_3122.dat"), ndmin=2)
+    want_dy = np.einsum("j,i,kji->k", g["phi_w"], g["pT_w"], ref4[:, :, :, 2])
+    assert np.allclose(dndy[:, 1], want_dy, rtol=3e-8)
+    vn = np.loadtxt(os.path.join(root, "results", "vn_continuous", "vn_211.dat"), ndmin=2)
+    assert vn.shape == (ny * 32, 9)
+    num = np.einsum("j,kji->ki", np.exp(2j * g["phi"]) * g["phi_w"], ref4[:, :, :, 0])
+    den = np.einsum("j,kji->ki", g["phi_w"], ref4[:, :, :, 0])
+    v2 = np.where(den < 1e-15, 0.0, np.abs(num) / np.where(den == 0, 1, den)).reshape(-1)
+    assert np.allclose(vn[:, 3], v2, rtol=1e-6, atol=1e-7)
+    avg = [float(x) for x in open(os.path.join(root, "average_thermodynamic_quantities.dat")).read().split()]
+    assert len(avg) == 5 and 0.14 < avg[0] < 0.16 and avg[3] == 0.0
+
+
+def test_cli_refuses_what_it_does_not_implement(tmp_path):
+    cells = synth.synth_surface(3, 3, seed=1)
+    for bad in (dict(operation=2), dict(mode=0), dict(df_mode=4)):
+        root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
+        r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "iS3D-amd:" in r.stderr
+        assert not os.listdir(os.path.join(root, "results", "vn_continuous"))

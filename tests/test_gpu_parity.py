@@ -1,0 +1,248 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs,
+against the committed golden vectors, and -- at BASELINE.json's full sizes -- through size-independent
+properties plus oracle spot checks on sampled bins.
+
+Tolerance: north_star asks <= 1e-6 relative (fp64).  The kernels reach ~1e-10; tests assert 2e-9 so that a
+regression of the arithmetic (not of the last bits) fails.  `relerr` uses an absolute floor of 1e-280 for
+the exact-zero / denormal tails (pT up to 40 GeV), see SURVEY.md section 4.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+from is3d_amd import api, inputs, synth
+from oracle import oracle  # the checker
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-9
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    assert api.load().is3d_device_count() >= 1
+    return torch
+
+
+def run_plan(torch, cells, sp, grid, df, opts, n=None, out=None, first=0):
+    """Device-resident entry: torch tensors provide memory and the stream; returns (numpy spectrum, status)."""
+    dev = torch.device("cuda:0")
+    n_all = len(cells["tau"])
+    n = n_all - first if n is None else n
+    tens = {k: torch.from_numpy(np.ascontiguousarray(cells[k])).to(dev) for k in synth.CELL_FIELDS}
+    plan = api.Plan(sp, grid, df, opts, max_cells=max(n, 1))
+    o = out if out is not None else torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
+    ptrs = {k: v.data_ptr() + 8 * first for k, v in tens.items()}
+    st = plan.execute(n, ptrs, o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    plan.close()
+    return o.cpu().numpy(), st
+
+
+SP7 = [211, 321, 2212, -2212, 3122, 333, 22]
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("df_mode", [1, 2])
+@pytest.mark.parametrize("flags", [dict(), dict(outflow=0, regulate_deltaf=0), dict(outflow=0), dict(regulate_deltaf=0),
+                                   dict(include_bulk_deltaf=0), dict(include_shear_deltaf=0)])
+def test_parity_matrix(fx, dim, df_mode, flags):
+    cells = synth.synth_surface(70 if dim == 3 else 9, dim, seed=100 + dim)
+    sp = inputs.species(SP7) if dim == 3 else fx["pikp"]
+    o = dict(dimension=dim, df_mode=df_mode, **flags)
+    ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], o)
+    for variant in (1, 2, 3, 4):
+        got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=variant))
+        assert st["kernel_variant"] == variant and st["code"] == 0
+        assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
+
+
+def test_config1_known_answers_on_device(fx, pins):
+    """The reference's own toy surface (config 1), closed form of SURVEY.md section 4."""
+    h = 0.197327053
+    v = dict(tau=0.5, eta=0.0, dat=1000.0, dax=0.0, day=0.0, dan=0.0, ux=0.0, uy=0.0, un=0.0, E=1.839 * h, T=0.786 * h, P=0.270 * h,
+             pixx=0.0, pixy=0.0, pixn=0.0, piyy=0.0, piyn=0.0, bulkPi=0.0)
+    cell = {k: np.array([x]) for k, x in v.items()}
+    for dfm in (1, 2):
+        o3, _ = api.smooth_spectra(cell, fx["pikp"], fx["grid"], fx["df"], dict(dimension=3, df_mode=dfm))
+        o2, _ = api.smooth_spectra(cell, fx["pikp"], fx["grid"], fx["df"], dict(dimension=2, df_mode=dfm))
+        o3, o2 = o3.reshape(21, 24, 32, 3), o2.reshape(1, 24, 32, 3)
+        for key, (y0, y2, bi) in pins["kat_config1"].items():
+            s, i = (int(x) for x in key.split(","))
+            assert abs(o3[10, 0, i, s] / y0 - 1) < 1e-10 and abs(o3[14, 0, i, s] / y2 - 1) < 1e-10 and abs(o2[0, 0, i, s] / bi - 1) < 1e-10
+        assert o3[0, 0, 31, 0] == 0.0   # exp overflow tail is exactly zero, never NaN
+        assert np.isfinite(o3).all() and np.isfinite(o2).all()
+
+
+def test_golden_vectors(fx, pins):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_64cell.npz"))
+    meta = pins["golden_64cell"]
+    s3 = synth.synth_surface(64, 3, seed=meta["seed3"])
+    s2 = synth.synth_surface(16, 2, seed=meta["seed2"])
+    for dfm in (1, 2):
+        got, _ = api.smooth_spectra(s3, inputs.species(meta["species3"]), fx["grid"], fx["df"], dict(dimension=3, df_mode=dfm))
+        assert relerr(got, z["s3_df%d" % dfm]) < TOL
+        got, _ = api.smooth_spectra(s2, fx["pikp"], fx["grid"], fx["df"], dict(dimension=2, df_mode=dfm))
+        assert relerr(got, z["s2_df%d" % dfm]) < TOL
+    hp = np.load(os.path.join(ROOT, "tests", "golden", "golden_highprec.npz"))
+    cellsets = {nm: {k: hp["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS} for nm in ("hand3", "seed3", "seed2")}
+    cellsets["hand2"] = {k: v[:2] for k, v in cellsets["hand3"].items()}
+    for case in pins["highprec_cases"]:
+        got, _ = api.smooth_spectra(cellsets[case["cells"]], fx["pikp"], fx["grid"], fx["df"], case["opts"])
+        assert relerr(got, hp[case["key"]]) < TOL, case["key"]
+
+
+def test_species_collapse_is_exact_and_full_urqmd_list(fx):
+    """305 urqmd species -> 75 (mass, sign) classes; the collapsed and the uncollapsed run agree to rounding and both
+    match the oracle; output order = order of the chosen list, species fastest."""
+    cells = synth.synth_surface(6, 3, seed=77)
+    sp = fx["urqmd"]
+    o = dict(dimension=3, df_mode=2)
+    a, sta = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+    b, stb = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, collapse_species=2))
+    assert sta["n_classes"] == 75 and stb["n_classes"] == 305
+    assert relerr(a, b) < 1e-13
+    ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], o)
+    assert relerr(a, ref) < TOL
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 65, 257])
+def test_ragged_and_empty_surfaces(fx, torch_mod, n):
+    cells = synth.synth_surface(n, 3, seed=5)
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::2])
+    o = dict(dimension=3, df_mode=1)
+    ref = oracle.dN_pTdpTdphidy(cells, fx["pikp"], g, fx["df"], o)
+    got, st = api.smooth_spectra(cells, fx["pikp"], g, fx["df"], o)
+    assert relerr(got, ref) < TOL
+    got2, _ = run_plan(torch_mod, cells, fx["pikp"], g, fx["df"], o)
+    assert np.array_equal(got, got2)          # host entry and device-resident entry run the same kernels
+    if n == 0:
+        assert not got.any()
+
+
+def test_odd_grids(fx):
+    """Grid lengths that are not multiples of the kernel tiles (phi 5, y 5 and 29, pT 3, eta 41 and 7)."""
+    rng = np.random.default_rng(3)
+    cells = synth.synth_surface(21, 3, seed=8)
+    g = dict(pT=np.array([0.1, 0.7, 2.5]), phi=np.sort(rng.random(5) * 2 * np.pi), y=np.linspace(-2, 2, 5), eta=fx["grid"]["eta"], eta_w=fx["grid"]["eta_w"])
+    for ygrid in (np.linspace(-2, 2, 5), np.linspace(-3.5, 3.5, 29)):
+        gg = dict(g, y=ygrid)
+        for dfm in (1, 2):
+            ref = oracle.dN_pTdpTdphidy(cells, fx["pikp"], gg, fx["df"], dict(dimension=3, df_mode=dfm))
+            for variant in (1, 2, 3, 4):
+                got, _ = api.smooth_spectra(cells, fx["pikp"], gg, fx["df"], dict(dimension=3, df_mode=dfm, kernel_variant=variant))
+                assert relerr(got, ref) < TOL
+    c2 = synth.synth_surface(5, 2, seed=9)
+    for neta in (41, 7):
+        eta = np.linspace(-2.0, 2.0, neta)
+        w = np.full(neta, eta[1] - eta[0])
+        w[[0, -1]] *= 0.5
+        gg = dict(g, eta=eta, eta_w=w)
+        ref = oracle.dN_pTdpTdphidy(c2, fx["pikp"], gg, fx["df"], dict(dimension=2, df_mode=2))
+        for variant in (1, 2, 3, 4):
+            got, _ = api.smooth_spectra(c2, fx["pikp"], gg, fx["df"], dict(dimension=2, df_mode=2, kernel_variant=variant))
+            assert relerr(got, ref) < TOL
+
+
+def test_skipped_cells_and_domain_error(fx):
+    """u.dsigma <= 0 cells contribute exactly 0 and are counted; their T is never looked up (smooth_kernels.cpp:137
+    precedes :200); a live cell outside the coefficient table is IS3D_EDOMAIN (reference: GSL abort)."""
+    cells = synth.synth_surface(40, 3, seed=12)
+    for k in ("dat", "dax", "day", "dan"):
+        cells[k][[3, 17, 39]] *= -1.0
+    cells["T"][17] = 0.05
+    cells["eta"][39] = np.nan            # garbage in a skipped cell must not leak
+    o = dict(dimension=3, df_mode=2)
+    ref = oracle.dN_pTdpTdphidy(cells, fx["pikp"], fx["grid"], fx["df"], o)
+    for variant in (1, 2):
+        got, st = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, kernel_variant=variant))
+        assert st["n_cells_skipped"] == 3 and st["bad_cell"] == -1
+        assert relerr(got, ref) < TOL and np.isfinite(got).all()
+    cells["T"][20] = 0.2004
+    cells["T"][30] = 0.09
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], o)
+    assert e.value.code == api.IS3D_EDOMAIN and "cell 20" in str(e.value)
+
+
+def test_passes_chunks_and_accumulate(fx, torch_mod):
+    """A workspace too small for the surface forces several passes over the cell axis; the chunk count is a tuning
+    knob; accumulate = 1 adds to the caller's array (reference semantics, :375)."""
+    cells = synth.synth_surface(300, 3, seed=21)
+    sp = inputs.species(SP7)
+    o = dict(dimension=3, df_mode=1)
+    base, st0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+    assert st0["n_passes"] == 1
+    small, st1 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, workspace_bytes=1 << 20))
+    assert st1["n_passes"] > 2 and relerr(small, base) < 1e-13
+    for ch in (1, 3, 50):
+        got, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, cell_chunks=ch))
+        assert relerr(got, base) < 1e-13
+    again, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+    assert np.array_equal(again, base)                       # fixed-order reduction: bitwise reproducible
+    acc, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, accumulate=1), out=base.copy())
+    assert relerr(acc, 2.0 * base) < 1e-15
+
+
+def _subset_oracle(fx, cells, sp_ids, ipT, iphi, opts):
+    g = fx["grid"]
+    sub = dict(g, pT=g["pT"][ipT], phi=g["phi"][iphi])
+    return oracle.dN_pTdpTdphidy(cells, inputs.species(sp_ids), sub, fx["df"], opts)
+
+
+def test_full_size_config3_properties_and_spot_checks(fx, torch_mod):
+    """BASELINE config 3: 1e6-cell 3+1D surface, Chapman-Enskog, 305 species.  (i) additivity over cell shards --
+    the property the multi-GPU path relies on; (ii) linearity in dsigma; (iii) bitwise reproducibility;
+    (iv) oracle parity on sampled (species, pT, phi) columns over ALL cells and all 21 rapidities."""
+    torch = torch_mod
+    n = 1000000
+    cells = synth.synth_surface(n, 3)
+    sp = fx["urqmd"]
+    o = dict(dimension=3, df_mode=2)
+    whole, st = run_plan(torch, cells, sp, fx["grid"], fx["df"], o)
+    assert st["n_classes"] == 75 and np.isfinite(whole).all() and (whole >= 0).all()
+    # (i) two shards, second accumulated onto the first
+    dev = torch.device("cuda:0")
+    lo, _ = run_plan(torch, cells, sp, fx["grid"], fx["df"], o, n=n // 2)
+    acc = torch.from_numpy(lo.copy()).to(dev)
+    both, _ = run_plan(torch, cells, sp, fx["grid"], fx["df"], dict(o, accumulate=1), n=n - n // 2, first=n // 2, out=acc)
+    assert relerr(both, whole) < 1e-12
+    # (ii) dsigma -> 2 dsigma on a 1e5-cell slice
+    sl = {k: v[:100000] for k, v in cells.items()}
+    a, _ = run_plan(torch, sl, sp, fx["grid"], fx["df"], o)
+    sl2 = {k: (2.0 * v if k in ("dat", "dax", "day", "dan") else v) for k, v in sl.items()}
+    b, _ = run_plan(torch, sl2, sp, fx["grid"], fx["df"], o)
+    assert relerr(b, 2.0 * a) < 1e-15
+    # (iii)
+    again, _ = run_plan(torch, cells, sp, fx["grid"], fx["df"], o)
+    assert np.array_equal(again, whole)
+    # (iv) sampled columns against the oracle over all 1e6 cells
+    w5 = whole.reshape(21, 24, 32, 305)
+    ids = [int(sp["mc_id"][s]) for s in (0, 120, 304)]
+    ipT, iphi = [2, 17], [1, 13]
+    ref = _subset_oracle(fx, cells, ids, ipT, iphi, o).reshape(21, 2, 2, 3)
+    got = w5[:, iphi][:, :, ipT][:, :, :, [0, 120, 304]]
+    assert relerr(got, ref) < TOL
+
+
+def test_full_size_config2_properties_and_spot_checks(fx, torch_mod):
+    """BASELINE config 2: 1e5-cell 2+1D boost-invariant surface, 14-moment, pi/K/p, 241-point eta quadrature."""
+    torch = torch_mod
+    n = 100000
+    cells = synth.synth_surface(n, 2)
+    o = dict(dimension=2, df_mode=1)
+    whole, _ = run_plan(torch, cells, fx["pikp"], fx["grid"], fx["df"], o)
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    parts = np.zeros_like(whole)
+    for r in range(4):
+        lo, hi = r * n // 4, (r + 1) * n // 4
+        p, _ = run_plan(torch, cells, fx["pikp"], fx["grid"], fx["df"], o, n=hi - lo, first=lo)
+        parts += p
+    assert relerr(parts, whole) < 1e-12
+    w4 = whole.reshape(1, 24, 32, 3)
+    ipT, iphi = [0, 9, 20], [0, 7, 23]
+    ref = _subset_oracle(fx, cells, [211, 321, 2212], ipT, iphi, o).reshape(1, 3, 3, 3)
+    assert relerr(w4[:, iphi][:, :, ipT], ref) < TOL

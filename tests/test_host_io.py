@@ -1,0 +1,179 @@
+"""CPU: the C++ readers/writers behind the C ABI (is3d_amd/csrc/host_io.cpp) against independent Python
+parsing of the same files -- formats and quirks of the reference."""
+import os
+
+import numpy as np
+import pytest
+
+import refformat
+from conftest import REFERENCE
+from is3d_amd import api, inputs, synth
+
+
+def test_parameter_reader_semantics(tmp_path):
+    """ParameterReader.cpp:38-155: '#' comments, blanks removed everywhere, case-insensitive names, last one wins."""
+    p = tmp_path / "iS3D_parameters.dat"
+    p.write_text("operation = 2  # first\n\n   \t\nDF_Mode\t=\t1.0e0 # case\nT_switch = 0.151\n d f _ m o d e = 2\n# only a comment\nx = -3.5e-2#c\noperation = 1\n")
+    assert api.param_get(str(p), "operation") == 1.0
+    assert api.param_get(str(p), "df_mode") == 2.0          # blanks inside the name are stripped too (arsenal.cpp:552-565)
+    assert api.param_get(str(p), "T_SWITCH") == 0.151
+    assert api.param_get(str(p), "x") == -3.5e-2
+    with pytest.raises(api.Is3dError) as e:
+        api.param_get(str(p), "dimension")                  # reference: exit(-1)
+    assert e.value.code == api.IS3D_EINVAL
+    with pytest.raises(api.Is3dError) as e:
+        api.param_get(str(tmp_path / "nope.dat"), "x")
+    assert e.value.code == api.IS3D_EIO
+    (tmp_path / "bad.dat").write_text("operation 1\n")
+    with pytest.raises(api.Is3dError):
+        api.param_get(str(tmp_path / "bad.dat"), "operation")
+
+
+def test_table_reader_drops_unterminated_last_line(tmp_path):
+    """readBlockData (arsenal.cpp:406-453): rows = newline-terminated lines; columns fixed by the first line."""
+    p = tmp_path / "t.dat"
+    p.write_text("\t0.5\t0.25\n 1.5 0.75 9\n2.5\t1.25\n\t")
+    t = api.table_read(str(p))
+    assert t.shape == (3, 2) and np.array_equal(t, [[0.5, 0.25], [1.5, 0.75], [2.5, 1.25]])
+    p.write_text("1 2\n3 4\n5 6")          # no final newline: the last line is lost, as in the reference
+    assert api.table_read(str(p)).shape == (2, 2)
+    p.write_text("1 2\n3\n")
+    with pytest.raises(api.Is3dError):
+        api.table_read(str(p))
+    p.write_text("\n1 2\n")
+    with pytest.raises(api.Is3dError):
+        api.table_read(str(p))
+
+
+def test_grid_tables_round_trip(tmp_path):
+    g = inputs.grid()
+    refformat.write_table(str(tmp_path / "phi.dat"), g["phi"], g["phi_w"], leading_tab=True, dangling_fragment=True)
+    t = api.table_read(str(tmp_path / "phi.dat"))
+    assert t.shape == (24, 2) and np.array_equal(t[:, 0], g["phi"]) and np.array_equal(t[:, 1], g["phi_w"])
+
+
+def test_surface_reader_mode1(tmp_path):
+    cells = synth.synth_surface(37, 3, seed=11)
+    path = str(tmp_path / "surface.dat")
+    synth.write_surface_dat(path, cells)
+    got, avg = api.surface_read_vh(path)
+    ref = refformat.read_surface_like_reference(path)
+    for k in synth.CELL_FIELDS:
+        assert np.array_equal(got[k], ref[k]), k
+        assert np.allclose(got[k], cells[k], rtol=4e-16, atol=0), k   # text round trip: (v / hbarc) * hbarc
+    # averages of readindata.cpp:422-466
+    ut = np.sqrt(1 + ref["ux"] ** 2 + ref["uy"] ** 2 + ref["tau"] ** 2 * ref["un"] ** 2)
+    uds = ut * ref["dat"] + ref["ux"] * ref["dax"] + ref["uy"] * ref["day"] + ref["un"] * ref["dan"]
+    dsds = ref["dat"] ** 2 - ref["dax"] ** 2 - ref["day"] ** 2 - ref["dan"] ** 2 / ref["tau"] ** 2
+    mag = np.abs(uds) + np.sqrt(np.abs(uds * uds - dsds))
+    assert np.allclose(avg[:3], [np.sum(ref[k] * mag) / np.sum(mag) for k in ("T", "E", "P")], rtol=1e-13)
+    assert avg[3] == 0.0 and avg[4] == 0.0
+
+
+def test_surface_reader_toy_file_and_errors(tmp_path):
+    p = tmp_path / "surface.dat"
+    p.write_text("0.5 0 0 0 1000.0 0 0 0 0 0 0 1.839  0.786  0.270 0 0 0 0 0 0\n")   # the reference's input/surface.dat
+    got, _ = api.surface_read_vh(str(p))
+    assert len(got["tau"]) == 1 and got["dat"][0] == 1000.0 and got["T"][0] == 0.786 * 0.197327053
+    p.write_text("0.5 0 0 0 1000.0 0 0 0 0 0 0 1.839  0.786  0.270 0 0 0 0 0 0")     # unterminated -> zero cells
+    got, _ = api.surface_read_vh(str(p))
+    assert len(got["tau"]) == 0
+    p.write_text("0.5 0 0 0 1000.0 0 0 0\n1 2 3 4 5 6 7 8\n")                          # token stream runs dry
+    with pytest.raises(api.Is3dError):
+        api.surface_read_vh(str(p))
+
+
+def test_pdg_reader(tmp_path):
+    fx = inputs.load_fixture()
+    particles = [r for r in fx["pdg_urqmd"] if r[3] >= 0]
+    path = str(tmp_path / "pdg.dat")
+    refformat.write_pdg(path, particles)
+    got = api.pdg_read(path)
+    ref = np.array(fx["pdg_urqmd"], dtype=np.float64)
+    assert len(got["mc_id"]) == 327
+    assert np.array_equal(got["mc_id"], ref[:, 0].astype(np.int64))
+    for i, k in enumerate(["mass", "gspin", "baryon", "sign"]):
+        assert np.array_equal(got[k], ref[:, i + 1]), k
+    # antibaryon follows its baryon; sign = -1 for even baryon number, also for baryon = 2 (readindata.cpp:1544)
+    i = list(got["mc_id"]).index(2212)
+    assert got["mc_id"][i + 1] == -2212 and got["baryon"][i + 1] == -1 and got["sign"][i + 1] == 1
+    # a file without trailing whitespace loses its last entry (the reference's `count - 1`, :1540)
+    refformat.write_pdg(path, particles[:3], trailing_blank=False)
+    with open(path, "rb") as f:
+        raw = f.read().rstrip()
+    with open(path, "wb") as f:
+        f.write(raw)
+    assert len(api.pdg_read(path)["mc_id"]) == 2
+
+
+def test_df_table_reader(tmp_path):
+    df = inputs.df_tables()
+    path = str(tmp_path / "c0.dat")
+    refformat.write_df_table(path, df["T"], df["c0"], "c0_T4 [fm^3/GeV^3 * GeV^4]")
+    T, v = api.df_table_read(path)
+    assert np.array_equal(T, df["T"]) and np.array_equal(v, df["c0"])   # only the mu_B = 0 block is kept
+
+
+def test_writers_format(tmp_path):
+    """emissionfunction.cpp:381-450, :729-772, :1053-1136."""
+    g = inputs.grid()
+    npart, npT, nphi, ny = 2, 32, 24, 21
+    rng = np.random.default_rng(0)
+    dN = rng.random(npart * npT * nphi * ny) * 10.0 ** rng.integers(-30, 3, npart * npT * nphi * ny)
+    os.makedirs(tmp_path / "results" / "vn_continuous")
+    res = str(tmp_path / "results")
+    api.write_results(res, 3, [211, -2212], g["pT"], g["pT_w"], g["phi"], g["phi_w"], g["y"], dN)
+    d4 = dN.reshape(ny, nphi, npT, npart)
+    lines = open(os.path.join(res, "dN_pTdpTdphidy.dat")).read().split("\n")
+    assert len(lines) == npart * ny * nphi * (npT + 1) + 1
+    assert lines[0] == "%.8e\t%.8e\t%.8e\t%.8e" % (g["y"][0], g["phi"][0], g["pT"][0], d4[0, 0, 0, 0])
+    assert lines[npT] == ""                                                      # blank line after each phi block
+    assert lines[npT + 1].split("\t")[1] == "%.8e" % g["phi"][1]
+    per = open(os.path.join(res, "dN_pTdpTdphidy_-2212.dat")).read().split("\n")
+    assert per[0] == "y\tphip\tpT\tdN_pTdpTdphidy"
+    assert per[1] == "%.8e\t%.8e\t%.8e\t%.8e" % (g["y"][0], g["phi"][0], g["pT"][0], d4[0, 0, 0, 1])
+    # dN/dy: default float format with 8 significant digits (no `scientific`)
+    dy = [ln.split("\t") for ln in open(os.path.join(res, "dN_dy_211.dat")).read().strip().split("\n")]
+    assert len(dy) == ny
+    want = np.einsum("j,i,kji->k", g["phi_w"], g["pT_w"], d4[:, :, :, 0])
+    assert dy[3][0] == "%5s" % ("%.8g" % g["y"][3])                              # setw(5) pads the y column
+    assert np.allclose([float(r[1]) for r in dy], want, rtol=2e-8)
+    # v_n: |sum w e^{ik phi} dN| / sum w dN, k = 1..7; rows per pT, blank line per y
+    vn = open(os.path.join(res, "vn_continuous", "vn_211.dat")).read().split("\n")
+    assert len(vn) == ny * (npT + 1) + 1
+    row = vn[5].split("\t")
+    assert len(row) == 9
+    num = np.sum(np.exp(2j * g["phi"]) * g["phi_w"] * d4[0, :, 5, 0])
+    assert abs(float(row[3]) - abs(num) / np.sum(g["phi_w"] * d4[0, :, 5, 0])) < 1e-7
+    # append mode: a second call doubles the file (emissionfunction.cpp:395)
+    api.write_results(res, 3, [211, -2212], g["pT"], g["pT_w"], g["phi"], g["phi_w"], g["y"], dN)
+    assert len(open(os.path.join(res, "dN_pTdpTdphidy.dat")).read().split("\n")) == 2 * (len(lines) - 1) + 1
+    # 2+1D: y printed as 0, one rapidity slice
+    os.makedirs(tmp_path / "r2" / "vn_continuous")
+    api.write_results(str(tmp_path / "r2"), 2, [211], g["pT"], g["pT_w"], g["phi"], g["phi_w"], g["y"], dN[:npT * nphi])
+    l2 = open(tmp_path / "r2" / "dN_pTdpTdphidy.dat").read().split("\n")
+    assert len(l2) == nphi * (npT + 1) + 1 and l2[0].startswith("0.00000000e+00\t")
+    with pytest.raises(api.Is3dError):
+        api.write_results(str(tmp_path / "missing_dir"), 2, [211], g["pT"], g["pT_w"], g["phi"], g["phi_w"], g["y"], dN[:npT * nphi])
+
+
+@pytest.mark.reference
+def test_readers_on_the_reference_files():
+    """The shipped data files parse to the fixture the GPU box uses (tests/golden/inputs_urqmd.json)."""
+    g = inputs.grid()
+    for key, rel in [("pT", "tables/pT_gauss_legendre_table.dat"), ("phi", "tables/phi_gauss_legendre_table.dat"),
+                     ("y", "tables/y_trapezoid_table_21pt.dat"), ("eta", "tables/eta/eta_trapezoid_table_241pt.dat")]:
+        t = api.table_read(os.path.join(REFERENCE, rel))
+        assert np.array_equal(t[:, 0], g[key]) and np.array_equal(t[:, 1], g[key + "_w"])
+    df = inputs.df_tables()
+    for name in ("c0", "c2", "F", "betabulk", "betapi"):
+        T, v = api.df_table_read(os.path.join(REFERENCE, "deltaf_coefficients/vh/urqmd", name + ".dat"))
+        assert np.array_equal(T, df["T"]) and np.array_equal(v, df[name])
+    pdg = api.pdg_read(os.path.join(REFERENCE, "PDG/pdg-urqmd_v3.3+.dat"))
+    ref = np.array(inputs.load_fixture()["pdg_urqmd"], dtype=np.float64)
+    assert np.array_equal(pdg["mc_id"], ref[:, 0].astype(np.int64)) and np.array_equal(pdg["mass"], ref[:, 1])
+    chosen = api.table_read(os.path.join(REFERENCE, "PDG/chosen_particles_urqmd_v3.3+.dat"))
+    assert chosen.shape == (305, 1) and np.array_equal(chosen[:, 0], inputs.load_fixture()["chosen_urqmd"])
+    surf, _ = api.surface_read_vh(os.path.join(REFERENCE, "input/surface.dat"))
+    assert len(surf["tau"]) == 1 and surf["P"][0] == 0.270 * 0.197327053
+    assert api.param_get(os.path.join(REFERENCE, "iS3D_parameters.dat"), "df_mode") == 4.0

@@ -1,0 +1,159 @@
+"""CPU: the oracle (oracle/cf_oracle.c) against everything that can pin it without the reference binary:
+closed-form known answers for the reference's own toy surface (config 1), scipy's independent natural
+cubic spline, an independent long-double restatement, and its own committed 64-cell vectors."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+from is3d_amd import inputs, synth
+from oracle import oracle
+
+HBARC = 0.197327053
+
+
+def toy_cell():
+    """input/surface.dat of the reference: `0.5 0 0 0 1000.0 0 0 0 0 0 0 1.839 0.786 0.270 0 0 0 0 0 0` (mode 1)."""
+    v = dict(tau=0.5, eta=0.0, dat=1000.0, dax=0.0, day=0.0, dan=0.0, ux=0.0, uy=0.0, un=0.0, E=1.839 * HBARC, T=0.786 * HBARC,
+             P=0.270 * HBARC, pixx=0.0, pixy=0.0, pixn=0.0, piyy=0.0, piyn=0.0, bulkPi=0.0)
+    return {k: np.array([x]) for k, x in v.items()}
+
+
+@pytest.mark.parametrize("df_mode", [1, 2])
+def test_config1_closed_form(fx, pins, df_mode):
+    """u = (1,0,0,0), pi = Pi = 0 => delta-f = 0: dN = g dsigma_tau mT cosh y / ((2 pi hbarc)^3 (exp(mT cosh y / T) + sign))."""
+    sp = fx["pikp"]
+    o3 = oracle.dN_pTdpTdphidy(toy_cell(), sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=df_mode)).reshape(21, 24, 32, 3)
+    o2 = oracle.dN_pTdpTdphidy(toy_cell(), sp, fx["grid"], fx["df"], dict(dimension=2, df_mode=df_mode)).reshape(1, 24, 32, 3)
+    for key, (y0, y2, bi) in pins["kat_config1"].items():
+        s, i = (int(x) for x in key.split(","))
+        assert abs(o3[10, 0, i, s] / y0 - 1) < 1e-11
+        assert abs(o3[14, 0, i, s] / y2 - 1) < 1e-11
+        assert abs(o2[0, 0, i, s] / bi - 1) < 1e-11
+    # azimuthal symmetry of the toy cell and y <-> -y symmetry at eta = 0
+    assert relerr(o3[:, 5], o3[:, 17]) < 1e-13
+    assert relerr(o3[3], o3[17]) < 1e-13
+    # closed form over the whole grid, including the exactly-zero tail (exp overflow -> 1/inf)
+    g = fx["grid"]
+    T = 0.786 * HBARC
+    pref = (2.0 * np.pi * HBARC) ** -3
+    mT = np.sqrt(sp["mass"][None, :] ** 2 + g["pT"][:, None] ** 2)
+    with np.errstate(over="ignore"):
+        for iy, y in enumerate(g["y"]):
+            e = mT * np.cosh(y)
+            ref = pref * sp["degeneracy"][None, :] * 1000.0 * e / (np.exp(e / T) + sp["sign"][None, :])
+            assert relerr(o3[iy, 3], ref) < 1e-12
+    assert o3[0, 0, 31, 0] == 0.0 and o3[10, 0, 31, 0] > 0.0
+
+
+def test_spline_matches_scipy_natural(fx, pins):
+    """GSL cspline restatement == scipy CubicSpline(bc_type='natural') on the five shipped tables."""
+    df = fx["df"]
+    for name, vals in pins["spline_scipy_natural"].items():
+        c = oracle.cspline_init(df["T"], df[name])
+        assert c[0] == 0.0 and c[-1] == 0.0
+        for T, ref in zip(pins["spline_T"], vals):
+            got = oracle.cspline_eval(df["T"], df[name], c, T)
+            assert abs(got - ref) <= 1e-12 * max(1.0, abs(ref)), (name, T)
+    # nodes are reproduced exactly, the right end is inside the domain, outside raises (GSL aborts)
+    c = oracle.cspline_init(df["T"], df["c0"])
+    assert oracle.cspline_eval(df["T"], df["c0"], c, df["T"][37]) == df["c0"][37]
+    assert oracle.cspline_eval(df["T"], df["c0"], c, df["T"][-1]) == df["c0"][-1]
+    for bad in (0.0999, 0.2001):
+        with pytest.raises(ValueError):
+            oracle.cspline_eval(df["T"], df["c0"], c, bad)
+
+
+def test_coefficient_scaling(fx):
+    """deltafReader.cpp:337-358: c0 = S/T^4, c2 = S/T^4; F = S*T, betabulk = S*T^4, betapi = S*T^4."""
+    df = fx["df"]
+    T = df["T"][55]
+    T4 = T * T * T * T
+    a = oracle.df_coefficients(df, 1, T)
+    assert a["c0"] == df["c0"][55] / T4 and a["c2"] == df["c2"][55] / T4
+    b = oracle.df_coefficients(df, 2, T)
+    assert b["F"] == df["F"][55] * T and b["betabulk"] == df["betabulk"][55] * T4 and b["betapi"] == df["betapi"][55] * T4
+
+
+def test_against_longdouble_restatement(fx, pins):
+    """tests/golden/golden_highprec.npz: independent numpy long-double restatement with scipy splines."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_highprec.npz"))
+    cellsets = {}
+    for nm in ("hand3", "seed3", "seed2"):
+        cellsets[nm] = {k: z["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS}
+    cellsets["hand2"] = {k: v[:2] for k, v in cellsets["hand3"].items()}
+    worst = 0.0
+    for case in pins["highprec_cases"]:
+        got = oracle.dN_pTdpTdphidy(cellsets[case["cells"]], fx["pikp"], fx["grid"], fx["df"], case["opts"])
+        worst = max(worst, relerr(got, z[case["key"]]))
+    assert worst < 5e-10, worst
+
+
+def test_golden_64cell_regression(fx, pins):
+    """The committed oracle vectors are reproduced bit for bit with one thread and to rounding with many."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_64cell.npz"))
+    meta = pins["golden_64cell"]
+    for k, sha in meta["sha256"].items():
+        assert hashlib.sha256(np.ascontiguousarray(z[k]).tobytes()).hexdigest() == sha
+    s3 = synth.synth_surface(64, 3, seed=meta["seed3"])
+    sp = inputs.species(meta["species3"])
+    got = oracle.dN_pTdpTdphidy(s3, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=2))
+    assert relerr(got, z["s3_df2"]) < 1e-13
+    s2 = synth.synth_surface(16, 2, seed=meta["seed2"])
+    got = oracle.dN_pTdpTdphidy(s2, fx["pikp"], fx["grid"], fx["df"], dict(dimension=2, df_mode=1))
+    assert relerr(got, z["s2_df1"]) < 1e-13
+
+
+def test_reference_shaped_variant_agrees(fx):
+    """Variant A (10 000-cell chunks + scratch + collapse(4) reduction, smooth_kernels.cpp:98-383) == variant B,
+    including a chunk size that divides the cell count exactly (the reference's empty last chunk, :351)."""
+    cells = synth.synth_surface(24, 3, seed=3)
+    sp = inputs.species([211, 2212])
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::4], phi=fx["grid"]["phi"][::3], y=fx["grid"]["y"][::2])
+    b = oracle.dN_pTdpTdphidy(cells, sp, g, fx["df"], dict(dimension=3, df_mode=1))
+    for chunk in (7, 8, 24, 10000):
+        a = oracle.dN_pTdpTdphidy(cells, sp, g, fx["df"], dict(dimension=3, df_mode=1), chunked=True, FO_chunk=chunk)
+        assert relerr(a, b) < 1e-13
+
+
+def test_skipped_and_empty_cells(fx):
+    """u.dsigma <= 0 cells contribute exactly 0 (intended semantics of :137), also when their T is outside the
+    coefficient table (the reference never evaluates the spline for them); an empty surface gives zeros;
+    the output is accumulated into (+=, :375)."""
+    cells = synth.synth_surface(6, 3, seed=5)
+    sp = fx["pikp"]
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::4], phi=fx["grid"]["phi"][::4])
+    o = dict(dimension=3, df_mode=2)
+    full = oracle.dN_pTdpTdphidy(cells, sp, g, fx["df"], o)
+    flipped = {k: v.copy() for k, v in cells.items()}
+    for k in ("dat", "dax", "day", "dan"):
+        flipped[k][[1, 4]] *= -1.0
+    flipped["T"][4] = 0.05
+    keep = {k: v[[0, 2, 3, 5]] for k, v in cells.items()}
+    assert relerr(oracle.dN_pTdpTdphidy(flipped, sp, g, fx["df"], o), oracle.dN_pTdpTdphidy(keep, sp, g, fx["df"], o)) < 1e-14
+    empty = {k: v[:0] for k, v in cells.items()}
+    assert not oracle.dN_pTdpTdphidy(empty, sp, g, fx["df"], o).any()
+    twice = oracle.dN_pTdpTdphidy(cells, sp, g, fx["df"], o, out=full.copy())
+    assert relerr(twice, 2.0 * full) < 1e-15
+
+
+def test_temperature_outside_table_is_an_error(fx):
+    cells = synth.synth_surface(3, 3, seed=6)
+    cells["T"][1] = 0.21
+    with pytest.raises(RuntimeError):
+        oracle.dN_pTdpTdphidy(cells, fx["pikp"], fx["grid"], fx["df"], dict(dimension=3, df_mode=1))
+
+
+def test_linearity_in_dsigma_and_degeneracy(fx):
+    """The spectrum is linear in dsigma_mu (with outflow the Heaviside factor is scale invariant) and in g."""
+    cells = synth.synth_surface(5, 2, seed=9)
+    sp = fx["pikp"]
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::2], phi=fx["grid"]["phi"][::2], eta=fx["grid"]["eta"][::8], eta_w=fx["grid"]["eta_w"][::8])
+    o = dict(dimension=2, df_mode=1)
+    a = oracle.dN_pTdpTdphidy(cells, sp, g, fx["df"], o)
+    c2 = {k: (2.0 * v if k in ("dat", "dax", "day", "dan") else v) for k, v in cells.items()}
+    assert relerr(oracle.dN_pTdpTdphidy(c2, sp, g, fx["df"], o), 2.0 * a) < 1e-15
+    sp3 = dict(sp, degeneracy=3.0 * sp["degeneracy"])
+    assert relerr(oracle.dN_pTdpTdphidy(cells, sp3, g, fx["df"], o), 3.0 * a) < 1e-15

@@ -1,0 +1,89 @@
+"""CPU: seeded synthetic surfaces and the N > 1 path (cell shards + one all-reduce) on gloo, world_size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+from is3d_amd import dist as idist
+from is3d_amd import inputs, synth
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_surface_properties(dim):
+    s = synth.synth_surface(5000, dim)
+    ut = np.sqrt(1 + s["ux"] ** 2 + s["uy"] ** 2 + s["tau"] ** 2 * s["un"] ** 2)
+    uds = ut * s["dat"] + s["ux"] * s["dax"] + s["uy"] * s["day"] + s["un"] * s["dan"]
+    assert (uds > 0).all()                                        # no skipped cells
+    assert s["T"].min() >= 0.140 and s["T"].max() <= 0.160        # inside the [0.1, 0.2] GeV coefficient tables
+    assert (s["tau"] >= 1).all() and (s["tau"] <= 10).all()
+    if dim == 2:
+        assert not s["dan"].any() and not s["un"].any() and not s["eta"].any() and not s["pixn"].any()
+    else:
+        assert np.abs(s["eta"]).max() <= 4.0 and s["dan"].any()
+    assert abs(np.mean(s["pixx"] / (0.02 * (s["E"] + s["P"])))) < 0.05 and abs(np.std(s["pixx"] / (0.02 * (s["E"] + s["P"]))) - 1) < 0.05
+
+
+def test_surface_is_counter_based():
+    """A rank can generate its own slice: cells depend only on (seed, global index)."""
+    a = synth.synth_surface(1000, 3)
+    b = synth.synth_surface(300, 3, first_cell=450)
+    for k in synth.CELL_FIELDS:
+        assert np.array_equal(a[k][450:750], b[k])
+    assert not np.array_equal(synth.synth_surface(10, 3, seed=1)["tau"], synth.synth_surface(10, 3, seed=2)["tau"])
+    assert synth.SEED_CONFIG2 == 20260001 and synth.SEED_CONFIG3 == 20260002
+
+
+def test_shard_bounds_cover_the_surface():
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [idist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        idist.shard_bounds(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle  # the CPU checker stands in for the GPU kernel here: this test is about the sharding
+    r, w, _ = idist.init_process_group("gloo")
+    g = inputs.grid()
+    grid = dict(pT=g["pT"][::4], phi=g["phi"][::4], y=g["y"][::3], eta=g["eta"], eta_w=g["eta_w"])
+    n = 37
+    lo, hi = idist.shard_bounds(n, r, w)
+    cells = synth.synth_surface(hi - lo, 3, seed=123, first_cell=lo)
+    part = oracle.dN_pTdpTdphidy(cells, inputs.species("pikp"), grid, inputs.df_tables(), dict(dimension=3, df_mode=2))
+    t = torch.from_numpy(part.copy())
+    idist.allreduce_spectrum(t)
+    dist.barrier()
+    if r == 0:
+        whole = oracle.dN_pTdpTdphidy(synth.synth_surface(n, 3, seed=123), inputs.species("pikp"), grid, inputs.df_tables(),
+                                      dict(dimension=3, df_mode=2))
+        q.put((t.numpy().copy(), whole))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_allreduce_to_the_whole_spectrum():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, whole = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert relerr(got, whole) < 1e-13

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Count the fp64 VALU instructions the main kernels execute per integrand evaluation, from the gfx950 ISA hipcc
+emits for is3d_amd/csrc/cf_kernels.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
+fp64-VALU roofline).  Method: for every cf_main_* instantiation take the basic blocks of the innermost loop
+that contains v_rcp_f64 (exactly one v_rcp_f64 is issued per evaluation) and divide the opcode histogram of
+those blocks by their v_rcp_f64 count.  For the 3+1D tile kernel that loop is the whole unit (header + rows),
+so the amortised exponentials are included; for 2+1D the per-unit header (<2 %) is outside the counted loop.
+
+flops: v_fma/v_fmac = 2, every other fp64 VALU op = 1 (v_rcp_f64 counts 1 although it issues at 1/4 rate).
+issue_cycles: 4 cycles per fp64-rate VALU wave-instruction, 16 for v_rcp_f64 (tools/ubench_fp64.hip measures
+4.4-5.3 and 17 at the reported 2.4 GHz clock), 2 for 32-bit integer VALU ops.
+"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "is3d_amd", "csrc", "cf_kernels.hip")
+OUT = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
+
+F64_OPS = ["v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64", "v_rcp_f64", "v_ldexp_f64",
+           "v_rndne_f64", "v_cvt_i32_f64", "v_mov_b64", "v_cmp", "v_cndmask_b32"]
+
+
+def demangle_params(sym):
+    m = re.match(r"_ZN4is3d(\d+)(cf_main_[a-z]+)I(.*?)EEvPKd", sym)
+    if not m:
+        return None
+    name, args = m.group(2), m.group(3)
+    vals = re.findall(r"L([bi])(\d+)E", args)
+    vals = [int(v) for _, v in vals]
+    if name == "cf_main_tile":
+        keys = ["CE", "DIM3", "OUTFLOW", "REG", "JT", "R"]
+    else:
+        keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
+    return name, dict(zip(keys, vals))
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        s_path = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-I", os.path.dirname(SRC), SRC, "-o", s_path], stderr=subprocess.DEVNULL)
+        text = open(s_path).read().split("\n")
+    kernels = {}
+    cur, blocks = None, None
+    for ln in text:
+        m = re.match(r"^(_ZN4is3d\d+cf_main_\w+):", ln)
+        if m:
+            cur = m.group(1)
+            blocks = [dict(depth=0, ops=collections.Counter())]
+            kernels[cur] = blocks
+            continue
+        if cur is None:
+            continue
+        if "s_endpgm" in ln:
+            cur = None
+            continue
+        m = re.match(r"^\.LBB\d+_\d+:(.*)", ln)
+        if m:
+            d = re.search(r"Depth=(\d+)", m.group(1))
+            blocks.append(dict(depth=int(d.group(1)) if d else 0, ops=collections.Counter()))
+            continue
+        m = re.match(r"^\s+([vs]_[a-z0-9_]+|ds_[a-z0-9_]+|global_[a-z0-9_]+)", ln)
+        if m:
+            blocks[-1]["ops"][m.group(1).replace("_e32", "").replace("_e64", "")] += 1
+    out = {}
+    for sym, blocks in kernels.items():
+        p = demangle_params(sym)
+        if not p:
+            continue
+        name, params = p
+        rb = [b for b in blocks if b["ops"].get("v_rcp_f64", 0) > 0]
+        if not rb:
+            continue
+        dmax = max(b["depth"] for b in rb)
+        hot = collections.Counter()
+        for b in blocks:
+            if b["depth"] >= dmax and dmax > 0:
+                hot.update(b["ops"])
+        n_eval = hot["v_rcp_f64"]
+        if n_eval == 0:
+            continue
+        f64 = {k: v for k, v in hot.items() if k.endswith("_f64") or k == "v_mov_b64"}
+        fma = hot["v_fma_f64"] + hot["v_fmac_f64"]
+        other = sum(v for k, v in f64.items() if k not in ("v_fma_f64", "v_fmac_f64", "v_mov_b64"))
+        flops = 2 * fma + other
+        full_rate = sum(v for k, v in f64.items() if k != "v_rcp_f64")
+        int_ops = sum(v for k, v in hot.items() if k.startswith("v_") and k not in f64)
+        cycles = 4 * full_rate + 16 * hot["v_rcp_f64"] + 2 * int_ops
+        key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
+        out[key] = dict(evals_in_loop=n_eval, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
+                        issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
+                        histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+    if "-v" in sys.argv:
+        for k, v in sorted(out.items()):
+            print(k, v["flop_per_eval"], v["valu_f64_instr_per_eval"], v["issue_cycles_per_eval"])
+    print("wrote", OUT, len(out), "kernels")
+
+
+if __name__ == "__main__":
+    main()
