@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_rNN.sh output directory (gpurun_out/prof_rNN) into the tracked files under profiles/:
+  rNN_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py`
+  rNN_pmc_summary.csv    per-kernel, per-counter values averaged per launch (separate --pmc passes)
+  rNN_pmc_traffic.json   HBM-side bytes per launch of the main kernel, corrected as MI355X_MICROARCH.md section HBM
+                         prescribes (FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 1/2 of the bytes
+                         of a 16-B-per-lane coalesced stream -> x2; WRITE_SIZE taken as is).
+usage: summarize_prof.py r01 config3"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload = sys.argv[2] if len(sys.argv) > 2 else "config3"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.reader(open(stats)))
+with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    for r in rows:
+        r[0] = r[0][:120]
+        w.writerow(r)
+main_avg_ns = None
+for r in rows[1:]:
+    if "cf_main" in r[0]:
+        main_avg_ns = float(r[3])
+
+agg = collections.defaultdict(float)
+cnt = collections.Counter()
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not name.startswith("is3d::"):
+                continue
+            k = (name[:60], r["Counter_Name"])
+            agg[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "launches", "value_per_launch"])
+    for k in sorted(agg):
+        w.writerow([k[0], k[1], cnt[k], "%.6g" % (agg[k] / cnt[k])])
+
+
+def per_launch(kern, counter):
+    for k in agg:
+        if kern in k[0] and k[1] == counter:
+            return agg[k] / cnt[k]
+    return None
+
+
+fetch, write = per_launch("cf_main", "FETCH_SIZE"), per_launch("cf_main", "WRITE_SIZE")
+bench = json.load(open(os.path.join(src, "trace_bench.json")))
+gui = per_launch("cf_main", "GRBM_GUI_ACTIVE")
+out = {workload: dict(cells=bench["config"]["cells_per_gpu"], kernel=bench["config"]["kernel"],
+                      FETCH_SIZE_KiB=fetch, WRITE_SIZE_KiB=write, fetch_correction=2.0,
+                      hbm_bytes_per_launch=(2.0 * fetch + write) * 1024.0,
+                      rocprof_avg_kernel_ms=main_avg_ns / 1e6 if main_avg_ns else None,
+                      bench_hip_event_kernel_ms=bench["kernel_ms"]["main"],
+                      GRBM_GUI_ACTIVE=gui,
+                      effective_clock_GHz=(gui / 8.0 / (main_avg_ns * 1e-9) / 1e9) if (main_avg_ns and gui) else None,
+                      SQ_INSTS_VALU=per_launch("cf_main", "SQ_INSTS_VALU"),
+                      SQ_ACTIVE_INST_VALU_quadcycles=per_launch("cf_main", "SQ_ACTIVE_INST_VALU"))}
+tp = os.path.join(dst, tag + "_pmc_traffic.json")
+old = json.load(open(tp)) if os.path.exists(tp) else {}
+old.update(out)
+json.dump(old, open(tp, "w"), indent=1)
+json.dump(bench, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
