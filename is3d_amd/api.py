@@ -46,7 +46,7 @@ class Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
                                          "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
                                          "accumulate", "device", "kernel_variant", "cell_chunks"]] + \
-               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("reserved", C.c_int32 * 7)]
+               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("zero_skip", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Status(C.Structure):
@@ -140,7 +140,7 @@ def _p(a):
 
 DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
                     include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1, accumulate=0, device=-1,
-                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0)
+                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0, zero_skip=0)
 
 
 def _pack_common(species, grid, df, opts):

@@ -72,6 +72,7 @@ struct MainGeom {
     int32_t Kacc;      // accumulator slots along k: K (3+1D) or 1 (2+1D)
     int32_t first_pass;  // 1: store partials, 0: add to them
     int32_t upc;       // tiled stream: units per cell within a stream (1 in 3+1D, rblocks in 2+1D)
+    int32_t zskip;     // 1: skip rows whose exponential is exactly zero for the whole wave
 };
 
 struct MainArgs {

@@ -494,7 +494,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr int BUF2 = UB * REC / 2;                       // double2 per buffer
     constexpr int NLD = (BUF2 + 255) / 256;
     static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
-    __shared__ double2 lbuf[2][BUF2];
+    __shared__ double2 lbuf[2][BUF2 + (4 + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -539,13 +539,28 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         }
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) E2[jj] = exp_full(pTD[jj] - bmax);
-        auto do_row = [&](const double *row, int r) {
-            const double mTA = mT * row[0], mTC = mT * row[1], mT2a = mT2s * row[2];
-            const double W = row[3];
-            const double E1 = exp_full(bmax - mTC);
+        // Rows are software-pipelined by hand: the operands and the exponential of row r+1 are fetched / computed
+        // before the evaluations of row r, so that neither LDS latency nor the 13-deep FMA chain of exp_core sits
+        // at the head of a row.  Exact-zero culling: exp(earg) == +0 below -745.2; then z = 0 for every phi of the
+        // tile and the row adds exactly +0 to its accumulators (what the reference computes as 1/(inf + sign) = 0).
+        // When that holds for all 64 lanes of the wave the row's evaluations are skipped: bitwise the same result,
+        // and on wide (y, eta) surfaces a quarter of all rows (high pT x large |y - eta|) go this way.
+        constexpr int RW = 4 + JT;
+        struct Row { double v[RW]; double mTC, E1; bool live; };
+        auto fetch = [&](Row &rw, const double *row) {
+#pragma unroll
+            for (int i = 0; i < RW; i++) rw.v[i] = row[i];
+            rw.mTC = mT * rw.v[1];
+            const double earg = bmax - rw.mTC;
+            rw.live = !(g.zskip && __all(earg < -745.2));
+            rw.E1 = exp_full(earg);
+        };
+        auto evals = [&](const Row &rw, int r) {
+            const double mTA = mT * rw.v[0], mT2a = mT2s * rw.v[2];
+            const double W = rw.v[3], mTC = rw.mTC, E1 = rw.E1;
 #pragma unroll
             for (int jj = 0; jj < JT; jj++) {
-                const double beta = row[4 + jj];
+                const double beta = rw.v[4 + jj];
                 double pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
                 const double z = E1 * E2[jj];
                 const double d = __builtin_fma(sign, z, 1.0);
@@ -567,13 +582,25 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 else acc[jj] = __builtin_fma(pds, w, acc[jj]);
             }
         };
+        const double *rows = U + 4 * JT;
+        Row cur, nxt;
+        fetch(cur, rows);
         if (DIM3) {
 #pragma unroll
-            for (int r = 0; r < R; r++) do_row(U + 4 * JT + r * (4 + JT), r);
+            for (int r = 0; r < R; r++) {
+                if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
+                if (cur.live) evals(cur, r);
+                if (r + 1 < R) cur = nxt;
+            }
         } else {
-            // eta quadrature rows all feed the same JT accumulators: keep the loop rolled (code size)
+            // eta quadrature rows all feed the same JT accumulators: keep the loop rolled (code size).  The fetch of
+            // "row R" reads the head of the next unit (or the pad behind the buffer); it is never evaluated.
 #pragma unroll 2
-            for (int r = 0; r < R; r++) do_row(U + 4 * JT + r * (4 + JT), 0);
+            for (int r = 0; r < R; r++) {
+                fetch(nxt, rows + (r + 1) * RW);
+                if (cur.live) evals(cur, 0);
+                cur = nxt;
+            }
         }
     };
 
@@ -697,7 +724,7 @@ static void launch_tile_t(const MainArgs &a, hipStream_t st)
 // Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.
 //   variant : 3+1D (JT x R rows of y) / 2+1D (JT x R rows of the eta table per unit)
 constexpr int kV1KT3 = 7, kV1KT2 = 4;
-constexpr int kTileJT3[3] = {8, 4, 6}, kTileR3[3] = {7, 7, 7};
+constexpr int kTileJT3[3] = {6, 8, 4}, kTileR3[3] = {7, 7, 7};
 constexpr int kTileJT2[3] = {8, 12, 4}, kTileR2[3] = {61, 61, 61};
 
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
