@@ -31,21 +31,30 @@ namespace is3d {
 // e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-12 Taylor of e^r, |r| <= ln2/2
 // (truncation 0.3466^13/13! = 1.7e-16).  Splitting mantissa and exponent lets two exponentials be
 // multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
+// 1/12!, 1/11!, ..., 1/3!
+__constant__ double kExpC[10] = {2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07,
+                                 2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04,
+                                 1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
+                                 1.66666666666666666667e-01};
+
 __device__ __forceinline__ void exp_core(double v, double &f, int &n)
 {
     double dn = __builtin_rint(v * IS3D_LOG2E);
     double r = __builtin_fma(-dn, IS3D_LN2_HI, v);
     r = __builtin_fma(-dn, IS3D_LN2_LO, r);
-    double p = 2.08767569878680989792e-09;             // 1/12!
-    p = __builtin_fma(p, r, 2.50521083854417187751e-08);  // 1/11!
-    p = __builtin_fma(p, r, 2.75573192239858906526e-07);  // 1/10!
-    p = __builtin_fma(p, r, 2.75573192239858906526e-06);  // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873015873e-05);  // 1/8!
-    p = __builtin_fma(p, r, 1.98412698412698412698e-04);  // 1/7!
-    p = __builtin_fma(p, r, 1.38888888888888888889e-03);  // 1/6!
-    p = __builtin_fma(p, r, 8.33333333333333333333e-03);  // 1/5!
-    p = __builtin_fma(p, r, 4.16666666666666666667e-02);  // 1/4!
-    p = __builtin_fma(p, r, 1.66666666666666666667e-01);  // 1/3!
+    // The non-inline Taylor coefficients come from constant memory, i.e. they sit in SGPRs: the Horner steps are
+    // then 3-address v_fma_f64 with a scalar addend.  (With literal constants hipcc keeps them in VGPRs and emits
+    // v_mov_b64 + v_fmac_f64 per step: 9 extra moves per exponential.)
+    double p = kExpC[0];
+    p = __builtin_fma(p, r, kExpC[1]);
+    p = __builtin_fma(p, r, kExpC[2]);
+    p = __builtin_fma(p, r, kExpC[3]);
+    p = __builtin_fma(p, r, kExpC[4]);
+    p = __builtin_fma(p, r, kExpC[5]);
+    p = __builtin_fma(p, r, kExpC[6]);
+    p = __builtin_fma(p, r, kExpC[7]);
+    p = __builtin_fma(p, r, kExpC[8]);
+    p = __builtin_fma(p, r, kExpC[9]);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     f = __builtin_fma(p, r, 1.0);
