@@ -14,7 +14,7 @@ constexpr double kHbarC = 0.197327053;  // src/cpp/iS3D.h:9
 //   p.dsigma            = mT*A_k + W_k*pT*B_j                        (W_k = 1 in 3+1D)
 //   p.u / T  (=: x)     = mT*Cp_k - pT*Dp_j
 //   14-moment  df/feqbar = mT^2*alpha_k + mT*pT*beta_jk + pT^2*gamma_j
-//   Chapman-E. df/feqbar = (mT^2*alpha_k + mT*pT*beta_jk + pT^2*gamma_j)/x + kappa*x
+//   Chapman-E. df/feqbar = (mT^2*alpha_k + mT*pT*beta_jk + pT^2*gamma_j)/x     (the kappa*x term is folded into alpha, beta, gamma; the kappa slot is 0)
 constexpr int kS1Rec = 4;
 constexpr int kS2Rec = 4;
 

@@ -240,7 +240,9 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             double Q0 = s.pitt * ch * ch + s.t2pinn * sh * sh - 2.0 * s.tpitn * ch * sh;
             l_A[c * K + k] = w * (ch * s.dat + sh * s.dan_tau);
             l_Cp[c * K + k] = C * s.invT;
-            l_al[c * K + k] = p.ce ? (s.shear * Q0 - s.Pb2) * s.invT : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
+            // Chapman-Enskog: the kappa*x term is folded in, (N' + kappa x^2)/x with x^2 = mT^2 Cp^2 - 2 mT pT Cp Dp + pT^2 Dp^2
+            const double Cpk = C * s.invT;
+            l_al[c * K + k] = p.ce ? ((s.shear * Q0 - s.Pb2) * s.invT + s.kappa * Cpk * Cpk) : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
             l_W[c * K + k] = w;
             l_ch[c * K + k] = ch; l_sh[c * K + k] = sh; l_C[c * K + k] = C;
         }
@@ -253,7 +255,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             double Q2 = s.pixx * cp * cp + s.piyy * sp * sp + 2.0 * s.pixy * cp * sp;
             l_B[c * J + j] = cp * s.dax + sp * s.day;
             l_Dp[c * J + j] = D * s.invT;
-            l_ga[c * J + j] = p.ce ? (s.shear * Q2 + s.Pb2) * s.invT : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
+            const double Dpj = D * s.invT;
+            l_ga[c * J + j] = p.ce ? ((s.shear * Q2 + s.Pb2) * s.invT + s.kappa * Dpj * Dpj) : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
             l_D[c * J + j] = D;
             l_E[c * J + j] = -2.0 * (s.pitx * cp + s.pity * sp);
             l_F[c * J + j] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
@@ -263,7 +266,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
         auto beta_of = [&](int c, int j, int k) {
             const CellScal &s = cs[c];
             double X = l_E[c * J + j] * l_ch[c * K + k] + l_F[c * J + j] * l_sh[c * K + k];
-            return p.ce ? s.shear * X * s.invT : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
+            return p.ce ? (s.shear * X * s.invT - 2.0 * s.kappa * l_Cp[c * K + k] * l_Dp[c * J + j])
+                        : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
         };
         if (!p.tiled) {
             // ---- phase 3 (flat): S1[cell][k][4], S2[cell][j][4], S3[cell][j][k] ----
@@ -273,7 +277,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             }
             for (int idx = tid; idx < ncb * J; idx += kPrepThreads) {
                 double *o = p.S2 + ((int64_t)cbase * J + idx) * kS2Rec;
-                o[0] = l_B[idx]; o[1] = l_Dp[idx]; o[2] = l_ga[idx]; o[3] = cs[idx / J].kappa;
+                o[0] = l_B[idx]; o[1] = l_Dp[idx]; o[2] = l_ga[idx]; o[3] = 0.0;   // kappa is folded into alpha/beta/gamma
             }
             const int JK = J * K;
             for (int idx = tid; idx < ncb * JK; idx += kPrepThreads) {
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 if (e < 4 * JT) {
                     const int jj = e >> 2, f = e & 3;
                     const int j = min(jt * JT + jj, J - 1);
-                    v = f == 0 ? l_B[c * J + j] : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : cs[c].kappa;
+                    v = f == 0 ? l_B[c * J + j] : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : 0.0;
                 } else {
                     const int q = e - 4 * JT, r = q / (4 + JT), f = q - r * (4 + JT);
                     const int k = rb * R + r;
@@ -536,14 +540,13 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
     auto process_unit = [&](const double *U) {
-        double pTB[JT], pTD[JT], pT2g[JT], E2[JT], kap = 0.0;
+        double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
         double bmax = -1.0e300;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
             pTB[jj] = pT * U[4 * jj + 0];
             pTD[jj] = pT * U[4 * jj + 1];
             pT2g[jj] = pT2s * U[4 * jj + 2];
-            if (CE) kap = hs * U[4 * jj + 3];
             bmax = __builtin_fmax(bmax, pTD[jj]);
         }
 #pragma unroll
@@ -574,17 +577,18 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 const double z = E1 * E2[jj];
                 const double d = __builtin_fma(sign, z, 1.0);
                 const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
-                double rr, inner;
+                // Chapman-Enskog: df = br / ((1 + sign z) x) with the kappa x term already inside br (cf_prep), so one
+                // reciprocal Rc = 1/((1 + sign z) x) gives df = br Rc and 1/(1 + sign z) = Rc x.
+                double rr, dfr;
                 if (CE) {
                     const double x = mTC - pTD[jj];
-                    const double Rc = rcp_nr1(d * x);  // one reciprocal for 1/(1 + sign z) and 1/x
-                    rr = Rc * x;
-                    inner = __builtin_fma(br, Rc * d, kap * x);
+                    dfr = rcp_nr1(d * x);
+                    rr = dfr * x;
                 } else {
                     rr = rcp_nr1(d);
-                    inner = br;
+                    dfr = rr;
                 }
-                const double u = REG ? fma_clamp01_half(rr, inner) : __builtin_fma(rr, inner, 1.0);
+                const double u = REG ? fma_clamp01_half(dfr, br) : __builtin_fma(dfr, br, 1.0);
                 const double w = (z * rr) * u;
                 if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
                 if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
