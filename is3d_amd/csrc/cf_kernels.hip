@@ -28,14 +28,14 @@ namespace is3d {
 #define IS3D_LN2_HI 6.93147180369123816490e-01 /* 0x3fe62e42fee00000: n*LN2_HI exact for |n| < 2^21 */
 #define IS3D_LN2_LO 1.90821492927058770002e-10 /* 0x3dea39ef35793c76 */
 
-// e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-12 Taylor of e^r, |r| <= ln2/2
-// (truncation 0.3466^13/13! = 1.7e-16).  Splitting mantissa and exponent lets two exponentials be
+// e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-10 near-minimax polynomial of e^r, |r| <= ln2/2.  Splitting mantissa and exponent lets two exponentials be
 // multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
-// 1/12!, 1/11!, ..., 1/3!
-__constant__ double kExpC[10] = {2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07,
-                                 2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04,
-                                 1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
-                                 1.66666666666666666667e-01};
+// e^r on |r| <= ln2/2 as a degree-10 polynomial (Chebyshev-node interpolant computed in long double, rounded to
+// double: max relative error 1.4e-15 over +-1.02 ln2/2); c10 .. c1, c0 = 1.
+__constant__ double kExpC[10] = {2.76263718333300477554e-07, 2.76401815125786182983e-06, 2.48015043178771474428e-05,
+                                 1.98411702685802050468e-04, 1.38888889325031097272e-03, 8.33333338566940792780e-03,
+                                 4.16666666665731558195e-02, 1.66666666665543999892e-01, 5.00000000000000555112e-01,
+                                 1.00000000000000666134e+00};
 
 __device__ __forceinline__ void exp_core(double v, double &f, int &n)
 {
@@ -55,8 +55,6 @@ __device__ __forceinline__ void exp_core(double v, double &f, int &n)
     p = __builtin_fma(p, r, kExpC[7]);
     p = __builtin_fma(p, r, kExpC[8]);
     p = __builtin_fma(p, r, kExpC[9]);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
     f = __builtin_fma(p, r, 1.0);
     n = (int)dn;
 }
@@ -696,7 +694,7 @@ cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, con
     r /= npT;
     const int j = (int)(r % J);
     const int k = (int)(r / J);
-    const int l = cls[sp] * npT + ipT;
+    const int l = cls[sp * npT + ipT];   // lane slot of (species, pT): lanes are sorted by mT, classes shared
     const int64_t stride = (int64_t)J * Kacc * Lpad;
     const double *p = partial + ((int64_t)j * Kacc + k) * Lpad + l;
     double s = 0.0;

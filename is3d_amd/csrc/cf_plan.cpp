@@ -161,14 +161,28 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     P->ncls = (int)cmass.size();
     P->L = P->ncls * P->npT;
     P->Lpad = ((P->L + 63) / 64) * 64;
+    // lane slots sorted by mT: a wave then holds momenta of similar energy, which is what makes the exact-zero
+    // row culling of the main kernel wave-uniform more often (and keeps exp arguments of a wave close together)
     std::vector<double> mT(P->Lpad, 1.0), pT(P->Lpad, 0.0), sg(P->Lpad, 1.0);
+    std::vector<int> order(P->L), slot_of(P->L);
+    std::vector<double> mT_nat(P->L);
     for (int c = 0; c < P->ncls; c++)
         for (int i = 0; i < P->npT; i++) {
             double m = cmass[c], p = g->pT[i];
-            mT[c * P->npT + i] = std::sqrt(m * m + p * p);  // :259
-            pT[c * P->npT + i] = p;
-            sg[c * P->npT + i] = csign[c];
+            mT_nat[c * P->npT + i] = std::sqrt(m * m + p * p);  // :259
+            order[c * P->npT + i] = c * P->npT + i;
         }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mT_nat[a] < mT_nat[b]; });
+    for (int s = 0; s < P->L; s++) {
+        const int nat = order[s], c = nat / P->npT, i = nat % P->npT;
+        slot_of[nat] = s;
+        mT[s] = mT_nat[nat];
+        pT[s] = g->pT[i];
+        sg[s] = csign[c];
+    }
+    std::vector<int> lane_sp((size_t)P->npart * P->npT);
+    for (int s = 0; s < P->npart; s++)
+        for (int i = 0; i < P->npT; i++) lane_sp[(size_t)s * P->npT + i] = slot_of[cls[s] * P->npT + i];
     std::vector<double> deg(sp->degeneracy, sp->degeneracy + P->npart);
     std::vector<double> cosphi(P->J), sinphi(P->J);
     for (int j = 0; j < P->J; j++) { cosphi[j] = std::cos(g->phi[j]); sinphi[j] = std::sin(g->phi[j]); }  // :43-48
@@ -181,7 +195,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     HIP_TRY(P->d_pT.upload(pT));
     HIP_TRY(P->d_sign.upload(sg));
     HIP_TRY(P->d_degeneracy.upload(deg));
-    HIP_TRY(P->d_cls.upload(cls));
+    HIP_TRY(P->d_cls.upload(lane_sp));
     HIP_TRY(P->d_cosphi.upload(cosphi));
     HIP_TRY(P->d_sinphi.upload(sinphi));
     HIP_TRY(P->d_kgrid.upload(kgrid));
