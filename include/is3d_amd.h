@@ -124,6 +124,8 @@ typedef struct {
     double ms_prep, ms_main, ms_finalize; /* device time of the three kernels (HIP events), summed over passes;
                                              filled by is3d_plan_timings / the host entry, else 0 */
     double ms_h2d, ms_d2h;              /* host entry only */
+    int64_t n_wave_rows;                /* (cell, row, wave) triples the tile kernel visited ...          */
+    int64_t n_wave_rows_culled;         /* ... and how many it skipped as exactly zero (zero_skip)        */
 } is3d_status;
 
 typedef struct is3d_plan is3d_plan;

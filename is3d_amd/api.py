@@ -52,7 +52,8 @@ class Options(C.Structure):
 class Status(C.Structure):
     _fields_ = [("code", C.c_int32), ("n_classes", C.c_int32), ("n_cells_skipped", C.c_int64), ("bad_cell", C.c_int64),
                 ("n_passes", C.c_int32), ("kernel_variant", C.c_int32), ("ms_prep", C.c_double), ("ms_main", C.c_double),
-                ("ms_finalize", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double)]
+                ("ms_finalize", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double), ("n_wave_rows", C.c_int64),
+                ("n_wave_rows_culled", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

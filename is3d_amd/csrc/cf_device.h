@@ -73,11 +73,13 @@ struct MainGeom {
     int32_t first_pass;  // 1: store partials, 0: add to them
     int32_t upc;       // tiled stream: units per cell within a stream (1 in 3+1D, rblocks in 2+1D)
     int32_t zskip;     // 1: skip rows whose exponential is exactly zero for the whole wave
+    int32_t wpb;       // lane-waves (= waves) per workgroup of the tile kernel: 2, 4 or 8
 };
 
 struct MainArgs {
     const double *S1, *S2, *S3, *TS, *lane_mT, *lane_pT, *lane_sign;
     double *partial;
+    unsigned long long *stats;   // [2] += wave-rows visited, [3] += wave-rows culled as exactly zero
     MainGeom g;
 };
 

@@ -496,14 +496,15 @@ __device__ __forceinline__ double fma_clamp01_half(double a, double b)
 // used scalar loads; each s_load sat 4 instructions in front of its s_waitcnt and the kernel ran at
 // ~60 % of its issue bound.)
 template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
-             const double *__restrict__ lane_sign, double *__restrict__ partial, MainGeom g)
+             const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats,
+             MainGeom g)
 {
     constexpr int REC = 4 * JT + R * (4 + JT);
     constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;  // units per batch (about 12 KB)
     constexpr int BUF2 = UB * REC / 2;                       // double2 per buffer
-    constexpr int NLD = (BUF2 + 255) / 256;
+    constexpr int NLD = (BUF2 + 127) / 128;                 // staging loads per thread for the smallest workgroup (2 waves)
     static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
     __shared__ double2 lbuf[2][BUF2 + (4 + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
 
@@ -517,7 +518,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     const int jt = sidx % g.jtiles; sidx /= g.jtiles;
     const int kt = sidx % g.ktiles; sidx /= g.ktiles;
     const int chunk = sidx;
-    const int lw = grp * kWPB + (tid >> 6);
+    const int nthr = blockDim.x;                            // 128, 256 or 512: g.wpb lane-waves share the stream
+    const int lw = grp * g.wpb + (tid >> 6);
     const bool wave_active = lw * 64 < g.Lpad;
     const int l = wave_active ? lw * 64 + (tid & 63) : 0;
 
@@ -537,6 +539,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
+    int n_rows = 0, n_dead = 0;   // wave-uniform bookkeeping for the executed-work accounting of bench.py
     auto process_unit = [&](const double *U) {
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
         double bmax = -1.0e300;
@@ -563,6 +566,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             rw.mTC = mT * rw.v[1];
             const double earg = bmax - rw.mTC;
             rw.live = !(g.zskip && __all(earg < -745.2));
+            n_rows += 1;
+            n_dead += rw.live ? 0 : 1;
             rw.E1 = exp_full(earg);
         };
         auto evals = [&](const Row &rw, int r) {
@@ -622,7 +627,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             const int n2 = min(UB, n_units) * (REC / 2);
 #pragma unroll
             for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * 256;
+                const int i = tid + t * nthr;
                 if (i < n2) lbuf[0][i] = src[i];
             }
         }
@@ -633,7 +638,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
 #pragma unroll
             for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * 256;
+                const int i = tid + t * nthr;
                 pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
             }
             if (wave_active) {
@@ -643,13 +648,19 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             }
 #pragma unroll
             for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * 256;
+                const int i = tid + t * nthr;
                 if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
             }
             __syncthreads();
         }
     }
     if (!wave_active) return;
+    if ((tid & 63) == 0) {
+        // the 2+1D loop fetches one row past each unit; those are not rows of the surface
+        const int fetched = DIM3 ? n_rows : n_rows - n_units;
+        atomicAdd(&stats[2], (unsigned long long)fetched);
+        atomicAdd(&stats[3], (unsigned long long)min(n_dead, fetched));
+    }
 
     const double unscale = REG ? 2.0 : 1.0;
     const int64_t JKacc = (int64_t)J * g.Kacc;
@@ -728,8 +739,8 @@ template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
 static void launch_tile_t(const MainArgs &a, hipStream_t st)
 {
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
-    hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, JT, R>), dim3(grid), dim3(kWPB * 64), 0, st, a.TS,
-                       a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
+    hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
+                       a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.stats, a.g);
 }
 
 // Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.

@@ -76,6 +76,7 @@ struct is3d_plan {
     DevBuf<double> d_splx, d_sply[3], d_splc[3];
     DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
     int rblocks = 1, upc = 1;   // row blocks of the tiled stream; units per cell within a stream
+    int wpb = 4;                // waves per workgroup of the main kernel
     DevBuf<unsigned long long> d_status;
     is3d::SplineDev spl{};
 
@@ -246,6 +247,16 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     // partial buffer <= 2 GiB
     {
         const int lane_waves = P->Lpad / 64;
+        // waves per workgroup: all waves of a workgroup stream the same records; idle waves (lane-wave count not a
+        // multiple) still occupy their SIMD slots, so take the size that wastes fewest, the larger one on ties
+        P->wpb = 4;
+        if (P->variant != 1) {
+            int best_waste = 1 << 30;
+            for (int w : {8, 4, 2}) {
+                int waste = ((lane_waves + w - 1) / w) * w - lane_waves;
+                if (waste * 64 < best_waste * 64 && waste < best_waste) { best_waste = waste; P->wpb = w; }
+            }
+        }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves
         int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24 * capacity + tasks_per_chunk - 1) / tasks_per_chunk;
@@ -264,7 +275,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
         HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
     }
     HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
-    HIP_TRY(P->d_status.alloc(2));
+    HIP_TRY(P->d_status.alloc(4));
     P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_TS.n + P->d_partial.n) * (int64_t)sizeof(double);
     *out = P.release();
     return IS3D_OK;
@@ -328,7 +339,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         }
     }
     P->last_passes = npasses;
-    unsigned long long init[2] = {~0ULL, 0ULL};
+    unsigned long long init[4] = {~0ULL, 0ULL, 0ULL, 0ULL};
     HIP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, st));
 
     int nch_used = 1;
@@ -368,10 +379,12 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.g.zskip = (o.zero_skip != 2);
             a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
             a.partial = P->d_partial.p;
+            a.stats = P->d_status.p;
             a.g.n_cells = nc;
             a.g.J = P->J; a.g.K = P->K;
             a.g.Lpad = P->Lpad;
-            a.g.G = (P->Lpad / 64 + is3d::kWavesPerBlock - 1) / is3d::kWavesPerBlock;
+            a.g.wpb = P->wpb;
+            a.g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
             a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles;
             a.g.nch = nch_used;
             a.g.NT = P->jtiles * P->ktiles * nch_used;
@@ -386,13 +399,15 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
     }
 
     if (status) {
-        unsigned long long h[2];
+        unsigned long long h[4];
         HIP_TRY(hipMemcpyAsync(h, P->d_status.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         status->n_classes = P->ncls;
         status->n_passes = npasses;
         status->kernel_variant = P->variant;
         status->n_cells_skipped = (int64_t)h[1];
+        status->n_wave_rows = (int64_t)h[2];
+        status->n_wave_rows_culled = (int64_t)h[3];
         status->bad_cell = (h[0] == ~0ULL) ? -1 : (int64_t)h[0];
         if (status->bad_cell >= 0) {
             status->code = IS3D_EDOMAIN;

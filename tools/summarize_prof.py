@@ -53,10 +53,12 @@ with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w", newline="") as f:
 
 
 def per_launch(kern, counter):
-    for k in agg:
+    """value per launch of the LAST matching kernel name (stale merged directories may hold older kernels)"""
+    hit = None
+    for k in sorted(agg):
         if kern in k[0] and k[1] == counter:
-            return agg[k] / cnt[k]
-    return None
+            hit = agg[k] / cnt[k]
+    return hit
 
 
 fetch, write = per_launch("cf_main", "FETCH_SIZE"), per_launch("cf_main", "WRITE_SIZE")
