@@ -61,7 +61,7 @@ typedef struct {
     const double *T, *P, *E;
     const double *pixx, *pixy, *pixn, *piyy, *piyn; /* other components reconstructed (:166-170) */
     const double *bulkPi;
-    const double *muB, *nB, *Vx, *Vy, *Vn; /* only read if include_baryon && include_baryondiff_deltaf */
+    const double *muB, *nB, *Vx, *Vy, *Vn; /* only read if include_baryon && include_baryondiff_deltaf (:186-197) */
 } is3d_cells;
 
 /* Replaces Mass, Sign, Degeneracy, Baryon (emissionfunction.cpp:1293-1307) */
@@ -79,21 +79,30 @@ typedef struct {
     int32_t n_eta; const double *eta, *eta_w; /* used when dimension == 2 */
 } is3d_grid;
 
-/* Replaces Deltaf_Data for the include_baryon = 0 branch: the mu_B = 0 rows of the coefficient
- * tables as loaded by load_df_coefficient_data (deltafReader.cpp:120-197), still carrying their
- * temperature scaling (c0*T^4, c2*T^4, F/T, betabulk/T^4, betapi/T^4).  The natural cubic splines
- * of construct_cubic_splines (deltafReader.cpp:300-322) are built inside. */
+/* Replaces Deltaf_Data: the coefficient tables as loaded by load_df_coefficient_data
+ * (deltafReader.cpp:120-197), still carrying their temperature scaling (c0*T^4, c1*T^3, c2*T^4, c3*T^4,
+ * c4*T^5, F/T, G, betabulk/T^4, betaV/T^3, betapi/T^4).  Every table is [n_muB][n_T], T fastest, row 0 =
+ * the lowest mu_B (= 0 in the shipped files).
+ *   include_baryon = 0: only row 0 of c0, c2 (df_mode 1) or F, betabulk, betapi (df_mode 2) is read
+ *     (n_muB may be 1, the other pointers NULL); natural cubic splines in T are built inside
+ *     (construct_cubic_splines, deltafReader.cpp:300-322; cubic_spline, :325-395).
+ *   include_baryon = 1: bilinear interpolation in (T, mu_B) over the full grids of c0..c4 (df_mode 1) or
+ *     F, G, betabulk, betaV, betapi (df_mode 2) (bilinear_interpolation, :412-484) -- with the intended
+ *     [imuB][iT] indexing; the reference's calculate_bilinear swaps the two indices (:404-407). */
 typedef struct {
     int32_t n_T;
-    const double *T;                    /* GeV, ascending */
-    const double *c0, *c2;              /* df_mode 1 */
-    const double *F, *betabulk, *betapi; /* df_mode 2 */
+    const double *T;                    /* GeV, ascending, uniform */
+    int32_t n_muB;
+    const double *muB;                  /* GeV, ascending, uniform; may be NULL when include_baryon = 0 */
+    const double *c0, *c1, *c2, *c3, *c4;           /* df_mode 1 */
+    const double *F, *G, *betabulk, *betaV, *betapi; /* df_mode 2 */
 } is3d_df_tables;
 
 typedef struct {
     int32_t dimension;                  /* 2 | 3                      DIMENSION  */
     int32_t df_mode;                    /* 1 14-moment | 2 Chapman-Enskog  DF_MODE */
-    int32_t include_baryon;             /* must be 0 (bilinear branch: not yet) */
+    int32_t include_baryon;             /* 1: mu_B/T in f_eq, bilinear (T, mu_B) coefficients (muB_fo; with
+                                           include_baryondiff_deltaf also nB_fo, Vx_fo, Vy_fo, Vn_fo) */
     int32_t include_bulk_deltaf;
     int32_t include_shear_deltaf;
     int32_t include_baryondiff_deltaf;  /* ignored unless include_baryon */
@@ -199,6 +208,10 @@ int is3d_pdg_read(const char *path, int32_t *n, int64_t *mc_id, double *mass, do
 /* Deltaf_Data::load_df_coefficient_data (src/cpp/deltafReader.cpp:65-219) for one file, mu_B = 0 row.
  * Two-call pattern (T == NULL -> only *n_T). */
 int is3d_df_table_read(const char *path, int32_t *n_T, double *T, double *value, int32_t capacity);
+/* The same file with every mu_B row (include_baryon = 1): value[iB * n_T + iT].  Two-call pattern
+ * (T == NULL -> only *n_T, *n_muB); capacity in doubles of `value`. */
+int is3d_df_table_read_full(const char *path, int32_t *n_T, int32_t *n_muB, double *T, double *muB, double *value,
+                            int64_t capacity);
 
 /* Writers (src/cpp/emissionfunction.cpp:381-450, :729-772, :1053-1136): append to
  * <dir>/dN_pTdpTdphidy.dat, <dir>/dN_pTdpTdphidy_<mcid>.dat, <dir>/dN_dy_<mcid>.dat,

@@ -39,7 +39,8 @@ class Grid(C.Structure):
 
 
 class DfTables(C.Structure):
-    _fields_ = [("n_T", C.c_int32), ("T", _dp), ("c0", _dp), ("c2", _dp), ("F", _dp), ("betabulk", _dp), ("betapi", _dp)]
+    _fields_ = [("n_T", C.c_int32), ("T", _dp), ("n_muB", C.c_int32), ("muB", _dp)] + \
+               [(n, _dp) for n in ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "betapi"]]
 
 
 class Options(C.Structure):
@@ -62,7 +63,8 @@ class Status(C.Structure):
 EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_plan_create",
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
-           "is3d_table_read", "is3d_surface_read_vh", "is3d_pdg_read", "is3d_df_table_read", "is3d_write_results"]
+           "is3d_table_read", "is3d_surface_read_vh", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
+           "is3d_write_results"]
 
 
 class Is3dError(RuntimeError):
@@ -120,6 +122,7 @@ def load():
                                        C.POINTER(_dp), _dp]
     L.is3d_pdg_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _dp, _dp, _dp, _dp, C.c_int32]
     L.is3d_df_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), _dp, _dp, C.c_int32]
+    L.is3d_df_table_read_full.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, C.c_int64]
     L.is3d_write_results.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, _dp, _dp,
                                      C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]
     _LIB = L
@@ -139,6 +142,8 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
+DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "betapi"]
+
 DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
                     include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1, accumulate=0, device=-1,
                     kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0, zero_skip=0)
@@ -152,10 +157,25 @@ def _pack_common(species, grid, df, opts):
     g = {k: _f64(grid[k]) for k in ["pT", "phi", "y", "eta", "eta_w"]}
     d = {k: _f64(df[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]}
     keep.update(sp=sp, g=g, d=d)
+    full = None
+    if "2d" in df:   # full (mu_B, T) grids: needed (and used) only with include_baryon = 1
+        full = {k: _f64(df["2d"][k]) for k in DF_NAMES_2D}
+        full["muB"] = _f64(df["muB"])
+        keep["full"] = full
     sps = Species(len(sp["mass"]), _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), _p(sp["baryon"]))
     gs = Grid(len(g["pT"]), _p(g["pT"]), len(g["phi"]), _p(g["phi"]), len(g["y"]), _p(g["y"]), len(g["eta"]),
               _p(g["eta"]), _p(g["eta_w"]))
-    ds = DfTables(len(d["T"]), _p(d["T"]), _p(d["c0"]), _p(d["c2"]), _p(d["F"]), _p(d["betabulk"]), _p(d["betapi"]))
+    ds = DfTables()
+    ds.n_T, ds.T = len(d["T"]), _p(d["T"])
+    if full is not None:
+        ds.n_muB, ds.muB = len(full["muB"]), _p(full["muB"])
+        for k in DF_NAMES_2D:
+            assert full[k].shape == (ds.n_muB, ds.n_T), k
+            setattr(ds, k, _p(full[k]))
+    else:
+        ds.n_muB = 1
+        for k in ["c0", "c2", "F", "betabulk", "betapi"]:
+            setattr(ds, k, _p(d[k]))
     os_ = Options()
     for k, v in o.items():
         setattr(os_, k, int(v))
@@ -286,6 +306,15 @@ def df_table_read(path):
     T, v = np.zeros(n.value), np.zeros(n.value)
     _check(L.is3d_df_table_read(path.encode(), C.byref(n), _p(T), _p(v), n.value))
     return T, v
+
+
+def df_table_read_full(path):
+    L = load()
+    nT, nB = C.c_int32(0), C.c_int32(0)
+    _check(L.is3d_df_table_read_full(path.encode(), C.byref(nT), C.byref(nB), None, None, None, 0))
+    T, B, v = np.zeros(nT.value), np.zeros(nB.value), np.zeros((nB.value, nT.value))
+    _check(L.is3d_df_table_read_full(path.encode(), C.byref(nT), C.byref(nB), _p(T), _p(B), _p(v), v.size))
+    return T, B, v
 
 
 def write_results(results_dir, dimension, mc_id, pT, pT_w, phi, phi_w, y, dN):

@@ -29,6 +29,13 @@ struct SplineDev {       // natural cubic spline, device copy: knots x, values y
 struct CellPtrs {        // device pointers to the caller's SoA (is3d_cells), may be null when unused
     const double *tau, *eta, *dat, *dax, *day, *dan, *ux, *uy, *un, *T, *P, *E;
     const double *pixx, *pixy, *pixn, *piyy, *piyn, *bulkPi;
+    const double *muB, *nB, *Vx, *Vy, *Vn;   // baryon diffusion arrays (include_baryon && include_baryondiff_deltaf)
+};
+
+struct BilinearDev {     // full (mu_B, T) coefficient grids for include_baryon = 1, device copies
+    int nT, nB;
+    const double *T, *muB;
+    const double *tab[5];  // df_mode 1: c0 c1 c2 c3 c4 ; df_mode 2: F G betabulk betaV betapi ; each [nB][nT]
 };
 
 struct PrepParams {
@@ -39,6 +46,9 @@ struct PrepParams {
     int32_t dim3;        // 1: 3+1D (k = y), 0: 2+1D (k = eta quadrature)
     int32_t ce;          // 1: Chapman-Enskog, 0: 14-moment
     int32_t include_bulk, include_shear;
+    int32_t baryon;      // include_baryon: bilinear coefficients, b*alpha_B in f_eq, b-linear delta-f terms
+    int32_t baryondiff;  // ... && include_baryondiff_deltaf: muB, nB, V^mu read from the cell arrays
+    BilinearDev bil;
     const double *cosphi, *sinphi;  // [J]
     const double *kgrid;            // [K] y values (3+1D) or eta nodes (2+1D)
     const double *kweight;          // [K] eta weights (2+1D), unused in 3+1D
@@ -59,7 +69,10 @@ struct PrepParams {
 //                     neutral padding (A = W = 0, Cp copied from row K-1, alpha = beta = 0)
 // 3+1D: stream s = jt*rblocks + rb, one unit per cell:        TS[(s*n_cells + cell)*REC]
 // 2+1D: stream s = jt, rblocks units per cell (eta blocks):   TS[((s*n_cells + cell)*rblocks + rb)*REC]
-inline int unit_rec_doubles(int JT, int R) { return 4 * JT + R * (4 + JT); }
+// include_baryon = 1 ("B" records): the header slot 3 holds L2_j, two doubles {alpha_B, 0} follow the header, and
+// every row carries two more scalars {L_k, 0} after W, where  b (mT L_k + pT L2_j)  is the part of df/feqbar
+// that is linear in the momentum and proportional to the baryon number b of the lane (cf_kernels.hip::cf_prep).
+inline int unit_rec_doubles(int JT, int R, int baryon = 0) { return baryon ? 4 * JT + 2 + R * (6 + JT) : 4 * JT + R * (4 + JT); }
 
 // ---- main kernel geometry ----
 struct MainGeom {
@@ -74,10 +87,11 @@ struct MainGeom {
     int32_t upc;       // tiled stream: units per cell within a stream (1 in 3+1D, rblocks in 2+1D)
     int32_t zskip;     // 1: skip rows whose exponential is exactly zero for the whole wave
     int32_t wpb;       // lane-waves (= waves) per workgroup of the tile kernel: 2, 4 or 8
+    int32_t baryon;    // 1: "B" unit records, lanes carry a baryon number
 };
 
 struct MainArgs {
-    const double *S1, *S2, *S3, *TS, *lane_mT, *lane_pT, *lane_sign;
+    const double *S1, *S2, *S3, *TS, *lane_mT, *lane_pT, *lane_sign, *lane_b;
     double *partial;
     unsigned long long *stats;   // [2] += wave-rows visited, [3] += wave-rows culled as exactly zero
     MainGeom g;

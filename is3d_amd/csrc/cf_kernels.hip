@@ -109,7 +109,30 @@ struct CellScal {
     double pitt, pitx, pity, tpitn, pixx, pixy, tpixn, piyy, tpiyn, t2pinn;
     double shear, Pb0, Pb2, kappa;
     double wvalid;  // 1.0 valid, 0.0 neutralised (skipped or out-of-table)
+    // include_baryon: alpha_B = mu_B/T; V^mu (V^tau reconstructed, :193); b1P = bulk1_coeff*Pi;
+    // cLin / cQ: coefficients of the parts of the diffusion term that are linear / quadratic in the momentum
+    double alphaB, Vt, Vx, Vy, tVn, b1P, cLin, cQ;
 };
+
+// Deltaf_Data::bilinear_interpolation (deltafReader.cpp:412-484) on the device copies of the full (mu_B, T) grids,
+// with the intended [imuB][iT] indexing (the reference's calculate_bilinear swaps the indices, :404-407).
+// Returns false outside the table (reference: printf + exit(-1), :423-427).
+__device__ __forceinline__ bool bilinear5(const BilinearDev &b, double T, double muB, double (&v)[5])
+{
+    const double T_min = b.T[0], B_min = b.muB[0];
+    const double dT = fabs(b.T[1] - b.T[0]), dB = fabs(b.muB[1] - b.muB[0]);
+    const int iTL = (int)floor((T - T_min) / dT), iTR = iTL + 1;
+    const int iBL = (int)floor((muB - B_min) / dB), iBR = iBL + 1;
+    if (!(iTL >= 0 && iTR < b.nT) || !(iBL >= 0 && iBR < b.nB)) return false;
+    const double TL = b.T[iTL], TR = b.T[iTR], BL = b.muB[iBL], BR = b.muB[iBR];
+    for (int k = 0; k < 5; k++) {
+        const double *f = b.tab[k];
+        const double f_LL = f[(size_t)iBL * b.nT + iTL], f_LR = f[(size_t)iBR * b.nT + iTL];
+        const double f_RL = f[(size_t)iBL * b.nT + iTR], f_RR = f[(size_t)iBR * b.nT + iTR];
+        v[k] = ((f_LL * (TR - T) + f_RL * (T - TL)) * (BR - muB) + (f_LR * (TR - T) + f_RR * (T - TL)) * (muB - BL)) / (dT * dB);
+    }
+    return true;
+}
 
 // gsl_interp_cspline evaluation (deltafReader.cpp:339-358 call sites) on LDS-resident tables.
 __device__ __forceinline__ double spline_eval_lds(int n, const double *x, const double *y, const double *c, double xq)
@@ -137,11 +160,12 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *sc = sy + nspl * nT;              // [nspl][nT]
     CellScal *cs = (CellScal *)(sc + nspl * nT);  // [CB]
     // per (cell, k): A, Cp, alpha, W, ch, sh, C ; per (cell, j): B, Dp, gamma, D, E, F
-    double *lk = (double *)(cs + kPrepCB);    // [7][CB][K]
-    double *lj = lk + 7 * kPrepCB * K;        // [6][CB][J]
+    double *lk = (double *)(cs + kPrepCB);    // [9][CB][K]
+    double *lj = lk + 9 * kPrepCB * K;        // [8][CB][J]
     const int CK = kPrepCB * K, CJ = kPrepCB * J;
     double *l_A = lk, *l_Cp = lk + CK, *l_al = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK, *l_C = lk + 6 * CK;
     double *l_B = lj, *l_Dp = lj + CJ, *l_ga = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_E = lj + 4 * CJ, *l_F = lj + 5 * CJ;
+    double *l_V1 = lk + 7 * CK, *l_Lk = lk + 8 * CK, *l_V2 = lj + 6 * CJ, *l_L2 = lj + 7 * CJ;   // include_baryon only
 
     const int tid = threadIdx.x;
     for (int i = tid; i < nT; i += kPrepThreads) {
@@ -170,7 +194,18 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             bool valid = udsigma > 0.0;                                           // :137
             if (!valid) atomicAdd(&p.status[1], 1ULL);
             double T = p.cells.T[gi];
-            if (valid && !(T >= sx[0] && T <= sx[nT - 1])) {                      // GSL domain error
+            double muB = 0.0, nB = 0.0, Vx = 0.0, Vy = 0.0, Vn = 0.0;
+            if (valid && p.baryon && p.baryondiff) {                              // :186-197
+                muB = p.cells.muB[gi]; nB = p.cells.nB[gi];
+                Vx = p.cells.Vx[gi]; Vy = p.cells.Vy[gi]; Vn = p.cells.Vn[gi];
+            }
+            double bl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (valid && p.baryon) {
+                if (!bilinear5(p.bil, T, muB, bl)) {                               // outside the (T, mu_B) table
+                    atomicMin(&p.status[0], (unsigned long long)gi);
+                    valid = false;
+                }
+            } else if (valid && !(T >= sx[0] && T <= sx[nT - 1])) {               // GSL domain error
                 atomicMin(&p.status[0], (unsigned long long)gi);
                 valid = false;
             }
@@ -190,17 +225,34 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 }
                 double bulkPi = p.include_bulk ? p.cells.bulkPi[gi] : 0.0;       // :173-175
                 double T2 = T * T, T4 = T2 * T2;
-                double shear, b0, b2, kappa = 0.0;
-                if (!p.ce) {                                                      // :222-229, deltafReader.cpp:337-344
-                    double c0 = spline_eval_lds(nT, sx, sy, sc, T) / T4;
-                    double c2 = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) / T4;
+                double shear, b0, b1 = 0.0, b2, kappa = 0.0, cLin = 0.0, cQ = 0.0;
+                const double T3 = T2 * T;
+                if (!p.ce) {                                                      // :222-229
+                    double c0, c2;
+                    if (p.baryon) {                                               // deltafReader.cpp:436-452
+                        c0 = bl[0] / T4; b1 = bl[1] / T3; c2 = bl[2] / T4;
+                        cLin = bl[3] / T4;                                        // c3
+                        cQ = bl[4] / (T4 * T);                                    // c4
+                    } else {                                                      // deltafReader.cpp:337-344
+                        c0 = spline_eval_lds(nT, sx, sy, sc, T) / T4;
+                        c2 = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) / T4;
+                    }
                     shear = 0.5 / (T2 * (E + P));
                     b0 = c0 - c2;
                     b2 = 4.0 * c2 - c0;
-                } else {                                                          // :230-237, deltafReader.cpp:352-358
-                    double F = spline_eval_lds(nT, sx, sy, sc, T) * T;
-                    double betabulk = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) * T4;
-                    double betapi = spline_eval_lds(nT, sx, sy + 2 * nT, sc + 2 * nT, T) * T4;
+                } else {                                                          // :230-237
+                    double F, betabulk, betapi;
+                    if (p.baryon) {                                               // deltafReader.cpp:454-468
+                        F = bl[0] * T; betabulk = bl[2] * T4; betapi = bl[4] * T4;
+                        const double G = bl[1], betaV = bl[3] * T3;
+                        b1 = G / betabulk;
+                        cLin = -1.0 / (T * betaV);                                // -(b/pu) V.p / betaV, pu = T x
+                        cQ = (nB / (E + P)) / betaV;                              // baryon_enthalpy_ratio V.p / betaV
+                    } else {                                                      // deltafReader.cpp:352-358
+                        F = spline_eval_lds(nT, sx, sy, sc, T) * T;
+                        betabulk = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) * T4;
+                        betapi = spline_eval_lds(nT, sx, sy + 2 * nT, sc + 2 * nT, T) * T4;
+                    }
                     shear = 0.5 / (betapi * T);
                     b0 = F / (T2 * betabulk);
                     b2 = 1.0 / (3.0 * T * betabulk);
@@ -213,6 +265,10 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 s.pixx = pixx; s.pixy = pixy; s.tpixn = tau * pixn; s.piyy = piyy; s.tpiyn = tau * piyn;
                 s.t2pinn = tau2 * pinn;
                 s.shear = shear; s.Pb0 = bulkPi * b0; s.Pb2 = bulkPi * b2; s.kappa = kappa;
+                s.alphaB = muB / T;                                               // :195
+                s.Vx = Vx; s.Vy = Vy; s.tVn = tau * Vn;
+                s.Vt = (Vx * ux + Vy * uy + tau2 * Vn * un) / ut;                 // :193
+                s.b1P = b1 * bulkPi; s.cLin = cLin; s.cQ = cQ;
                 s.wvalid = 1.0;
             } else {
                 // neutral cell: p.dsigma == 0 for every momentum, finite distribution -> contributes 0
@@ -220,6 +276,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 s.ut = 1.0; s.ux = s.uy = s.tau_un = 0.0; s.invT = 1.0; s.eta = 0.0;
                 s.pitt = s.pitx = s.pity = s.tpitn = s.pixx = s.pixy = s.tpixn = s.piyy = s.tpiyn = s.t2pinn = 0.0;
                 s.shear = s.Pb0 = s.Pb2 = s.kappa = 0.0;
+                s.alphaB = s.Vt = s.Vx = s.Vy = s.tVn = s.b1P = s.cLin = s.cQ = 0.0;
                 s.wvalid = 0.0;
             }
             cs[tid] = s;
@@ -240,7 +297,18 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             l_Cp[c * K + k] = C * s.invT;
             // Chapman-Enskog: the kappa*x term is folded in, (N' + kappa x^2)/x with x^2 = mT^2 Cp^2 - 2 mT pT Cp Dp + pT^2 Dp^2
             const double Cpk = C * s.invT;
-            l_al[c * K + k] = p.ce ? ((s.shear * Q0 - s.Pb2) * s.invT + s.kappa * Cpk * Cpk) : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
+            double alpha = p.ce ? ((s.shear * Q0 - s.Pb2) * s.invT + s.kappa * Cpk * Cpk) : (s.shear * Q0 + s.Pb2 * C * C + s.Pb0);
+            if (p.baryon) {
+                // V.p = mT V1_k - pT V2_j.  14-moment: (c3 b + c4 pu) V.p;  Chapman-Enskog, times x: (rho x - b/T) V.p / betaV.
+                // The part without b is a quadratic form (folded into alpha, beta, gamma); the part with b is linear:
+                // b (mT L_k + pT L2_j), together with the bulk term b1 b pu Pi (14-moment) / b1 b Pi x (Chapman-Enskog).
+                const double V1 = ch * s.Vt - sh * s.tVn;
+                const double Cq = p.ce ? Cpk : C;
+                alpha += s.cQ * Cq * V1;
+                l_V1[c * K + k] = V1;
+                l_Lk[c * K + k] = s.b1P * Cq + s.cLin * V1;
+            }
+            l_al[c * K + k] = alpha;
             l_W[c * K + k] = w;
             l_ch[c * K + k] = ch; l_sh[c * K + k] = sh; l_C[c * K + k] = C;
         }
@@ -254,7 +322,15 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             l_B[c * J + j] = cp * s.dax + sp * s.day;
             l_Dp[c * J + j] = D * s.invT;
             const double Dpj = D * s.invT;
-            l_ga[c * J + j] = p.ce ? ((s.shear * Q2 + s.Pb2) * s.invT + s.kappa * Dpj * Dpj) : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
+            double gamma = p.ce ? ((s.shear * Q2 + s.Pb2) * s.invT + s.kappa * Dpj * Dpj) : (s.shear * Q2 + s.Pb2 * D * D - s.Pb0);
+            if (p.baryon) {
+                const double V2 = cp * s.Vx + sp * s.Vy;
+                const double Dq = p.ce ? Dpj : D;
+                gamma += s.cQ * Dq * V2;
+                l_V2[c * J + j] = V2;
+                l_L2[c * J + j] = -(s.b1P * Dq + s.cLin * V2);
+            }
+            l_ga[c * J + j] = gamma;
             l_D[c * J + j] = D;
             l_E[c * J + j] = -2.0 * (s.pitx * cp + s.pity * sp);
             l_F[c * J + j] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
@@ -264,8 +340,13 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
         auto beta_of = [&](int c, int j, int k) {
             const CellScal &s = cs[c];
             double X = l_E[c * J + j] * l_ch[c * K + k] + l_F[c * J + j] * l_sh[c * K + k];
-            return p.ce ? (s.shear * X * s.invT - 2.0 * s.kappa * l_Cp[c * K + k] * l_Dp[c * J + j])
-                        : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
+            double beta = p.ce ? (s.shear * X * s.invT - 2.0 * s.kappa * l_Cp[c * K + k] * l_Dp[c * J + j])
+                               : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
+            if (p.baryon) {
+                const double Cq = p.ce ? l_Cp[c * K + k] : l_C[c * K + k], Dq = p.ce ? l_Dp[c * J + j] : l_D[c * J + j];
+                beta -= s.cQ * (Cq * l_V2[c * J + j] + Dq * l_V1[c * K + k]);
+            }
+            return beta;
         };
         if (!p.tiled) {
             // ---- phase 3 (flat): S1[cell][k][4], S2[cell][j][4], S3[cell][j][k] ----
@@ -284,7 +365,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             }
         } else {
             // ---- phase 3 (tiled): unit records, consecutive threads -> consecutive doubles ----
-            const int JT = p.JT, R = p.R, REC = 4 * JT + R * (4 + JT);
+            const int JT = p.JT, R = p.R;
+            const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
             const int units_per_cell = p.jtiles * p.rblocks;
             const int per_cell = units_per_cell * REC;
             for (int idx = tid; idx < ncb * per_cell; idx += kPrepThreads) {
@@ -296,13 +378,16 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 if (e < 4 * JT) {
                     const int jj = e >> 2, f = e & 3;
                     const int j = min(jt * JT + jj, J - 1);
-                    v = f == 0 ? l_B[c * J + j] : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : 0.0;
+                    v = f == 0 ? l_B[c * J + j] : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
+                } else if (e < HDR) {
+                    v = (e == 4 * JT) ? cs[c].alphaB : 0.0;
                 } else {
-                    const int q = e - 4 * JT, r = q / (4 + JT), f = q - r * (4 + JT);
+                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                     const int k = rb * R + r;
                     if (k < K) {
                         if (f < 4) v = f == 0 ? l_A[c * K + k] : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
-                        else v = beta_of(c, min(jt * JT + (f - 4), J - 1), k);
+                        else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : 0.0;
+                        else v = beta_of(c, min(jt * JT + (f - RS), J - 1), k);
                     } else {
                         v = (f == 1) ? l_Cp[c * K + K - 1] : 0.0;   // neutral padding row
                     }
@@ -320,7 +405,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 
 size_t prep_lds_bytes(int nT, int nspl, int J, int K)
 {
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)kPrepCB * (7 * K + 6 * J)) + sizeof(CellScal) * kPrepCB;
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)kPrepCB * (9 * K + 8 * J)) + sizeof(CellScal) * kPrepCB;
 }
 
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
@@ -495,18 +580,21 @@ __device__ __forceinline__ double fma_clamp01_half(double a, double b)
 // compiler can hoist far ahead of their use, so no evaluation waits on memory.  (The first version
 // used scalar loads; each s_load sat 4 instructions in front of its s_waitcnt and the kernel ran at
 // ~60 % of its issue bound.)
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R>
 __global__ void __launch_bounds__(512)
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
-             const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats,
-             MainGeom g)
+             const double *__restrict__ lane_sign, const double *__restrict__ lane_b, double *__restrict__ partial,
+             unsigned long long *__restrict__ stats, MainGeom g)
 {
-    constexpr int REC = 4 * JT + R * (4 + JT);
+    // unit record layout (cf_device.h); BARYON records carry alpha_B after the header and L_k in every row
+    constexpr int HDR = 4 * JT + (BARYON ? 2 : 0);
+    constexpr int RS = BARYON ? 6 : 4;          // row scalars before the beta entries
+    constexpr int REC = HDR + R * (RS + JT);
     constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;  // units per batch (about 12 KB)
     constexpr int BUF2 = UB * REC / 2;                       // double2 per buffer
     constexpr int NLD = (BUF2 + 127) / 128;                 // staging loads per thread for the smallest workgroup (2 waves)
     static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
-    __shared__ double2 lbuf[2][BUF2 + (4 + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
+    __shared__ double2 lbuf[2][BUF2 + (RS + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -527,6 +615,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
     const double hs = REG ? 0.5 : 1.0;  // u = (1 + df) * hs
     const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
+    const double bq = BARYON ? lane_b[l] : 0.0;              // baryon number of the lane's species class
+    const double hbmT = hs * bq * mT, hbpT = hs * bq * pT;
     const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
     const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
     const int n_units = (c1 - c0) * g.upc;
@@ -548,6 +638,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             pTB[jj] = pT * U[4 * jj + 0];
             pTD[jj] = pT * U[4 * jj + 1];
             pT2g[jj] = pT2s * U[4 * jj + 2];
+            if (BARYON) pT2g[jj] = __builtin_fma(hbpT, U[4 * jj + 3], pT2g[jj]);   // + hs b pT L2_j
             bmax = __builtin_fmax(bmax, pTD[jj]);
         }
 #pragma unroll
@@ -558,24 +649,26 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         // tile and the row adds exactly +0 to its accumulators (what the reference computes as 1/(inf + sign) = 0).
         // When that holds for all 64 lanes of the wave the row's evaluations are skipped: bitwise the same result,
         // and on wide (y, eta) surfaces a quarter of all rows (high pT x large |y - eta|) go this way.
-        constexpr int RW = 4 + JT;
+        const double baB = BARYON ? bq * U[4 * JT] : 0.0;   // b mu_B / T: f_eq = 1/(exp(x - b alpha_B) + sign)
+        constexpr int RW = RS + JT;
         struct Row { double v[RW]; double mTC, E1; bool live; };
         auto fetch = [&](Row &rw, const double *row) {
 #pragma unroll
             for (int i = 0; i < RW; i++) rw.v[i] = row[i];
             rw.mTC = mT * rw.v[1];
-            const double earg = bmax - rw.mTC;
+            const double earg = BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC;
             rw.live = !(g.zskip && __all(earg < -745.2));
             n_rows += 1;
             n_dead += rw.live ? 0 : 1;
             rw.E1 = exp_full(earg);
         };
         auto evals = [&](const Row &rw, int r) {
-            const double mTA = mT * rw.v[0], mT2a = mT2s * rw.v[2];
+            const double mTA = mT * rw.v[0];
+            const double mT2a = BARYON ? __builtin_fma(hbmT, rw.v[4], mT2s * rw.v[2]) : mT2s * rw.v[2];   // + hs b mT L_k
             const double W = rw.v[3], mTC = rw.mTC, E1 = rw.E1;
 #pragma unroll
             for (int jj = 0; jj < JT; jj++) {
-                const double beta = rw.v[4 + jj];
+                const double beta = rw.v[RS + jj];
                 double pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
                 const double z = E1 * E2[jj];
                 const double d = __builtin_fma(sign, z, 1.0);
@@ -598,7 +691,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 else acc[jj] = __builtin_fma(pds, w, acc[jj]);
             }
         };
-        const double *rows = U + 4 * JT;
+        const double *rows = U + HDR;
         Row cur, nxt;
         fetch(cur, rows);
         if (DIM3) {
@@ -739,8 +832,12 @@ template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
 static void launch_tile_t(const MainArgs &a, hipStream_t st)
 {
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
-    hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
-                       a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.stats, a.g);
+    if (a.g.baryon)
+        hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, true, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
+                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g);
+    else
+        hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, false, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
+                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g);
 }
 
 // Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.

@@ -7,7 +7,7 @@ constexpr int kWavesPerBlock = 4;
 size_t prep_lds_bytes(int nT, int nspl, int J, int K);
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 void main_tile_shape(int variant, int dim3, int *JT, int *KT);
-hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st);
+hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st);  // a.g.baryon selects the B kernels
 hipError_t launch_finalize(const double *partial, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
                            int accumulate, hipStream_t stream);

@@ -71,7 +71,10 @@ struct is3d_plan {
     size_t bytes_per_cell = 0;
     double prefactor = 0;
 
-    DevBuf<double> d_mT, d_pT, d_sign, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
+    DevBuf<double> d_mT, d_pT, d_sign, d_lane_b, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
+    DevBuf<double> d_bilT, d_bilB, d_biltab[5];
+    is3d::BilinearDev bil{};
+    bool baryon = false, baryondiff = false;
     DevBuf<int> d_cls;
     DevBuf<double> d_splx, d_sply[3], d_splc[3];
     DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
@@ -98,8 +101,15 @@ static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_ta
     if (o->dimension != 2 && o->dimension != 3) return fail(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", o->dimension);
     if (o->df_mode != 1 && o->df_mode != 2)
         return fail(IS3D_EINVAL, "df_mode must be 1 (14-moment) or 2 (Chapman-Enskog) on this path (got %d)", o->df_mode);
-    if (o->include_baryon)
-        return fail(IS3D_EINVAL, "include_baryon = 1 (bilinear (T, muB) coefficients, baryon diffusion) is not implemented yet");
+    if (o->include_baryon) {
+        if (o->kernel_variant == 1) return fail(IS3D_EINVAL, "include_baryon = 1 runs on the tile kernel only (kernel_variant 2-4)");
+        if (!sp->baryon) return fail(IS3D_EINVAL, "include_baryon = 1 needs the species' baryon numbers");
+        if (df->n_muB < 2 || !df->muB) return fail(IS3D_EINVAL, "include_baryon = 1 needs the full (T, muB) coefficient tables");
+        for (int i = 1; i < df->n_muB; i++)
+            if (!(df->muB[i] > df->muB[i - 1])) return fail(IS3D_EINVAL, "coefficient table muB values must ascend");
+        if (o->df_mode == 1 && (!df->c1 || !df->c3 || !df->c4)) return fail(IS3D_EINVAL, "include_baryon = 1, df_mode 1 needs c0..c4 tables");
+        if (o->df_mode == 2 && (!df->G || !df->betaV)) return fail(IS3D_EINVAL, "include_baryon = 1, df_mode 2 needs F, G, betabulk, betaV, betapi tables");
+    }
     if (sp->n < 1 || !sp->mass || !sp->sign || !sp->degeneracy) return fail(IS3D_EINVAL, "empty species list");
     if (g->n_pT < 1 || g->n_phi < 1 || !g->pT || !g->phi) return fail(IS3D_EINVAL, "empty pT/phi grid");
     if (o->dimension == 3 && (g->n_y < 1 || !g->y)) return fail(IS3D_EINVAL, "dimension 3 needs a y grid");
@@ -149,14 +159,18 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
-    std::vector<double> cmass, csign;
+    // (with include_baryon the baryon number enters f_eq and delta-f, so it is part of the class key)
+    P->baryon = o->include_baryon != 0;
+    P->baryondiff = P->baryon && o->include_baryondiff_deltaf != 0;
+    std::vector<double> cmass, csign, cbar;
     const bool collapse = (o->collapse_species != 2);
     for (int s = 0; s < P->npart; s++) {
         int found = -1;
+        const double bs = P->baryon ? sp->baryon[s] : 0.0;
         if (collapse)
             for (size_t c = 0; c < cmass.size(); c++)
-                if (cmass[c] == sp->mass[s] && csign[c] == sp->sign[s]) { found = (int)c; break; }
-        if (found < 0) { found = (int)cmass.size(); cmass.push_back(sp->mass[s]); csign.push_back(sp->sign[s]); }
+                if (cmass[c] == sp->mass[s] && csign[c] == sp->sign[s] && cbar[c] == bs) { found = (int)c; break; }
+        if (found < 0) { found = (int)cmass.size(); cmass.push_back(sp->mass[s]); csign.push_back(sp->sign[s]); cbar.push_back(bs); }
         cls[s] = found;
     }
     P->ncls = (int)cmass.size();
@@ -164,7 +178,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     P->Lpad = ((P->L + 63) / 64) * 64;
     // lane slots sorted by mT: a wave then holds momenta of similar energy, which is what makes the exact-zero
     // row culling of the main kernel wave-uniform more often (and keeps exp arguments of a wave close together)
-    std::vector<double> mT(P->Lpad, 1.0), pT(P->Lpad, 0.0), sg(P->Lpad, 1.0);
+    std::vector<double> mT(P->Lpad, 1.0), pT(P->Lpad, 0.0), sg(P->Lpad, 1.0), lb(P->Lpad, 0.0);
     std::vector<int> order(P->L), slot_of(P->L);
     std::vector<double> mT_nat(P->L);
     for (int c = 0; c < P->ncls; c++)
@@ -180,6 +194,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
         mT[s] = mT_nat[nat];
         pT[s] = g->pT[i];
         sg[s] = csign[c];
+        lb[s] = cbar[c];
     }
     std::vector<int> lane_sp((size_t)P->npart * P->npT);
     for (int s = 0; s < P->npart; s++)
@@ -195,6 +210,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     HIP_TRY(P->d_mT.upload(mT));
     HIP_TRY(P->d_pT.upload(pT));
     HIP_TRY(P->d_sign.upload(sg));
+    HIP_TRY(P->d_lane_b.upload(lb));
     HIP_TRY(P->d_degeneracy.upload(deg));
     HIP_TRY(P->d_cls.upload(lane_sp));
     HIP_TRY(P->d_cosphi.upload(cosphi));
@@ -221,6 +237,22 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
         P->spl.y[s] = P->d_sply[s].p;
         P->spl.c[s] = P->d_splc[s].p;
     }
+    if (P->baryon) {
+        // full (mu_B, T) grids for the bilinear branch (deltafReader.cpp:412-484)
+        const double *t5[5];
+        if (!P->ce) { t5[0] = df->c0; t5[1] = df->c1; t5[2] = df->c2; t5[3] = df->c3; t5[4] = df->c4; }
+        else { t5[0] = df->F; t5[1] = df->G; t5[2] = df->betabulk; t5[3] = df->betaV; t5[4] = df->betapi; }
+        std::vector<double> bs(df->muB, df->muB + df->n_muB);
+        HIP_TRY(P->d_bilT.upload(xs));
+        HIP_TRY(P->d_bilB.upload(bs));
+        P->bil.nT = df->n_T; P->bil.nB = df->n_muB;
+        P->bil.T = P->d_bilT.p; P->bil.muB = P->d_bilB.p;
+        for (int k = 0; k < 5; k++) {
+            std::vector<double> tv(t5[k], t5[k] + (size_t)df->n_T * df->n_muB);
+            HIP_TRY(P->d_biltab[k].upload(tv));
+            P->bil.tab[k] = P->d_biltab[k].p;
+        }
+    }
     if (is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K) > 160 * 1024)
         return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
 
@@ -232,7 +264,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;   // k tiles are separate tasks only in 3+1D
     P->upc = (tiled && !P->dim3) ? P->rblocks : 1;            // 2+1D: eta blocks are consecutive units of one stream
     if (tiled)
-        P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT);
+        P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0);
     else
         P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
     int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
@@ -325,6 +357,8 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         if (o.include_shear_deltaf && (!cells->pixx || !cells->pixy || !cells->pixn || !cells->piyy || !cells->piyn))
             return fail(IS3D_EINVAL, "include_shear_deltaf needs pixx, pixy, pixn, piyy, piyn");
         if (o.include_bulk_deltaf && !cells->bulkPi) return fail(IS3D_EINVAL, "include_bulk_deltaf needs bulkPi");
+        if (P->baryondiff && (!cells->muB || !cells->nB || !cells->Vx || !cells->Vy || !cells->Vn))
+            return fail(IS3D_EINVAL, "include_baryon && include_baryondiff_deltaf need muB, nB, Vx, Vy, Vn");
     }
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(P->device));
@@ -361,6 +395,9 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             pp.dim3 = P->dim3; pp.ce = P->ce;
             pp.include_bulk = o.include_bulk_deltaf != 0;
             pp.include_shear = o.include_shear_deltaf != 0;
+            pp.baryon = P->baryon; pp.baryondiff = P->baryondiff;
+            pp.bil = P->bil;
+            pp.cells.muB = cells->muB; pp.cells.nB = cells->nB; pp.cells.Vx = cells->Vx; pp.cells.Vy = cells->Vy; pp.cells.Vn = cells->Vn;
             pp.cosphi = P->d_cosphi.p; pp.sinphi = P->d_sinphi.p;
             pp.kgrid = P->d_kgrid.p; pp.kweight = P->d_kweight.p;
             pp.spl = P->spl;
@@ -377,7 +414,8 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.S1 = P->d_S1.p; a.S2 = P->d_S2.p; a.S3 = P->d_S3.p; a.TS = P->d_TS.p;
             a.g.upc = P->upc;
             a.g.zskip = (o.zero_skip != 2);
-            a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
+            a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p; a.lane_b = P->d_lane_b.p;
+            a.g.baryon = P->baryon;
             a.partial = P->d_partial.p;
             a.stats = P->d_status.p;
             a.g.n_cells = nc;
@@ -455,17 +493,20 @@ extern "C" int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *
     (void)is3d_plan_set_timing(P, 1);
 
     const int64_t n = cells->n_cells;
-    const double *src[18] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
-                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
+    const bool diff = opts->include_baryon && opts->include_baryondiff_deltaf;
+    const double *src[23] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
+                             diff ? cells->muB : nullptr, diff ? cells->nB : nullptr, diff ? cells->Vx : nullptr,
+                             diff ? cells->Vy : nullptr, diff ? cells->Vn : nullptr};
     DevBuf<double> dcell, dout;
-    HIP_TRY(dcell.alloc((size_t)std::max<int64_t>(n, 1) * 18));
+    HIP_TRY(dcell.alloc((size_t)std::max<int64_t>(n, 1) * 23));
     HIP_TRY(dout.alloc((size_t)P->nout));
     hipEvent_t e0, e1, e2, e3;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2)); HIP_TRY(hipEventCreate(&e3));
     struct EvGuard { hipEvent_t e[4]; ~EvGuard() { for (auto x : e) (void)hipEventDestroy(x); } } evg{{e0, e1, e2, e3}};
     HIP_TRY(hipEventRecord(e0, nullptr));
-    const double *dptr[18];
-    for (int a = 0; a < 18; a++) {
+    const double *dptr[23];
+    for (int a = 0; a < 23; a++) {
         dptr[a] = nullptr;
         if (src[a] && n > 0) {
             HIP_TRY(hipMemcpyAsync(dcell.p + (size_t)a * n, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
@@ -479,6 +520,7 @@ extern "C" int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *
     dc.tau = dptr[0]; dc.eta = dptr[1]; dc.dat = dptr[2]; dc.dax = dptr[3]; dc.day = dptr[4]; dc.dan = dptr[5];
     dc.ux = dptr[6]; dc.uy = dptr[7]; dc.un = dptr[8]; dc.T = dptr[9]; dc.P = dptr[10]; dc.E = dptr[11];
     dc.pixx = dptr[12]; dc.pixy = dptr[13]; dc.pixn = dptr[14]; dc.piyy = dptr[15]; dc.piyn = dptr[16]; dc.bulkPi = dptr[17];
+    dc.muB = dptr[18]; dc.nB = dptr[19]; dc.Vx = dptr[20]; dc.Vy = dptr[21]; dc.Vn = dptr[22];
     is3d_status st{};
     rc = is3d_plan_execute(P, &dc, dout.p, nullptr, &st);
     if (rc) { if (status) *status = st; return rc; }

@@ -328,6 +328,43 @@ extern "C" int is3d_df_table_read(const char *path, int32_t *n_T, double *T, dou
     return IS3D_OK;
 }
 
+// The same file with all mu_B rows (include_baryon = 1): value[iB * n_T + iT], storage order of
+// load_df_coefficient_data (deltafReader.cpp:168-196).
+extern "C" int is3d_df_table_read_full(const char *path, int32_t *n_T, int32_t *n_muB, double *T, double *muB, double *value,
+                                       int64_t capacity)
+{
+    if (!path || !n_T || !n_muB) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "couldn't open coefficient file %s", path);
+    const char *p = text.c_str();
+    char *q;
+    long nT = strtol(p, &q, 10);
+    if (q == p || nT < 1) return io_fail(IS3D_EIO, "%s: bad T dimension", path);
+    p = q;
+    long nB = strtol(p, &q, 10);
+    if (q == p || nB < 1) return io_fail(IS3D_EIO, "%s: bad muB dimension", path);
+    p = q;
+    while (*p && isspace((unsigned char)*p)) p++;
+    while (*p && *p != '\n') p++;
+    *n_T = (int32_t)nT;
+    *n_muB = (int32_t)nB;
+    if (!T) return IS3D_OK;
+    if (!muB || !value || (int64_t)nT * nB > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %lld < %ld", path, (long long)capacity, nT * nB);
+    for (long ib = 0; ib < nB; ib++)
+        for (long i = 0; i < nT; i++) {
+            double v3[3];
+            for (int c = 0; c < 3; c++) {
+                v3[c] = strtod(p, &q);
+                if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, ib * nT + i);
+                p = q;
+            }
+            T[i] = v3[0];
+            muB[ib] = v3[1];
+            value[ib * nT + i] = v3[2];
+        }
+    return IS3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // write_dN_pTdpTdphidy_toFile (src/cpp/emissionfunction.cpp:381-450), write_continuous_vn_toFile
 // (:1053-1136), write_dN_dy_toFile (:729-772); same order as calculate_spectra calls them (:1678-1686).

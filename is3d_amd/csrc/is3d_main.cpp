@@ -9,7 +9,7 @@
 // and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
 // (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
-// Scope: operation = 1, mode = 1, df_mode in {1, 2}, include_baryon = 0.  Anything else is refused
+// Scope: operation = 1, mode = 1, df_mode in {1, 2}, include_baryon in {0, 1}.  Anything else is refused
 // with a message instead of silently doing something different from the reference.
 #include <cmath>
 #include <cstdio>
@@ -91,7 +91,6 @@ int main(int argc, char **argv)
     if (operation != 1) DIE("operation = %d: only operation = 1 (smooth momentum spectra) is on this path", operation);
     if (mode != 1) DIE("mode = %d: only the mode-1 (gpu-vh) surface format is read so far", mode);
     if (df_mode != 1 && df_mode != 2) DIE("df_mode = %d: only 1 (14-moment) and 2 (Chapman-Enskog)", df_mode);
-    if (include_baryon) DIE("include_baryon = 1 is not implemented yet");
     const char *pdg_path, *df_dir;
     if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
     else if (hrg_eos == 2) { pdg_path = "PDG/pdg_smash.dat"; df_dir = "deltaf_coefficients/vh/smash/"; }
@@ -100,15 +99,16 @@ int main(int argc, char **argv)
     double t0 = now_s();
     // ---- surface (iS3D.cpp:90-98) ----
     int64_t n_cells = 0;
-    if (is3d_surface_read_vh("input/surface.dat", 0, 0, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
+    if (is3d_surface_read_vh("input/surface.dat", include_baryon, include_diff, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
     std::vector<std::vector<double>> arr(23);
     double *ptr[23];
     for (int a = 0; a < 23; a++) {
-        arr[a].assign(a < 18 ? (size_t)n_cells : 0, 0.0);
-        ptr[a] = a < 18 ? arr[a].data() : nullptr;
+        const bool used = a < 18 || (a == 18 && include_baryon) || (a > 18 && include_diff);
+        arr[a].assign(used ? (size_t)n_cells : 0, 0.0);
+        ptr[a] = used ? arr[a].data() : nullptr;
     }
     double avg[5] = {0, 0, 0, 0, 0};
-    if (n_cells > 0 && is3d_surface_read_vh("input/surface.dat", 0, 0, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
+    if (n_cells > 0 && is3d_surface_read_vh("input/surface.dat", include_baryon, include_diff, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
     {
         std::ofstream f("average_thermodynamic_quantities.dat", std::ios_base::out);
         f << std::setprecision(15) << avg[0] << "\n" << avg[1] << "\n" << avg[2] << "\n" << avg[3] << "\n" << avg[4];
@@ -140,15 +140,26 @@ int main(int argc, char **argv)
         read_table("tables/y_trapezoid_table_21pt.dat", y, yw) || read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
         DIE("%s", is3d_last_error());
     // ---- delta-f coefficient tables (iS3D.cpp:144-145) ----
-    const char *names[5] = {"c0.dat", "c2.dat", "F.dat", "betabulk.dat", "betapi.dat"};
-    std::vector<double> Tk, tab[5];
-    for (int t = 0; t < 5; t++) {
+    //      include_baryon = 0: the mu_B = 0 rows; include_baryon = 1: the full (mu_B, T) grids (deltafReader.cpp:134)
+    const char *names[10] = {"c0.dat", "c1.dat", "c2.dat", "c3.dat", "c4.dat", "F.dat", "G.dat", "betabulk.dat", "betaV.dat", "betapi.dat"};
+    std::vector<double> Tk, Bk, tab[10];
+    for (int t = 0; t < 10; t++) {
         std::string p = std::string(df_dir) + names[t];
-        int32_t nT = 0;
-        if (is3d_df_table_read(p.c_str(), &nT, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
-        Tk.resize(nT);
-        tab[t].resize(nT);
-        if (is3d_df_table_read(p.c_str(), &nT, Tk.data(), tab[t].data(), nT)) DIE("%s", is3d_last_error());
+        int32_t nT = 0, nB = 0;
+        const bool spline_table = (t == 0 || t == 2 || t == 5 || t == 7 || t == 9);   // c0 c2 F betabulk betapi
+        if (!include_baryon && !spline_table) continue;   // only the bilinear branch looks at c1 c3 c4 G betaV
+        if (is3d_df_table_read_full(p.c_str(), &nT, &nB, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (!include_baryon) {
+            Tk.resize(nT);
+            Bk.assign(1, 0.0);
+            tab[t].resize(nT);
+            if (is3d_df_table_read(p.c_str(), &nT, Tk.data(), tab[t].data(), nT)) DIE("%s", is3d_last_error());
+        } else {
+            Tk.resize(nT);
+            Bk.resize(nB);
+            tab[t].resize((size_t)nT * nB);
+            if (is3d_df_table_read_full(p.c_str(), &nT, &nB, Tk.data(), Bk.data(), tab[t].data(), (int64_t)tab[t].size())) DIE("%s", is3d_last_error());
+        }
     }
     double t1 = now_s();
     printf("Total number of freezeout cells: %lld\nNumber of chosen particles: %zu\n", (long long)n_cells, mcid.size());
@@ -160,12 +171,14 @@ int main(int argc, char **argv)
     cells.dat = ptr[8]; cells.dax = ptr[9]; cells.day = ptr[10]; cells.dan = ptr[11];
     cells.pixx = ptr[12]; cells.pixy = ptr[13]; cells.pixn = ptr[14]; cells.piyy = ptr[15]; cells.piyn = ptr[16];
     cells.bulkPi = ptr[17];
+    cells.muB = ptr[18]; cells.nB = ptr[19]; cells.Vx = ptr[20]; cells.Vy = ptr[21]; cells.Vn = ptr[22];
     is3d_species sp{(int32_t)mcid.size(), mass.data(), sign.data(), deg.data(), bar.data()};
     is3d_grid grid{(int32_t)pT.size(), pT.data(), (int32_t)phi.size(), phi.data(), (int32_t)y.size(), y.data(),
                    (int32_t)eta.size(), eta.data(), etaw.data()};
-    is3d_df_tables df{(int32_t)Tk.size(), Tk.data(), tab[0].data(), tab[1].data(), tab[2].data(), tab[3].data(), tab[4].data()};
+    is3d_df_tables df{(int32_t)Tk.size(), Tk.data(), (int32_t)Bk.size(), Bk.data(), tab[0].data(), tab[1].data(), tab[2].data(),
+                      tab[3].data(), tab[4].data(), tab[5].data(), tab[6].data(), tab[7].data(), tab[8].data(), tab[9].data()};
     is3d_options opts{};
-    opts.dimension = dimension; opts.df_mode = df_mode; opts.include_baryon = 0;
+    opts.dimension = dimension; opts.df_mode = df_mode; opts.include_baryon = include_baryon;
     opts.include_bulk_deltaf = include_bulk; opts.include_shear_deltaf = include_shear; opts.include_baryondiff_deltaf = include_diff;
     opts.regulate_deltaf = regulate; opts.outflow = outflow;
     opts.accumulate = 0; opts.device = -1; opts.kernel_variant = variant;

@@ -32,6 +32,20 @@ def df_tables():
     return {k: np.array(d[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]}
 
 
+DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "betapi"]
+
+
+def df_tables_full():
+    """df_tables() plus the full (mu_B, T) grids of all ten coefficient tables (include_baryon = 1):
+    keys T, muB and one [n_muB][n_T] array per name in DF_NAMES_2D under key "2d"."""
+    z = np.load(os.path.join(_ROOT, "tests", "golden", "df_urqmd_full.npz"))
+    d = df_tables()
+    assert np.array_equal(d["T"], z["T"])
+    d["muB"] = z["muB"].copy()
+    d["2d"] = {k: np.ascontiguousarray(z[k]) for k in DF_NAMES_2D}
+    return d
+
+
 def species(which="pikp"):
     """which: 'pikp' (chosen_particles_pikp.dat) | 'urqmd' (chosen_particles_urqmd_v3.3+.dat, 305) |
     list of mc_ids.  Order = order of the chosen list (emissionfunction.cpp:336-351)."""

@@ -37,7 +37,10 @@ def _uniform(seed, counters):
     return (z >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
 
 
-def synth_surface(n_cells, dimension, seed=None, first_cell=0):
+BARYON_FIELDS = ["muB", "nB", "Vx", "Vy", "Vn"]
+
+
+def synth_surface(n_cells, dimension, seed=None, first_cell=0, baryon=False):
     """Cells [first_cell, first_cell + n_cells) of the infinite seeded surface -> dict of float64 arrays
     (CELL_FIELDS plus x, y).  A rank of a sharded run asks for its own slice directly."""
     if dimension not in (2, 3):
@@ -85,6 +88,13 @@ def synth_surface(n_cells, dimension, seed=None, first_cell=0):
         s["dan"] = 0.1 * dat * (2.0 * U(15) - 1.0)
         s["pixn"] = 0.02 * (E + P) * N(16) / tau
         s["piyn"] = 0.02 * (E + P) * N(18) / tau
+    if baryon:
+        # include_baryon = 1 extras: mu_B inside the [0, 0.8] GeV table, net baryon density, diffusion current V^mu
+        s["muB"] = 0.05 + 0.35 * U(20)
+        s["nB"] = 0.02 + 0.08 * U(21)
+        s["Vx"] = 0.002 * N(22)
+        s["Vy"] = 0.002 * N(24)
+        s["Vn"] = (0.002 * N(26) / tau) if dimension == 3 else np.zeros(n_cells)
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in s.items()}
 
 
@@ -95,4 +105,6 @@ def write_surface_dat(path, s):
     cols = [s["tau"], s["x"], s["y"], s["eta"], s["dat"], s["dax"], s["day"], s["dan"], s["ux"], s["uy"], s["un"],
             s["E"] / h, s["T"] / h, s["P"] / h, s["pixx"] / h, s["pixy"] / h, s["pixn"] / h, s["piyy"] / h,
             s["piyn"] / h, s["bulkPi"] / h]
+    if "muB" in s:   # include_baryon: + muB [fm^-1]; include_baryondiff_deltaf: + nB Vx Vy Vn (readindata.cpp:399-420)
+        cols += [s["muB"] / h, s["nB"], s["Vx"], s["Vy"], s["Vn"]]
     np.savetxt(path, np.column_stack(cols), fmt="%.17e", delimiter=" ")

@@ -129,6 +129,11 @@ typedef struct {
     const double *T;        /* knots, GeV (deltafReader.cpp:184-196, first points_T rows) */
     const double *c0, *c2;  /* 14 moment, scaled by T^4  (deltafReader.cpp:337-344) */
     const double *F, *betabulk, *betapi; /* Chapman-Enskog: F/T, betabulk/T^4, betapi/T^4 (:352-358) */
+    /* include_baryon = 1 only: the full (mu_B, T) tables as load_df_coefficient_data stores them,
+     * data[iB][iT] (deltafReader.cpp:168-196); order c0 c1 c2 c3 c4 F G betabulk betaV betapi */
+    int n_muB;
+    const double *muB;
+    const double *t2d[10];
 } oracle_df_tables;
 
 typedef struct {
@@ -171,16 +176,65 @@ static int eval_df(const oracle_df_tables *t, const double *sc0, const double *s
     return 0;
 }
 
+/* Deltaf_Data::bilinear_interpolation (deltafReader.cpp:412-484), INTENDED indexing: the reference's
+ * calculate_bilinear reads f_data[iT][imuB] (:404-407) although the tables are stored [imuB][iT]
+ * (:168-196) -- a transposed-index defect (out of bounds for T > 0.18 GeV); the restatement uses
+ * f_data[imuB][iT].  Returns -1 outside the table (reference: printf + exit(-1), :423-427). */
+static int eval_df_bilinear(const oracle_df_tables *t, int df_mode, double T, double muB, df_coeff *df)
+{
+    memset(df, 0, sizeof(*df));
+    const int nT = t->n_T, nB = t->n_muB;
+    if (nB < 2 || !t->muB) return -4;
+    const double T_min = t->T[0], muB_min = t->muB[0];
+    const double dT = fabs(t->T[1] - t->T[0]), dmuB = fabs(t->muB[1] - t->muB[0]);
+    int iTL = (int)floor((T - T_min) / dT), iTR = iTL + 1;
+    int iBL = (int)floor((muB - muB_min) / dmuB), iBR = iBL + 1;
+    if (!(iTL >= 0 && iTR < nT) || !(iBL >= 0 && iBR < nB)) return -1;
+    const double TL = t->T[iTL], TR = t->T[iTR], BL = t->muB[iBL], BR = t->muB[iBR];
+    double v[10];
+    for (int k = 0; k < 10; k++) {
+        const double *f = t->t2d[k];
+        if (!f) return -4;
+        double f_LL = f[(size_t)iBL * nT + iTL], f_LR = f[(size_t)iBR * nT + iTL];
+        double f_RL = f[(size_t)iBL * nT + iTR], f_RR = f[(size_t)iBR * nT + iTR];
+        v[k] = ((f_LL * (TR - T) + f_RL * (T - TL)) * (BR - muB) + (f_LR * (TR - T) + f_RR * (T - TL)) * (muB - BL)) / (dT * dmuB);
+    }
+    double T3 = T * T * T, T4 = T3 * T, T5 = T4 * T;
+    if (df_mode == 1) {                                        /* :436-452 */
+        df->c0 = v[0] / T4; df->c1 = v[1] / T3; df->c2 = v[2] / T4; df->c3 = v[3] / T4; df->c4 = v[4] / T5;
+    } else if (df_mode == 2) {                                 /* :454-468 */
+        df->F = v[5] * T; df->G = v[6]; df->betabulk = v[7] * T4; df->betaV = v[8] * T3; df->betapi = v[9] * T4;
+    } else {
+        return -2;
+    }
+    return 0;
+}
+
+/* out10 = {c0,c1,c2,c3,c4,F,G,betabulk,betaV,betapi} by the bilinear branch */
+int oracle_df_coefficients_bilinear(const oracle_df_tables *t, int df_mode, double T, double muB, double *out10)
+{
+    df_coeff df;
+    int rc = eval_df_bilinear(t, df_mode, T, muB, &df);
+    out10[0] = df.c0; out10[1] = df.c1; out10[2] = df.c2; out10[3] = df.c3; out10[4] = df.c4;
+    out10[5] = df.F; out10[6] = df.G; out10[7] = df.betabulk; out10[8] = df.betaV; out10[9] = df.betapi;
+    return rc;
+}
+
+/* construct_cubic_splines (deltafReader.cpp:300-322) on the mu_B = 0 rows; s holds 5 x n_T second-derivative arrays */
+static void init_splines(const oracle_df_tables *t, double *s)
+{
+    const int n = t->n_T;
+    const double *rows[5] = {t->c0, t->c2, t->F, t->betabulk, t->betapi};
+    for (int k = 0; k < 5; k++)
+        if (rows[k]) oracle_cspline_init(n, t->T, rows[k], s + (size_t)k * n);
+}
+
 /* Exposed so tests can pin the coefficient evaluation on its own. out = {c0,c2,F,betabulk,betapi} */
 int oracle_df_coefficients(const oracle_df_tables *t, int df_mode, double T, double *out5)
 {
     int n = t->n_T, rc;
     double *s = (double *)calloc((size_t)5 * n, sizeof(double));
-    oracle_cspline_init(n, t->T, t->c0, s);
-    oracle_cspline_init(n, t->T, t->c2, s + n);
-    oracle_cspline_init(n, t->T, t->F, s + 2 * n);
-    oracle_cspline_init(n, t->T, t->betabulk, s + 3 * n);
-    oracle_cspline_init(n, t->T, t->betapi, s + 4 * n);
+    init_splines(t, s);
     df_coeff df;
     rc = eval_df(t, s, s + n, s + 2 * n, s + 3 * n, s + 4 * n, df_mode, T, &df);
     out5[0] = df.c0; out5[1] = df.c2; out5[2] = df.F; out5[3] = df.betabulk; out5[4] = df.betapi;
@@ -248,8 +302,11 @@ static int load_cell(const cell_arrays *a, long ic, const oracle_opts *o, const 
         c->baryon_enthalpy_ratio = nB / (E + P);
     }
 
-    df_coeff df;                                               /* :200 */
-    if (eval_df(t, sc0, sc2, sF, sbb, sbp, o->df_mode, T, &df)) return -1;
+    df_coeff df;                                               /* :200, deltafReader.cpp:486-504 */
+    if (o->include_baryon) {
+        int brc = eval_df_bilinear(t, o->df_mode, T, muB, &df);
+        if (brc) return brc;
+    } else if (eval_df(t, sc0, sc2, sF, sbb, sbp, o->df_mode, T, &df)) return -1;
     c->c3 = df.c3; c->c4 = df.c4; c->betaV = df.betaV;
 
     switch (o->df_mode) {                                      /* :220-242 */
@@ -323,7 +380,7 @@ static int check_inputs(const oracle_opts *o, const oracle_grid *g)
 {
     if (o->dimension != 2 && o->dimension != 3) return -3;
     if (o->df_mode != 1 && o->df_mode != 2) return -2;
-    if (o->include_baryon) return -4; /* bilinear (T, muB) branch not restated yet */
+    /* include_baryon = 1 needs the full (mu_B, T) tables: checked in eval_df_bilinear (-4 when absent) */
     if (g->pT_tab_length < 1 || g->phi_tab_length < 1) return -3;
     return 0;
 }
@@ -334,7 +391,7 @@ static int check_inputs(const oracle_opts *o, const oracle_grid *g)
  * y_tab_length even in 2+1D, emissionfunction.cpp:276) and is ACCUMULATED INTO (+=, :375).
  * Index: iS3D = ipart + npart * (ipT + npT * (iphip + nphi * iy))   (:363)
  * Returns 0, or <0: -1 T outside the coefficient table (GSL would abort), -2 df_mode, -3 bad
- * dimension/grid, -4 include_baryon not restated.
+ * dimension/grid, -4 include_baryon = 1 without the full (mu_B, T) tables.
  */
 int oracle_dN_pTdpTdphidy(long FO_length, int npart, const double *Mass, const double *Sign,
                           const double *Degeneracy, const double *Baryon, const cell_arrays *a,
@@ -356,11 +413,7 @@ int oracle_dN_pTdpTdphidy(long FO_length, int npart, const double *Mass, const d
 
     int n = t->n_T;
     double *s = (double *)calloc((size_t)5 * n, sizeof(double));
-    oracle_cspline_init(n, t->T, t->c0, s);
-    oracle_cspline_init(n, t->T, t->c2, s + n);
-    oracle_cspline_init(n, t->T, t->F, s + 2 * n);
-    oracle_cspline_init(n, t->T, t->betabulk, s + 3 * n);
-    oracle_cspline_init(n, t->T, t->betapi, s + 4 * n);
+    init_splines(t, s);
 
     const long long nspec = (long long)npart * npT * nphi * y_pts;
     int nthreads = 1;
@@ -448,11 +501,7 @@ int oracle_dN_pTdpTdphidy_chunked(long FO_length, int npart, const double *Mass,
     else for (int iy = 0; iy < y_pts; iy++) yValues[iy] = g->y[iy];
     int n = t->n_T;
     double *s = (double *)calloc((size_t)5 * n, sizeof(double));
-    oracle_cspline_init(n, t->T, t->c0, s);
-    oracle_cspline_init(n, t->T, t->c2, s + n);
-    oracle_cspline_init(n, t->T, t->F, s + 2 * n);
-    oracle_cspline_init(n, t->T, t->betabulk, s + 3 * n);
-    oracle_cspline_init(n, t->T, t->betapi, s + 4 * n);
+    init_splines(t, s);
 
     /* the reference sizes the scratch with y_tab_length even in 2+1D (:98); only iy < y_pts is touched */
     size_t scratch_n = (size_t)npart * (size_t)FO_chunk * npT * nphi * (size_t)y_pts;

@@ -22,7 +22,11 @@ class _CellArrays(C.Structure):
 
 
 class _DfTables(C.Structure):
-    _fields_ = [("n_T", C.c_int), ("T", _dp), ("c0", _dp), ("c2", _dp), ("F", _dp), ("betabulk", _dp), ("betapi", _dp)]
+    _fields_ = [("n_T", C.c_int), ("T", _dp), ("c0", _dp), ("c2", _dp), ("F", _dp), ("betabulk", _dp), ("betapi", _dp),
+                ("n_muB", C.c_int), ("muB", _dp), ("t2d", _dp * 10)]
+
+
+DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "betapi"]
 
 
 class _Opts(C.Structure):
@@ -85,6 +89,14 @@ def cspline_eval(x, y, c, xq):
 def _df_struct(df):
     keep = {k: _f64(df[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]}
     st = _DfTables(len(keep["T"]), *[_p(keep[k]) for k in ["T", "c0", "c2", "F", "betabulk", "betapi"]])
+    if "2d" in df:   # full (mu_B, T) tables for include_baryon = 1
+        keep["muB"] = _f64(df["muB"])
+        st.n_muB = len(keep["muB"])
+        st.muB = _p(keep["muB"])
+        for i, name in enumerate(DF_NAMES_2D):
+            keep["2d_" + name] = _f64(df["2d"][name])
+            assert keep["2d_" + name].shape == (st.n_muB, st.n_T)
+            st.t2d[i] = _p(keep["2d_" + name])
     return st, keep
 
 
@@ -96,6 +108,17 @@ def df_coefficients(df, df_mode, T):
     if rc:
         raise ValueError("T outside the coefficient table")
     return dict(zip(["c0", "c2", "F", "betabulk", "betapi"], out))
+
+
+def df_coefficients_bilinear(df, df_mode, T, muB):
+    """-> dict of the ten coefficients by the (intended) bilinear branch, temperature scaling undone."""
+    st, keep = _df_struct(df)
+    out = np.zeros(10)
+    lib().oracle_df_coefficients_bilinear.argtypes = [C.POINTER(_DfTables), C.c_int, C.c_double, C.c_double, _dp]
+    rc = lib().oracle_df_coefficients_bilinear(C.byref(st), int(df_mode), float(T), float(muB), _p(out))
+    if rc:
+        raise ValueError("(T, muB) outside the coefficient table (rc=%d)" % rc)
+    return dict(zip(DF_NAMES_2D, out))
 
 
 DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,

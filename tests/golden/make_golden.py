@@ -45,6 +45,18 @@ def coefficients_scipy(df, df_mode, T):
     return dict(F=S("F") * T, betabulk=S("betabulk") * T4, betapi=S("betapi") * T4)
 
 
+def coefficients_bilinear_scipy(dff, df_mode, T, muB):
+    """deltafReader.cpp:436-468 with scipy's multilinear RegularGridInterpolator (intended [muB][T] indexing)."""
+    from scipy.interpolate import RegularGridInterpolator
+
+    def S(name):
+        return float(RegularGridInterpolator((dff["muB"], dff["T"]), dff["2d"][name], method="linear")([[muB, T]])[0])
+    T3, T4 = T ** 3, T ** 4
+    if df_mode == 1:
+        return dict(c0=S("c0") / T4, c1=S("c1") / T3, c2=S("c2") / T4, c3=S("c3") / T4, c4=S("c4") / (T4 * T))
+    return dict(F=S("F") * T, G=S("G"), betabulk=S("betabulk") * T4, betaV=S("betaV") * T3, betapi=S("betapi") * T4)
+
+
 def highprec_spectrum(cells, sp, grid, df, opts):
     """Appendix A of SURVEY.md, long double, loops over cells only."""
     dim, dfm = opts["dimension"], opts["df_mode"]
@@ -54,6 +66,8 @@ def highprec_spectrum(cells, sp, grid, df, opts):
     cosphi = np.cos(grid["phi"]).astype(LD)   # the reference forms cos/sin in double (:43-48)
     sinphi = np.sin(grid["phi"]).astype(LD)
     mass, sign, g = sp["mass"].astype(LD), sp["sign"].astype(LD), sp["degeneracy"].astype(LD)
+    inc_b, inc_diff = opts.get("include_baryon", 0), opts.get("include_baryondiff_deltaf", 0)
+    bar = sp["baryon"].astype(LD)
     ny = len(grid["y"]) if dim == 3 else 1
     nsp, npT, nphi = len(mass), len(pT), len(cosphi)
     out = np.zeros((ny, nphi, npT, nsp), dtype=LD)
@@ -80,15 +94,27 @@ def highprec_spectrum(cells, sp, grid, df, opts):
             pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut
             pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut
         bulkPi = f["bulkPi"] if inc_bulk else LD(0)
-        co = coefficients_scipy(df, dfm, float(T))
+        muB = nB = Vx = Vy = Vn = Vt = LD(0)
+        if inc_b and inc_diff:
+            muB, nB = LD(cells["muB"][c]), LD(cells["nB"][c])
+            Vx, Vy, Vn = LD(cells["Vx"][c]), LD(cells["Vy"][c]), LD(cells["Vn"][c])
+            Vt = (Vx * ux + Vy * uy + tau2 * Vn * un) / ut
+        alphaB, rho = muB / T, nB / (E + P)
+        co = coefficients_bilinear_scipy(df, dfm, float(T), float(muB)) if inc_b else coefficients_scipy(df, dfm, float(T))
+        b1 = c3 = c4 = LD(0)
+        betaV = LD(1)
         if dfm == 1:
             shear = LD(0.5) / (T * T * (E + P))
             b0 = LD(co["c0"]) - LD(co["c2"])
             b2 = 4 * LD(co["c2"]) - LD(co["c0"])
+            if inc_b:
+                b1, c3, c4 = LD(co["c1"]), LD(co["c3"]), LD(co["c4"])
         else:
             shear = LD(0.5) / (LD(co["betapi"]) * T)
             b0 = LD(co["F"]) / (T * T * LD(co["betabulk"]))
             b2 = 1 / (3 * T * LD(co["betabulk"]))
+            if inc_b:
+                b1, betaV = LD(co["G"]) / LD(co["betabulk"]), LD(co["betaV"])
         if dim == 3:
             ys = grid["y"].astype(LD)
             etas, ws = np.array([f["eta"]], dtype=LD), np.array([1], dtype=LD)
@@ -109,14 +135,16 @@ def highprec_spectrum(cells, sp, grid, df, opts):
         t2pn = tau2 * pn
         pds = w * (pt * dat + px * dax + py * day + pn * dan)
         pu = pt * ut - px * ux - py * uy - t2pn * un
-        feq = 1 / (np.exp(pu / T) + sg)
+        bb = bar[None, None, None, None, :]
+        feq = 1 / (np.exp(pu / T - bb * alphaB) + sg)
+        Vp = Vt * pt - Vx * px - Vy * py - Vn * t2pn
         feqbar = 1 - sg * feq
         pipp = pitt * pt * pt + pixx * px * px + piyy * py * py + pinn * t2pn * t2pn + 2 * (
             -(pitx * px + pity * py) * pt + pixy * px * py + t2pn * (pixn * px + piyn * py - pitn * pt))
         if dfm == 1:
-            dfc = feqbar * (shear * pipp + (b0 * m2 + b2 * pu * pu) * bulkPi)
+            dfc = feqbar * (shear * pipp + (b0 * m2 + (b1 * bb + b2 * pu) * pu) * bulkPi + (c3 * bb + c4 * pu) * Vp)
         else:
-            dfc = feqbar * (shear * pipp / pu + (b0 * pu + b2 * (pu - m2 / pu)) * bulkPi)
+            dfc = feqbar * (shear * pipp / pu + (b0 * pu + b1 * bb + b2 * (pu - m2 / pu)) * bulkPi + (rho - bb / pu) * Vp / betaV)
         if reg:
             dfc = np.clip(dfc, -1, 1)
         term = pds * feq * (1 + dfc)
@@ -168,8 +196,23 @@ def main():
                 chk = oracle.dN_pTdpTdphidy(cells, sp, grid, df, o)
                 den = np.maximum(np.abs(hp[key]), 1e-280)
                 print("%-22s oracle vs long-double restatement: max rel %.3e" % (key, np.max(np.abs(chk - hp[key]) / den)))
-    for nm, cells in [("hand3", hc), ("seed3", seeded3), ("seed2", seeded2)]:
-        for k in synth.CELL_FIELDS:
+    # include_baryon = 1: bilinear (T, muB) coefficients, b mu_B / T in f_eq, baryon diffusion
+    dff = inputs.df_tables_full()
+    spb = inputs.species([211, 2212, -2212])
+    sb3 = synth.synth_surface(3, 3, seed=17, baryon=True)
+    sb2 = synth.synth_surface(2, 2, seed=18, baryon=True)
+    for name, cells, dim in [("seedb3", sb3, 3), ("seedb2", sb2, 2)]:
+        for dfm in (1, 2):
+            for diff in (1, 0):
+                o = dict(dimension=dim, df_mode=dfm, include_baryon=1, include_baryondiff_deltaf=diff)
+                key = "%s_df%d_diff%d" % (name, dfm, diff)
+                hp[key] = highprec_spectrum(cells, spb, grid, dff, o).astype(np.float64)
+                cases.append(dict(key=key, cells=name, opts=o, species=[211, 2212, -2212]))
+                chk = oracle.dN_pTdpTdphidy(cells, spb, grid, dff, o)
+                den = np.maximum(np.abs(hp[key]), 1e-280)
+                print("%-22s oracle vs long-double restatement: max rel %.3e" % (key, np.max(np.abs(chk - hp[key]) / den)))
+    for nm, cells in [("hand3", hc), ("seed3", seeded3), ("seed2", seeded2), ("seedb3", sb3), ("seedb2", sb2)]:
+        for k in synth.CELL_FIELDS + (synth.BARYON_FIELDS if "muB" in cells else []):
             hp["cells_%s_%s" % (nm, k)] = cells[k]
     np.savez_compressed(os.path.join(HERE, "golden_highprec.npz"), **hp)
 

@@ -48,6 +48,17 @@ def read_df_table(path, n_keep_muB=1):
     return T, val
 
 
+def read_df_table_full(path):
+    """all mu_B rows: -> T[nT], muB[nB], values[nB][nT] (deltafReader.cpp:168-196 storage order)"""
+    import numpy as np
+    with open(path) as f:
+        nT = int(f.readline())
+        nB = int(f.readline())
+        f.readline()
+        a = np.array([[float(x) for x in f.readline().split()] for _ in range(nT * nB)])
+    return a[:nT, 0].copy(), a[::nT, 1].copy(), a[:, 2].reshape(nB, nT).copy()
+
+
 def read_pdg(path):
     """Token stream; antibaryon appended after each baryon; sign from baryon parity."""
     with open(path) as f:
@@ -89,6 +100,13 @@ def main():
     with open(OUT, "w") as f:
         json.dump(d, f, separators=(",", ":"))
         f.write("\n")
+    # full (mu_B, T) tables for the include_baryon = 1 branch (bilinear interpolation): binary, 10 x 81 x 101
+    import numpy as np
+    full = {}
+    for name in ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "betapi"]:
+        T, muB, v = read_df_table_full(os.path.join(REF, "deltaf_coefficients/vh/urqmd", name + ".dat"))
+        full["T"], full["muB"], full[name] = T, muB, v
+    np.savez_compressed(os.path.join(os.path.dirname(OUT), "df_urqmd_full.npz"), **full)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(pdg), "pdg entries;",
           {k: len(v["x"]) for k, v in grids.items()}, len(d["chosen_urqmd"]), "chosen")
 

@@ -15,10 +15,10 @@ set_FO_temperature		= 1      # ignored by the smooth path
 T_switch			= 0.151
 dimension  		     	= {dimension}      # 2: boost invariant, 3: full 3+1D
 df_mode		                = {df_mode}     # 1: 14-moment, 2: Chapman-Enskog
-include_baryon            	= 0
+include_baryon            	= {include_baryon}
 Include_Bulk_Deltaf       	= {include_bulk_deltaf}     # names are case-insensitive
 include_shear_deltaf      	= {include_shear_deltaf}
-include_baryondiff_deltaf 	= 0
+include_baryondiff_deltaf 	= {include_baryondiff_deltaf}
 regulate_deltaf           	= {regulate_deltaf}
 outflow 			= {outflow}	             # Theta(p.dsigma)
 
@@ -62,7 +62,8 @@ def make_run_dir(root, cells, species_ids, params):
     df = inputs.df_tables()
     for d in ("input", "PDG", "tables/eta", "deltaf_coefficients/vh/urqmd", "results/vn_continuous"):
         os.makedirs(os.path.join(root, d), exist_ok=True)
-    p = dict(operation=1, mode=1, dimension=3, df_mode=1, include_bulk_deltaf=1, include_shear_deltaf=1, regulate_deltaf=1, outflow=1)
+    p = dict(operation=1, mode=1, dimension=3, df_mode=1, include_bulk_deltaf=1, include_shear_deltaf=1, regulate_deltaf=1, outflow=1,
+             include_baryon=0, include_baryondiff_deltaf=0)
     p.update(params)
     with open(os.path.join(root, "iS3D_parameters.dat"), "w") as f:
         f.write(PARAMS_TEMPLATE.format(**p))
@@ -71,8 +72,17 @@ def make_run_dir(root, cells, species_ids, params):
     write_table(os.path.join(root, "tables", "phi_gauss_legendre_table.dat"), g["phi"], g["phi_w"], leading_tab=True, dangling_fragment=True)
     write_table(os.path.join(root, "tables", "y_trapezoid_table_21pt.dat"), g["y"], g["y_w"])
     write_table(os.path.join(root, "tables", "eta", "eta_trapezoid_table_241pt.dat"), g["eta"], g["eta_w"])
-    for name in ("c0", "c2", "F", "betabulk", "betapi"):
-        write_df_table(os.path.join(root, "deltaf_coefficients", "vh", "urqmd", name + ".dat"), df["T"], df[name], name)
+    if p["include_baryon"]:
+        dff = inputs.df_tables_full()   # all ten tables with every mu_B row, as the shipped files have them
+        for name in inputs.DF_NAMES_2D:
+            with open(os.path.join(root, "deltaf_coefficients", "vh", "urqmd", name + ".dat"), "w") as f:
+                f.write("%d\n%d\nT [GeV]\t\tmuB [GeV]\t\t%s\n" % (len(dff["T"]), len(dff["muB"]), name))
+                for ib, mub in enumerate(dff["muB"]):
+                    for it, t in enumerate(dff["T"]):
+                        f.write("%s\t\t%s\t\t%s\n" % (repr(float(t)), repr(float(mub)), repr(float(dff["2d"][name][ib, it]))))
+    else:
+        for name in ("c0", "c2", "F", "betabulk", "betapi"):
+            write_df_table(os.path.join(root, "deltaf_coefficients", "vh", "urqmd", name + ".dat"), df["T"], df[name], name)
     particles = [r for r in fx["pdg_urqmd"] if r[3] >= 0]
     write_pdg(os.path.join(root, "PDG", "pdg-urqmd_v3.3+.dat"), particles)
     with open(os.path.join(root, "PDG", "chosen_particles.dat"), "w") as f:
@@ -86,7 +96,10 @@ def read_surface_like_reference(path):
     a = np.loadtxt(path, ndmin=2)
     h = synth.HBARC
     names = ["tau", "x", "y", "eta", "dat", "dax", "day", "dan", "ux", "uy", "un", "E", "T", "P", "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi"]
+    if a.shape[1] >= 25:   # + muB [fm^-1], nB, Vx, Vy, Vn (include_baryon && include_baryondiff_deltaf)
+        names = names + ["muB", "nB", "Vx", "Vy", "Vn"]
     s = {n: a[:, i].copy() for i, n in enumerate(names)}
-    for n in ("E", "T", "P", "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi"):
-        s[n] = s[n] * h
+    for n in ("E", "T", "P", "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi", "muB"):
+        if n in s:
+            s[n] = s[n] * h
     return s

@@ -61,6 +61,24 @@ def test_cli_run_directory(tmp_path, fx, dim, df_mode):
     assert len(avg) == 5 and 0.14 < avg[0] < 0.16 and avg[3] == 0.0
 
 
+@pytest.mark.parametrize("df_mode", [1, 2])
+def test_cli_include_baryon(tmp_path, fx, df_mode):
+    """25-column surface (muB, nB, Vx, Vy, Vn), full (T, mu_B) coefficient files, bilinear branch."""
+    ids = [211, 2212, -2212]
+    cells = synth.synth_surface(9, 3, seed=55, baryon=True)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(dimension=3, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=1))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    ref = oracle.dN_pTdpTdphidy(parsed, inputs.species(ids), fx["grid"], inputs.df_tables_full(),
+                                dict(dimension=3, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=1))
+    allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
+    want = np.transpose(ref.reshape(21, 24, 32, 3), (3, 0, 1, 2)).reshape(-1)
+    assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8
+    avg = [float(x) for x in open(os.path.join(root, "average_thermodynamic_quantities.dat")).read().split()]
+    assert 0.05 < avg[3] < 0.4 and 0.02 < avg[4] < 0.1     # mu_B and n_B averages are filled now
+
+
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
     for bad in (dict(operation=2), dict(mode=0), dict(df_mode=4)):

@@ -60,6 +60,45 @@ def test_parity_matrix(fx, dim, df_mode, flags):
         assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("df_mode", [1, 2])
+@pytest.mark.parametrize("diff", [1, 0])
+def test_parity_include_baryon(fx, dim, df_mode, diff):
+    """include_baryon = 1 -- b mu_B/T in f_eq, bilinear (T, mu_B) coefficients (intended
+    indexing), bulk1 and baryon-diffusion terms (smooth_kernels.cpp:186-197, :254, :297, :306-307, :316-317)."""
+    dff = inputs.df_tables_full()
+    cells = synth.synth_surface(40 if dim == 3 else 6, dim, seed=200 + dim, baryon=True)
+    sp = inputs.species([211, 2212, -2212, 3122, -3122, 321])
+    for flags in (dict(), dict(outflow=0, regulate_deltaf=0), dict(include_bulk_deltaf=0), dict(include_shear_deltaf=0)):
+        o = dict(dimension=dim, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=diff, **flags)
+        ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], dff, o)
+        for variant in (2, 3, 4):
+            got, st = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, kernel_variant=variant))
+            assert relerr(got, ref) < TOL, (variant, flags, relerr(got, ref))
+    # classes now carry the baryon number: p and pbar are different classes, Lambda/Lambdabar too
+    _, st = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(dimension=dim, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=diff))
+    assert st["n_classes"] == 6
+    _, st0 = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(dimension=dim, df_mode=df_mode))
+    assert st0["n_classes"] == 4
+
+
+def test_include_baryon_domain_and_validation(fx):
+    dff = inputs.df_tables_full()
+    cells = synth.synth_surface(12, 3, seed=9, baryon=True)
+    sp = inputs.species([2212, -2212])
+    o = dict(dimension=3, df_mode=1, include_baryon=1, include_baryondiff_deltaf=1)
+    cells["muB"][5] = 0.81                      # outside the (T, mu_B) table: reference prints and exits (:423-427)
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, sp, fx["grid"], dff, o)
+    assert e.value.code == api.IS3D_EDOMAIN and "cell 5" in str(e.value)
+    with pytest.raises(api.Is3dError) as e:     # the mu_B = 0 rows alone are not enough
+        api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+    assert e.value.code == api.IS3D_EINVAL
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, kernel_variant=1))
+    assert e.value.code == api.IS3D_EINVAL
+
+
 def test_config1_known_answers_on_device(fx, pins):
     """The reference's own toy surface (config 1), closed form of SURVEY.md section 4."""
     h = 0.197327053
@@ -89,9 +128,14 @@ def test_golden_vectors(fx, pins):
         assert relerr(got, z["s2_df%d" % dfm]) < TOL
     hp = np.load(os.path.join(ROOT, "tests", "golden", "golden_highprec.npz"))
     cellsets = {nm: {k: hp["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS} for nm in ("hand3", "seed3", "seed2")}
+    for nm in ("seedb3", "seedb2"):
+        cellsets[nm] = {k: hp["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS + synth.BARYON_FIELDS}
     cellsets["hand2"] = {k: v[:2] for k, v in cellsets["hand3"].items()}
+    dff = inputs.df_tables_full()
     for case in pins["highprec_cases"]:
-        got, _ = api.smooth_spectra(cellsets[case["cells"]], fx["pikp"], fx["grid"], fx["df"], case["opts"])
+        sp = inputs.species(case["species"]) if "species" in case else fx["pikp"]
+        df = dff if case["opts"].get("include_baryon") else fx["df"]
+        got, _ = api.smooth_spectra(cellsets[case["cells"]], sp, fx["grid"], df, case["opts"])
         assert relerr(got, hp[case["key"]]) < TOL, case["key"]
 
 

@@ -83,12 +83,48 @@ def test_against_longdouble_restatement(fx, pins):
     cellsets = {}
     for nm in ("hand3", "seed3", "seed2"):
         cellsets[nm] = {k: z["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS}
+    for nm in ("seedb3", "seedb2"):   # include_baryon = 1 cases: bilinear (T, muB) coefficients by scipy's multilinear interpolator
+        cellsets[nm] = {k: z["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS + synth.BARYON_FIELDS}
     cellsets["hand2"] = {k: v[:2] for k, v in cellsets["hand3"].items()}
+    dff = inputs.df_tables_full()
     worst = 0.0
+    n_baryon = 0
     for case in pins["highprec_cases"]:
-        got = oracle.dN_pTdpTdphidy(cellsets[case["cells"]], fx["pikp"], fx["grid"], fx["df"], case["opts"])
+        sp = inputs.species(case["species"]) if "species" in case else fx["pikp"]
+        df = dff if case["opts"].get("include_baryon") else fx["df"]
+        n_baryon += int(bool(case["opts"].get("include_baryon")))
+        got = oracle.dN_pTdpTdphidy(cellsets[case["cells"]], sp, fx["grid"], df, case["opts"])
         worst = max(worst, relerr(got, z[case["key"]]))
+    assert n_baryon == 8
     assert worst < 5e-10, worst
+
+
+def test_bilinear_branch(fx):
+    """include_baryon = 1: bilinear (T, muB) interpolation with the INTENDED [imuB][iT] indexing (the reference swaps
+    the indices, deltafReader.cpp:404-407); nodes are reproduced, outside the table is an error, and at muB = 0 with
+    the diffusion switch off only the c1 / G term distinguishes the branch from the spline branch."""
+    dff = inputs.df_tables_full()
+    T, B = dff["T"], dff["muB"]
+    c = oracle.df_coefficients_bilinear(dff, 1, T[40], B[7])
+    T4 = T[40] * T[40] * T[40] * T[40]
+    assert abs(c["c0"] * T4 / dff["2d"]["c0"][7, 40] - 1) < 1e-12 and abs(c["c3"] * T4 / dff["2d"]["c3"][7, 40] - 1) < 1e-12
+    mid = oracle.df_coefficients_bilinear(dff, 2, 0.5 * (T[10] + T[11]), 0.5 * (B[3] + B[4]))
+    want = 0.25 * (dff["2d"]["G"][3, 10] + dff["2d"]["G"][3, 11] + dff["2d"]["G"][4, 10] + dff["2d"]["G"][4, 11])
+    assert abs(mid["G"] - want) < 1e-12 * max(1.0, abs(want))
+    for bad in ((0.0999, 0.1), (0.2005, 0.1), (0.15, -0.01), (0.15, 0.805)):
+        with pytest.raises(ValueError):
+            oracle.df_coefficients_bilinear(dff, 1, *bad)
+    cells = synth.synth_surface(4, 3, seed=31, baryon=True)
+    sp = inputs.species([211, 2212, -2212])
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::4], phi=fx["grid"]["phi"][::4])
+    on = oracle.dN_pTdpTdphidy(cells, sp, g, dff, dict(dimension=3, df_mode=1, include_baryon=1, include_baryondiff_deltaf=1))
+    off = oracle.dN_pTdpTdphidy(cells, sp, g, dff, dict(dimension=3, df_mode=1, include_baryon=1, include_baryondiff_deltaf=0))
+    r_on, r_off = on.reshape(21, 6, 8, 3), off.reshape(21, 6, 8, 3)
+    assert (r_on[8:13, :, :3, 1] > 1.2 * r_off[8:13, :, :3, 1]).all()      # soft mid-rapidity protons gain exp(+mu_B/T)
+    assert (r_on[8:13, :, :3, 2] < 0.8 * r_off[8:13, :, :3, 2]).all()      # antiprotons lose it
+    cells["T"][2] = 0.2001
+    with pytest.raises(RuntimeError):
+        oracle.dN_pTdpTdphidy(cells, sp, g, dff, dict(dimension=3, df_mode=1, include_baryon=1, include_baryondiff_deltaf=1))
 
 
 def test_golden_64cell_regression(fx, pins):
