@@ -200,6 +200,15 @@ int is3d_table_read(const char *path, int64_t *n_rows, int32_t *n_cols, double *
 int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t include_baryondiff_deltaf,
                          int32_t dimension, int64_t *n_cells, double *const *cell_arrays23, double *avg5);
 
+/* FO_data_reader::read_surf_switch (src/cpp/readindata.cpp:133-144) for the viscous-hydro surface formats the
+ * smooth path accepts: mode 0 read_surf_VH_old (:148-318), 1 read_surf_VH (:320-468), 4 read_surf_VH_MUSIC (:552-668),
+ * 6 read_surf_VH_MUSIC_New (:671-810), 7 read_surf_VH_hiceventgen (:1059-1196).  Same calling pattern and array order
+ * as is3d_surface_read_vh; every format is converted to the kernel's conventions the way the reference does (tau
+ * Jacobians, hbar*c, p = T s - e, u = gamma v); muB is stored whenever the array is given (modes 4, 6, 7 always
+ * carry it), nB and V^mu are zero in modes 4, 6, 7.  Other modes: IS3D_EINVAL. */
+int is3d_surface_read(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                      int32_t dimension, int64_t *n_cells, double *const *cell_arrays23, double *avg5);
+
 /* PDG_Data::read_resonances_conventional (src/cpp/readindata.cpp:1440-1568), reduced to what the
  * smooth path uses.  Two-call pattern (mc_id == NULL -> only *n).  Arrays of capacity entries. */
 int is3d_pdg_read(const char *path, int32_t *n, int64_t *mc_id, double *mass, double *gspin,

@@ -63,7 +63,7 @@ class Status(C.Structure):
 EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_plan_create",
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
-           "is3d_table_read", "is3d_surface_read_vh", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
+           "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_write_results"]
 
 
@@ -120,6 +120,8 @@ def load():
     L.is3d_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp, C.c_int64]
     L.is3d_surface_read_vh.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
                                        C.POINTER(_dp), _dp]
+    L.is3d_surface_read.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                    C.POINTER(_dp), _dp]
     L.is3d_pdg_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _dp, _dp, _dp, _dp, C.c_int32]
     L.is3d_df_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), _dp, _dp, C.c_int32]
     L.is3d_df_table_read_full.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, C.c_int64]
@@ -285,6 +287,19 @@ def surface_read_vh(path, include_baryon=0, include_baryondiff_deltaf=0, dimensi
     avg = np.zeros(5)
     if n.value > 0:
         _check(L.is3d_surface_read_vh(path.encode(), include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), ptrs, _p(avg)))
+    return arrs, avg
+
+
+def surface_read(path, mode, include_baryon=0, include_baryondiff_deltaf=0, dimension=3):
+    """is3d_surface_read: modes 0, 1, 4, 6, 7 -> (dict of the 23 arrays, averages)."""
+    L = load()
+    n = C.c_int64(0)
+    _check(L.is3d_surface_read(path.encode(), mode, include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), None, None))
+    arrs = {f: np.zeros(n.value) for f in SURFACE_READ_ORDER}
+    ptrs = (_dp * 23)(*[_p(arrs[f]) for f in SURFACE_READ_ORDER])
+    avg = np.zeros(5)
+    if n.value > 0:
+        _check(L.is3d_surface_read(path.encode(), mode, include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), ptrs, _p(avg)))
     return arrs, avg
 
 

@@ -239,6 +239,133 @@ extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// FO_data_reader::read_surf_switch (src/cpp/readindata.cpp:133-144) for the viscous-hydro formats the smooth
+// path accepts (emissionfunction.cpp:1503: MODE 0, 1, 4, 6, 7; 5 = vorticity/polarisation and 2, 3 = VAH are
+// other paths).  Token stream per cell, converted to the kernel's conventions exactly as the reference does:
+//   0  read_surf_VH_old         :148-318   26 cols: tau x y eta | dat dax day dan | ut ux uy un | E T P |
+//                                          pitt pitx pity pitn pixx pixy pixn piyy piyn pinn | bulkPi [muB][nB Vt Vx Vy Vn]
+//   1  read_surf_VH             :320-468   20 cols (see is3d_surface_read_vh)
+//   4  read_surf_VH_MUSIC       :552-668   27 cols: tau x y eta(->0) | d0..d3 (x tau; d3 -> 0 in 2+1D) | ut ux uy un(/tau) |
+//                                          E T muB s (P = s T - E) | 10 pi (x hbarc; n components / tau, nn / tau^2) | bulkPi
+//   6  read_surf_VH_MUSIC_New   :671-810   29 cols: as 4 with muS muC after muB, eta and d3 ignored (-> 0)
+//   7  read_surf_VH_hiceventgen :1059-1196 26 cols, GeV units: tau x y eta(->0) | da_tau da_x da_y (x tau) da_eta(->0) |
+//                                          vx vy vn(->0): u = gamma v | 4 pi^t* ignored, pixx pixy pixz(/tau) piyy piyz(/tau) pizz ignored |
+//                                          bulkPi | T E P muB
+// hbar*c multiplies E, T, P, pi**, bulkPi, muB in modes 0, 1, 4, 6.  u^tau and the pi^{tau mu}, pi^{eta eta} columns are
+// read and dropped: the kernel reconstructs them (smooth_kernels.cpp:133, :166-170).
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                                 int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
+{
+    if (mode == 1) return is3d_surface_read_vh(path, include_baryon, include_baryondiff_deltaf, dimension, n_cells, A, avg5);
+    if (mode != 0 && mode != 4 && mode != 6 && mode != 7)
+        return io_fail(IS3D_EINVAL, "surface mode %d is not a viscous-hydro format of the smooth path (0, 1, 4, 6, 7)", mode);
+    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    int64_t rows;
+    int32_t cols;
+    int rc = parse_table(text, path, &rows, &cols, nullptr);
+    if (rc) return rc;
+    if (!A) { *n_cells = rows; return IS3D_OK; }
+    if (*n_cells < rows) return io_fail(IS3D_EINVAL, "%s: arrays hold %lld cells, file has %lld", path, (long long)*n_cells, (long long)rows);
+    *n_cells = rows;
+    enum { iT, iP, iE, itau, ieta, iux, iuy, iun, idat, idax, iday, idan, ipixx, ipixy, ipixn, ipiyy, ipiyn, ibulk, imuB, inB, iVx, iVy, iVn };
+    for (int a = 0; a <= ibulk; a++)
+        if (!A[a]) return io_fail(IS3D_EINVAL, "cell array %d is NULL", a);
+    const char *p = text.c_str();
+    bool short_read = false;
+    auto next = [&]() -> double {
+        char *q;
+        double x = strtod(p, &q);
+        if (q == p) { short_read = true; return 0.0; }
+        p = q;
+        return x;
+    };
+    double Tavg = 0, Eavg = 0, Pavg = 0, muBavg = 0, nBavg = 0, vol = 0;
+    for (int64_t i = 0; i < rows; i++) {
+        double tau = next();
+        (void)next();  // x
+        (void)next();  // y
+        double eta = next();
+        double dat, dax, day, dan, ux, uy, un, E, T, P, pixx, pixy, pixn, piyy, piyn, bulkPi, muB = 0.0, nB = 0.0;
+        double Vx = 0.0, Vy = 0.0, Vn = 0.0;
+        if (mode == 0) {
+            dat = next(); dax = next(); day = next(); dan = next();
+            if (dimension == 2 && dan != 0.0)   // reference: message + exit(-1), readindata.cpp:180-184
+                return io_fail(IS3D_EINVAL, "%s: 2+1d boost invariant surface read-in error at cell # %lld: dsigma_eta is not zero", path, (long long)i);
+            (void)next();  // ut
+            ux = next(); uy = next(); un = next();
+            E = next() * kHbarC; T = next() * kHbarC; P = next() * kHbarC;
+            for (int k = 0; k < 4; k++) (void)next();  // pitt pitx pity pitn
+            pixx = next() * kHbarC; pixy = next() * kHbarC; pixn = next() * kHbarC;
+            piyy = next() * kHbarC; piyn = next() * kHbarC;
+            (void)next();  // pinn
+            bulkPi = next() * kHbarC;
+            if (include_baryon) muB = next() * kHbarC;
+            if (include_baryondiff_deltaf) {
+                nB = next();
+                (void)next();  // Vt
+                Vx = next(); Vy = next(); Vn = next();
+            }
+        } else if (mode == 4 || mode == 6) {
+            eta = 0.0;
+            dat = next() * tau; dax = next() * tau; day = next() * tau;
+            dan = next() * tau;
+            if (mode == 6 || dimension == 2) dan = 0.0;   // :586-592 (old format zeroes it in 2+1D), :729-730 (new: always)
+            (void)next();  // ut
+            ux = next(); uy = next();
+            un = next() / tau;
+            E = next() * kHbarC; T = next() * kHbarC; muB = next() * kHbarC;
+            if (mode == 6) { (void)next(); (void)next(); }   // muS, muC
+            P = next() * T - E;                              // entropy density: p = T s - e
+            for (int k = 0; k < 4; k++) (void)next();        // pitt pitx pity pitn
+            pixx = next() * kHbarC; pixy = next() * kHbarC; pixn = next() * kHbarC / tau;
+            piyy = next() * kHbarC; piyn = next() * kHbarC / tau;
+            (void)next();  // pinn
+            bulkPi = next() * kHbarC;
+        } else {  // mode 7, hic-eventgen: already in GeV units
+            eta = 0.0;
+            dat = next() * tau; dax = next() * tau; day = next() * tau;
+            (void)next();
+            dan = 0.0;
+            double vx = next(), vy = next();
+            (void)next();  // vn -> 0
+            double ut = sqrt(1.0 / (1.0 - vx * vx - vy * vy));   // :1108-1111
+            ux = ut * vx; uy = ut * vy; un = 0.0;
+            for (int k = 0; k < 4; k++) (void)next();            // pi^tt pi^tx pi^ty pi^tz
+            pixx = next(); pixy = next(); pixn = next() / tau;
+            piyy = next(); piyn = next() / tau;
+            (void)next();  // pi^zz
+            bulkPi = next();
+            T = next(); E = next(); P = next(); muB = next();
+        }
+        if (short_read) return io_fail(IS3D_EIO, "%s: ran out of numbers at cell %lld (mode %d)", path, (long long)i, mode);
+        A[itau][i] = tau; A[ieta][i] = eta;
+        A[idat][i] = dat; A[idax][i] = dax; A[iday][i] = day; A[idan][i] = dan;
+        A[iux][i] = ux; A[iuy][i] = uy; A[iun][i] = un;
+        A[iE][i] = E; A[iT][i] = T; A[iP][i] = P;
+        A[ipixx][i] = pixx; A[ipixy][i] = pixy; A[ipixn][i] = pixn; A[ipiyy][i] = piyy; A[ipiyn][i] = piyn;
+        A[ibulk][i] = bulkPi;
+        if (A[imuB]) A[imuB][i] = muB;
+        if (A[inB]) A[inB][i] = nB;
+        if (A[iVx]) A[iVx][i] = Vx;
+        if (A[iVy]) A[iVy][i] = Vy;
+        if (A[iVn]) A[iVn][i] = Vn;
+        double ut = sqrt(1.0 + ux * ux + uy * uy + tau * tau * un * un);
+        double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+        double dsigma_dsigma = dat * dat - dax * dax - day * day - dan * dan / (tau * tau);
+        double mag = fabs(udsigma) + sqrt(fabs(udsigma * udsigma - dsigma_dsigma));
+        vol += mag;
+        Eavg += E * mag; Tavg += T * mag; Pavg += P * mag; muBavg += muB * mag; nBavg += nB * mag;
+    }
+    if (avg5) {
+        avg5[0] = Tavg / vol; avg5[1] = Eavg / vol; avg5[2] = Pavg / vol; avg5[3] = muBavg / vol; avg5[4] = nBavg / vol;
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // PDG_Data::read_resonances_conventional  (src/cpp/readindata.cpp:1440-1568)
 //   token stream: 12 header fields + decays x 8 fields; an antiparticle entry follows each
 //   baryon > 0; the entry produced by the read attempt that hits EOF is dropped (Nparticle =

@@ -9,7 +9,7 @@
 // and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
 // (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
-// Scope: operation = 1, mode = 1, df_mode in {1, 2}, include_baryon in {0, 1}.  Anything else is refused
+// Scope: operation = 1, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2}, include_baryon in {0, 1}.  Anything else is refused
 // with a message instead of silently doing something different from the reference.
 #include <cmath>
 #include <cstdio>
@@ -89,7 +89,8 @@ int main(int argc, char **argv)
     GET(outflow, "outflow");
 #undef GET
     if (operation != 1) DIE("operation = %d: only operation = 1 (smooth momentum spectra) is on this path", operation);
-    if (mode != 1) DIE("mode = %d: only the mode-1 (gpu-vh) surface format is read so far", mode);
+    if (mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
+        DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
     if (df_mode != 1 && df_mode != 2) DIE("df_mode = %d: only 1 (14-moment) and 2 (Chapman-Enskog)", df_mode);
     const char *pdg_path, *df_dir;
     if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
@@ -99,7 +100,7 @@ int main(int argc, char **argv)
     double t0 = now_s();
     // ---- surface (iS3D.cpp:90-98) ----
     int64_t n_cells = 0;
-    if (is3d_surface_read_vh("input/surface.dat", include_baryon, include_diff, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
+    if (is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
     std::vector<std::vector<double>> arr(23);
     double *ptr[23];
     for (int a = 0; a < 23; a++) {
@@ -108,7 +109,7 @@ int main(int argc, char **argv)
         ptr[a] = used ? arr[a].data() : nullptr;
     }
     double avg[5] = {0, 0, 0, 0, 0};
-    if (n_cells > 0 && is3d_surface_read_vh("input/surface.dat", include_baryon, include_diff, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
+    if (n_cells > 0 && is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
     {
         std::ofstream f("average_thermodynamic_quantities.dat", std::ios_base::out);
         f << std::setprecision(15) << avg[0] << "\n" << avg[1] << "\n" << avg[2] << "\n" << avg[3] << "\n" << avg[4];

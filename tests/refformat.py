@@ -91,6 +91,39 @@ def make_run_dir(root, cells, species_ids, params):
     return root
 
 
+def write_surface_mode(path, s, mode, include_baryon=0, include_baryondiff=0):
+    """A surface.dat in one of the other viscous-hydro formats (readindata.cpp:148-318, :552-810, :1059-1196).  The
+    columns the readers drop (u^tau, pi^{tau mu}, pi^{eta eta}, mu_S, mu_C, V^tau) get recognisable junk."""
+    h, n = synth.HBARC, len(s["tau"])
+    tau = s["tau"]
+    ut = np.sqrt(1 + s["ux"] ** 2 + s["uy"] ** 2 + tau ** 2 * s["un"] ** 2)
+    junk = np.full(n, 7.0)
+    muB = s.get("muB", np.zeros(n))
+    if mode == 0:
+        cols = [tau, s["x"], s["y"], s["eta"], s["dat"], s["dax"], s["day"], s["dan"], ut, s["ux"], s["uy"], s["un"],
+                s["E"] / h, s["T"] / h, s["P"] / h, junk, junk, junk, junk, s["pixx"] / h, s["pixy"] / h, s["pixn"] / h,
+                s["piyy"] / h, s["piyn"] / h, junk, s["bulkPi"] / h]
+        if include_baryon:
+            cols.append(muB / h)
+        if include_baryondiff:
+            cols += [s["nB"], junk, s["Vx"], s["Vy"], s["Vn"]]
+    elif mode in (4, 6):
+        ent = (s["E"] + s["P"]) / s["T"]                       # entropy density, fm^-3: p = T s - e
+        cols = [tau, s["x"], s["y"], junk, s["dat"] / tau, s["dax"] / tau, s["day"] / tau, s["dan"] / tau, ut, s["ux"], s["uy"],
+                s["un"] * tau, s["E"] / h, s["T"] / h, muB / h]
+        if mode == 6:
+            cols += [junk, junk]
+        cols += [ent, junk, junk, junk, junk, s["pixx"] / h, s["pixy"] / h, s["pixn"] * tau / h, s["piyy"] / h,
+                 s["piyn"] * tau / h, junk, s["bulkPi"] / h]
+    elif mode == 7:
+        cols = [tau, s["x"], s["y"], junk, s["dat"] / tau, s["dax"] / tau, s["day"] / tau, junk, s["ux"] / ut, s["uy"] / ut, junk,
+                junk, junk, junk, junk, s["pixx"], s["pixy"], s["pixn"] * tau, s["piyy"], s["piyn"] * tau, junk, s["bulkPi"],
+                s["T"], s["E"], s["P"], muB]
+    else:
+        raise ValueError(mode)
+    np.savetxt(path, np.column_stack(cols), fmt="%.17e", delimiter=" ")
+
+
 def read_surface_like_reference(path):
     """What read_surf_VH does to a mode-1 file (readindata.cpp:343-410), in numpy: -> dict of the 18 arrays."""
     a = np.loadtxt(path, ndmin=2)

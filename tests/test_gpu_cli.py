@@ -79,9 +79,31 @@ def test_cli_include_baryon(tmp_path, fx, df_mode):
     assert 0.05 < avg[3] < 0.4 and 0.02 < avg[4] < 0.1     # mu_B and n_B averages are filled now
 
 
+@pytest.mark.parametrize("mode", [0, 4, 6, 7])
+def test_cli_other_surface_formats(tmp_path, fx, mode):
+    """The other viscous-hydro surface formats end to end: 2+1D boost-invariant MUSIC /
+    hic-eventgen files and the old 26-column gpu-vh file."""
+    dim = 3 if mode == 0 else 2
+    ids = [211, 321, 2212]
+    cells = synth.synth_surface(11, dim, seed=70 + mode)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(dimension=dim, df_mode=2, mode=mode))
+    refformat.write_surface_mode(os.path.join(root, "input", "surface.dat"), cells, mode)
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    parsed, _ = api.surface_read(os.path.join(root, "input", "surface.dat"), mode, 0, 0, dim)   # reader parity: tests/test_host_io.py
+    ref = oracle.dN_pTdpTdphidy(parsed, inputs.species(ids), fx["grid"], fx["df"], dict(dimension=dim, df_mode=2))
+    ny = 21 if dim == 3 else 1
+    allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
+    want = np.transpose(ref.reshape(ny, 24, 32, 3), (3, 0, 1, 2)).reshape(-1)
+    assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8
+    # and the physics is the one of the mode-1 file of the same cells
+    ref1 = oracle.dN_pTdpTdphidy(cells, inputs.species(ids), fx["grid"], fx["df"], dict(dimension=dim, df_mode=2))
+    assert relerr(ref, ref1, floor=1e-250) < 1e-10
+
+
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=2), dict(mode=0), dict(df_mode=4)):
+    for bad in (dict(operation=2), dict(mode=2), dict(mode=5), dict(df_mode=4)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr

@@ -83,6 +83,54 @@ def test_surface_reader_toy_file_and_errors(tmp_path):
         api.surface_read_vh(str(p))
 
 
+def test_surface_reader_other_formats(tmp_path):
+    """Modes 0 (old gpu-vh), 4 / 6 (MUSIC old / new), 7 (hic-eventgen): same cells written in each format parse to the
+    same kernel-convention arrays as the mode-1 file (tau Jacobians, hbar*c, p = T s - e, u = gamma v), and the
+    format-specific overrides hold (eta -> 0 in 4/6/7, dsigma_eta -> 0, mu_B always carried by 4/6/7)."""
+    path = str(tmp_path / "surface.dat")
+    c3 = synth.synth_surface(29, 3, seed=21, baryon=True)
+    c2 = synth.synth_surface(17, 2, seed=22, baryon=True)
+    keys = [k for k in synth.CELL_FIELDS if k not in ("eta", "dan")]
+
+    refformat.write_surface_mode(path, c3, 0, include_baryon=1, include_baryondiff=1)
+    got, avg = api.surface_read(path, 0, 1, 1, 3)
+    for k in synth.CELL_FIELDS + synth.BARYON_FIELDS:
+        assert np.allclose(got[k], c3[k], rtol=5e-16, atol=0), k
+    refformat.write_surface_mode(path, c3, 0)
+    got0, _ = api.surface_read(path, 0, 0, 0, 3)
+    assert np.array_equal(got0["T"], got["T"]) and not got0["muB"].any()
+    with pytest.raises(api.Is3dError):      # old format: dsigma_eta != 0 in a 2+1D run is fatal (readindata.cpp:180-184)
+        api.surface_read(path, 0, 0, 0, 2)
+
+    for mode in (4, 6):
+        for cells, dim in ((c3, 3), (c2, 2)):
+            refformat.write_surface_mode(path, cells, mode)
+            got, avg = api.surface_read(path, mode, 1, 0, dim)
+            for k in keys:
+                assert np.allclose(got[k], cells[k], rtol=4e-15, atol=0), (mode, k)
+            assert not got["eta"].any()                                    # both MUSIC readers put the cell at eta = 0
+            if mode == 6 or dim == 2:
+                assert not got["dan"].any()
+            else:
+                assert np.allclose(got["dan"], cells["dan"], rtol=4e-15)
+            assert np.allclose(got["muB"], cells["muB"], rtol=4e-16) and not got["nB"].any() and not got["Vx"].any()
+            assert 0.05 < avg[3] < 0.4 and avg[4] == 0.0
+
+    refformat.write_surface_mode(path, c2, 7)
+    got, avg = api.surface_read(path, 7, 0, 0, 2)
+    for k in keys:
+        assert np.allclose(got[k], c2[k], rtol=4e-15, atol=1e-18), k
+    assert not got["eta"].any() and not got["dan"].any() and not got["un"].any()
+    with pytest.raises(api.Is3dError) as e:
+        api.surface_read(path, 5, 0, 0, 3)
+    assert e.value.code == api.IS3D_EINVAL
+    # mode 1 through the switch == the dedicated entry
+    synth.write_surface_dat(path, c3)
+    a, _ = api.surface_read(path, 1, 1, 1, 3)
+    b, _ = api.surface_read_vh(path, 1, 1, 3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
 def test_pdg_reader(tmp_path):
     fx = inputs.load_fixture()
     particles = [r for r in fx["pdg_urqmd"] if r[3] >= 0]
