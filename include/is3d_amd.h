@@ -166,6 +166,16 @@ int64_t is3d_plan_output_size(const is3d_plan *plan);
  * when status != NULL (then the stream is synchronised). */
 int is3d_plan_execute(is3d_plan *plan, const is3d_cells *cells, double *dN_out, void *hip_stream,
                       is3d_status *status);
+/* Derived observables from a device-resident spectrum of this plan's shape (what the reference's writers reduce on
+ * the host: emissionfunction.cpp:639-677, :729-772, :1053-1136).  pT_w / phi_w: HOST arrays of the quadrature weights
+ * (column 2 of the pT / phi tables).  Outputs are DEVICE arrays, any may be NULL:
+ *   dNdy          [n_species][n_y_eff]            sum_phi sum_pT w_phi w_pT dN
+ *   dN2pipTdpTdy  [n_species][n_y_eff][n_pT]      sum_phi w_phi dN / (2 pi)
+ *   vn            [n_species][n_y_eff][n_pT][7]   |sum_phi w_phi e^{i k phi} dN| / sum_phi w_phi dN, k = 1..7 (0 if the
+ *                                                 denominator is below 1e-15)
+ * Asynchronous on hip_stream. */
+int is3d_plan_observables(is3d_plan *plan, const double *dN_dev, const double *pT_w, const double *phi_w, double *dNdy,
+                          double *dN2pipTdpTdy, double *vn, void *hip_stream);
 /* Enable (1) / disable (0) HIP-event timing of the three kernels on subsequent executes. */
 int is3d_plan_set_timing(is3d_plan *plan, int32_t enable);
 /* Synchronises the recorded events of the last execute and fills status->ms_*. */

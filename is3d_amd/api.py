@@ -61,7 +61,7 @@ class Status(C.Structure):
 
 
 EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_plan_create",
-           "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings",
+           "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_write_results"]
@@ -112,6 +112,7 @@ def load():
     L.is3d_plan_workspace_bytes.argtypes = [C.c_void_p]
     L.is3d_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.is3d_plan_execute.argtypes = [C.c_void_p, C.POINTER(Cells), C.c_void_p, C.c_void_p, C.POINTER(Status)]
+    L.is3d_plan_observables.argtypes = [C.c_void_p, C.c_void_p, _dp, _dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.is3d_plan_set_timing.argtypes = [C.c_void_p, C.c_int32]
     L.is3d_plan_timings.argtypes = [C.c_void_p, C.POINTER(Status)]
     L.is3d_plan_destroy.argtypes = [C.c_void_p]
@@ -244,6 +245,12 @@ class Plan:
                                       C.byref(st) if want_status else None)
         _check(rc)
         return st.as_dict() if want_status else None
+
+    def observables(self, dN_ptr, pT_w, phi_w, dndy_ptr=0, spec2pi_ptr=0, vn_ptr=0, stream=0):
+        """is3d_plan_observables: device pointers (ints) in and out, host weight arrays."""
+        pw, fw = _f64(pT_w), _f64(phi_w)
+        _check(load().is3d_plan_observables(self._h, C.c_void_p(int(dN_ptr)), _p(pw), _p(fw), C.c_void_p(int(dndy_ptr or 0)),
+                                            C.c_void_p(int(spec2pi_ptr or 0)), C.c_void_p(int(vn_ptr or 0)), C.c_void_p(int(stream or 0))))
 
     def timings(self):
         st = Status()

@@ -886,4 +886,78 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
 
 const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : "cf_main_tile"; }
 
+// ------------------------------------------------------------------------------------------------
+// Derived observables from the device-resident spectrum: what the reference's writers
+// compute on the host before printing -- write_dN_twopipTdpTdy_toFile (emissionfunction.cpp:639-677),
+// write_continuous_vn_toFile (:1053-1136), write_dN_dy_toFile (:729-772) -- so that a caller that only wants
+// these does not pull 39 MB of spectrum through PCIe and text.
+//   cf_obs_phi : thread <-> (species, pT, y): phi sums -> dN/(2 pi pT dpT dy) and v_1..v_7
+//   cf_obs_dndy: thread <-> (species, y): the double sum of write_dN_dy_toFile, in its loop order (phi outer, pT inner)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cf_obs_phi(const double *__restrict__ dN, const double *__restrict__ phi_w, const double *__restrict__ coskphi,
+           const double *__restrict__ sinkphi, double *__restrict__ spec2pi, double *__restrict__ vn, int npart, int npT,
+           int J, int ny)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sp fastest, then pT, then y: coalesced reads
+    if (idx >= (int64_t)npart * npT * ny) return;
+    const int sp = (int)(idx % npart);
+    const int ipT = (int)((idx / npart) % npT);
+    const int iy = (int)(idx / ((int64_t)npart * npT));
+    double re[7], im[7], den = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) { re[k] = 0.0; im[k] = 0.0; }
+    for (int j = 0; j < J; j++) {
+        const double v = dN[sp + (int64_t)npart * (ipT + (int64_t)npT * (j + (int64_t)J * iy))];
+        const double w = phi_w[j];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            re[k] += coskphi[k * J + j] * w * v;     // cos((k+1) phi) * w * dN, as :1106-1107
+            im[k] += sinkphi[k * J + j] * w * v;
+        }
+        den += w * v;
+        s2 += w * v / (2.0 * M_PI);                  // :665
+    }
+    const int64_t o = ((int64_t)sp * ny + iy) * npT + ipT;
+    if (spec2pi) spec2pi[o] = s2;
+    if (vn) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            double x = sqrt(re[k] * re[k] + im[k] * im[k]) / den;
+            if (den < 1.e-15) x = 0.0;               // :1121
+            vn[o * 7 + k] = x;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_obs_dndy(const double *__restrict__ dN, const double *__restrict__ phi_w, const double *__restrict__ pT_w,
+            double *__restrict__ dndy, int npart, int npT, int J, int ny)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npart * ny) return;
+    const int sp = idx % npart, iy = idx / npart;
+    double s = 0.0;
+    for (int j = 0; j < J; j++)
+        for (int i = 0; i < npT; i++)
+            s += phi_w[j] * pT_w[i] * dN[sp + (int64_t)npart * (i + (int64_t)npT * (j + (int64_t)J * iy))];   // :761
+    dndy[(int64_t)sp * ny + iy] = s;
+}
+
+hipError_t launch_observables(const double *dN, const double *phi_w, const double *pT_w, const double *coskphi,
+                              const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
+                              int ny, hipStream_t st)
+{
+    if (spec2pi || vn) {
+        const int64_t n = (int64_t)npart * npT * ny;
+        hipLaunchKernelGGL(cf_obs_phi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dN, phi_w, coskphi, sinkphi, spec2pi,
+                           vn, npart, npT, J, ny);
+    }
+    if (dndy) {
+        const int n = npart * ny;
+        hipLaunchKernelGGL(cf_obs_dndy, dim3((n + 255) / 256), dim3(256), 0, st, dN, phi_w, pT_w, dndy, npart, npT, J, ny);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace is3d

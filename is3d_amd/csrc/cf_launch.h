@@ -12,4 +12,7 @@ hipError_t launch_finalize(const double *partial, const int *cls, const double *
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
                            int accumulate, hipStream_t stream);
 const char *main_kernel_name(int variant);
+hipError_t launch_observables(const double *dN, const double *phi_w, const double *pT_w, const double *coskphi,
+                              const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
+                              int ny, hipStream_t st);
 }  // namespace is3d

@@ -73,6 +73,7 @@ struct is3d_plan {
 
     DevBuf<double> d_mT, d_pT, d_sign, d_lane_b, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
     DevBuf<double> d_bilT, d_bilB, d_biltab[5];
+    DevBuf<double> d_coskphi, d_sinkphi, d_phiw, d_pTw;   // derived observables
     is3d::BilinearDev bil{};
     bool baryon = false, baryondiff = false;
     DevBuf<int> d_cls;
@@ -217,6 +218,18 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     HIP_TRY(P->d_sinphi.upload(sinphi));
     HIP_TRY(P->d_kgrid.upload(kgrid));
     HIP_TRY(P->d_kweight.upload(kweight));
+    {
+        std::vector<double> ck((size_t)7 * P->J), sk((size_t)7 * P->J);
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < P->J; j++) {
+                ck[(size_t)k * P->J + j] = std::cos(((double)k + 1.0) * g->phi[j]);   // emissionfunction.cpp:1106
+                sk[(size_t)k * P->J + j] = std::sin(((double)k + 1.0) * g->phi[j]);
+            }
+        HIP_TRY(P->d_coskphi.upload(ck));
+        HIP_TRY(P->d_sinkphi.upload(sk));
+        HIP_TRY(P->d_phiw.alloc(P->J));
+        HIP_TRY(P->d_pTw.alloc(P->npT));
+    }
 
     // ---- splines (deltafReader.cpp:300-322) ----
     const double *tabs[3] = {nullptr, nullptr, nullptr};
@@ -453,6 +466,20 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                         (long long)status->bad_cell);
         }
     }
+    return IS3D_OK;
+}
+
+extern "C" int is3d_plan_observables(is3d_plan *P, const double *dN_dev, const double *pT_w, const double *phi_w, double *dNdy_dev,
+                                     double *dN2pipTdpTdy_dev, double *vn_dev, void *hip_stream)
+{
+    if (!P || !dN_dev || !phi_w) return fail(IS3D_EINVAL, "null argument");
+    if (dNdy_dev && !pT_w) return fail(IS3D_EINVAL, "dN/dy needs the pT weights");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipMemcpyAsync(P->d_phiw.p, phi_w, (size_t)P->J * sizeof(double), hipMemcpyHostToDevice, st));
+    if (pT_w) HIP_TRY(hipMemcpyAsync(P->d_pTw.p, pT_w, (size_t)P->npT * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(is3d::launch_observables(dN_dev, P->d_phiw.p, P->d_pTw.p, P->d_coskphi.p, P->d_sinkphi.p, dNdy_dev, dN2pipTdpTdy_dev,
+                                     vn_dev, P->npart, P->npT, P->J, P->ny_eff, st));
     return IS3D_OK;
 }
 

@@ -231,6 +231,47 @@ def test_passes_chunks_and_accumulate(fx, torch_mod):
     assert relerr(acc, 2.0 * base) < 1e-15
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+def test_device_observables(fx, torch_mod, dim):
+    """dN/dy, dN/(2 pi pT dpT dy) and v_n on the device == the reductions of the reference's
+    writers (emissionfunction.cpp:639-677, :729-772, :1053-1136) applied to the oracle's spectrum."""
+    torch = torch_mod
+    g = fx["grid_w"]
+    cells = synth.synth_surface(50 if dim == 3 else 8, dim, seed=300 + dim)
+    sp = inputs.species(SP7)
+    o = dict(dimension=dim, df_mode=2)
+    ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], o)
+    ny = 21 if dim == 3 else 1
+    r4 = ref.reshape(ny, 24, 32, 7)
+    dev = torch.device("cuda:0")
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}
+    plan = api.Plan(sp, fx["grid"], fx["df"], o, max_cells=len(cells["tau"]))
+    out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.execute(len(cells["tau"]), {k: v.data_ptr() for k, v in tens.items()}, out.data_ptr(), st)
+    dndy = torch.zeros(7 * ny, dtype=torch.float64, device=dev)
+    s2pi = torch.zeros(7 * ny * 32, dtype=torch.float64, device=dev)
+    vn = torch.zeros(7 * ny * 32 * 7, dtype=torch.float64, device=dev)
+    plan.observables(out.data_ptr(), g["pT_w"], g["phi_w"], dndy.data_ptr(), s2pi.data_ptr(), vn.data_ptr(), st)
+    torch.cuda.synchronize()
+    want_dndy = np.einsum("j,i,kjis->sk", g["phi_w"], g["pT_w"], r4)
+    assert relerr(dndy.cpu().numpy().reshape(7, ny), want_dndy) < TOL
+    want_s2pi = np.einsum("j,kjis->ski", g["phi_w"], r4) / (2.0 * np.pi)
+    assert relerr(s2pi.cpu().numpy().reshape(7, ny, 32), want_s2pi) < TOL
+    den = np.einsum("j,kjis->ski", g["phi_w"], r4)
+    got_vn = vn.cpu().numpy().reshape(7, ny, 32, 7)
+    for k in range(7):
+        num = np.abs(np.einsum("j,kjis->ski", np.exp(1j * (k + 1) * g["phi"]) * g["phi_w"], r4))
+        want = np.where(den < 1e-15, 0.0, num / np.where(den == 0, 1.0, den))
+        ok = den > 1e-200            # where the spectrum is ~1e-300 the ratio is numerical noise in both
+        assert np.max(np.abs(got_vn[:, :, :, k] - want)[ok]) < 1e-7
+        assert (got_vn[:, :, :, k][den < 1e-15] == 0.0).all()
+    # only some outputs requested
+    plan.observables(out.data_ptr(), g["pT_w"], g["phi_w"], dndy_ptr=dndy.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    plan.close()
+
+
 def _subset_oracle(fx, cells, sp_ids, ipT, iphi, opts):
     g = fx["grid"]
     sub = dict(g, pT=g["pT"][ipT], phi=g["phi"][iphi])
