@@ -53,7 +53,7 @@ def isa_counts(kernel_name, wl, JT_R):
     d = json.load(open(p))
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
     if kernel_name == "cf_main_tile":
-        key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
+        key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,BARYON=0,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
     else:
         key = "cf_main_direct:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,KT=%d" % (ce, d3, JT_R[1])
     return d.get(key)

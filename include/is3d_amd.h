@@ -120,7 +120,9 @@ typedef struct {
                                            distinct (mass, sign) and scale by degeneracy */
     int32_t zero_skip;                  /* 0 default(on) | 1 on | 2 off: wave-level culling of rows whose
                                            exp(-p.u/T) is exactly +0 (bitwise-identical result) */
-    int32_t reserved[6];
+    int32_t waves_per_group;            /* 0 default | 2, 4, 8: lane-waves per workgroup of the tile kernel (they share
+                                           one LDS-staged coefficient stream) */
+    int32_t reserved[5];
 } is3d_options;
 
 typedef struct {

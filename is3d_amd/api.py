@@ -47,7 +47,7 @@ class Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
                                          "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
                                          "accumulate", "device", "kernel_variant", "cell_chunks"]] + \
-               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("zero_skip", C.c_int32), ("reserved", C.c_int32 * 6)]
+               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("zero_skip", C.c_int32), ("waves_per_group", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Status(C.Structure):
@@ -149,7 +149,7 @@ DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "bet
 
 DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
                     include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1, accumulate=0, device=-1,
-                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0, zero_skip=0)
+                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0, zero_skip=0, waves_per_group=0)
 
 
 def _pack_common(species, grid, df, opts):

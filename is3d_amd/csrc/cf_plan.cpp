@@ -301,6 +301,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
                 int waste = ((lane_waves + w - 1) / w) * w - lane_waves;
                 if (waste * 64 < best_waste * 64 && waste < best_waste) { best_waste = waste; P->wpb = w; }
             }
+            if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves

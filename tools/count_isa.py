@@ -34,7 +34,7 @@ def demangle_params(sym):
     vals = re.findall(r"L([bi])(\d+)E", args)
     vals = [int(v) for _, v in vals]
     if name == "cf_main_tile":
-        keys = ["CE", "DIM3", "OUTFLOW", "REG", "JT", "R"]
+        keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R"]
     else:
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
     return name, dict(zip(keys, vals))
