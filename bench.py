@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)")
     a = ap.parse_args()
 
     import torch
@@ -117,10 +119,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    local = local % torch.cuda.device_count()   # ranks may share a GPU only in a --backend gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        idist.init_process_group("nccl")
+        idist.init_process_group(a.backend)
         import torch.distributed as dist
 
     wl = workload(a.workload)

@@ -56,3 +56,26 @@ def species(which="pikp"):
     return dict(mc_id=np.array([r[0] for r in rows], dtype=np.int64), mass=np.array([r[1] for r in rows], dtype=np.float64),
                 degeneracy=np.array([r[2] for r in rows], dtype=np.float64), baryon=np.array([r[3] for r in rows], dtype=np.float64),
                 sign=np.array([r[4] for r in rows], dtype=np.float64))
+
+
+def feqmod_tables(T_avg, deta_min=1.e-5, mass_pion0=0.138):
+    """What the modified-equilibrium path (df_mode 3, 4) needs besides the coefficient tables: generalized
+    Gauss-Laguerre nodes (alpha = 1, 2; tables/gla_roots_weights_32_points.txt), ALL species of the PDG file
+    (the Jonah z(Pi/P), lambda(Pi/P) tables sum over them, deltafReader.cpp:249-265), the surface-averaged
+    temperature as read back from average_thermodynamic_quantities.dat (15 significant digits) and the
+    parameters deta_min, mass_pion0 (iS3D_parameters.dat)."""
+    fx = load_fixture()
+    g = fx["gla_32"]
+    pdg = np.array(fx["pdg_urqmd"], dtype=np.float64)
+    return dict(root1=np.array(g["root1"]), weight1=np.array(g["weight1"]), root2=np.array(g["root2"]), weight2=np.array(g["weight2"]),
+                pdg_mass=pdg[:, 1].copy(), pdg_degeneracy=pdg[:, 2].copy(), pdg_sign=pdg[:, 4].copy(),
+                T_avg=float("%.15g" % T_avg), deta_min=float(deta_min), mass_pion0=float(mass_pion0))
+
+
+def surface_average_T(cells):
+    """Surface-volume weighted temperature of readindata.cpp:422-450 (what Plasma::load_thermodynamic_averages reads back)."""
+    ut = np.sqrt(1 + cells["ux"] ** 2 + cells["uy"] ** 2 + cells["tau"] ** 2 * cells["un"] ** 2)
+    uds = ut * cells["dat"] + cells["ux"] * cells["dax"] + cells["uy"] * cells["day"] + cells["un"] * cells["dan"]
+    dsds = cells["dat"] ** 2 - cells["dax"] ** 2 - cells["day"] ** 2 - cells["dan"] ** 2 / cells["tau"] ** 2
+    mag = np.abs(uds) + np.sqrt(np.abs(uds * uds - dsds))
+    return float(np.sum(cells["T"] * mag) / np.sum(mag))

@@ -582,3 +582,366 @@ int oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* ==========================================================================================
+ * Modified-equilibrium smooth kernel (df_mode 3 "Mike", 4 "Jonah"): SURVEY.md 8f rank 3.
+ * Restates EmissionFunctionArray::calculate_dN_ptdptdphidy_feqmod
+ * (src/cpp/emissionfunction_smooth_kernels.cpp:396-996) for include_baryon = 0, with its helpers:
+ *   Milne_Basis, Shear_Stress::boost_pimunu_to_lrf           src/cpp/viscous_correction.cpp:8-27, :99-115
+ *   GaussThermal, neq_int, J10_int, J20_int, E_mod_int, P_mod_int   src/cpp/gaussThermal.cpp
+ *   Deltaf_Data::compute_jonah_coefficients                  src/cpp/deltafReader.cpp:222-297
+ *   Deltaf_Data::cubic_spline cases 2/3 and 4                src/cpp/deltafReader.cpp:347-384
+ *   does_feqmod_breakdown, is_linear_pion0_density_negative  src/cpp/emissionfunction.cpp:96-150
+ * GSL's LU inverse (:690-707) is replaced by the cofactor inverse; the reference's own iterative
+ * refinement of p_mod = A^-1 p (:915-926) is kept, so the solve converges to the same solution.
+ * Reference quirks kept on purpose: p.dsigma = eta_weight (pt dat + px dax + py day) + pn dan (the
+ * dsigma_eta term is outside the weight, :876, :905); in 2+1D the eta nodes are scaled by detA when
+ * detA_min < detA < 1 (:727-728, :902-903); shared A_copy/A_inv scratch (a race under OpenMP, :479-483)
+ * is private here.
+ * ========================================================================================== */
+typedef struct {
+    int n_pts;                       /* Gauss-Laguerre points (tables/gla_roots_weights_32_points.txt) */
+    const double *root1, *weight1;   /* alpha = 1 */
+    const double *root2, *weight2;   /* alpha = 2 */
+    int n_pdg;                       /* ALL species of the PDG file: the Jonah E/P sums run over them (:249-265) */
+    const double *pdg_mass, *pdg_degeneracy, *pdg_sign;
+    double T_avg;                    /* surface-averaged temperature as read back from average_thermodynamic_quantities.dat */
+    double deta_min, mass_pion0;     /* parameters deta_min, mass_pion0 */
+} oracle_feqmod_tables;
+
+#define JONAH_POINTS 301
+typedef struct {
+    double lambda_squared[JONAH_POINTS], z[JONAH_POINTS], bulkPi_over_Peq[JONAH_POINTS];
+    double c_lambda[JONAH_POINTS], c_z[JONAH_POINTS];
+    double bulkPi_over_Peq_max;
+} jonah_tab;
+
+static double E_mod_int(double pbar, double mbar, double lambda, double sign)
+{
+    double scale2 = (1.0 + lambda) * (1.0 + lambda);
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    return sqrt(pbar * pbar * scale2 + mbar * mbar) * exp(pbar) / (exp(Ebar) + sign);
+}
+static double P_mod_int(double pbar, double mbar, double lambda, double sign)
+{
+    double scale2 = (1.0 + lambda) * (1.0 + lambda);
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    return pbar * pbar * scale2 / sqrt(pbar * pbar * scale2 + mbar * mbar) * exp(pbar) / (exp(Ebar) + sign);
+}
+static double gauss1d_mod(double (*f)(double, double, double, double), const double *r, const double *w, int n, double mbar, double lambda, double sign)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) s += w[k] * f(r[k], mbar, lambda, sign);
+    return s;
+}
+static double neq_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    return pbar * exp(pbar) / (exp(Ebar - baryon * alphaB) + sign);
+}
+static double J10_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return pbar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);
+}
+static double J20_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return Ebar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);
+}
+static double gauss_thermal(double (*f)(double, double, double, double, double), const double *r, const double *w, int n, double mbar, double alphaB, double baryon, double sign)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) s += w[k] * f(r[k], mbar, alphaB, baryon, sign);
+    return s;
+}
+
+/* deltafReader.cpp:222-297 */
+static void compute_jonah(const oracle_feqmod_tables *q, jonah_tab *J)
+{
+    const double lambda_min = -1.0, lambda_max = 2.0;
+    const double delta_lambda = (lambda_max - lambda_min) / ((double)JONAH_POINTS - 1.0);
+    const double T = q->T_avg;
+    J->bulkPi_over_Peq_max = -1.0;
+    for (int i = 0; i < JONAH_POINTS; i++) {
+        double lambda = lambda_min + (double)i * delta_lambda;
+        double E = 0.0, P = 0.0, E_mod = 0.0, P_mod = 0.0;
+        for (int n = 0; n < q->n_pdg; n++) {
+            double degeneracy = q->pdg_degeneracy[n], mass = q->pdg_mass[n], sign = q->pdg_sign[n];
+            double mbar = mass / T;
+            if (mass == 0.0) continue;
+            E += degeneracy * gauss1d_mod(E_mod_int, q->root2, q->weight2, q->n_pts, mbar, 0.0, sign);
+            P += (1.0 / 3.0) * degeneracy * gauss1d_mod(P_mod_int, q->root2, q->weight2, q->n_pts, mbar, 0.0, sign);
+            E_mod += degeneracy * gauss1d_mod(E_mod_int, q->root2, q->weight2, q->n_pts, mbar, lambda, sign);
+            P_mod += (1.0 / 3.0) * degeneracy * gauss1d_mod(P_mod_int, q->root2, q->weight2, q->n_pts, mbar, lambda, sign);
+        }
+        double z = E / E_mod;
+        double bulkPi_over_Peq = (P_mod / P) * z - 1.0;
+        J->lambda_squared[i] = lambda * lambda;
+        J->z[i] = z;
+        J->bulkPi_over_Peq[i] = bulkPi_over_Peq;
+        J->bulkPi_over_Peq_max = fmax(J->bulkPi_over_Peq_max, bulkPi_over_Peq);
+    }
+    oracle_cspline_init(JONAH_POINTS, J->bulkPi_over_Peq, J->lambda_squared, J->c_lambda);
+    oracle_cspline_init(JONAH_POINTS, J->bulkPi_over_Peq, J->z, J->c_z);
+}
+
+/* exposed for tests: out = [301 x {lambda^2, z, bulkPi/Peq}] then bulkPi_over_Peq_max */
+int oracle_jonah_tables(const oracle_feqmod_tables *q, double *out)
+{
+    jonah_tab *J = (jonah_tab *)malloc(sizeof(jonah_tab));
+    compute_jonah(q, J);
+    for (int i = 0; i < JONAH_POINTS; i++) { out[3 * i] = J->lambda_squared[i]; out[3 * i + 1] = J->z[i]; out[3 * i + 2] = J->bulkPi_over_Peq[i]; }
+    out[3 * JONAH_POINTS] = J->bulkPi_over_Peq_max;
+    free(J);
+    return 0;
+}
+
+static void inv3(const double A[3][3], double Ai[3][3], double *det)
+{
+    double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    double d = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    *det = d;
+    Ai[0][0] = c00 / d; Ai[1][0] = c01 / d; Ai[2][0] = c02 / d;
+    Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / d;
+    Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / d;
+    Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / d;
+    Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / d;
+    Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / d;
+    Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / d;
+}
+static void matvec3(const double A[3][3], const double x[3], double y[3])
+{
+    for (int i = 0; i < 3; i++) y[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
+}
+
+/* Returns 0, or <0: -1 T (or bulkPi/P) outside a table, -2 df_mode, -3 dimension/grid, -4 include_baryon (not restated for feqmod). */
+int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
+                                 const double *Baryon, const cell_arrays *a, const oracle_df_tables *t, const oracle_feqmod_tables *q,
+                                 const oracle_grid *g, const oracle_opts *o, double *dN_pTdpTdphidy, long *n_breakdown)
+{
+    if (o->dimension != 2 && o->dimension != 3) return -3;
+    if (o->df_mode != 3 && o->df_mode != 4) return -2;
+    if (o->include_baryon) return -4;
+    const int DF_MODE = o->df_mode;
+    const double two_pi2_hbarC3 = 2.0 * pow(M_PI, 2) * pow(ORACLE_HBARC, 3);        /* iS3D.h:11 */
+    const double prefactor = pow(2.0 * M_PI * ORACLE_HBARC, -3);
+    const double detA_min = q->deta_min;
+    const int npT = g->pT_tab_length, nphi = g->phi_tab_length;
+    double *cosphi = (double *)malloc(sizeof(double) * nphi), *sinphi = (double *)malloc(sizeof(double) * nphi);
+    for (int i = 0; i < nphi; i++) { cosphi[i] = cos(g->phi[i]); sinphi[i] = sin(g->phi[i]); }
+    int y_pts = g->y_tab_length, eta_pts = 1;
+    if (o->dimension == 2) { y_pts = 1; eta_pts = g->eta_tab_length; }
+    double *yValues = (double *)malloc(sizeof(double) * (y_pts > 0 ? y_pts : 1));
+    if (o->dimension == 2) yValues[0] = 0.0;
+    else for (int iy = 0; iy < y_pts; iy++) yValues[iy] = g->y[iy];
+    const int n = t->n_T;
+    double *s = (double *)calloc((size_t)5 * n, sizeof(double));
+    init_splines(t, s);
+    const double *sF = s + 2 * n, *sbb = s + 3 * n, *sbp = s + 4 * n;
+    jonah_tab *J = (jonah_tab *)malloc(sizeof(jonah_tab));
+    if (DF_MODE == 4) compute_jonah(q, J);
+    const long long nspec = (long long)npart * npT * nphi * y_pts;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    double *part = (double *)calloc((size_t)nspec * nthreads, sizeof(double));
+    int err = 0;
+    long breakdown = 0;
+#pragma omp parallel
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double *acc = part + (size_t)tid * nspec;
+#pragma omp for schedule(static) reduction(+ : breakdown)
+        for (long ic = 0; ic < FO_length; ic++) {
+            double tau = a->tau[ic], tau2 = tau * tau;
+            double eta_cell = (o->dimension == 3) ? a->eta[ic] : 0.0;
+            double dat = a->dat[ic], dax = a->dax[ic], day = a->day[ic], dan = a->dan[ic];
+            double ux = a->ux[ic], uy = a->uy[ic], un = a->un[ic];
+            double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+            double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+            if (udsigma <= 0.0) continue;                                            /* :502 */
+            double ut2 = ut * ut, ux2 = ux * ux, uy2 = uy * uy;
+            double uperp = sqrt(ux * ux + uy * uy), utperp = sqrt(1.0 + ux * ux + uy * uy);
+            double T = a->T[ic], P = a->P[ic], E = a->E[ic];
+            double pitt = 0, pitx = 0, pity = 0, pitn = 0, pixx = 0, pixy = 0, pixn = 0, piyy = 0, piyn = 0, pinn = 0;
+            if (o->include_shear_deltaf) {                                           /* :531-545 */
+                pixx = a->pixx[ic]; pixy = a->pixy[ic]; pixn = a->pixn[ic]; piyy = a->piyy[ic]; piyn = a->piyn[ic];
+                pinn = (pixx * (ux2 - ut2) + piyy * (uy2 - ut2) + 2.0 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp * utperp);
+                pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut;
+                pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut;
+                pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut;
+                pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
+            }
+            double bulkPi = o->include_bulk_deltaf ? a->bulkPi[ic] : 0.0;
+            if (DF_MODE == 4) {                                                      /* :584-590 */
+                if (bulkPi < -P) bulkPi = -(1.0 - 1.e-5) * P;
+                else if (bulkPi / P > J->bulkPi_over_Peq_max) bulkPi = P * (J->bulkPi_over_Peq_max - 1.e-5);
+            }
+            /* evaluate_df_coefficients -> cubic_spline, deltafReader.cpp:347-384 */
+            double F = 0, G = 0, betabulk = 0, betapi = 0, lambda = 0, z = 0, delta_lambda = 0, delta_z = 0;
+            double T4 = T * T * T * T, v;
+            int bad = 0;
+            if (DF_MODE == 3) {
+                if (oracle_cspline_eval(n, t->T, t->F, sF, T, &v)) bad = 1; else F = v * T;
+                G = 0.0;
+                if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, T, &v)) bad = 1; else betabulk = v * T4;
+                if (oracle_cspline_eval(n, t->T, t->betapi, sbp, T, &v)) bad = 1; else betapi = v * T4;
+            } else {
+                double lambda_squared = 0.0;
+                if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->lambda_squared, J->c_lambda, bulkPi / P, &lambda_squared)) bad = 1;
+                if (bulkPi < 0.0) lambda = -sqrt(lambda_squared);
+                else if (bulkPi > 0.0) lambda = sqrt(lambda_squared);
+                if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->z, J->c_z, bulkPi / P, &z)) bad = 1;
+                if (oracle_cspline_eval(n, t->T, t->betapi, sbp, T, &v)) bad = 1; else betapi = v * T4;
+                delta_lambda = bulkPi / (5.0 * betapi - 3.0 * P * (E + P) / E);
+                delta_z = -3.0 * delta_lambda * P / E;
+            }
+            if (bad) {
+#pragma omp atomic write
+                err = -1;
+                continue;
+            }
+            /* Milne_Basis, viscous_correction.cpp:8-27 */
+            double sinhL = tau * un / utperp, coshL = ut / utperp;
+            double Xt = uperp * coshL, Zt = sinhL, Xn = uperp * sinhL / tau, Zn = coshL / tau;
+            double Xx = 1.0, Yx = 0.0, Xy = 0.0, Yy = 1.0;
+            if (uperp > 1.e-5) { Xx = utperp * ux / uperp; Yx = -uy / uperp; Xy = utperp * uy / uperp; Yy = ux / uperp; }
+            /* boost_pimunu_to_lrf, viscous_correction.cpp:99-115 */
+            double pixx_LRF = pitt * Xt * Xt + pixx * Xx * Xx + piyy * Xy * Xy + tau2 * tau2 * pinn * Xn * Xn
+                            + 2.0 * (-Xt * (pitx * Xx + pity * Xy) + pixy * Xx * Xy + tau2 * Xn * (pixn * Xx + piyn * Xy - pitn * Xt));
+            double pixy_LRF = Yx * (-pitx * Xt + pixx * Xx + pixy * Xy + tau2 * pixn * Xn) + Yy * (-pity * Xt + pixy * Xx + piyy * Xy + tau2 * piyn * Xn);
+            double pixz_LRF = Zt * (pitt * Xt - pitx * Xx - pity * Xy - tau2 * pitn * Xn) - tau2 * Zn * (pitn * Xt - pixn * Xx - piyn * Xy - tau2 * pinn * Xn);
+            double piyy_LRF = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
+            double piyz_LRF = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
+            double pizz_LRF = -(pixx_LRF + piyy_LRF);
+            double T_mod = T, alphaB = 0.0, alphaB_mod = 0.0;
+            if (DF_MODE == 3) { T_mod = T + bulkPi * F / betabulk; alphaB_mod = alphaB + bulkPi * G / betabulk; }   /* :627-631 */
+            double shear_coeff = 0.5 / (betapi * T);
+            double bulk0_coeff = F / (T * T * betabulk), bulk1_coeff = G / betabulk, bulk2_coeff = 1.0 / (3.0 * T * betabulk);
+            double shear_mod = 0.5 / betapi;
+            double bulk_mod = bulkPi / (3.0 * betabulk);
+            if (DF_MODE == 4) bulk_mod = lambda;
+            double A[3][3] = {{1.0 + pixx_LRF * shear_mod + bulk_mod, pixy_LRF * shear_mod, pixz_LRF * shear_mod},
+                              {pixy_LRF * shear_mod, 1.0 + piyy_LRF * shear_mod + bulk_mod, piyz_LRF * shear_mod},
+                              {pixz_LRF * shear_mod, piyz_LRF * shear_mod, 1.0 + pizz_LRF * shear_mod + bulk_mod}};
+            double Axx = A[0][0], Axy = A[0][1], Axz = A[0][2], Ayy = A[1][1], Ayz = A[1][2], Azz = A[2][2];
+            double detA = Axx * (Ayy * Azz - Ayz * Ayz) - Axy * (Axy * Azz - Ayz * Axz) + Axz * (Axy * Ayz - Ayy * Axz);   /* :668 */
+            double A_inv[3][3], det_unused;
+            inv3(A, A_inv, &det_unused);
+            double neq_fact = T * T * T / two_pi2_hbarC3, dn_fact = bulkPi / betabulk, J20_fact = T * neq_fact, N10_fact = neq_fact;
+            double nmod_fact = T_mod * T_mod * T_mod / two_pi2_hbarC3;
+            /* does_feqmod_breakdown, emissionfunction.cpp:109-150 (fast = 0) */
+            int feqmod_breaks_down = 0;
+            if (DF_MODE == 3) {
+                double mbar_pion0 = q->mass_pion0 / T;
+                double neq_pion0 = neq_fact * gauss_thermal(neq_int, q->root1, q->weight1, q->n_pts, mbar_pion0, 0., 0., -1.);
+                double J20_pion0 = J20_fact * gauss_thermal(J20_int, q->root2, q->weight2, q->n_pts, mbar_pion0, 0., 0., -1.);
+                double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * F / T / T) / betabulk;
+                if (detA <= detA_min || (neq_pion0 + dn_pion0) < 0.0) feqmod_breaks_down = 1;
+            }
+            if (feqmod_breaks_down) breakdown++;
+            double eta_scale = 1.0;
+            if (detA > detA_min && detA < 1.0 && o->dimension == 2) eta_scale = detA;   /* :727-728 */
+            double eta1 = eta_cell, w1 = 1.0;
+            const double *etaValues = (o->dimension == 2) ? g->eta : &eta1;
+            const double *etaWeights = (o->dimension == 2) ? g->eta_w : &w1;
+            for (int ipart = 0; ipart < npart; ipart++) {
+                double mass = Mass[ipart], mass2 = mass * mass, sign = Sign[ipart], degeneracy = Degeneracy[ipart], baryon = Baryon[ipart];
+                double chem = baryon * alphaB, chem_mod = baryon * alphaB_mod;
+                double renorm = 1.0;
+                if (o->include_bulk_deltaf) {
+                    if (DF_MODE == 3) {                                              /* :747-760 */
+                        double mbar = mass / T, mbar_mod = mass / T_mod;
+                        double neq = neq_fact * degeneracy * gauss_thermal(neq_int, q->root1, q->weight1, q->n_pts, mbar, alphaB, baryon, sign);
+                        double N10 = baryon * N10_fact * degeneracy * gauss_thermal(J10_int, q->root1, q->weight1, q->n_pts, mbar, alphaB, baryon, sign);
+                        double J20 = J20_fact * degeneracy * gauss_thermal(J20_int, q->root2, q->weight2, q->n_pts, mbar, alphaB, baryon, sign);
+                        double n_linear = neq + dn_fact * (neq + N10 * G + J20 * F / T / T);
+                        double n_mod = nmod_fact * degeneracy * gauss_thermal(neq_int, q->root1, q->weight1, q->n_pts, mbar_mod, alphaB_mod, baryon, sign);
+                        renorm = n_linear / n_mod;
+                    } else {
+                        renorm = z;
+                    }
+                }
+                if (isnan(renorm) || isinf(renorm)) continue;                        /* :768-772 */
+                if (o->dimension == 3) renorm /= detA;                               /* :774-777 */
+                for (int ipT = 0; ipT < npT; ipT++) {
+                    double pT = g->pT[ipT], mT = sqrt(mass2 + pT * pT), mT_over_tau = mT / tau;
+                    for (int iphip = 0; iphip < nphi; iphip++) {
+                        double px = pT * cosphi[iphip], py = pT * sinphi[iphip];
+                        for (int iy = 0; iy < y_pts; iy++) {
+                            double y = yValues[iy], sum = 0.0;
+                            for (int ieta = 0; ieta < eta_pts; ieta++) {
+                                double eta = etaValues[ieta], eta_weight = etaWeights[ieta];
+                                int narrow = 0;
+                                if (o->dimension == 3 && !feqmod_breaks_down)
+                                    if (detA < 0.01 && fabs(y - eta) < detA) narrow = 1;  /* :807-813 */
+                                double pdotdsigma, f;
+                                if (feqmod_breaks_down || narrow) {
+                                    double pt = mT * cosh(y - eta), pn = mT_over_tau * sinh(y - eta), tau2_pn = tau2 * pn;
+                                    pdotdsigma = eta_weight * (pt * dat + px * dax + py * day) + pn * dan;   /* :828 */
+                                    if (o->outflow && pdotdsigma <= 0.0) continue;
+                                    double pdotu = pt * ut - px * ux - py * uy - tau2_pn * un;
+                                    double pimunu_pmu_pnu = pitt * pt * pt + pixx * px * px + piyy * py * py + pinn * tau2_pn * tau2_pn
+                                        + 2.0 * (-(pitx * px + pity * py) * pt + pixy * px * py + tau2_pn * (pixn * px + piyn * py - pitn * pt));
+                                    double df;
+                                    if (DF_MODE == 3) {                                  /* :833-858 */
+                                        double feq = 1.0 / (exp(pdotu / T - chem) + sign), feqbar = 1.0 - sign * feq;
+                                        double df_shear = shear_coeff * pimunu_pmu_pnu / pdotu;
+                                        double df_bulk = (bulk0_coeff * pdotu + bulk1_coeff * baryon + bulk2_coeff * (pdotu - mass2 / pdotu)) * bulkPi;
+                                        df = feqbar * (df_shear + df_bulk);
+                                        if (o->regulate_deltaf) df = fmax(-1.0, fmin(df, 1.0));
+                                        f = feq * (1.0 + df);
+                                    } else {                                             /* :859-880 */
+                                        double feq = 1.0 / (exp(pdotu / T) + sign), feqbar = 1.0 - sign * feq;
+                                        double df_shear = feqbar * shear_coeff * pimunu_pmu_pnu / pdotu;
+                                        double df_bulk = delta_z - 3.0 * delta_lambda + feqbar * delta_lambda * (pdotu - mass2 / pdotu) / T;
+                                        df = df_shear + df_bulk;
+                                        if (o->regulate_deltaf) df = fmax(-1.0, fmin(df, 1.0));
+                                        f = feq * (1.0 + df);
+                                    }
+                                } else {
+                                    double pt = mT * cosh(y - eta_scale * eta), pn = mT_over_tau * sinh(y - eta_scale * eta), tau2_pn = tau2 * pn;
+                                    pdotdsigma = eta_weight * (pt * dat + px * dax + py * day) + pn * dan;   /* :905 */
+                                    if (o->outflow && pdotdsigma <= 0.0) continue;
+                                    double pLRF[3] = {-Xt * pt + Xx * px + Xy * py + Xn * tau2_pn, Yx * px + Yy * py, -Zt * pt + Zn * tau2_pn};
+                                    double pmod[3], prev[3], back[3], dp3[3], dmod[3];
+                                    matvec3(A_inv, pLRF, pmod);
+                                    for (int it = 0; it < 5; it++) {                     /* :915-926 */
+                                        prev[0] = pmod[0]; prev[1] = pmod[1]; prev[2] = pmod[2];
+                                        matvec3(A, prev, back);
+                                        dp3[0] = pLRF[0] - back[0]; dp3[1] = pLRF[1] - back[1]; dp3[2] = pLRF[2] - back[2];
+                                        double dp = sqrt(dp3[0] * dp3[0] + dp3[1] * dp3[1] + dp3[2] * dp3[2]);
+                                        if (dp <= 1.e-16) break;
+                                        matvec3(A_inv, dp3, dmod);
+                                        pmod[0] = prev[0] + dmod[0]; pmod[1] = prev[1] + dmod[1]; pmod[2] = prev[2] + dmod[2];
+                                    }
+                                    double E_mod = sqrt(mass2 + pmod[0] * pmod[0] + pmod[1] * pmod[1] + pmod[2] * pmod[2]);
+                                    f = fabs(renorm) / (exp(E_mod / T_mod - chem_mod) + sign);   /* :934 */
+                                }
+                                sum += (pdotdsigma * f);
+                            }
+                            long long iS3D = (long long)ipart + (long long)npart * ((long long)ipT + (long long)npT * ((long long)iphip + (long long)nphi * (long long)iy));
+                            acc[iS3D] += (prefactor * degeneracy * sum);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!err)
+        for (long long i = 0; i < nspec; i++) {
+            double tot = 0.0;
+            for (int th = 0; th < nthreads; th++) tot += part[(size_t)th * nspec + i];
+            dN_pTdpTdphidy[i] += tot;
+        }
+    if (n_breakdown) *n_breakdown = breakdown;
+    free(part); free(s); free(J); free(yValues); free(cosphi); free(sinphi);
+    return err;
+}

@@ -170,3 +170,60 @@ def num_threads():
 def set_num_threads(n):
     lib().oracle_set_num_threads(int(n))
     return num_threads()
+
+
+class _FeqmodTables(C.Structure):
+    _fields_ = [("n_pts", C.c_int), ("root1", _dp), ("weight1", _dp), ("root2", _dp), ("weight2", _dp), ("n_pdg", C.c_int),
+                ("pdg_mass", _dp), ("pdg_degeneracy", _dp), ("pdg_sign", _dp), ("T_avg", C.c_double), ("deta_min", C.c_double),
+                ("mass_pion0", C.c_double)]
+
+
+def _feqmod_struct(fq):
+    keep = {k: _f64(fq[k]) for k in ["root1", "weight1", "root2", "weight2", "pdg_mass", "pdg_degeneracy", "pdg_sign"]}
+    st = _FeqmodTables(len(keep["root1"]), _p(keep["root1"]), _p(keep["weight1"]), _p(keep["root2"]), _p(keep["weight2"]),
+                       len(keep["pdg_mass"]), _p(keep["pdg_mass"]), _p(keep["pdg_degeneracy"]), _p(keep["pdg_sign"]),
+                       float(fq["T_avg"]), float(fq["deta_min"]), float(fq["mass_pion0"]))
+    return st, keep
+
+
+def jonah_tables(fq):
+    """-> (lambda^2[301], z[301], bulkPi/Peq[301], bulkPi_over_Peq_max): Deltaf_Data::compute_jonah_coefficients."""
+    st, keep = _feqmod_struct(fq)
+    out = np.zeros(3 * 301 + 1)
+    lib().oracle_jonah_tables.argtypes = [C.POINTER(_FeqmodTables), _dp]
+    lib().oracle_jonah_tables(C.byref(st), _p(out))
+    t = out[:903].reshape(301, 3)
+    return t[:, 0].copy(), t[:, 1].copy(), t[:, 2].copy(), float(out[903])
+
+
+def dN_pTdpTdphidy_feqmod(cells, species, grid, df, fq, opts, out=None):
+    """Modified-equilibrium smooth spectra (df_mode 3 | 4), calculate_dN_ptdptdphidy_feqmod.  Returns (spectrum, n_breakdown)."""
+    o = dict(DEFAULT_OPTS)
+    o.update(opts)
+    n = len(cells["tau"])
+    keep = {}
+    ca = _CellArrays()
+    for f in CELL_FIELDS:
+        if f in cells and cells[f] is not None:
+            keep[f] = _f64(cells[f])
+            setattr(ca, f, _p(keep[f]))
+    sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy", "baryon"]}
+    npart = len(sp["mass"])
+    g = {k: _f64(grid[k]) for k in ["pT", "phi", "y", "eta", "eta_w"]}
+    gs = _Grid(len(g["pT"]), _p(g["pT"]), len(g["phi"]), _p(g["phi"]), len(g["y"]), _p(g["y"]), len(g["eta"]), _p(g["eta"]), _p(g["eta_w"]))
+    st, keep_df = _df_struct(df)
+    fs, keep_fq = _feqmod_struct(fq)
+    os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
+    ny = 1 if o["dimension"] == 2 else len(g["y"])
+    size = npart * len(g["pT"]) * len(g["phi"]) * ny
+    if out is None:
+        out = np.zeros(size)
+    nb = C.c_long(0)
+    L = lib()
+    L.oracle_dN_pTdpTdphidy_feqmod.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_CellArrays), C.POINTER(_DfTables),
+                                               C.POINTER(_FeqmodTables), C.POINTER(_Grid), C.POINTER(_Opts), _dp, C.POINTER(C.c_long)]
+    rc = L.oracle_dN_pTdpTdphidy_feqmod(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), _p(sp["baryon"]), C.byref(ca),
+                                        C.byref(st), C.byref(fs), C.byref(gs), C.byref(os_), _p(out), C.byref(nb))
+    if rc:
+        raise RuntimeError("oracle_dN_pTdpTdphidy_feqmod failed rc=%d" % rc)
+    return out, int(nb.value)

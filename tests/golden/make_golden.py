@@ -154,6 +154,134 @@ def highprec_spectrum(cells, sp, grid, df, opts):
     return out.reshape(-1)
 
 
+def jonah_tables_ld(fq):
+    """Deltaf_Data::compute_jonah_coefficients (deltafReader.cpp:222-297) in long double, vectorised."""
+    T = LD(fq["T_avg"])
+    r, w = fq["root2"].astype(LD)[None, :], fq["weight2"].astype(LD)[None, :]
+    keep = fq["pdg_mass"] != 0.0
+    mbar = (fq["pdg_mass"][keep].astype(LD) / T)[:, None]
+    g = fq["pdg_degeneracy"][keep].astype(LD)
+    sg = fq["pdg_sign"][keep].astype(LD)[:, None]
+    Ebar = np.sqrt(r * r + mbar * mbar)
+    feq = np.exp(r) / (np.exp(Ebar) + sg)
+
+    def EP(lam):
+        s2 = (1 + lam) ** 2
+        em = np.sqrt(r * r * s2 + mbar * mbar)
+        return np.sum(g * np.sum(w * em * feq, axis=1)), np.sum(g * np.sum(w * r * r * s2 / em * feq, axis=1)) / 3
+    E0, P0 = EP(LD(0))
+    lam = LD(-1) + np.arange(301).astype(LD) * (LD(3) / LD(300))
+    z, bp = np.zeros(301, dtype=LD), np.zeros(301, dtype=LD)
+    for i in range(301):
+        Em, Pm = EP(lam[i])
+        z[i] = E0 / Em
+        bp[i] = (Pm / P0) * z[i] - 1
+    return (lam * lam).astype(np.float64), z.astype(np.float64), bp.astype(np.float64)
+
+
+def highprec_feqmod(cells, sp, grid, df, fq, opts):
+    """calculate_dN_ptdptdphidy_feqmod (smooth_kernels.cpp:396-996), include_baryon = 0, in long double with numpy linear
+    algebra and scipy splines -- independent of the oracle's C.  Cells whose feqmod breaks down (df_mode 3) or rows in the
+    narrow window (3+1D, detA < 0.01) are NOT handled: the generator asserts that none occurs in the chosen cells."""
+    dim, dfm = opts["dimension"], opts["df_mode"]
+    outflow = opts.get("outflow", 1)
+    pT = grid["pT"].astype(LD)
+    cosphi, sinphi = np.cos(grid["phi"]).astype(LD), np.sin(grid["phi"]).astype(LD)
+    mass, sign, gdeg = sp["mass"].astype(LD), sp["sign"].astype(LD), sp["degeneracy"].astype(LD)
+    ny = len(grid["y"]) if dim == 3 else 1
+    out = np.zeros((ny, len(cosphi), len(pT), len(mass)), dtype=LD)
+    pref = LD(float(2.0 * np.pi * 0.197327053)) ** -3
+    two_pi2_hbarC3 = LD(float(2.0 * np.pi ** 2 * 0.197327053 ** 3))
+    mT = np.sqrt(mass[:, None] ** 2 + pT[None, :] ** 2)
+    if dfm == 4:
+        l2, zt, bpt = jonah_tables_ld(fq)
+        S_l2, S_z = CubicSpline(bpt, l2, bc_type="natural"), CubicSpline(bpt, zt, bc_type="natural")
+        bp_max = float(np.max(bpt))
+    r1, w1, r2, w2 = (fq[k].astype(LD) for k in ("root1", "weight1", "root2", "weight2"))
+    for c in range(len(cells["tau"])):
+        f = {k: LD(cells[k][c]) for k in synth.CELL_FIELDS}
+        tau, tau2 = f["tau"], f["tau"] ** 2
+        ux, uy, un = f["ux"], f["uy"], f["un"]
+        ut = np.sqrt(1 + ux * ux + uy * uy + tau2 * un * un)
+        dat, dax, day, dan = f["dat"], f["dax"], f["day"], f["dan"]
+        assert ut * dat + ux * dax + uy * day + un * dan > 0
+        T, P, E = f["T"], f["P"], f["E"]
+        pixx, pixy, pixn, piyy, piyn = f["pixx"], f["pixy"], f["pixn"], f["piyy"], f["piyn"]
+        uperp, utperp = np.sqrt(ux * ux + uy * uy), np.sqrt(1 + ux * ux + uy * uy)
+        pinn = (pixx * (ux * ux - ut * ut) + piyy * (uy * uy - ut * ut) + 2 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp ** 2)
+        pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut
+        pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut
+        pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut
+        pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut
+        bulkPi = f["bulkPi"]
+        co = coefficients_scipy(df, 2, float(T))
+        F, betabulk, betapi = LD(co["F"]), LD(co["betabulk"]), LD(co["betapi"])
+        # contravariant Milne components (tau, x, y, eta) of the LRF triad, viscous_correction.cpp:8-27
+        sinhL, coshL = tau * un / utperp, ut / utperp
+        X = np.array([uperp * coshL, utperp * ux / uperp, utperp * uy / uperp, uperp * sinhL / tau], dtype=LD)
+        Y = np.array([0, -uy / uperp, ux / uperp, 0], dtype=LD)
+        Z = np.array([sinhL, 0, 0, coshL / tau], dtype=LD)
+        pi = np.array([[pitt, pitx, pity, pitn], [pitx, pixx, pixy, pixn], [pity, pixy, piyy, piyn], [pitn, pixn, piyn, pinn]], dtype=LD)
+        gdn = np.array([1, -1, -1, -tau2], dtype=LD)            # lowering: e_mu = g_{mu nu} e^nu
+        tri = [X * gdn, Y * gdn, Z * gdn]
+        piL = np.array([[a @ pi @ b for b in tri] for a in tri], dtype=LD)      # pi^{ij}_LRF = e^i_mu e^j_nu pi^{mu nu}
+        if dfm == 4:
+            if bulkPi < -P:
+                bulkPi = -(1 - LD(1e-5)) * P
+            elif bulkPi / P > bp_max:
+                bulkPi = P * (LD(bp_max) - LD(1e-5))
+            lam = np.sign(bulkPi) * np.sqrt(LD(float(S_l2(float(bulkPi / P)))))
+            renorm, T_mod, bulk_mod = LD(float(S_z(float(bulkPi / P)))), T, lam
+        else:
+            T_mod, bulk_mod = T + bulkPi * F / betabulk, bulkPi / (3 * betabulk)
+        A = np.eye(3, dtype=LD) * (1 + bulk_mod) + piL / (2 * betapi)
+        A[2, 2] = 1 + bulk_mod - (piL[0, 0] + piL[1, 1]) / (2 * betapi)          # pizz_LRF = -(pixx_LRF + piyy_LRF), :114
+        detA = np.linalg.det(A.astype(np.float64))
+        Ainv = np.linalg.inv(A.astype(np.float64)).astype(LD)
+        for _ in range(3):                                                        # Newton-Schulz polish in long double
+            Ainv = Ainv @ (2 * np.eye(3, dtype=LD) - A @ Ainv)
+        assert detA > 0.02, "generator cells must stay away from the breakdown branches"
+        eta_scale = LD(detA) if (dim == 2 and fq["deta_min"] < detA < 1.0) else LD(1)
+        if dim == 3:
+            ys, etas, ws = grid["y"].astype(LD), np.array([f["eta"]], dtype=LD), np.array([1], dtype=LD)
+        else:
+            ys, etas, ws = np.array([0], dtype=LD), grid["eta"].astype(LD), grid["eta_w"].astype(LD)
+        d = ys[:, None] - eta_scale * etas[None, :]
+        ch, sh = np.cosh(d)[:, :, None, None, None], np.sinh(d)[:, :, None, None, None]
+        w = ws[None, :, None, None, None]
+        mTb = mT.T[None, None, None, :, :]
+        px = (pT[None, :] * cosphi[:, None])[None, None, :, :, None]
+        py = (pT[None, :] * sinphi[:, None])[None, None, :, :, None]
+        pt, t2pn = mTb * ch, tau * mTb * sh
+        pn = t2pn / tau2
+        pds = w * (pt * dat + px * dax + py * day) + pn * dan                      # dsigma_eta outside the weight, :905
+        pL = [-(e[0] * pt) + e[1] * px + e[2] * py + e[3] * t2pn for e in (X, Y, Z)]     # -X.p etc with p_mu lowered: :907-909
+        pm = [Ainv[i, 0] * pL[0] + Ainv[i, 1] * pL[1] + Ainv[i, 2] * pL[2] for i in range(3)]
+        Emod = np.sqrt((mass ** 2)[None, None, None, None, :] + pm[0] ** 2 + pm[1] ** 2 + pm[2] ** 2)
+        if dfm == 3:
+            mbar, mbm = mass / T, mass / T_mod
+            neqf = T ** 3 / two_pi2_hbarC3
+
+            def gt(kind, mb, r, wq):
+                Eb = np.sqrt(r[None, :] ** 2 + mb[:, None] ** 2)
+                q = np.exp(Eb) + sign[:, None]
+                if kind == "neq":
+                    return np.sum(wq * r * np.exp(r) / q, axis=1)
+                return np.sum(wq * Eb * np.exp(r + Eb) / (q * q), axis=1)
+            neq = neqf * gdeg * gt("neq", mbar, r1, w1)
+            J20 = T * neqf * gdeg * gt("J20", mbar, r2, w2)
+            n_lin = neq + (bulkPi / betabulk) * (neq + J20 * F / T / T)
+            n_mod = (T_mod ** 3 / two_pi2_hbarC3) * gdeg * gt("neq", mbm, r1, w1)
+            renorm = (n_lin / n_mod)[None, None, None, None, :]
+        ren = np.abs(renorm) / (LD(detA) if dim == 3 else LD(1))
+        fm = ren / (np.exp(Emod / T_mod) + sign[None, None, None, None, :])
+        term = pds * fm
+        if outflow:
+            term = np.where(pds <= 0, LD(0), term)
+        out += pref * gdeg[None, None, None, :] * term.sum(axis=1)
+    return out.reshape(-1)
+
+
 def hand_cells():
     """Toy cell of input/surface.dat with flow, shear and bulk switched on, plus two tilted cells."""
     h = 0.197327053
@@ -211,7 +339,22 @@ def main():
                 chk = oracle.dN_pTdpTdphidy(cells, spb, grid, dff, o)
                 den = np.maximum(np.abs(hp[key]), 1e-280)
                 print("%-22s oracle vs long-double restatement: max rel %.3e" % (key, np.max(np.abs(chk - hp[key]) / den)))
-    for nm, cells in [("hand3", hc), ("seed3", seeded3), ("seed2", seeded2), ("seedb3", sb3), ("seedb2", sb2)]:
+    # modified equilibrium (df_mode 3 Mike, 4 Jonah): SURVEY.md 8f rank 3
+    sf3 = synth.synth_surface(3, 3, seed=27)
+    sf2 = synth.synth_surface(2, 2, seed=28)
+    for name, cells, dim in [("seedf3", sf3, 3), ("seedf2", sf2, 2)]:
+        fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+        for dfm in (4, 3):
+            o = dict(dimension=dim, df_mode=dfm)
+            key = "%s_feqmod%d" % (name, dfm)
+            hp[key] = highprec_feqmod(cells, sp, grid, df, fq, o).astype(np.float64)
+            cases.append(dict(key=key, cells=name, opts=o, feqmod=True))
+            chk, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, grid, df, fq, o)
+            assert nb == 0
+            den = np.maximum(np.abs(hp[key]), 1e-280)
+            print("%-22s oracle vs long-double restatement: max rel %.3e" % (key, np.max(np.abs(chk - hp[key]) / den)))
+    cells_all = [("hand3", hc), ("seed3", seeded3), ("seed2", seeded2), ("seedb3", sb3), ("seedb2", sb2), ("seedf3", sf3), ("seedf2", sf2)]
+    for nm, cells in cells_all:
         for k in synth.CELL_FIELDS + (synth.BARYON_FIELDS if "muB" in cells else []):
             hp["cells_%s_%s" % (nm, k)] = cells[k]
     np.savez_compressed(os.path.join(HERE, "golden_highprec.npz"), **hp)

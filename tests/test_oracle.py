@@ -89,13 +89,23 @@ def test_against_longdouble_restatement(fx, pins):
     dff = inputs.df_tables_full()
     worst = 0.0
     n_baryon = 0
+    for nm in ("seedf3", "seedf2"):   # modified-equilibrium cases (df_mode 3, 4)
+        cellsets[nm] = {k: z["cells_%s_%s" % (nm, k)] for k in synth.CELL_FIELDS}
+    n_feqmod = 0
     for case in pins["highprec_cases"]:
         sp = inputs.species(case["species"]) if "species" in case else fx["pikp"]
         df = dff if case["opts"].get("include_baryon") else fx["df"]
         n_baryon += int(bool(case["opts"].get("include_baryon")))
-        got = oracle.dN_pTdpTdphidy(cellsets[case["cells"]], sp, fx["grid"], df, case["opts"])
+        cells = cellsets[case["cells"]]
+        if case.get("feqmod"):
+            n_feqmod += 1
+            fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+            got, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], df, fq, case["opts"])
+            assert nb == 0
+        else:
+            got = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], df, case["opts"])
         worst = max(worst, relerr(got, z[case["key"]]))
-    assert n_baryon == 8
+    assert n_baryon == 8 and n_feqmod == 4
     assert worst < 5e-10, worst
 
 
@@ -125,6 +135,33 @@ def test_bilinear_branch(fx):
     cells["T"][2] = 0.2001
     with pytest.raises(RuntimeError):
         oracle.dN_pTdpTdphidy(cells, sp, g, dff, dict(dimension=3, df_mode=1, include_baryon=1, include_baryondiff_deltaf=1))
+
+
+def test_feqmod_tables_and_breakdown(fx):
+    """Modified equilibrium (df_mode 3, 4): the Jonah tables pass through (lambda, z, Pi/P) = (0, 1, 0) and are monotone
+    in Pi/P (GSL needs ascending abscissae); a df_mode-3 cell whose linearised pion density is negative falls back to the
+    Chapman-Enskog linear delta-f for the whole cell (does_feqmod_breakdown, emissionfunction.cpp:109-138), which in
+    3+1D (eta weight 1) is exactly the df_mode-2 spectrum."""
+    cells = synth.synth_surface(5, 3, seed=41)
+    fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    l2, z, bp, bpmax = oracle.jonah_tables(fq)
+    assert abs(l2[100]) < 1e-25 and abs(z[100] - 1) < 1e-14 and abs(bp[100]) < 1e-14      # lambda = -1 + 100 * 0.01 = 0
+    assert (np.diff(bp) > 0).all() and bp[0] == -1.0 and bpmax == bp[-1]
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::4], phi=fx["grid"]["phi"][::4])
+    sp = fx["pikp"]
+    ok, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, dict(dimension=3, df_mode=3))
+    assert nb == 0
+    bad = {k: v.copy() for k, v in cells.items()}
+    bad["bulkPi"][:] = -5.0 * bad["P"]            # n_linear(pion0) < 0  ->  breakdown in every cell
+    fb, nb = oracle.dN_pTdpTdphidy_feqmod(bad, sp, g, fx["df"], fq, dict(dimension=3, df_mode=3))
+    assert nb == 5
+    ce = oracle.dN_pTdpTdphidy(bad, sp, g, fx["df"], dict(dimension=3, df_mode=2))
+    assert relerr(fb, ce) < 1e-14
+    # df_mode 4 clamps Pi to (-P, Pi_max) instead of breaking down (smooth_kernels.cpp:584-590): finite, positive spectrum
+    j4, nb = oracle.dN_pTdpTdphidy_feqmod(bad, sp, g, fx["df"], fq, dict(dimension=3, df_mode=4))
+    assert nb == 0 and np.isfinite(j4).all() and (j4 >= 0).all() and j4.max() > 0
+    with pytest.raises(RuntimeError):
+        oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, dict(dimension=3, df_mode=2))
 
 
 def test_golden_64cell_regression(fx, pins):
