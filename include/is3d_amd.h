@@ -98,9 +98,26 @@ typedef struct {
     const double *F, *G, *betabulk, *betaV, *betapi; /* df_mode 2 */
 } is3d_df_tables;
 
+/* Extra inputs of the modified-equilibrium path (df_mode 3, 4): replaces the Gauss_Laguerre *laguerre argument of
+ * calculate_dN_ptdptdphidy_feqmod (emissionfunction.h:182), the PDG/Plasma inputs of
+ * Deltaf_Data::compute_jonah_coefficients (deltafReader.cpp:222-297) and the members DETA_MIN, MASS_PION0
+ * (emissionfunction.cpp:184, :188). */
+typedef struct {
+    int32_t n_gla;                      /* Gauss-Laguerre points per alpha (32 in tables/gla_roots_weights_32_points.txt) */
+    const double *root1, *weight1;      /* alpha = 1 (Gauss_Laguerre::load_roots_and_weights, readindata.cpp:24-53) */
+    const double *root2, *weight2;      /* alpha = 2 */
+    int32_t n_pdg;                      /* ALL species of the PDG file (df_mode 4: the z(Pi/P), lambda(Pi/P) tables sum over them) */
+    const double *pdg_mass, *pdg_degeneracy, *pdg_sign;
+    double T_avg;                       /* Plasma::temperature: the surface average as read back from
+                                           average_thermodynamic_quantities.dat (df_mode 4) */
+    double deta_min;                    /* parameter deta_min */
+    double mass_pion0;                  /* parameter mass_pion0 */
+} is3d_feqmod_tables;
+
 typedef struct {
     int32_t dimension;                  /* 2 | 3                      DIMENSION  */
-    int32_t df_mode;                    /* 1 14-moment | 2 Chapman-Enskog  DF_MODE */
+    int32_t df_mode;                    /* 1 14-moment | 2 Chapman-Enskog | 3 modified equilibrium (Mike) | 4 (Jonah);
+                                           3 and 4 only through the *_feqmod entries, include_baryon = 0   DF_MODE */
     int32_t include_baryon;             /* 1: mu_B/T in f_eq, bilinear (T, mu_B) coefficients (muB_fo; with
                                            include_baryondiff_deltaf also nB_fo, Vx_fo, Vy_fo, Vn_fo) */
     int32_t include_bulk_deltaf;
@@ -137,6 +154,10 @@ typedef struct {
     double ms_h2d, ms_d2h;              /* host entry only */
     int64_t n_wave_rows;                /* (cell, row, wave) triples the tile kernel visited ...          */
     int64_t n_wave_rows_culled;         /* ... and how many it skipped as exactly zero (zero_skip)        */
+    int64_t n_cells_breakdown;          /* df_mode 3: cells where feqmod breaks down (linearised delta-f used, the count
+                                           the reference prints, smooth_kernels.cpp:983-986)              */
+    int64_t n_cells_narrow;             /* df_mode 3, 4 in 3+1D: cells with detA < 0.01, whose rows |y - eta| < detA use
+                                           the linearised delta-f (:807-813)                               */
 } is3d_status;
 
 typedef struct is3d_plan is3d_plan;
@@ -155,12 +176,24 @@ int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *species, co
                         const is3d_df_tables *df, const is3d_options *opts, double *dN_out,
                         is3d_status *status);
 
+/* The same for df_mode 3 / 4: what a maintainer calls from calculate_dN_ptdptdphidy_feqmod
+ * (emissionfunction.h:182, smooth_kernels.cpp:396-996, call site emissionfunction.cpp:1584).  df needs betapi
+ * (df_mode 4) or F, betabulk, betapi (df_mode 3), row 0. */
+int is3d_smooth_spectra_feqmod(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                               const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts,
+                               double *dN_out, is3d_status *status);
+
 /*
  * Device-resident API.  A plan holds the species classes, grids and spline tables on the device and
  * the workspaces sized for up to max_cells cells per execute.
  */
 int is3d_plan_create(is3d_plan **plan, const is3d_species *species, const is3d_grid *grid,
                      const is3d_df_tables *df, const is3d_options *opts, int64_t max_cells);
+/* plan for df_mode 3 / 4; execute, observables, timings as for any plan.  df_mode 4 builds the 301-point
+ * lambda(Pi/P), z(Pi/P) tables on the host here (deltafReader.cpp:222-297), ~0.1 s. */
+int is3d_plan_create_feqmod(is3d_plan **plan, const is3d_species *species, const is3d_grid *grid,
+                            const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts,
+                            int64_t max_cells);
 /* length of dN_out in doubles */
 int64_t is3d_plan_output_size(const is3d_plan *plan);
 /* cells->* and dN_out are DEVICE pointers on the plan's device; hip_stream is a hipStream_t (NULL =

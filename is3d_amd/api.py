@@ -43,6 +43,12 @@ class DfTables(C.Structure):
                [(n, _dp) for n in ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "betapi"]]
 
 
+class FeqmodTables(C.Structure):
+    _fields_ = [("n_gla", C.c_int32), ("root1", _dp), ("weight1", _dp), ("root2", _dp), ("weight2", _dp), ("n_pdg", C.c_int32),
+                ("pdg_mass", _dp), ("pdg_degeneracy", _dp), ("pdg_sign", _dp), ("T_avg", C.c_double), ("deta_min", C.c_double),
+                ("mass_pion0", C.c_double)]
+
+
 class Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
                                          "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
@@ -54,13 +60,14 @@ class Status(C.Structure):
     _fields_ = [("code", C.c_int32), ("n_classes", C.c_int32), ("n_cells_skipped", C.c_int64), ("bad_cell", C.c_int64),
                 ("n_passes", C.c_int32), ("kernel_variant", C.c_int32), ("ms_prep", C.c_double), ("ms_main", C.c_double),
                 ("ms_finalize", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double), ("n_wave_rows", C.c_int64),
-                ("n_wave_rows_culled", C.c_int64)]
+                ("n_wave_rows_culled", C.c_int64), ("n_cells_breakdown", C.c_int64), ("n_cells_narrow", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_plan_create",
+EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_smooth_spectra_feqmod", "is3d_plan_create",
+           "is3d_plan_create_feqmod",
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
@@ -106,6 +113,10 @@ def load():
                                       C.POINTER(Options), _dp, C.POINTER(Status)]
     L.is3d_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
                                    C.POINTER(Options), C.c_int64]
+    L.is3d_smooth_spectra_feqmod.argtypes = [C.POINTER(Cells), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
+                                             C.POINTER(FeqmodTables), C.POINTER(Options), _dp, C.POINTER(Status)]
+    L.is3d_plan_create_feqmod.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
+                                          C.POINTER(FeqmodTables), C.POINTER(Options), C.c_int64]
     L.is3d_plan_output_size.restype = C.c_int64
     L.is3d_plan_output_size.argtypes = [C.c_void_p]
     L.is3d_plan_workspace_bytes.restype = C.c_int64
@@ -187,8 +198,18 @@ def _pack_common(species, grid, df, opts):
     return sps, gs, ds, os_, nout, keep
 
 
-def smooth_spectra(cells, species, grid, df, opts=None, out=None):
-    """Host-pointer entry is3d_smooth_spectra (the drop-in for calculate_dN_pTdpTdphidy).
+def _pack_feqmod(fq, keep):
+    """is3d_feqmod_tables from the dict of is3d_amd.inputs.feqmod_tables()."""
+    a = {k: _f64(fq[k]) for k in ["root1", "weight1", "root2", "weight2", "pdg_mass", "pdg_degeneracy", "pdg_sign"]}
+    keep["fq"] = a
+    return FeqmodTables(len(a["root1"]), _p(a["root1"]), _p(a["weight1"]), _p(a["root2"]), _p(a["weight2"]), len(a["pdg_mass"]),
+                        _p(a["pdg_mass"]), _p(a["pdg_degeneracy"]), _p(a["pdg_sign"]), float(fq["T_avg"]), float(fq["deta_min"]),
+                        float(fq["mass_pion0"]))
+
+
+def smooth_spectra(cells, species, grid, df, opts=None, out=None, fq=None):
+    """Host-pointer entry is3d_smooth_spectra (the drop-in for calculate_dN_pTdpTdphidy); with fq (df_mode 3, 4)
+    is3d_smooth_spectra_feqmod (the drop-in for calculate_dN_ptdptdphidy_feqmod).
     cells: dict of numpy arrays (host).  Returns (dN flat numpy array, status dict)."""
     L = load()
     sps, gs, ds, os_, nout, keep = _pack_common(species, grid, df, opts)
@@ -207,7 +228,11 @@ def smooth_spectra(cells, species, grid, df, opts=None, out=None):
         out = np.zeros(nout)
     assert out.dtype == np.float64 and out.size == nout and out.flags.c_contiguous
     st = Status()
-    rc = L.is3d_smooth_spectra(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), _p(out), C.byref(st))
+    if fq is not None:
+        fqs = _pack_feqmod(fq, keep)
+        rc = L.is3d_smooth_spectra_feqmod(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(fqs), C.byref(os_), _p(out), C.byref(st))
+    else:
+        rc = L.is3d_smooth_spectra(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), _p(out), C.byref(st))
     _check(rc)
     return out, st.as_dict()
 
@@ -216,11 +241,15 @@ class Plan:
     """Device-resident plan (is3d_plan_*).  Cell arrays and the output are device pointers (ints),
     e.g. torch tensors' data_ptr(); `stream` is a hipStream_t handle (torch.cuda.current_stream().cuda_stream)."""
 
-    def __init__(self, species, grid, df, opts=None, max_cells=1):
+    def __init__(self, species, grid, df, opts=None, max_cells=1, fq=None):
         L = load()
         sps, gs, ds, os_, nout, keep = _pack_common(species, grid, df, opts)
         self._h = C.c_void_p()
-        _check(L.is3d_plan_create(C.byref(self._h), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), int(max_cells)))
+        if fq is not None:
+            fqs = _pack_feqmod(fq, keep)
+            _check(L.is3d_plan_create_feqmod(C.byref(self._h), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(fqs), C.byref(os_), int(max_cells)))
+        else:
+            _check(L.is3d_plan_create(C.byref(self._h), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), int(max_cells)))
         self.output_size = int(L.is3d_plan_output_size(self._h))
         assert self.output_size == nout
         self.workspace_bytes = int(L.is3d_plan_workspace_bytes(self._h))

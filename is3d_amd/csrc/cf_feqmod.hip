@@ -1,0 +1,712 @@
+// cf_feqmod.hip -- gfx950 kernels of the modified-equilibrium smooth path (df_mode 3, 4); see cf_feqmod.h for the
+// factorisation.  Reference: EmissionFunctionArray::calculate_dN_ptdptdphidy_feqmod
+// (/root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:396-996) and its helpers Milne_Basis /
+// Shear_Stress::boost_pimunu_to_lrf (viscous_correction.cpp:8-27, :99-115), GaussThermal (gaussThermal.cpp),
+// does_feqmod_breakdown (emissionfunction.cpp:109-150), Deltaf_Data::cubic_spline (deltafReader.cpp:347-384).
+//
+//   cf_prep_feqmod    lanes <-> cells: per-cell A, A^-1, T_mod, renorm (df_mode 4), breakdown test (df_mode 3), the
+//                     quadratic-form coefficients as tiled unit records, fallback records for flagged cells
+//   cf_feqmod_renorm  df_mode 3: thread <-> (cell, species class): n_linear / n_mod by Gauss-Laguerre quadrature
+//   cf_main_feqmod    lanes <-> (species class, pT), LDS-staged coefficient stream as in cf_main_tile; one sqrt and one
+//                     exp per evaluation (the exponential does not factorise here); fp64 VALU bound
+//   cf_feqmod_compact ordered list of flagged cells (single workgroup scan, deterministic)
+//   cf_feqmod_linear  thread <-> (lane, phi, y): linearised delta-f for flagged cells / narrow rows, added to chunk 0
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cf_feqmod.h"
+#include "cf_launch.h"
+#include "cf_math.h"
+
+namespace is3d {
+
+constexpr int kFqCB = 4;           // cells per workgroup batch of the prep kernel
+constexpr int kFqThreads = 256;
+
+struct FqScal {
+    double dat, dax, day, dan_tau, eta, eta_scale;
+    double live;                   // 1: cell is evaluated with feqmod; 0: neutral in the stream (skipped, bad, breakdown)
+    double rn;                     // df_mode 4: |renorm| folded into A_k, W_k; df_mode 3: 1
+    double invTm2;                 // 1 / T_mod^2
+    double Xt, tXn, Zt, tZn;       // a_k = (-Xt ch + tXn sh, 0, -Zt ch + tZn sh)
+    double Xx, Xy, Yx, Yy;         // b_j = (Xx cos + Xy sin, Yx cos + Yy sin, 0)
+    double Ai[9];                  // A^-1, row major
+    double detA;
+    double narrow;                 // 1: 3+1D cell with detA < 0.01: rows with |y - eta| < detA go to the linear kernel
+};
+
+enum FbIdx { FB_DAT = 0, FB_DAX, FB_DAY, FB_DAN, FB_UT, FB_UX, FB_UY, FB_UN, FB_TAU, FB_ETA, FB_T,
+             FB_PITT, FB_PITX, FB_PITY, FB_PITN, FB_PIXX, FB_PIXY, FB_PIXN, FB_PIYY, FB_PIYN, FB_PINN,
+             FB_SHEAR, FB_CA, FB_CB, FB_DETA, FB_KIND, FB_END };
+static_assert(FB_END <= kFbRec, "fallback record too small");
+
+// GaussThermal integrands at alpha_B = 0 (gaussThermal.cpp; neq_int, J20_int)
+__device__ __forceinline__ double gt_neq(const double *root, const double *weight, int n, double mbar, double sign)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
+        s += weight[k] * (pbar * exp(pbar) / (exp(Ebar) + sign));
+    }
+    return s;
+}
+__device__ __forceinline__ double gt_J20(const double *root, const double *weight, int n, double mbar, double sign)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
+        const double qstat = exp(Ebar) + sign;
+        s += weight[k] * (Ebar * exp(pbar + Ebar) / (qstat * qstat));
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
+{
+    extern __shared__ double lds[];
+    const int nT = p.spl.n, J = p.J, K = p.K, nj = p.nj, ngl = p.ngl;
+    double *sx = lds;                          // [nT]
+    double *sy = sx + nT;                      // [3][nT]
+    double *sc = sy + 3 * nT;                  // [3][nT]
+    double *jx = sc + 3 * nT;                  // [5][nj]: x, lambda^2, z, c_lambda, c_z
+    double *gl = jx + 5 * nj;                  // [4][ngl]
+    FqScal *cs = (FqScal *)(gl + 4 * ngl);     // [CB]
+    double *lk = (double *)(cs + kFqCB);       // [6][CB][K]: A, alphaf, W, a'x, a'y, a'z
+    double *lj = lk + 6 * kFqCB * K;           // [5][CB][J]: B, gammaf, b'x, b'y, b'z
+    const int CK = kFqCB * K, CJ = kFqCB * J;
+    double *l_A = lk, *l_al = lk + CK, *l_W = lk + 2 * CK, *l_ax = lk + 3 * CK, *l_ay = lk + 4 * CK, *l_az = lk + 5 * CK;
+    double *l_B = lj, *l_ga = lj + CJ, *l_bx = lj + 2 * CJ, *l_by = lj + 3 * CJ, *l_bz = lj + 4 * CJ;
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nT; i += kFqThreads) {
+        sx[i] = p.spl.x[i];
+        for (int s = 0; s < 3; s++) { sy[s * nT + i] = p.spl.y[s][i]; sc[s * nT + i] = p.spl.c[s][i]; }
+    }
+    for (int i = tid; i < nj; i += kFqThreads) {
+        jx[i] = p.jx[i]; jx[nj + i] = p.jl2[i]; jx[2 * nj + i] = p.jz[i]; jx[3 * nj + i] = p.jcl[i]; jx[4 * nj + i] = p.jcz[i];
+    }
+    for (int i = tid; i < 4 * ngl; i += kFqThreads) gl[i] = p.gl[i];
+    __syncthreads();
+    const double two_pi2_hbarC3 = 2.0 * M_PI * M_PI * (kHbarC * kHbarC * kHbarC);   // iS3D.h:11
+
+    const int nbatch = (p.n_cells + kFqCB - 1) / kFqCB;
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int cbase = batch * kFqCB;
+        const int ncb = min(kFqCB, p.n_cells - cbase);
+
+        // ---- phase 1: per-cell scalars (smooth_kernels.cpp:486-735) ----
+        if (tid < ncb) {
+            const int cell = cbase + tid;
+            const int64_t gi = p.cell0 + cell;
+            FqScal s;
+            const double tau = p.cells.tau[gi], tau2 = tau * tau;
+            const double dat = p.cells.dat[gi], dax = p.cells.dax[gi], day = p.cells.day[gi], dan = p.cells.dan[gi];
+            const double ux = p.cells.ux[gi], uy = p.cells.uy[gi], un = p.cells.un[gi];
+            const double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+            const double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+            bool valid = udsigma > 0.0;                                               // :502
+            if (!valid) atomicAdd(&p.status[1], 1ULL);
+            const double T = p.cells.T[gi];
+            if (valid && !(T >= sx[0] && T <= sx[nT - 1])) {                          // GSL domain error in the reference
+                atomicMin(&p.status[0], (unsigned long long)gi);
+                valid = false;
+            }
+            const double P = p.cells.P[gi], E = p.cells.E[gi];
+            double bulkPi = (valid && p.include_bulk) ? p.cells.bulkPi[gi] : 0.0;
+            if (valid && p.mode == 4) {                                               // :584-590
+                if (bulkPi < -P) bulkPi = -(1.0 - 1.e-5) * P;
+                else if (bulkPi / P > p.bp_max) bulkPi = P * (p.bp_max - 1.e-5);
+                const double r = bulkPi / P;
+                if (!(r >= jx[0] && r <= jx[nj - 1])) {                               // outside the Jonah table (P <= 0, NaN)
+                    atomicMin(&p.status[0], (unsigned long long)gi);
+                    valid = false;
+                }
+            }
+            int flag = 0;
+            s.narrow = 0.0;
+            if (valid) {
+                const double ut2 = ut * ut, ux2 = ux * ux, uy2 = uy * uy;
+                const double uperp = sqrt(ux * ux + uy * uy), utperp = sqrt(1.0 + ux * ux + uy * uy);
+                double pitt = 0, pitx = 0, pity = 0, pitn = 0, pixx = 0, pixy = 0, pixn = 0, piyy = 0, piyn = 0, pinn = 0;
+                if (p.include_shear) {                                                // :531-545
+                    pixx = p.cells.pixx[gi]; pixy = p.cells.pixy[gi]; pixn = p.cells.pixn[gi];
+                    piyy = p.cells.piyy[gi]; piyn = p.cells.piyn[gi];
+                    pinn = (pixx * (ux2 - ut2) + piyy * (uy2 - ut2) + 2.0 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp * utperp);
+                    pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut;
+                    pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut;
+                    pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut;
+                    pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
+                }
+                // evaluate_df_coefficients -> cubic_spline (deltafReader.cpp:347-384)
+                const double T4 = T * T * T * T;
+                double F = 0.0, betabulk = 0.0, lambda = 0.0, z = 0.0, delta_lambda = 0.0, delta_z = 0.0;
+                const double betapi = spline_eval_lds(nT, sx, sy + 2 * nT, sc + 2 * nT, T) * T4;
+                if (p.mode == 3) {
+                    F = spline_eval_lds(nT, sx, sy, sc, T) * T;
+                    betabulk = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) * T4;
+                } else {
+                    const double r = bulkPi / P;
+                    const double lambda_squared = spline_eval_lds(nj, jx, jx + nj, jx + 3 * nj, r);
+                    if (bulkPi < 0.0) lambda = -sqrt(lambda_squared);
+                    else if (bulkPi > 0.0) lambda = sqrt(lambda_squared);
+                    z = spline_eval_lds(nj, jx, jx + 2 * nj, jx + 4 * nj, r);
+                    delta_lambda = bulkPi / (5.0 * betapi - 3.0 * P * (E + P) / E);
+                    delta_z = -3.0 * delta_lambda * P / E;
+                }
+                // Milne_Basis (viscous_correction.cpp:8-27)
+                const double sinhL = tau * un / utperp, coshL = ut / utperp;
+                const double Xt = uperp * coshL, Zt = sinhL, Xn = uperp * sinhL / tau, Zn = coshL / tau;
+                double Xx = 1.0, Yx = 0.0, Xy = 0.0, Yy = 1.0;
+                if (uperp > 1.e-5) { Xx = utperp * ux / uperp; Yx = -uy / uperp; Xy = utperp * uy / uperp; Yy = ux / uperp; }
+                // boost_pimunu_to_lrf (viscous_correction.cpp:99-115)
+                const double pixx_LRF = pitt * Xt * Xt + pixx * Xx * Xx + piyy * Xy * Xy + tau2 * tau2 * pinn * Xn * Xn
+                                      + 2.0 * (-Xt * (pitx * Xx + pity * Xy) + pixy * Xx * Xy + tau2 * Xn * (pixn * Xx + piyn * Xy - pitn * Xt));
+                const double pixy_LRF = Yx * (-pitx * Xt + pixx * Xx + pixy * Xy + tau2 * pixn * Xn) + Yy * (-pity * Xt + pixy * Xx + piyy * Xy + tau2 * piyn * Xn);
+                const double pixz_LRF = Zt * (pitt * Xt - pitx * Xx - pity * Xy - tau2 * pitn * Xn) - tau2 * Zn * (pitn * Xt - pixn * Xx - piyn * Xy - tau2 * pinn * Xn);
+                const double piyy_LRF = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
+                const double piyz_LRF = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
+                const double pizz_LRF = -(pixx_LRF + piyy_LRF);
+                double T_mod = T;
+                if (p.mode == 3) T_mod = T + bulkPi * F / betabulk;                   // :627-631
+                const double shear_mod = 0.5 / betapi;
+                const double bulk_mod = (p.mode == 4) ? lambda : bulkPi / (3.0 * betabulk);
+                const double Axx = 1.0 + pixx_LRF * shear_mod + bulk_mod, Axy = pixy_LRF * shear_mod, Axz = pixz_LRF * shear_mod;
+                const double Ayy = 1.0 + piyy_LRF * shear_mod + bulk_mod, Ayz = piyz_LRF * shear_mod;
+                const double Azz = 1.0 + pizz_LRF * shear_mod + bulk_mod;
+                const double detA = Axx * (Ayy * Azz - Ayz * Ayz) - Axy * (Axy * Azz - Ayz * Axz) + Axz * (Axy * Ayz - Ayy * Axz);   // :668
+                // cofactor inverse of the symmetric A (the reference: GSL LU + iterative refinement, :690-707, :915-926)
+                const double c00 = Ayy * Azz - Ayz * Ayz, c01 = Ayz * Axz - Axy * Azz, c02 = Axy * Ayz - Ayy * Axz;
+                const double dd = Axx * c00 + Axy * c01 + Axz * c02;
+                s.Ai[0] = c00 / dd; s.Ai[1] = c01 / dd; s.Ai[2] = c02 / dd;
+                s.Ai[3] = s.Ai[1]; s.Ai[4] = (Axx * Azz - Axz * Axz) / dd; s.Ai[5] = (Axy * Axz - Axx * Ayz) / dd;
+                s.Ai[6] = s.Ai[2]; s.Ai[7] = s.Ai[5]; s.Ai[8] = (Axx * Ayy - Axy * Axy) / dd;
+                // does_feqmod_breakdown (emissionfunction.cpp:109-150, fast = 0)
+                bool breakdown = false;
+                if (p.mode == 3) {
+                    const double neq_fact = T * T * T / two_pi2_hbarC3, J20_fact = T * neq_fact;
+                    const double mbar_pion0 = p.mass_pion0 / T;
+                    const double neq_pion0 = neq_fact * gt_neq(gl, gl + ngl, ngl, mbar_pion0, -1.0);
+                    const double J20_pion0 = J20_fact * gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar_pion0, -1.0);
+                    const double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * F / T / T) / betabulk;
+                    if (detA <= p.detA_min || (neq_pion0 + dn_pion0) < 0.0) breakdown = true;
+                }
+                double eta_scale = 1.0;
+                if (detA > p.detA_min && detA < 1.0 && !p.dim3) eta_scale = detA;     // :727-728
+                double rn = 1.0;
+                if (p.mode == 4) {                                                    // :761-777
+                    if (p.include_bulk) rn = z;
+                    if (p.dim3) rn /= detA;
+                    rn = fabs(rn);
+                    if (isnan(rn) || isinf(rn)) rn = 0.0;                             // :768-772: every species skipped
+                }
+                const bool narrow = p.dim3 && !breakdown && detA < 0.01;              // :807-813
+                s.dat = dat; s.dax = dax; s.day = day; s.dan_tau = dan / tau;
+                s.eta = p.dim3 ? p.cells.eta[gi] : 0.0;
+                s.eta_scale = eta_scale;
+                s.live = breakdown ? 0.0 : 1.0;
+                s.rn = rn;
+                s.invTm2 = 1.0 / (T_mod * T_mod);
+                s.Xt = Xt; s.tXn = tau * Xn; s.Zt = Zt; s.tZn = tau * Zn;
+                s.Xx = Xx; s.Xy = Xy; s.Yx = Yx; s.Yy = Yy;
+                s.detA = detA;
+                s.narrow = narrow ? 1.0 : 0.0;
+                flag = breakdown ? 1 : (narrow ? 2 : 0);
+                if (p.mode == 3) {
+                    double *cr = p.CR + (int64_t)cell * kCrRec;
+                    cr[0] = T; cr[1] = T_mod; cr[2] = bulkPi / betabulk; cr[3] = F; cr[4] = detA; cr[5] = s.live;
+                    cr[6] = 0.0; cr[7] = 0.0;
+                }
+                if (flag) {
+                    double *fb = p.FB + (int64_t)cell * kFbRec;
+                    fb[FB_DAT] = dat; fb[FB_DAX] = dax; fb[FB_DAY] = day; fb[FB_DAN] = dan;
+                    fb[FB_UT] = ut; fb[FB_UX] = ux; fb[FB_UY] = uy; fb[FB_UN] = un; fb[FB_TAU] = tau; fb[FB_ETA] = s.eta; fb[FB_T] = T;
+                    fb[FB_PITT] = pitt; fb[FB_PITX] = pitx; fb[FB_PITY] = pity; fb[FB_PITN] = pitn; fb[FB_PIXX] = pixx;
+                    fb[FB_PIXY] = pixy; fb[FB_PIXN] = pixn; fb[FB_PIYY] = piyy; fb[FB_PIYN] = piyn; fb[FB_PINN] = pinn;
+                    fb[FB_SHEAR] = 0.5 / (betapi * T);
+                    if (p.mode == 3) {                                                // :833-858 with baryon terms off
+                        fb[FB_CA] = (F / (T * T * betabulk)) * bulkPi;
+                        fb[FB_CB] = (1.0 / (3.0 * T * betabulk)) * bulkPi;
+                    } else {                                                          // :859-880
+                        fb[FB_CA] = delta_z - 3.0 * delta_lambda;
+                        fb[FB_CB] = delta_lambda / T;
+                    }
+                    fb[FB_DETA] = detA;
+                    fb[FB_KIND] = (double)flag;
+                }
+            } else {
+                s.live = 0.0;
+                if (p.mode == 3) {
+                    double *cr = p.CR + (int64_t)cell * kCrRec;
+                    for (int i = 0; i < kCrRec; i++) cr[i] = 0.0;
+                    cr[0] = 1.0; cr[1] = 1.0; cr[4] = 1.0;
+                }
+            }
+            if (s.live == 0.0) {
+                // neutral cell: p.dsigma == 0 for every momentum and (E_mod/T_mod)^2 = mT^2 stays finite
+                s.dat = s.dax = s.day = s.dan_tau = 0.0;
+                s.eta = 0.0; s.eta_scale = 1.0; s.rn = 0.0; s.invTm2 = 1.0;
+                s.Xt = s.tXn = s.Zt = s.tZn = 0.0;
+                s.Xx = s.Xy = s.Yx = s.Yy = 0.0;
+                for (int i = 0; i < 9; i++) s.Ai[i] = 0.0;
+                s.detA = 1.0; s.narrow = 0.0;
+            }
+            p.flag[cell] = flag;
+            cs[tid] = s;
+        }
+        __syncthreads();
+
+        // ---- phase 2: (cell, k) quantities ----
+        for (int idx = tid; idx < ncb * K; idx += kFqThreads) {
+            const int c = idx / K, k = idx - c * K;
+            const FqScal &s = cs[c];
+            double dlt, w;
+            if (p.dim3) { dlt = p.kgrid[k] - s.eta; w = 1.0; }                        // y - eta_cell
+            else { dlt = 0.0 - s.eta_scale * p.kgrid[k]; w = p.kweight[k]; }          // y = 0, eta = eta_scale * node, :902-903
+            double v = s.live;
+            if (s.narrow != 0.0 && fabs(dlt) < s.detA) v = 0.0;                       // row goes to the linear kernel
+            const double ch = cosh(dlt), sh = sinh(dlt);
+            const double a0 = -s.Xt * ch + s.tXn * sh, a2 = -s.Zt * ch + s.tZn * sh;  // p_LRF = mT a + pT b, :913
+            const double ax = s.Ai[0] * a0 + s.Ai[2] * a2, ay = s.Ai[3] * a0 + s.Ai[5] * a2, az = s.Ai[6] * a0 + s.Ai[8] * a2;
+            l_A[idx] = (v * s.rn) * (w * ch * s.dat + sh * s.dan_tau);                // dsigma_eta outside the eta weight, :905
+            l_W[idx] = (v * s.rn) * w;
+            l_al[idx] = (1.0 + (ax * ax + ay * ay + az * az)) * s.invTm2;
+            l_ax[idx] = ax; l_ay[idx] = ay; l_az[idx] = az;
+        }
+        // ---- phase 2b: (cell, j) quantities ----
+        for (int idx = tid; idx < ncb * J; idx += kFqThreads) {
+            const int c = idx / J, j = idx - c * J;
+            const FqScal &s = cs[c];
+            const double cp = p.cosphi[j], sp = p.sinphi[j];
+            const double b0 = s.Xx * cp + s.Xy * sp, b1 = s.Yx * cp + s.Yy * sp;
+            const double bx = s.Ai[0] * b0 + s.Ai[1] * b1, by = s.Ai[3] * b0 + s.Ai[4] * b1, bz = s.Ai[6] * b0 + s.Ai[7] * b1;
+            l_B[idx] = cp * s.dax + sp * s.day;
+            l_ga[idx] = ((bx * bx + by * by + bz * bz) - 1.0) * s.invTm2;
+            l_bx[idx] = bx; l_by[idx] = by; l_bz[idx] = bz;
+        }
+        __syncthreads();
+
+        // ---- phase 3: unit records (layout of cf_device.h, slots as in cf_feqmod.h) ----
+        {
+            const int JT = p.JT, R = p.R;
+            const int HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
+            const int units_per_cell = p.jtiles * p.rblocks;
+            const int per_cell = units_per_cell * REC;
+            for (int idx = tid; idx < ncb * per_cell; idx += kFqThreads) {
+                const int c = idx / per_cell;
+                const int rem = idx - c * per_cell;
+                const int ut = rem / REC, e = rem - ut * REC;
+                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
+                double v = 0.0;
+                if (e < HDR) {
+                    const int jj = e >> 2, f = e & 3;
+                    const int j = min(jt * JT + jj, J - 1);
+                    if (f == 0) v = l_B[c * J + j];
+                    else if (f == 1) v = l_ga[c * J + j];
+                } else {
+                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
+                    const int k = rb * R + r;
+                    const int kc = min(k, K - 1);   // padding rows copy the quadratic form of row K-1 with p.dsigma = 0
+                    if (f == 0) v = (k < K) ? l_A[c * K + kc] : 0.0;
+                    else if (f == 1) v = l_al[c * K + kc];
+                    else if (f == 2) v = (k < K) ? l_W[c * K + kc] : 0.0;
+                    else if (f >= 4) {
+                        const int j = min(jt * JT + (f - 4), J - 1);
+                        v = 2.0 * (l_ax[c * K + kc] * l_bx[c * J + j] + l_ay[c * K + kc] * l_by[c * J + j] + l_az[c * K + kc] * l_bz[c * J + j]) * cs[c].invTm2;
+                    }
+                }
+                const int64_t cell = cbase + c;
+                int64_t unit;
+                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;
+                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
+                p.TS[unit * REC + e] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K)
+{
+    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J)) + sizeof(FqScal) * kFqCB;
+}
+
+hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
+{
+    if (p.n_cells <= 0) return hipSuccess;
+    const int nbatch = (p.n_cells + kFqCB - 1) / kFqCB;
+    const int grid = nbatch < 4096 ? nbatch : 4096;
+    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K);
+    hipLaunchKernelGGL(cf_prep_feqmod, dim3(grid), dim3(kFqThreads), lds, st, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// df_mode 3 renormalisation, smooth_kernels.cpp:747-777: renorm = n_linear / n_mod per (cell, species); the degeneracy
+// cancels in the ratio, so one value per (mass, sign) class serves all its species.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cf_feqmod_renorm(const double *__restrict__ CR, const double *__restrict__ gl, int ngl, const double *__restrict__ cls_mass,
+                 const double *__restrict__ cls_sign, int ncls, int n_cells, int include_bulk, int dim3, double *__restrict__ RN)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_cells * ncls) return;
+    const int cell = (int)(idx / ncls), c = (int)(idx - (int64_t)cell * ncls);
+    const double *cr = CR + (int64_t)cell * kCrRec;
+    double renorm = 0.0;
+    if (cr[5] != 0.0) {
+        const double T = cr[0], T_mod = cr[1], dn_fact = cr[2], F = cr[3], detA = cr[4];
+        renorm = 1.0;
+        if (include_bulk) {
+            const double two_pi2_hbarC3 = 2.0 * M_PI * M_PI * (kHbarC * kHbarC * kHbarC);
+            const double neq_fact = T * T * T / two_pi2_hbarC3, J20_fact = T * neq_fact;
+            const double nmod_fact = T_mod * T_mod * T_mod / two_pi2_hbarC3;
+            const double mass = cls_mass[c], sign = cls_sign[c];
+            const double mbar = mass / T, mbar_mod = mass / T_mod;
+            const double neq = neq_fact * gt_neq(gl, gl + ngl, ngl, mbar, sign);
+            const double J20 = J20_fact * gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sign);
+            const double n_linear = neq + dn_fact * (neq + J20 * F / T / T);          // G = 0 without baryon
+            const double n_mod = nmod_fact * gt_neq(gl, gl + ngl, ngl, mbar_mod, sign);
+            renorm = n_linear / n_mod;
+        }
+        if (isnan(renorm) || isinf(renorm)) renorm = 0.0;                             // :768-772: species skipped in this cell
+        else {
+            if (dim3) renorm /= detA;
+            renorm = fabs(renorm);
+        }
+    }
+    RN[idx] = renorm;
+}
+
+hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, const double *cls_mass, const double *cls_sign,
+                                int ncls, int n_cells, int include_bulk, int is_dim3, double *RN, hipStream_t st)
+{
+    if (n_cells <= 0) return hipSuccess;
+    const int64_t n = (int64_t)n_cells * ncls;
+    hipLaunchKernelGGL(cf_feqmod_renorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CR, gl, ngl, cls_mass, cls_sign,
+                       ncls, n_cells, include_bulk, is_dim3, RN);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// cf_main_feqmod: same task decomposition, LDS staging and partial layout as cf_main_tile (cf_kernels.hip).
+// Per evaluation: X2 = fma(mT pT, betaf, mT^2 alphaf + pT^2 gammaf); X = sqrt (v_rsq_f64 + 6 FMA); z = exp(-X) (17 ops);
+// f = z / (1 + sign z) (v_rcp_f64 + 3); acc += max(pds, 0) f.  ~36 fp64 VALU instructions, nothing amortised over the
+// tile except the row and column products.  Rows whose X exceeds 745.2 for every lane and phi of the tile (z = +0
+// exactly) are culled as in cf_main_tile.
+// ------------------------------------------------------------------------------------------------
+template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R>
+__global__ void __launch_bounds__(512)
+cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
+               const double *__restrict__ lane_sign, const double *__restrict__ RN, const int32_t *__restrict__ lane_cls,
+               int ncls, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g)
+{
+    constexpr int HDR = 4 * JT;
+    constexpr int RW = 4 + JT;
+    constexpr int REC = HDR + R * RW;
+    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
+    constexpr int BUF2 = UB * REC / 2;
+    constexpr int NLD = (BUF2 + 127) / 128;
+    static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
+    __shared__ double2 lbuf[2][BUF2 + RW / 2 + 1];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int stream = (q / g.G) * 8 + xcd;
+    if (stream >= g.NT) return;
+    int sidx = stream;
+    const int jt = sidx % g.jtiles; sidx /= g.jtiles;
+    const int kt = sidx % g.ktiles; sidx /= g.ktiles;
+    const int chunk = sidx;
+    const int nthr = blockDim.x;
+    const int lw = grp * g.wpb + (tid >> 6);
+    const bool wave_active = lw * 64 < g.Lpad;
+    const int l = wave_active ? lw * 64 + (tid & 63) : 0;
+
+    const int J = g.J, K = g.K;
+    const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
+    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    const int n_units = (c1 - c0) * g.upc;
+    const int s_tile = DIM3 ? (jt * g.ktiles + kt) : jt;
+    const double2 *src = (const double2 *)(TS + (((int64_t)s_tile * g.n_cells + c0) * g.upc) * REC);
+    const int nb = (n_units + UB - 1) / UB;
+    const double *rn_col = MODE3 ? RN + lane_cls[l] : nullptr;
+
+    constexpr int NACC = DIM3 ? JT * R : JT;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+
+    int n_rows = 0, n_dead = 0;
+    auto process_unit = [&](const double *U, double rn) {
+        double pTB[JT], pT2g[JT];
+        const double rpT = MODE3 ? rn * pT : pT, rmT = MODE3 ? rn * mT : mT;
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) {
+            pTB[jj] = rpT * U[4 * jj + 0];
+            pT2g[jj] = pT2 * U[4 * jj + 1];
+        }
+        struct Row { double v[RW]; };
+        auto fetch = [&](Row &rw, const double *row) {
+#pragma unroll
+            for (int i = 0; i < RW; i++) rw.v[i] = row[i];
+        };
+        auto evals = [&](const Row &rw, int r) {
+            const double mTA = rmT * rw.v[0];
+            const double a = mT2 * rw.v[1];
+            const double W = rw.v[2];
+            double X2[JT];
+            double x2min = 1.0e300;
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) {
+                X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
+                x2min = __builtin_fmin(x2min, X2[jj]);
+            }
+            n_rows += 1;
+            if (g.zskip && __all(x2min > 555400.0)) { n_dead += 1; return; }   // X > 745.25: exp(-X) == +0 for the whole wave-row
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) {
+                const double X = sqrt_nr(X2[jj]);
+                const double z = exp_full(-X);
+                const double d = __builtin_fma(sign, z, 1.0);
+                const double rr = rcp_nr1(d);
+                double pds = __builtin_fma(pTB[jj], W, mTA);
+                if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
+                const double w = z * rr;
+                if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+            }
+        };
+        const double *rows = U + HDR;
+        Row cur, nxt;
+        fetch(cur, rows);
+        if (DIM3) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
+                evals(cur, r);
+                if (r + 1 < R) cur = nxt;
+            }
+        } else {
+#pragma unroll 2
+            for (int r = 0; r < R; r++) {
+                fetch(nxt, rows + (r + 1) * RW);   // "row R" reads the head of the next unit (or the pad); never evaluated
+                evals(cur, 0);
+                cur = nxt;
+            }
+        }
+    };
+
+    double2 pre[NLD];
+    if (nb > 0) {
+        {
+            const int n2 = min(UB, n_units) * (REC / 2);
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * nthr;
+                if (i < n2) lbuf[0][i] = src[i];
+            }
+        }
+        __syncthreads();
+        for (int ib = 0; ib < nb; ib++) {
+            const bool more = ib + 1 < nb;
+            const int n2next = more ? min(UB, n_units - (ib + 1) * UB) * (REC / 2) : 0;
+            const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * nthr;
+                pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
+            }
+            if (wave_active) {
+                const int nu = min(UB, n_units - ib * UB);
+                const double *base = (const double *)lbuf[ib & 1];
+                const int u0 = ib * UB;
+                double rn = 1.0;
+                if (MODE3) rn = rn_col[(int64_t)(c0 + u0 / g.upc) * ncls];
+                for (int u = 0; u < nu; u++) {
+                    double rn_next = 1.0;
+                    if (MODE3) {
+                        const int un = min(u0 + u + 1, n_units - 1);
+                        rn_next = rn_col[(int64_t)(c0 + un / g.upc) * ncls];
+                    }
+                    process_unit(base + u * REC, rn);
+                    rn = rn_next;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * nthr;
+                if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
+            }
+            __syncthreads();
+        }
+    }
+    if (!wave_active) return;
+    if ((tid & 63) == 0) {
+        atomicAdd(&stats[2], (unsigned long long)n_rows);
+        atomicAdd(&stats[3], (unsigned long long)n_dead);
+    }
+
+    const int64_t JKacc = (int64_t)J * g.Kacc;
+    double *pp = partial + (int64_t)chunk * JKacc * g.Lpad;
+#pragma unroll
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = jt * JT + jj;
+        if (j < J) {
+            if (DIM3) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int k = kt * R + r;
+                    if (k < K) {
+                        double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + l;
+                        *o = g.first_pass ? acc[jj * R + r] : (*o + acc[jj * R + r]);
+                    }
+                }
+            } else {
+                double *o = pp + (int64_t)j * g.Lpad + l;
+                *o = g.first_pass ? acc[jj] : (*o + acc[jj]);
+            }
+        }
+    }
+}
+
+template <bool DIM3, bool OF, bool M3, int JT, int R>
+static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
+{
+    const int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
+                       a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g);
+}
+
+template <bool DIM3, bool OF, bool M3>
+static void launch_fq_variant(int variant, const FqMainArgs &a, hipStream_t st)
+{
+    // tile shapes of main_tile_shape (cf_kernels.hip): variants 2, 3, 4
+    switch (variant) {
+    case 3: launch_fq_t<DIM3, OF, M3, (DIM3 ? 8 : 12), (DIM3 ? 7 : 61)>(a, st); break;
+    case 4: launch_fq_t<DIM3, OF, M3, 4, (DIM3 ? 7 : 61)>(a, st); break;
+    default: launch_fq_t<DIM3, OF, M3, (DIM3 ? 6 : 8), (DIM3 ? 7 : 61)>(a, st); break;
+    }
+}
+
+hipError_t launch_main_feqmod(int variant, int dim3, int outflow, int mode3, const FqMainArgs &a, hipStream_t st)
+{
+    if (a.g.n_cells <= 0) return hipSuccess;
+    const int sel = (dim3 ? 4 : 0) | (outflow ? 2 : 0) | (mode3 ? 1 : 0);
+    switch (sel) {
+    case 0: launch_fq_variant<false, false, false>(variant, a, st); break;
+    case 1: launch_fq_variant<false, false, true>(variant, a, st); break;
+    case 2: launch_fq_variant<false, true, false>(variant, a, st); break;
+    case 3: launch_fq_variant<false, true, true>(variant, a, st); break;
+    case 4: launch_fq_variant<true, false, false>(variant, a, st); break;
+    case 5: launch_fq_variant<true, false, true>(variant, a, st); break;
+    case 6: launch_fq_variant<true, true, false>(variant, a, st); break;
+    default: launch_fq_variant<true, true, true>(variant, a, st); break;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered compaction of the flagged cells: one workgroup scans the flags in index order, so the list (and with it the
+// summation order of cf_feqmod_linear) is the same on every run.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+cf_feqmod_compact(const int32_t *__restrict__ flag, int n, int32_t *__restrict__ list, int32_t *__restrict__ count,
+                  unsigned long long *__restrict__ status)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int off = 0, n1 = 0, n2 = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int f = (i < n) ? flag[i] : 0;
+        const bool m = f != 0;
+        n1 += (f == 1);
+        n2 += (f == 2);
+        const unsigned long long bal = __ballot(m);
+        const int pre = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wsum[w] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int qv = 0; qv < 16; qv++) {
+            const int sq = wsum[qv];
+            if (qv < w) woff += sq;
+            tot += sq;
+        }
+        if (m) list[off + woff + pre] = i;
+        off += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = off;
+    if (n1) atomicAdd(&status[4], (unsigned long long)n1);
+    if (n2) atomicAdd(&status[5], (unsigned long long)n2);
+}
+
+hipError_t launch_feqmod_compact(const int32_t *flag, int n, int32_t *list, int32_t *count, unsigned long long *status,
+                                 hipStream_t st)
+{
+    hipLaunchKernelGGL(cf_feqmod_compact, dim3(1), dim3(1024), 0, st, flag, n, list, count, status);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linearised delta-f for the flagged cells, in the reference's form (smooth_kernels.cpp:822-884): rare by construction
+// (breakdown cells, the |y - eta| < detA window of nearly singular cells), so written for clarity: libm exp/cosh/sinh,
+// one thread per (lane, phi, y) looping over the list; the per-cell record arrives through wave-uniform loads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cf_feqmod_linear(FqLinearArgs a)
+{
+    const int n = *a.count;
+    if (n == 0) return;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)a.Lpad * a.J * a.Kacc;
+    if (idx >= total) return;
+    const int l = (int)(idx % a.Lpad);
+    const int jk = (int)(idx / a.Lpad);
+    const int j = jk / a.Kacc, k = jk - j * a.Kacc;
+    const double mT = a.lane_mT[l], pT = a.lane_pT[l], sign = a.lane_sign[l], mass = a.lane_mass[l];
+    const double mass2 = mass * mass;
+    const double px = pT * a.cosphi[j], py = pT * a.sinphi[j];
+    const double y = a.dim3 ? a.kgrid[k] : 0.0;
+    const int n_eta = a.dim3 ? 1 : a.K;
+    double total_sum = 0.0;
+    for (int e = 0; e < n; e++) {
+        const double *fb = a.FB + (int64_t)a.list[e] * kFbRec;
+        const double tau = fb[FB_TAU], tau2 = tau * tau, T = fb[FB_T];
+        const double mT_over_tau = mT / tau;
+        const bool narrow_only = fb[FB_KIND] == 2.0;
+        double sum = 0.0;
+        for (int ie = 0; ie < n_eta; ie++) {
+            const double eta = a.dim3 ? fb[FB_ETA] : a.kgrid[ie];
+            const double eta_weight = a.dim3 ? 1.0 : a.kweight[ie];
+            if (narrow_only && !(fabs(y - eta) < fb[FB_DETA])) continue;             // :807-813
+            const double pt = mT * cosh(y - eta), pn = mT_over_tau * sinh(y - eta), tau2_pn = tau2 * pn;
+            const double pdotdsigma = eta_weight * (pt * fb[FB_DAT] + px * fb[FB_DAX] + py * fb[FB_DAY]) + pn * fb[FB_DAN];   // :828
+            if (a.outflow && pdotdsigma <= 0.0) continue;
+            const double pdotu = pt * fb[FB_UT] - px * fb[FB_UX] - py * fb[FB_UY] - tau2_pn * fb[FB_UN];
+            const double pimunu_pmu_pnu = fb[FB_PITT] * pt * pt + fb[FB_PIXX] * px * px + fb[FB_PIYY] * py * py + fb[FB_PINN] * tau2_pn * tau2_pn
+                + 2.0 * (-(fb[FB_PITX] * px + fb[FB_PITY] * py) * pt + fb[FB_PIXY] * px * py + tau2_pn * (fb[FB_PIXN] * px + fb[FB_PIYN] * py - fb[FB_PITN] * pt));
+            const double feq = 1.0 / (exp(pdotu / T) + sign), feqbar = 1.0 - sign * feq;
+            const double df_shear = fb[FB_SHEAR] * pimunu_pmu_pnu / pdotu;
+            double df;
+            if (a.mode == 3) df = feqbar * (df_shear + fb[FB_CA] * pdotu + fb[FB_CB] * (pdotu - mass2 / pdotu));          // :833-858
+            else df = feqbar * df_shear + fb[FB_CA] + feqbar * fb[FB_CB] * (pdotu - mass2 / pdotu);                         // :859-880
+            if (a.regulate) df = fmax(-1.0, fmin(df, 1.0));
+            sum += pdotdsigma * (feq * (1.0 + df));
+        }
+        total_sum += sum;
+    }
+    a.partial[idx] += total_sum;
+}
+
+hipError_t launch_feqmod_linear(const FqLinearArgs &a, hipStream_t st)
+{
+    const int64_t total = (int64_t)a.Lpad * a.J * a.Kacc;
+    hipLaunchKernelGGL(cf_feqmod_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace is3d

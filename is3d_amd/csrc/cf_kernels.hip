@@ -18,59 +18,10 @@
 #include <stdint.h>
 
 #include "cf_launch.h"
+#include "cf_math.h"
 
 namespace is3d {
 
-// ------------------------------------------------------------------------------------------------
-// fp64 building blocks (gfx950 has no v_exp_f64; v_rcp_f64 is an approximation)
-// ------------------------------------------------------------------------------------------------
-#define IS3D_LOG2E 1.44269504088896338700e+00
-#define IS3D_LN2_HI 6.93147180369123816490e-01 /* 0x3fe62e42fee00000: n*LN2_HI exact for |n| < 2^21 */
-#define IS3D_LN2_LO 1.90821492927058770002e-10 /* 0x3dea39ef35793c76 */
-
-// e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-10 near-minimax polynomial of e^r, |r| <= ln2/2.  Splitting mantissa and exponent lets two exponentials be
-// multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
-// e^r on |r| <= ln2/2 as a degree-10 polynomial (Chebyshev-node interpolant computed in long double, rounded to
-// double: max relative error 1.4e-15 over +-1.02 ln2/2); c10 .. c1, c0 = 1.
-__constant__ double kExpC[10] = {2.76263718333300477554e-07, 2.76401815125786182983e-06, 2.48015043178771474428e-05,
-                                 1.98411702685802050468e-04, 1.38888889325031097272e-03, 8.33333338566940792780e-03,
-                                 4.16666666665731558195e-02, 1.66666666665543999892e-01, 5.00000000000000555112e-01,
-                                 1.00000000000000666134e+00};
-
-__device__ __forceinline__ void exp_core(double v, double &f, int &n)
-{
-    double dn = __builtin_rint(v * IS3D_LOG2E);
-    double r = __builtin_fma(-dn, IS3D_LN2_HI, v);
-    r = __builtin_fma(-dn, IS3D_LN2_LO, r);
-    // The non-inline Taylor coefficients come from constant memory, i.e. they sit in SGPRs: the Horner steps are
-    // then 3-address v_fma_f64 with a scalar addend.  (With literal constants hipcc keeps them in VGPRs and emits
-    // v_mov_b64 + v_fmac_f64 per step: 9 extra moves per exponential.)
-    double p = kExpC[0];
-    p = __builtin_fma(p, r, kExpC[1]);
-    p = __builtin_fma(p, r, kExpC[2]);
-    p = __builtin_fma(p, r, kExpC[3]);
-    p = __builtin_fma(p, r, kExpC[4]);
-    p = __builtin_fma(p, r, kExpC[5]);
-    p = __builtin_fma(p, r, kExpC[6]);
-    p = __builtin_fma(p, r, kExpC[7]);
-    p = __builtin_fma(p, r, kExpC[8]);
-    p = __builtin_fma(p, r, kExpC[9]);
-    f = __builtin_fma(p, r, 1.0);
-    n = (int)dn;
-}
-
-__device__ __forceinline__ double ldexp_fast(double f, int n) { return __builtin_amdgcn_ldexp(f, n); }  // v_ldexp_f64
-
-// 1/d: v_rcp_f64 seed + two Newton steps (each squares the relative error)
-__device__ __forceinline__ double rcp_nr(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
-}
 
 // Tail of one integrand evaluation, shared by both main kernels.
 //   z = exp(-p.u/T), x = p.u/T, br = mT^2 alpha + mT pT beta + pT^2 gamma, pds = p.dsigma (weighted)
@@ -132,23 +83,6 @@ __device__ __forceinline__ bool bilinear5(const BilinearDev &b, double T, double
         v[k] = ((f_LL * (TR - T) + f_RL * (T - TL)) * (BR - muB) + (f_LR * (TR - T) + f_RR * (T - TL)) * (muB - BL)) / (dT * dB);
     }
     return true;
-}
-
-// gsl_interp_cspline evaluation (deltafReader.cpp:339-358 call sites) on LDS-resident tables.
-__device__ __forceinline__ double spline_eval_lds(int n, const double *x, const double *y, const double *c, double xq)
-{
-    int lo = 0, hi = n - 1;
-    while (hi > lo + 1) {
-        int i = (hi + lo) >> 1;
-        if (x[i] > xq) hi = i; else lo = i;
-    }
-    double x_lo = x[lo], dx = x[lo + 1] - x_lo;
-    double y_lo = y[lo], dy = y[lo + 1] - y_lo;
-    double delx = xq - x_lo;
-    double c_i = c[lo], c_ip1 = c[lo + 1];
-    double b_i = (dy / dx) - dx * (c_ip1 + 2.0 * c_i) / 3.0;
-    double d_i = (c_ip1 - c_i) / (3.0 * dx);
-    return y_lo + delx * (b_i + delx * (c_i + delx * d_i));
 }
 
 __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
@@ -551,28 +485,6 @@ cf_main_direct(const double *__restrict__ S1, const double *__restrict__ S2, con
 //   acc += max(pds,0) * (z*r) * u    (the factor 2 is restored once, when the accumulators are stored).
 // 3+1D: JT*KT accumulators.  2+1D: JT accumulators, loop over the whole eta table.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double exp_full(double v)
-{
-    double f; int n;
-    exp_core(v, f, n);
-    return ldexp_fast(f, n);
-}
-
-__device__ __forceinline__ double rcp_nr1(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);      // 4.5e-8 relative (measured, tools/ubench_fp64.hip)
-    double e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);           // 2e-15
-}
-
-// fma with the VOP3 clamp modifier: result clamped to [0, 1] (NaN -> 0 under DX10_CLAMP)
-__device__ __forceinline__ double fma_clamp01_half(double a, double b)
-{
-    double u;
-    asm("v_fma_f64 %0, %1, %2, 0.5 clamp" : "=v"(u) : "v"(a), "v"(b));
-    return u;
-}
-
 // The tile's coefficients are staged through LDS: the 4 waves of a workgroup (4 different lane-waves,
 // same tile and cell chunk) stream ONE contiguous run of unit records (cf_device.h) with coalesced
 // 16-byte loads, double-buffered (global -> registers while the previous batch is being consumed ->

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/is3d_amd.h"
+#include "cf_feqmod.h"
 #include "cf_launch.h"
 #include "errors.h"
 #include "spline.h"
@@ -84,6 +85,13 @@ struct is3d_plan {
     DevBuf<unsigned long long> d_status;
     is3d::SplineDev spl{};
 
+    // modified equilibrium (df_mode 3, 4)
+    bool feqmod = false;
+    int nj = 0, ngl = 0;
+    double bp_max = 0.0, detA_min = 0.0, mass_pion0 = 0.0;
+    DevBuf<double> d_gl, d_jonah, d_cls_mass, d_cls_sign, d_lane_mass, d_RN, d_CR, d_FB;
+    DevBuf<int32_t> d_lane_cls, d_flag, d_list, d_count;
+
     bool timing = false;
     std::vector<hipEvent_t> ev_list;  // [pass][0..3]: start, after prep, after main; last: after finalize
     int last_passes = 0;
@@ -96,12 +104,23 @@ struct is3d_plan {
     }
 };
 
-static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df, const is3d_options *o)
+static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df, const is3d_feqmod_tables *fq,
+                    const is3d_options *o)
 {
     if (!sp || !g || !df || !o) return fail(IS3D_EINVAL, "null argument");
     if (o->dimension != 2 && o->dimension != 3) return fail(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", o->dimension);
-    if (o->df_mode != 1 && o->df_mode != 2)
-        return fail(IS3D_EINVAL, "df_mode must be 1 (14-moment) or 2 (Chapman-Enskog) on this path (got %d)", o->df_mode);
+    if (fq) {
+        if (o->df_mode != 3 && o->df_mode != 4) return fail(IS3D_EINVAL, "the feqmod entries take df_mode 3 or 4 (got %d)", o->df_mode);
+        if (o->include_baryon) return fail(IS3D_EINVAL, "df_mode 3/4 with include_baryon = 1 is not supported on this path");
+        if (o->kernel_variant == 1) return fail(IS3D_EINVAL, "df_mode 3/4 runs on the tile kernel only (kernel_variant 0, 2-4)");
+        if (fq->n_gla < 1 || fq->n_gla > 256 || !fq->root1 || !fq->weight1 || !fq->root2 || !fq->weight2)
+            return fail(IS3D_EINVAL, "df_mode 3/4 needs the Gauss-Laguerre roots and weights for alpha = 1, 2");
+        if (!df->betapi) return fail(IS3D_EINVAL, "df_mode 3/4 needs the betapi table");
+        if (o->df_mode == 3 && (!df->F || !df->betabulk)) return fail(IS3D_EINVAL, "df_mode 3 needs the F and betabulk tables");
+        if (o->df_mode == 4 && (fq->n_pdg < 1 || !fq->pdg_mass || !fq->pdg_degeneracy || !fq->pdg_sign || !(fq->T_avg > 0.0)))
+            return fail(IS3D_EINVAL, "df_mode 4 needs the full PDG list and the surface-averaged temperature");
+    } else if (o->df_mode != 1 && o->df_mode != 2)
+        return fail(IS3D_EINVAL, "df_mode must be 1 (14-moment) or 2 (Chapman-Enskog) on this entry (got %d); 3 and 4 go through is3d_*_feqmod", o->df_mode);
     if (o->include_baryon) {
         if (o->kernel_variant == 1) return fail(IS3D_EINVAL, "include_baryon = 1 runs on the tile kernel only (kernel_variant 2-4)");
         if (!sp->baryon) return fail(IS3D_EINVAL, "include_baryon = 1 needs the species' baryon numbers");
@@ -131,12 +150,58 @@ extern "C" int is3d_device_count(void)
     return n;
 }
 
-extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df,
-                                const is3d_options *o, int64_t max_cells)
+// Deltaf_Data::compute_jonah_coefficients (deltafReader.cpp:222-297): lambda in [-1, 2] on 301 points; for each the
+// hadron-gas energy density and pressure with momenta rescaled by (1 + lambda), by 32-point Gauss-Laguerre (alpha = 2)
+// quadrature over ALL species of the PDG file at the surface-averaged temperature; z = E/E_mod, Pi/P = (P_mod/P) z - 1.
+// Host table setup (the reference does the same once per run); out = {Pi/P, lambda^2, z}.
+static void jonah_tables(const is3d_feqmod_tables *fq, std::vector<double> &bp, std::vector<double> &l2, std::vector<double> &zz,
+                         double &bp_max)
+{
+    const int n = 301;
+    const double lambda_min = -1.0, lambda_max = 2.0;
+    const double delta_lambda = (lambda_max - lambda_min) / ((double)n - 1.0);
+    const double T = fq->T_avg;
+    bp.assign(n, 0.0); l2.assign(n, 0.0); zz.assign(n, 0.0);
+    auto sums = [&](double lambda, double &E, double &P) {
+        E = 0.0; P = 0.0;
+        const double scale2 = (1.0 + lambda) * (1.0 + lambda);
+        for (int s = 0; s < fq->n_pdg; s++) {
+            const double mass = fq->pdg_mass[s], mbar = mass / T, sign = fq->pdg_sign[s];
+            if (mass == 0.0) continue;   // photons skipped, :257
+            double e = 0.0, pr = 0.0;
+            for (int k = 0; k < fq->n_gla; k++) {
+                const double pbar = fq->root2[k], w = fq->weight2[k];
+                const double Ebar = std::sqrt(pbar * pbar + mbar * mbar);
+                const double Es = std::sqrt(pbar * pbar * scale2 + mbar * mbar);
+                const double thermal = std::exp(pbar) / (std::exp(Ebar) + sign);
+                e += w * (Es * thermal);                               // E_mod_int, gaussThermal.cpp
+                pr += w * (pbar * pbar * scale2 / Es * thermal);       // P_mod_int
+            }
+            E += fq->pdg_degeneracy[s] * e;
+            P += (1.0 / 3.0) * fq->pdg_degeneracy[s] * pr;
+        }
+    };
+    double E0, P0;
+    sums(0.0, E0, P0);
+    bp_max = -1.0;
+    for (int i = 0; i < n; i++) {
+        const double lambda = lambda_min + (double)i * delta_lambda;
+        double Em, Pm;
+        sums(lambda, Em, Pm);
+        const double z = E0 / Em;
+        bp[i] = (Pm / P0) * z - 1.0;
+        l2[i] = lambda * lambda;
+        zz[i] = z;
+        bp_max = std::max(bp_max, bp[i]);
+    }
+}
+
+static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df,
+                            const is3d_feqmod_tables *fq, const is3d_options *o, int64_t max_cells)
 {
     if (!out) return fail(IS3D_EINVAL, "null plan pointer");
     *out = nullptr;
-    int rc = validate(sp, g, df, o);
+    int rc = validate(sp, g, df, fq, o);
     if (rc) return rc;
     if (max_cells < 1) max_cells = 1;
     if (max_cells > (int64_t)1 << 40) return fail(IS3D_EINVAL, "max_cells too large");
@@ -148,6 +213,7 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     HIP_TRY(hipGetDevice(&P->device));
     P->dim3 = (o->dimension == 3);
     P->ce = (o->df_mode == 2);
+    P->feqmod = fq != nullptr;
     P->npart = sp->n;
     P->npT = g->n_pT;
     P->J = g->n_phi;
@@ -234,7 +300,13 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
     // ---- splines (deltafReader.cpp:300-322) ----
     const double *tabs[3] = {nullptr, nullptr, nullptr};
     int nspl;
-    if (!P->ce) { tabs[0] = df->c0; tabs[1] = df->c2; nspl = 2; }
+    if (P->feqmod) {
+        // df_mode 3: F, betabulk, betapi; df_mode 4 reads betapi only (the other two slots mirror it, unused)
+        tabs[0] = (o->df_mode == 3) ? df->F : df->betapi;
+        tabs[1] = (o->df_mode == 3) ? df->betabulk : df->betapi;
+        tabs[2] = df->betapi;
+        nspl = 3;
+    } else if (!P->ce) { tabs[0] = df->c0; tabs[1] = df->c2; nspl = 2; }
     else { tabs[0] = df->F; tabs[1] = df->betabulk; tabs[2] = df->betapi; nspl = 3; }
     std::vector<double> xs(df->T, df->T + df->n_T);
     HIP_TRY(P->d_splx.upload(xs));
@@ -266,7 +338,40 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
             P->bil.tab[k] = P->d_biltab[k].p;
         }
     }
-    if (is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K) > 160 * 1024)
+    if (P->feqmod) {
+        P->ngl = fq->n_gla;
+        P->detA_min = fq->deta_min;
+        P->mass_pion0 = fq->mass_pion0;
+        std::vector<double> gl((size_t)4 * P->ngl);
+        for (int k = 0; k < P->ngl; k++) {
+            gl[k] = fq->root1[k]; gl[P->ngl + k] = fq->weight1[k]; gl[2 * P->ngl + k] = fq->root2[k]; gl[3 * P->ngl + k] = fq->weight2[k];
+        }
+        HIP_TRY(P->d_gl.upload(gl));
+        std::vector<double> jon;
+        if (o->df_mode == 4) {
+            std::vector<double> bp, l2, zz, cl, cz;
+            jonah_tables(fq, bp, l2, zz, P->bp_max);
+            // gsl_spline_init on (bulkPi_over_Peq, lambda_squared) and (bulkPi_over_Peq, z), deltafReader.cpp:311-320
+            if (!is3d::natural_cspline_init(bp, l2, cl) || !is3d::natural_cspline_init(bp, zz, cz))
+                return fail(IS3D_EINVAL, "df_mode 4: bulkPi/Peq(lambda) is not ascending at T_avg = %.6g GeV (GSL would abort here)", fq->T_avg);
+            P->nj = (int)bp.size();
+            for (const auto *v : {&bp, &l2, &zz, &cl, &cz}) jon.insert(jon.end(), v->begin(), v->end());
+        } else {
+            P->nj = 2;   // unused placeholder so that the prep kernel's LDS layout stays valid
+            jon.assign(10, 0.0);
+            jon[1] = 1.0;
+        }
+        HIP_TRY(P->d_jonah.upload(jon));
+        std::vector<double> lane_mass(P->Lpad, 1.0);
+        std::vector<int32_t> lane_cls(P->Lpad, 0);
+        for (int s = 0; s < P->L; s++) { lane_mass[s] = cmass[order[s] / P->npT]; lane_cls[s] = order[s] / P->npT; }
+        HIP_TRY(P->d_lane_mass.upload(lane_mass));
+        HIP_TRY(P->d_lane_cls.upload(lane_cls));
+        HIP_TRY(P->d_cls_mass.upload(cmass));
+        HIP_TRY(P->d_cls_sign.upload(csign));
+        if (is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K) > 160 * 1024)
+            return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
+    } else if (is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K) > 160 * 1024)
         return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
 
     // ---- tiling / workspace ----
@@ -280,6 +385,9 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
         P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0);
     else
         P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
+    if (P->feqmod)   // fallback record, flag, list entry; df_mode 3: cell record + |renorm| per class
+        P->bytes_per_cell += sizeof(double) * is3d::kFbRec + 2 * sizeof(int32_t) +
+                             (o->df_mode == 3 ? sizeof(double) * ((size_t)is3d::kCrRec + P->ncls) : 0);
     int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
     int64_t pc = ws / (int64_t)P->bytes_per_cell;
     if (pc < 1) pc = 1;
@@ -314,22 +422,50 @@ extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const i
         P->nch_max = (int)nch;
     }
     if (tiled) {
-        HIP_TRY(P->d_TS.alloc((size_t)pc * (P->bytes_per_cell / sizeof(double))));
+        HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0)));
     } else {
         HIP_TRY(P->d_S1.alloc((size_t)pc * P->K * is3d::kS1Rec));
         HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
         HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
     }
     HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
-    HIP_TRY(P->d_status.alloc(4));
-    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_TS.n + P->d_partial.n) * (int64_t)sizeof(double);
+    HIP_TRY(P->d_status.alloc(8));
+    if (P->feqmod) {
+        HIP_TRY(P->d_FB.alloc((size_t)pc * is3d::kFbRec));
+        HIP_TRY(P->d_flag.alloc((size_t)pc));
+        HIP_TRY(P->d_list.alloc((size_t)pc));
+        HIP_TRY(P->d_count.alloc(1));
+        if (o->df_mode == 3) {
+            HIP_TRY(P->d_CR.alloc((size_t)pc * is3d::kCrRec));
+            HIP_TRY(P->d_RN.alloc((size_t)pc * P->ncls));
+        }
+    }
+    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_TS.n + P->d_partial.n + P->d_FB.n + P->d_CR.n + P->d_RN.n) * (int64_t)sizeof(double) +
+                   (int64_t)(P->d_flag.n + P->d_list.n) * (int64_t)sizeof(int32_t);
     *out = P.release();
     return IS3D_OK;
 }
 
+extern "C" int is3d_plan_create(is3d_plan **out, const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df,
+                                const is3d_options *o, int64_t max_cells)
+{
+    return plan_create_impl(out, sp, g, df, nullptr, o, max_cells);
+}
+
+extern "C" int is3d_plan_create_feqmod(is3d_plan **out, const is3d_species *sp, const is3d_grid *g, const is3d_df_tables *df,
+                                       const is3d_feqmod_tables *fq, const is3d_options *o, int64_t max_cells)
+{
+    if (!fq) return fail(IS3D_EINVAL, "null feqmod tables");
+    return plan_create_impl(out, sp, g, df, fq, o, max_cells);
+}
+
 extern "C" int64_t is3d_plan_output_size(const is3d_plan *P) { return P ? P->nout : 0; }
 extern "C" int64_t is3d_plan_workspace_bytes(const is3d_plan *P) { return P ? P->workspace : 0; }
-extern "C" const char *is3d_plan_main_kernel_name(const is3d_plan *P) { return is3d::main_kernel_name(P ? P->variant : 2); }
+extern "C" const char *is3d_plan_main_kernel_name(const is3d_plan *P)
+{
+    if (P && P->feqmod) return "cf_main_feqmod";
+    return is3d::main_kernel_name(P ? P->variant : 2);
+}
 extern "C" int is3d_plan_tile_shape(const is3d_plan *P, int32_t *JT, int32_t *R)
 {
     if (!P || !JT || !R) return fail(IS3D_EINVAL, "null argument");
@@ -387,7 +523,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         }
     }
     P->last_passes = npasses;
-    unsigned long long init[4] = {~0ULL, 0ULL, 0ULL, 0ULL};
+    unsigned long long init[8] = {~0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
     HIP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, st));
 
     int nch_used = 1;
@@ -400,6 +536,52 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         for (int pass = 0; pass < npasses; pass++) {
             const int64_t c0 = (int64_t)pass * P->pass_cells;
             const int32_t nc = (int32_t)std::min<int64_t>(P->pass_cells, n - c0);
+            if (P->feqmod) {
+                is3d::FqPrepParams fp{};
+                fp.cells = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                            cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
+                fp.cell0 = c0; fp.n_cells = nc; fp.J = P->J; fp.K = P->K;
+                fp.dim3 = P->dim3; fp.mode = o.df_mode;
+                fp.include_bulk = o.include_bulk_deltaf != 0; fp.include_shear = o.include_shear_deltaf != 0;
+                fp.cosphi = P->d_cosphi.p; fp.sinphi = P->d_sinphi.p; fp.kgrid = P->d_kgrid.p; fp.kweight = P->d_kweight.p;
+                fp.spl = P->spl;
+                fp.nj = P->nj;
+                fp.jx = P->d_jonah.p; fp.jl2 = fp.jx + P->nj; fp.jz = fp.jx + 2 * P->nj; fp.jcl = fp.jx + 3 * P->nj; fp.jcz = fp.jx + 4 * P->nj;
+                fp.bp_max = P->bp_max;
+                fp.ngl = P->ngl; fp.gl = P->d_gl.p;
+                fp.detA_min = P->detA_min; fp.mass_pion0 = P->mass_pion0;
+                fp.JT = P->JT; fp.R = P->KT; fp.jtiles = P->jtiles; fp.rblocks = P->rblocks;
+                fp.TS = P->d_TS.p; fp.CR = P->d_CR.p; fp.FB = P->d_FB.p; fp.flag = P->d_flag.p;
+                fp.status = P->d_status.p;
+                if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
+                HIP_TRY(is3d::launch_prep_feqmod(fp, st));
+                if (o.df_mode == 3)
+                    HIP_TRY(is3d::launch_feqmod_renorm(P->d_CR.p, P->d_gl.p, P->ngl, P->d_cls_mass.p, P->d_cls_sign.p, P->ncls, nc,
+                                                       fp.include_bulk, P->dim3, P->d_RN.p, st));
+                if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 1], st));
+                is3d::FqMainArgs a{};
+                a.TS = P->d_TS.p; a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
+                a.RN = P->d_RN.p; a.lane_cls = P->d_lane_cls.p; a.ncls = P->ncls;
+                a.partial = P->d_partial.p; a.stats = P->d_status.p;
+                a.g.upc = P->upc; a.g.zskip = (o.zero_skip != 2); a.g.baryon = 0;
+                a.g.n_cells = nc; a.g.J = P->J; a.g.K = P->K; a.g.Lpad = P->Lpad; a.g.wpb = P->wpb;
+                a.g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
+                a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles; a.g.nch = nch_used;
+                a.g.NT = P->jtiles * P->ktiles * nch_used; a.g.Kacc = P->Kacc; a.g.first_pass = (pass == 0);
+                HIP_TRY(is3d::launch_main_feqmod(P->variant, P->dim3, o.outflow != 0, o.df_mode == 3, a, st));
+                // flagged cells (breakdown, narrow rows): ordered list, then the linearised delta-f on top of chunk 0
+                HIP_TRY(is3d::launch_feqmod_compact(P->d_flag.p, nc, P->d_list.p, P->d_count.p, P->d_status.p, st));
+                is3d::FqLinearArgs la{};
+                la.FB = P->d_FB.p; la.list = P->d_list.p; la.count = P->d_count.p;
+                la.lane_mT = P->d_mT.p; la.lane_pT = P->d_pT.p; la.lane_sign = P->d_sign.p; la.lane_mass = P->d_lane_mass.p;
+                la.cosphi = P->d_cosphi.p; la.sinphi = P->d_sinphi.p; la.kgrid = P->d_kgrid.p; la.kweight = P->d_kweight.p;
+                la.partial = P->d_partial.p;
+                la.J = P->J; la.K = P->K; la.Kacc = P->Kacc; la.Lpad = P->Lpad; la.dim3 = P->dim3; la.mode = o.df_mode;
+                la.outflow = o.outflow != 0; la.regulate = o.regulate_deltaf != 0;
+                HIP_TRY(is3d::launch_feqmod_linear(la, st));
+                if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 2], st));
+                continue;
+            }
             is3d::PrepParams pp{};
             pp.cells = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
                         cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
@@ -451,7 +633,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
     }
 
     if (status) {
-        unsigned long long h[4];
+        unsigned long long h[8];
         HIP_TRY(hipMemcpyAsync(h, P->d_status.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         status->n_classes = P->ncls;
@@ -460,11 +642,13 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         status->n_cells_skipped = (int64_t)h[1];
         status->n_wave_rows = (int64_t)h[2];
         status->n_wave_rows_culled = (int64_t)h[3];
+        status->n_cells_breakdown = (int64_t)h[4];
+        status->n_cells_narrow = (int64_t)h[5];
         status->bad_cell = (h[0] == ~0ULL) ? -1 : (int64_t)h[0];
         if (status->bad_cell >= 0) {
             status->code = IS3D_EDOMAIN;
-            return fail(IS3D_EDOMAIN, "cell %lld: T outside the delta-f coefficient table (the reference aborts in gsl_spline_eval here)",
-                        (long long)status->bad_cell);
+            return fail(IS3D_EDOMAIN, "cell %lld: T%s outside the coefficient table (the reference aborts in gsl_spline_eval here)",
+                        (long long)status->bad_cell, (P->feqmod && o.df_mode == 4) ? " (or bulkPi/P)" : "");
         }
     }
     return IS3D_OK;
@@ -510,12 +694,13 @@ extern "C" int is3d_plan_timings(is3d_plan *P, is3d_status *status)
 // ---------------------------------------------------------------------------------------------
 // one-shot host entry
 // ---------------------------------------------------------------------------------------------
-extern "C" int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
-                                   const is3d_df_tables *df, const is3d_options *opts, double *dN_out, is3d_status *status)
+static int smooth_spectra_impl(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                               const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts, double *dN_out,
+                               is3d_status *status)
 {
     if (!cells || !dN_out) return fail(IS3D_EINVAL, "null argument");
     is3d_plan *P = nullptr;
-    int rc = is3d_plan_create(&P, species, grid, df, opts, std::max<int64_t>(cells->n_cells, 1));
+    int rc = plan_create_impl(&P, species, grid, df, fq, opts, std::max<int64_t>(cells->n_cells, 1));
     if (rc) { if (status) { memset(status, 0, sizeof *status); status->code = rc; status->bad_cell = -1; } return rc; }
     struct Guard { is3d_plan *p; ~Guard() { is3d_plan_destroy(p); } } guard{P};
     (void)is3d_plan_set_timing(P, 1);
@@ -565,4 +750,18 @@ extern "C" int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *
     st.code = IS3D_OK;
     if (status) *status = st;
     return IS3D_OK;
+}
+
+extern "C" int is3d_smooth_spectra(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                                   const is3d_df_tables *df, const is3d_options *opts, double *dN_out, is3d_status *status)
+{
+    return smooth_spectra_impl(cells, species, grid, df, nullptr, opts, dN_out, status);
+}
+
+extern "C" int is3d_smooth_spectra_feqmod(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                                          const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts,
+                                          double *dN_out, is3d_status *status)
+{
+    if (!fq) return fail(IS3D_EINVAL, "null feqmod tables");
+    return smooth_spectra_impl(cells, species, grid, df, fq, opts, dN_out, status);
 }

@@ -40,14 +40,16 @@ def test_shared_object_is_pure_c_abi():
 def test_struct_layouts_match_header(tmp_path):
     """ctypes mirrors == what a C compiler makes of include/is3d_amd.h (sizes and a few offsets)."""
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "is3d_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "is3d_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(is3d_options), offsetof(is3d_options, workspace_bytes), sizeof(is3d_status), offsetof(is3d_status, ms_prep),'
-                   'sizeof(is3d_cells), sizeof(is3d_grid), sizeof(is3d_species), sizeof(is3d_df_tables), offsetof(is3d_status, bad_cell));return 0;}\n')
+                   'sizeof(is3d_cells), sizeof(is3d_grid), sizeof(is3d_species), sizeof(is3d_df_tables), offsetof(is3d_status, bad_cell),'
+                   'sizeof(is3d_feqmod_tables), offsetof(is3d_feqmod_tables, T_avg), offsetof(is3d_status, n_cells_narrow));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     c = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     py = [ctypes.sizeof(api.Options), api.Options.workspace_bytes.offset, ctypes.sizeof(api.Status), api.Status.ms_prep.offset,
-          ctypes.sizeof(api.Cells), ctypes.sizeof(api.Grid), ctypes.sizeof(api.Species), ctypes.sizeof(api.DfTables), api.Status.bad_cell.offset]
+          ctypes.sizeof(api.Cells), ctypes.sizeof(api.Grid), ctypes.sizeof(api.Species), ctypes.sizeof(api.DfTables), api.Status.bad_cell.offset,
+          ctypes.sizeof(api.FeqmodTables), api.FeqmodTables.T_avg.offset, api.Status.n_cells_narrow.offset]
     assert c == py
 
 

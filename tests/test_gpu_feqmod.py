@@ -1,0 +1,178 @@
+"""GPU (-m gpu): the modified-equilibrium smooth path (df_mode 3 "Mike", 4 "Jonah") through the
+C ABI (is3d_smooth_spectra_feqmod / is3d_plan_create_feqmod) against the oracle's restatement of
+calculate_dN_ptdptdphidy_feqmod (smooth_kernels.cpp:396-996) and the committed long-double vectors.
+
+Tolerance as in test_gpu_parity.py (north_star: <= 1e-6 relative, asserted 2e-9).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+from is3d_amd import api, inputs, synth
+from oracle import oracle  # the checker
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-9
+SP6 = [211, 321, 2212, -2212, 3122, 333]
+
+
+def fq_for(cells, **kw):
+    return inputs.feqmod_tables(inputs.surface_average_T(cells), **kw)
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("df_mode", [3, 4])
+@pytest.mark.parametrize("flags", [dict(), dict(outflow=0, regulate_deltaf=0), dict(include_bulk_deltaf=0), dict(include_shear_deltaf=0)])
+def test_feqmod_parity_matrix(fx, dim, df_mode, flags):
+    cells = synth.synth_surface(70 if dim == 3 else 9, dim, seed=300 + dim)
+    sp = inputs.species(SP6) if dim == 3 else fx["pikp"]
+    fq = fq_for(cells)
+    o = dict(dimension=dim, df_mode=df_mode, **flags)
+    ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], fx["df"], fq, o)
+    for variant in (2, 3, 4):
+        got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=variant), fq=fq)
+        assert st["code"] == 0 and st["n_cells_breakdown"] == nb
+        assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
+
+
+def test_feqmod_golden_vectors(fx, pins):
+    """The committed long-double restatement (tests/golden/make_golden.py::highprec_feqmod)."""
+    hp = np.load(os.path.join(ROOT, "tests", "golden", "golden_highprec.npz"))
+    n = 0
+    for case in pins["highprec_cases"]:
+        if not case.get("feqmod"):
+            continue
+        cells = {k: hp["cells_%s_%s" % (case["cells"], k)] for k in synth.CELL_FIELDS}
+        sp = inputs.species(case["species"]) if "species" in case else fx["pikp"]
+        got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], case["opts"], fq=fq_for(cells))
+        assert relerr(got, hp[case["key"]]) < TOL, case["key"]
+        n += 1
+    assert n == 4
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_feqmod_breakdown_cells_use_linear_df(fx, dim):
+    """df_mode 3: cells whose linearised pion density is negative (or detA <= deta_min) are evaluated with the
+    Chapman-Enskog delta-f (does_feqmod_breakdown, emissionfunction.cpp:109-150); mixed with healthy cells here so that
+    both kernels contribute to the same bins.  In 2+1D the reference keeps dsigma_eta outside the eta weight (:828)."""
+    cells = synth.synth_surface(40 if dim == 3 else 8, dim, seed=310 + dim)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["bulkPi"][::3] = -5.0 * cells["P"][::3]
+    if dim == 2:
+        cells["dan"] = 0.02 * cells["dat"]     # not boost invariant, but it exercises the unweighted dsigma_eta term
+    sp = inputs.species(SP6) if dim == 3 else fx["pikp"]
+    fq = fq_for(cells)
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::2])
+    for flags in (dict(), dict(outflow=0, regulate_deltaf=0)):
+        o = dict(dimension=dim, df_mode=3, **flags)
+        ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, o)
+        assert nb == len(cells["tau"][::3]) - int(np.sum(synth_skipped(cells)[::3]))
+        got, st = api.smooth_spectra(cells, sp, g, fx["df"], o, fq=fq)
+        assert st["n_cells_breakdown"] == nb
+        assert relerr(got, ref) < TOL, relerr(got, ref)
+    # all cells broken, 3+1D: exactly the Chapman-Enskog (df_mode 2) spectrum of the regular path
+    if dim == 3:
+        cells["bulkPi"][:] = -5.0 * cells["P"]
+        got, st = api.smooth_spectra(cells, sp, g, fx["df"], dict(dimension=3, df_mode=3), fq=fq)
+        ce, _ = api.smooth_spectra(cells, sp, g, fx["df"], dict(dimension=3, df_mode=2))
+        assert relerr(got, ce) < TOL
+
+
+def synth_skipped(cells):
+    ut = np.sqrt(1 + cells["ux"] ** 2 + cells["uy"] ** 2 + cells["tau"] ** 2 * cells["un"] ** 2)
+    return (ut * cells["dat"] + cells["ux"] * cells["dax"] + cells["uy"] * cells["day"] + cells["un"] * cells["dan"]) <= 0.0
+
+
+def test_feqmod_narrow_rows(fx):
+    """3+1D, detA < 0.01: the rows with |y - eta| < detA switch to the linearised delta-f (smooth_kernels.cpp:807-813).
+    df_mode 4 with bulkPi -> -P drives lambda -> -1 and detA -> 0; the cell rapidities are put on top of y nodes."""
+    cells = synth.synth_surface(12, 3, seed=321)
+    cells = {k: v.copy() for k, v in cells.items()}
+    for k in ("pixx", "pixy", "pixn", "piyy", "piyn"):
+        cells[k] *= 0.05
+    cells["bulkPi"][:] = -0.95 * cells["P"]          # lambda ~ -0.89, detA ~ 1.5e-3
+    y = fx["grid"]["y"]
+    cells["eta"][:] = y[(np.arange(12) * 2) % len(y)] + 1.0e-4
+    sp = fx["pikp"]
+    fq = fq_for(cells)
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::3])
+    for flags in (dict(), dict(outflow=0, regulate_deltaf=0)):
+        o = dict(dimension=3, df_mode=4, **flags)
+        ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, o)
+        got, st = api.smooth_spectra(cells, sp, g, fx["df"], o, fq=fq)
+        assert st["n_cells_narrow"] > 0, "test surface has no detA < 0.01 cell"
+        assert relerr(got, ref) < TOL, relerr(got, ref)
+
+
+def test_feqmod_full_species_list_and_status(fx):
+    cells = synth.synth_surface(6, 3, seed=77)
+    sp = fx["urqmd"]
+    fq = fq_for(cells)
+    for dfm in (3, 4):
+        o = dict(dimension=3, df_mode=dfm)
+        got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o, fq=fq)
+        assert st["n_classes"] == 75
+        ref, _ = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], fx["df"], fq, o)
+        assert relerr(got, ref) < TOL
+        got2, st2 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, collapse_species=2), fq=fq)
+        assert st2["n_classes"] == 305 and relerr(got2, got) < 1e-12
+
+
+def test_feqmod_plan_passes_accumulate_and_skipped(fx):
+    """Device-resident plan with df_mode 3/4: several workspace passes, explicit chunk counts, accumulate, cells with
+    u.dsigma <= 0 (contribute 0) and the zero-skip switch all give the one-pass result."""
+    import torch
+    cells = synth.synth_surface(300, 3, seed=333)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["dat"][5:300:17] *= -1.0
+    cells["bulkPi"][7:300:23] = -5.0 * cells["P"][7:300:23]
+    sp = inputs.species(SP6)
+    fq = fq_for(cells)
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::3], phi=fx["grid"]["phi"][::2])
+    dev = torch.device("cuda:0")
+    tens = {k: torch.from_numpy(np.ascontiguousarray(cells[k])).to(dev) for k in synth.CELL_FIELDS}
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    for dfm in (3, 4):
+        o = dict(dimension=3, df_mode=dfm)
+        ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, o)
+        one, st1 = api.smooth_spectra(cells, sp, g, fx["df"], o, fq=fq)
+        assert relerr(one, ref) < TOL and st1["n_cells_skipped"] > 0 and st1["n_cells_breakdown"] == nb
+        for extra in (dict(workspace_bytes=1 << 20), dict(cell_chunks=3), dict(zero_skip=2), dict(waves_per_group=4)):
+            plan = api.Plan(sp, g, fx["df"], dict(o, **extra), max_cells=300, fq=fq)
+            assert plan.main_kernel_name == "cf_main_feqmod"
+            out = torch.ones(plan.output_size, dtype=torch.float64, device=dev)
+            st = plan.execute(300, ptrs, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            if "workspace_bytes" in extra:
+                assert st["n_passes"] > 1
+            assert st["n_cells_breakdown"] == nb
+            assert relerr(out.cpu().numpy(), one) < 1e-12, extra
+            plan.close()
+        plan = api.Plan(sp, g, fx["df"], dict(o, accumulate=1), max_cells=300, fq=fq)
+        out = torch.from_numpy(2.0 * one).to(dev)
+        plan.execute(300, ptrs, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert relerr(out.cpu().numpy(), 3.0 * one) < 1e-12
+        plan.close()
+
+
+def test_feqmod_argument_errors(fx):
+    cells = synth.synth_surface(4, 3, seed=1)
+    fq = fq_for(cells)
+    sp = fx["pikp"]
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=3))           # needs the feqmod entry
+    assert e.value.code == -1
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=2), fq=fq)    # entry takes 3 | 4 only
+    assert e.value.code == -1
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, sp, fx["grid"], inputs.df_tables_full(), dict(dimension=3, df_mode=4, include_baryon=1), fq=fq)
+    assert e.value.code == -1
+    hot = {k: v.copy() for k, v in cells.items()}
+    hot["T"][2] = 0.5                                                                               # outside the table
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(hot, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=4), fq=fq)
+    assert e.value.code == -3 and "cell 2" in str(e.value)
