@@ -52,14 +52,16 @@ def isa_counts(kernel_name, wl, JT_R):
         return None
     d = json.load(open(p))
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
-    if kernel_name == "cf_main_tile":
+    if kernel_name == "cf_main_feqmod":
+        key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1])
+    elif kernel_name == "cf_main_tile":
         key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,BARYON=0,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
     else:
         key = "cf_main_direct:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,KT=%d" % (ce, d3, JT_R[1])
     return d.get(key)
 
 
-def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0):
+def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     """The oracle (variant B, a scratch-free port of smooth_kernels.cpp:106-349; OpenMP over cells) on the first
     cells of the same surface, all host cores.  Also the reference-shaped variant A (chunk + scratch + reduce)."""
     from is3d_amd import synth
@@ -70,19 +72,25 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0):
     # a 1-GPU box owns a 16-core share of the host (and the oracle keeps one 39 MB partial spectrum per thread)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = oracle.set_num_threads(min(16, avail))
+    if fq is not None:
+        run = lambda c, **kw: oracle.dN_pTdpTdphidy_feqmod(c, sp, grid, df, fq, opts)
+    else:
+        run = lambda c, **kw: oracle.dN_pTdpTdphidy(c, sp, grid, df, opts, **kw)
     probe = synth.synth_surface(2 * threads, wl["dimension"])
     t0 = time.time()
-    oracle.dN_pTdpTdphidy(probe, sp, grid, df, opts)
+    run(probe)
     t_probe = max(time.time() - t0, 1e-3)
     n = int(max(2 * threads, min(8192, 2 * threads * (0.5 * seconds_budget / t_probe))))
     n -= n % threads
     cells = synth.synth_surface(n, wl["dimension"])
     t0 = time.time()
-    oracle.dN_pTdpTdphidy(cells, sp, grid, df, opts)
+    run(cells)
     tb = time.time() - t0
     res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, kind="port",
-               sample="first %d cells of the workload surface x all %d species x %d bins, oracle variant B (no scratch), %.1f s" % (
-                   n, len(sp["mass"]), nbins, tb))
+               sample="first %d cells of the workload surface x all %d species x %d bins, oracle %s, %.1f s" % (
+                   n, len(sp["mass"]), nbins, "feqmod restatement" if fq is not None else "variant B (no scratch)", tb))
+    if fq is not None:
+        return res
     # variant A: the reference's own structure; scratch = npart*chunk*bins*8 B must fit
     na = n
     while na * per_cell * 8 > 6e9 and na > threads:
@@ -102,6 +110,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--df-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
     ap.add_argument("--cells", type=int, default=0, help="override cells per GPU (parity/dev runs)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -127,6 +137,9 @@ def main():
         import torch.distributed as dist
 
     wl = workload(a.workload)
+    if a.df_mode:
+        wl["text"] += " -- df_mode overridden to %d" % a.df_mode
+        wl["df_mode"] = a.df_mode
     g = inputs.grid()
     grid = dict(pT=g["pT"], phi=g["phi"], y=g["y"], eta=g["eta"], eta_w=g["eta_w"])
     df = inputs.df_tables()
@@ -137,7 +150,10 @@ def main():
     cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
     tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}   # resident in HBM before timing
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local)
-    plan = api.Plan(sp, grid, df, opts, max_cells=max(n_loc, 1))
+    fq = None
+    if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, (this shard's) average temperature
+        fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    plan = api.Plan(sp, grid, df, opts, max_cells=max(n_loc, 1), fq=fq)
     plan.set_timing(True)
     out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
     ptrs = {k: v.data_ptr() for k, v in tens.items()}
@@ -223,7 +239,7 @@ def main():
                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"]))),
                    roofline=roofline, roofline_valu=rv)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df)
+            res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, fq=fq)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
     plan.close()

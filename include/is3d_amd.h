@@ -267,6 +267,10 @@ int is3d_df_table_read(const char *path, int32_t *n_T, double *T, double *value,
 int is3d_df_table_read_full(const char *path, int32_t *n_T, int32_t *n_muB, double *T, double *muB, double *value,
                             int64_t capacity);
 
+/* Gauss_Laguerre::load_roots_and_weights (src/cpp/readindata.cpp:24-53; tables/gla_roots_weights_32_points.txt).
+ * Two-call pattern (root == NULL -> only the shape); root/weight[alpha * n_points + k], capacity in doubles each. */
+int is3d_gla_read(const char *path, int32_t *n_alpha, int32_t *n_points, double *root, double *weight, int64_t capacity);
+
 /* Writers (src/cpp/emissionfunction.cpp:381-450, :729-772, :1053-1136): append to
  * <dir>/dN_pTdpTdphidy.dat, <dir>/dN_pTdpTdphidy_<mcid>.dat, <dir>/dN_dy_<mcid>.dat,
  * <dir>/vn_continuous/vn_<mcid>.dat in the reference's formatting.  pT/phi/y carry nodes and

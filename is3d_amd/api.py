@@ -71,7 +71,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
-           "is3d_write_results"]
+           "is3d_gla_read", "is3d_write_results"]
 
 
 class Is3dError(RuntimeError):
@@ -137,6 +137,7 @@ def load():
     L.is3d_pdg_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _dp, _dp, _dp, _dp, C.c_int32]
     L.is3d_df_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), _dp, _dp, C.c_int32]
     L.is3d_df_table_read_full.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, C.c_int64]
+    L.is3d_gla_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, C.c_int64]
     L.is3d_write_results.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, _dp, _dp,
                                      C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]
     _LIB = L
@@ -366,6 +367,16 @@ def df_table_read_full(path):
     T, B, v = np.zeros(nT.value), np.zeros(nB.value), np.zeros((nB.value, nT.value))
     _check(L.is3d_df_table_read_full(path.encode(), C.byref(nT), C.byref(nB), _p(T), _p(B), _p(v), v.size))
     return T, B, v
+
+
+def gla_read(path):
+    """is3d_gla_read -> (root[n_alpha][n_points], weight[n_alpha][n_points])"""
+    L = load()
+    na, npts = C.c_int32(), C.c_int32()
+    _check(L.is3d_gla_read(path.encode(), C.byref(na), C.byref(npts), None, None, 0))
+    r, w = np.zeros((na.value, npts.value)), np.zeros((na.value, npts.value))
+    _check(L.is3d_gla_read(path.encode(), C.byref(na), C.byref(npts), _p(r), _p(w), r.size))
+    return r, w
 
 
 def write_results(results_dir, dimension, mc_id, pT, pT_w, phi, phi_w, y, dN):

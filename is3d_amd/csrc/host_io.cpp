@@ -492,6 +492,39 @@ extern "C" int is3d_df_table_read_full(const char *path, int32_t *n_T, int32_t *
     return IS3D_OK;
 }
 
+// Gauss_Laguerre::load_roots_and_weights (src/cpp/readindata.cpp:24-53): "n_alpha n_points" then n_alpha * n_points
+// rows "alpha root weight" (the alpha column is a dummy there too).
+extern "C" int is3d_gla_read(const char *path, int32_t *n_alpha, int32_t *n_points, double *root, double *weight, int64_t capacity)
+{
+    if (!path || !n_alpha || !n_points) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "couldn't open gauss laguerre file %s", path);
+    const char *p = text.c_str();
+    char *q;
+    long na = strtol(p, &q, 10);
+    if (q == p || na < 1) return io_fail(IS3D_EIO, "%s: bad alpha count", path);
+    p = q;
+    long np = strtol(p, &q, 10);
+    if (q == p || np < 1) return io_fail(IS3D_EIO, "%s: bad point count", path);
+    p = q;
+    *n_alpha = (int32_t)na;
+    *n_points = (int32_t)np;
+    if (!root) return IS3D_OK;
+    if (!weight || (int64_t)na * np > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %lld < %ld", path, (long long)capacity, na * np);
+    for (long i = 0; i < na * np; i++) {
+        (void)strtol(p, &q, 10);
+        if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, i);
+        p = q;
+        root[i] = strtod(p, &q);
+        if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, i);
+        p = q;
+        weight[i] = strtod(p, &q);
+        if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path, i);
+        p = q;
+    }
+    return IS3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // write_dN_pTdpTdphidy_toFile (src/cpp/emissionfunction.cpp:381-450), write_continuous_vn_toFile
 // (:1053-1136), write_dN_dy_toFile (:729-772); same order as calculate_spectra calls them (:1678-1686).

@@ -9,7 +9,9 @@
 // and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
 // (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
-// Scope: operation = 1, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2}, include_baryon in {0, 1}.  Anything else is refused
+// Scope: operation = 1, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2} with include_baryon in {0, 1}, df_mode in {3, 4}
+// (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
+// averages it has just written, as the reference does) with include_baryon = 0.  Anything else is refused
 // with a message instead of silently doing something different from the reference.
 #include <cmath>
 #include <cstdio>
@@ -91,7 +93,9 @@ int main(int argc, char **argv)
     if (operation != 1) DIE("operation = %d: only operation = 1 (smooth momentum spectra) is on this path", operation);
     if (mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
         DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
-    if (df_mode != 1 && df_mode != 2) DIE("df_mode = %d: only 1 (14-moment) and 2 (Chapman-Enskog)", df_mode);
+    if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
+    const bool feqmod = df_mode == 3 || df_mode == 4;
+    if (feqmod && include_baryon) DIE("df_mode = %d with include_baryon = 1 is not on this path", df_mode);
     const char *pdg_path, *df_dir;
     if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
     else if (hrg_eos == 2) { pdg_path = "PDG/pdg_smash.dat"; df_dir = "deltaf_coefficients/vh/smash/"; }
@@ -186,9 +190,36 @@ int main(int argc, char **argv)
     const int ny_eff = (dimension == 2) ? 1 : (int)y.size();
     std::vector<double> dN(mcid.size() * pT.size() * phi.size() * (size_t)ny_eff, 0.0);
     is3d_status st{};
-    printf("computing thermal spectra from vhydro with df...\n");
-    int rc = is3d_smooth_spectra(&cells, &sp, &grid, &df, &opts, dN.data(), &st);
+    printf(feqmod ? "computing thermal spectra from vhydro with feqmod...\n" : "computing thermal spectra from vhydro with df...\n");
+    int rc;
+    if (feqmod) {
+        // emissionfunction.cpp:1309-1319: Gauss-Laguerre tables, Plasma::load_thermodynamic_averages (the file written
+        // above, read back as text), parameters deta_min and mass_pion0 (:184, :188)
+        int32_t n_alpha = 0, n_pts = 0;
+        const char *gla_path = "tables/gla_roots_weights_32_points.txt";
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (n_alpha < 3) DIE("%s: needs alpha = 0, 1, 2", gla_path);
+        std::vector<double> groot((size_t)n_alpha * n_pts), gweight((size_t)n_alpha * n_pts);
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, groot.data(), gweight.data(), (int64_t)groot.size())) DIE("%s", is3d_last_error());
+        double deta_min, mass_pion0, T_avg = 0.0;
+        if (get_param("deta_min", &deta_min) || get_param("mass_pion0", &mass_pion0)) return 1;
+        {
+            FILE *tf = fopen("average_thermodynamic_quantities.dat", "r");
+            if (!tf || fscanf(tf, "%lf", &T_avg) != 1) DIE("Error opening average thermodynamic file");
+            fclose(tf);
+        }
+        is3d_feqmod_tables fq{};
+        fq.n_gla = n_pts;
+        fq.root1 = groot.data() + n_pts; fq.weight1 = gweight.data() + n_pts;
+        fq.root2 = groot.data() + 2 * (size_t)n_pts; fq.weight2 = gweight.data() + 2 * (size_t)n_pts;
+        fq.n_pdg = npdg; fq.pdg_mass = pmass.data(); fq.pdg_degeneracy = pg.data(); fq.pdg_sign = ps.data();
+        fq.T_avg = T_avg; fq.deta_min = deta_min; fq.mass_pion0 = mass_pion0;
+        rc = is3d_smooth_spectra_feqmod(&cells, &sp, &grid, &df, &fq, &opts, dN.data(), &st);
+    } else {
+        rc = is3d_smooth_spectra(&cells, &sp, &grid, &df, &opts, dN.data(), &st);
+    }
     if (rc) DIE("is3d_smooth_spectra failed (%d): %s", rc, is3d_last_error());
+    if (feqmod) printf("\nfeqmod breaks down for %lld cells\n\n", (long long)st.n_cells_breakdown);   // smooth_kernels.cpp:989
     double t2 = now_s();
     if (is3d_write_results("results", dimension, sp.n, mcid.data(), grid.n_pT, pT.data(), pTw.data(), grid.n_phi, phi.data(),
                            phiw.data(), grid.n_y, y.data(), dN.data()))

@@ -23,6 +23,7 @@ regulate_deltaf           	= {regulate_deltaf}
 outflow 			= {outflow}	             # Theta(p.dsigma)
 
 deta_min 			= 1.e-5
+mass_pion0			= 0.138  # lightest pion mass for the feqmod breakdown test
 group_particles                 = 0
 """
 
@@ -83,6 +84,13 @@ def make_run_dir(root, cells, species_ids, params):
     else:
         for name in ("c0", "c2", "F", "betabulk", "betapi"):
             write_df_table(os.path.join(root, "deltaf_coefficients", "vh", "urqmd", name + ".dat"), df["T"], df[name], name)
+    # tables/gla_roots_weights_32_points.txt layout: "n_alpha\tn_points", rows "alpha\troot\tweight"; alpha = 0 is never read
+    gla = fx["gla_32"]
+    with open(os.path.join(root, "tables", "gla_roots_weights_32_points.txt"), "w") as f:
+        f.write("3\t%d\n" % len(gla["root1"]))
+        for al, (rk, wk) in enumerate([("root1", "weight1"), ("root1", "weight1"), ("root2", "weight2")]):
+            for r, w in zip(gla[rk], gla[wk]):
+                f.write("%d\t%s\t%s\n" % (al, repr(float(r) * (7.0 if al == 0 else 1.0)), repr(float(w))))
     particles = [r for r in fx["pdg_urqmd"] if r[3] >= 0]
     write_pdg(os.path.join(root, "PDG", "pdg-urqmd_v3.3+.dat"), particles)
     with open(os.path.join(root, "PDG", "chosen_particles.dat"), "w") as f:

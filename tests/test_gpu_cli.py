@@ -103,8 +103,31 @@ def test_cli_other_surface_formats(tmp_path, fx, mode):
 
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=2), dict(mode=2), dict(mode=5), dict(df_mode=4)):
+    for bad in (dict(operation=2), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr
         assert not os.listdir(os.path.join(root, "results", "vn_continuous"))
+
+
+@pytest.mark.parametrize("dim,df_mode", [(3, 4), (3, 3), (2, 4)])
+def test_cli_feqmod(tmp_path, fx, dim, df_mode):
+    """df_mode 3 / 4 end to end: Gauss-Laguerre file, deta_min / mass_pion0, the surface averages read back as text
+    (Plasma::load_thermodynamic_averages), the full PDG list for the Jonah tables."""
+    ids = [211, -2212, 3122, 321]
+    cells = synth.synth_surface(23 if dim == 3 else 7, dim, seed=60 + dim)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["bulkPi"][3] = -5.0 * cells["P"][3]            # one breakdown cell in df_mode 3
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(dimension=dim, df_mode=df_mode))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    T_avg = float(open(os.path.join(root, "average_thermodynamic_quantities.dat")).read().split()[0])
+    assert abs(T_avg / inputs.surface_average_T(parsed) - 1) < 1e-12
+    fq = inputs.feqmod_tables(T_avg)
+    ref, nb = oracle.dN_pTdpTdphidy_feqmod(parsed, inputs.species(ids), fx["grid"], fx["df"], fq, dict(dimension=dim, df_mode=df_mode))
+    assert "feqmod breaks down for %d cells" % nb in r.stdout and nb == (1 if df_mode == 3 else 0)
+    ny = 21 if dim == 3 else 1
+    allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
+    want = np.transpose(ref.reshape(ny, 24, 32, 4), (3, 0, 1, 2)).reshape(-1)
+    assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8

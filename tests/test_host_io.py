@@ -162,6 +162,20 @@ def test_df_table_reader(tmp_path):
     assert np.array_equal(T, df["T"]) and np.array_equal(v, df["c0"])   # only the mu_B = 0 block is kept
 
 
+def test_gla_reader(tmp_path):
+    """Gauss_Laguerre::load_roots_and_weights (readindata.cpp:24-53): header 'n_alpha n_points', rows 'alpha root weight'."""
+    import refformat
+    root = refformat.make_run_dir(str(tmp_path), synth.synth_surface(2, 3, seed=1), [211], dict())
+    r, w = api.gla_read(os.path.join(root, "tables", "gla_roots_weights_32_points.txt"))
+    g = inputs.load_fixture()["gla_32"]
+    assert r.shape == (3, 32) and np.array_equal(r[1], g["root1"]) and np.array_equal(w[1], g["weight1"])
+    assert np.array_equal(r[2], g["root2"]) and np.array_equal(w[2], g["weight2"])
+    # generalized Gauss-Laguerre: sum_k w_k = Gamma(alpha + 1), sum_k w_k x_k = Gamma(alpha + 2)
+    assert abs(w[1].sum() - 1.0) < 1e-13 and abs(w[2].sum() - 2.0) < 1e-13 and abs((w[1] * r[1]).sum() - 2.0) < 1e-12
+    with pytest.raises(api.Is3dError):
+        api.gla_read(os.path.join(root, "tables", "missing.txt"))
+
+
 def test_writers_format(tmp_path):
     """emissionfunction.cpp:381-450, :729-772, :1053-1136."""
     g = inputs.grid()

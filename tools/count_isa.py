@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Count the fp64 VALU instructions the main kernels execute per integrand evaluation, from the gfx950 ISA hipcc
-emits for is3d_amd/csrc/cf_kernels.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
+emits for is3d_amd/csrc/cf_kernels.hip and cf_feqmod.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
 fp64-VALU roofline).  Method: for every cf_main_* instantiation take the basic blocks of the innermost loop
 that contains v_rcp_f64 (exactly one v_rcp_f64 is issued per evaluation) and divide the opcode histogram of
 those blocks by their v_rcp_f64 count.  For the 3+1D tile kernel that loop is the whole unit (header + rows),
@@ -19,7 +19,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "is3d_amd", "csrc", "cf_kernels.hip")
+SRCS = [os.path.join(ROOT, "is3d_amd", "csrc", "cf_kernels.hip"), os.path.join(ROOT, "is3d_amd", "csrc", "cf_feqmod.hip")]
 OUT = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
 
 F64_OPS = ["v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64", "v_rcp_f64", "v_ldexp_f64",
@@ -35,17 +35,21 @@ def demangle_params(sym):
     vals = [int(v) for _, v in vals]
     if name == "cf_main_tile":
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R"]
+    elif name == "cf_main_feqmod":
+        keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R"]
     else:
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
     return name, dict(zip(keys, vals))
 
 
 def main():
+    text = []
     with tempfile.TemporaryDirectory() as td:
-        s_path = os.path.join(td, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                               "-I", os.path.dirname(SRC), SRC, "-o", s_path], stderr=subprocess.DEVNULL)
-        text = open(s_path).read().split("\n")
+        for src in SRCS:
+            s_path = os.path.join(td, "k.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                   "-I", os.path.dirname(src), src, "-o", s_path], stderr=subprocess.DEVNULL)
+            text += open(s_path).read().split("\n")
     kernels = {}
     cur, blocks = None, None
     for ln in text:
