@@ -59,6 +59,7 @@ struct PrepParams {
     int32_t JT, R;                  // tile: JT phi's x R rows (rows = y's in 3+1D, eta nodes in 2+1D)
     int32_t jtiles, rblocks;        // ceil(J/JT), ceil(K/R)
     double *TS;
+    const unsigned long long *pds_bound;   // tiled stream: bits of a bound on |p.dsigma| over all lanes and cells (cf_pds_bound)
     unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count
 };
 
@@ -69,6 +70,9 @@ struct PrepParams {
 //                     neutral padding (A = W = 0, Cp copied from row K-1, alpha = beta = 0)
 // 3+1D: stream s = jt*rblocks + rb, one unit per cell:        TS[(s*n_cells + cell)*REC]
 // 2+1D: stream s = jt, rblocks units per cell (eta blocks):   TS[((s*n_cells + cell)*rblocks + rb)*REC]
+// Scale: A_k and B_j are stored times 2^-e, one integer e per execute chosen (cf_pds_bound) so that |p.dsigma| 2^-e <= 1
+// for every lane and cell; cf_finalize multiplies 2^e back.  With |p.dsigma| <= 1 the outflow test max(p.dsigma, 0) is
+// the VOP3 clamp modifier of the add/fma that forms p.dsigma (no v_max_f64).  Exact: powers of two.
 // include_baryon = 1 ("B" records): the header slot 3 holds L2_j, two doubles {alpha_B, 0} follow the header, and
 // every row carries two more scalars {L_k, 0} after W, where  b (mT L_k + pT L2_j)  is the part of df/feqbar
 // that is linear in the momentum and proportional to the baryon number b of the lane (cf_kernels.hip::cf_prep).

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "cf_launch.h"
 #include "cf_math.h"
 
@@ -50,6 +52,52 @@ __device__ __forceinline__ double eval_tail(double z, double x, double br, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// cf_pds_bound: a bound on |p.dsigma| = |mT (ch dat + sh dan/tau) w + pT w (cos dax + sin day)| over all lanes, bins and
+// cells of an execute, for the power-of-two scale of the tiled stream (cf_device.h):
+//   mTmax (|dat| + |dan|/tau) cosh(max_k |y_k - eta|) + pTmax (|dax| + |day|)     (x max eta weight in 2+1D)
+// Bits of a non-negative double order like unsigned integers, so atomicMax on the bit pattern is a float max.
+// Non-finite cells are ignored (they are skipped or reported by cf_prep).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cf_pds_bound(CellPtrs cells, int64_t n_cells, int dim3, double kmin, double kmax, double gw2d, double mTmax, double pTmax,
+             unsigned long long *__restrict__ out)
+{
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += (int64_t)gridDim.x * blockDim.x) {
+        double g = gw2d;
+        if (dim3) {
+            const double eta = cells.eta[i];
+            g = cosh(fmax(fabs(kmin - eta), fabs(kmax - eta)));
+        }
+        const double b = (mTmax * (fabs(cells.dat[i]) + fabs(cells.dan[i] / cells.tau[i])) + pTmax * (fabs(cells.dax[i]) + fabs(cells.day[i]))) * g;
+        if (b < 1.0e300) m = fmax(m, b);   // false for NaN
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+// 2^-e (and optionally 2^e) with |p.dsigma| < 2^e; 1 when there is no bound (empty or all-zero surface, flat streams)
+__device__ __forceinline__ double pds_scale(const unsigned long long *bound_bits, double *inverse)
+{
+    int e = 0;
+    if (bound_bits) {
+        const double b = __longlong_as_double((long long)*bound_bits);
+        if (b > 0.0) (void)frexp(b, &e);
+    }
+    if (inverse) *inverse = ldexp(1.0, e);
+    return ldexp(1.0, -e);
+}
+
+hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3, double kmin, double kmax, double gw2d, double mTmax,
+                            double pTmax, unsigned long long *out, hipStream_t st)
+{
+    if (n_cells <= 0) return hipSuccess;
+    const int grid = (int)std::min<int64_t>((n_cells + 255) / 256, 2048);
+    hipLaunchKernelGGL(cf_pds_bound, dim3(grid), dim3(256), 0, st, cells, n_cells, is_dim3, kmin, kmax, gw2d, mTmax, pTmax, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // cf_prep
 // ------------------------------------------------------------------------------------------------
 constexpr int kPrepCB = 4;          // cells per workgroup batch
@@ -60,6 +108,7 @@ struct CellScal {
     double pitt, pitx, pity, tpitn, pixx, pixy, tpixn, piyy, tpiyn, t2pinn;
     double shear, Pb0, Pb2, kappa;
     double wvalid;  // 1.0 valid, 0.0 neutralised (skipped or out-of-table)
+    double psc;     // tiled stream: p.dsigma is stored times psc = 2^-e (cf_device.h)
     // include_baryon: alpha_B = mu_B/T; V^mu (V^tau reconstructed, :193); b1P = bulk1_coeff*Pi;
     // cLin / cQ: coefficients of the parts of the diffusion term that are linear / quadratic in the momentum
     double alphaB, Vt, Vx, Vy, tVn, b1P, cLin, cQ;
@@ -300,6 +349,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
         } else {
             // ---- phase 3 (tiled): unit records, consecutive threads -> consecutive doubles ----
             const int JT = p.JT, R = p.R;
+            const double psc = pds_scale(p.pds_bound, nullptr);
             const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
             const int units_per_cell = p.jtiles * p.rblocks;
             const int per_cell = units_per_cell * REC;
@@ -312,14 +362,14 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 if (e < 4 * JT) {
                     const int jj = e >> 2, f = e & 3;
                     const int j = min(jt * JT + jj, J - 1);
-                    v = f == 0 ? l_B[c * J + j] : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
+                    v = f == 0 ? l_B[c * J + j] * psc : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
                 } else if (e < HDR) {
                     v = (e == 4 * JT) ? cs[c].alphaB : 0.0;
                 } else {
                     const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                     const int k = rb * R + r;
                     if (k < K) {
-                        if (f < 4) v = f == 0 ? l_A[c * K + k] : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
+                        if (f < 4) v = f == 0 ? l_A[c * K + k] * psc : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
                         else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : 0.0;
                         else v = beta_of(c, min(jt * JT + (f - RS), J - 1), k);
                     } else {
@@ -581,7 +631,10 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 #pragma unroll
             for (int jj = 0; jj < JT; jj++) {
                 const double beta = rw.v[RS + jj];
-                double pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
+                // |p.dsigma 2^-e| <= 1 (cf_device.h), so Theta(p.dsigma) p.dsigma is the clamp modifier of the instruction that forms it
+                double pds;
+                if (OUTFLOW) pds = DIM3 ? add_clamp01(mTA, pTB[jj]) : fma_clamp01(pTB[jj], W, mTA);
+                else pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
                 const double z = E1 * E2[jj];
                 const double d = __builtin_fma(sign, z, 1.0);
                 const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
@@ -598,7 +651,6 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 }
                 const double u = REG ? fma_clamp01_half(dfr, br) : __builtin_fma(dfr, br, 1.0);
                 const double w = (z * rr) * u;
-                if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
                 if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
                 else acc[jj] = __builtin_fma(pds, w, acc[jj]);
             }
@@ -700,7 +752,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 __global__ void __launch_bounds__(256)
 cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, const double *__restrict__ degeneracy,
             double *__restrict__ out, int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch,
-            double prefactor, int accumulate)
+            double prefactor, int accumulate, const unsigned long long *__restrict__ pds_bound)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nout) return;
@@ -715,18 +767,20 @@ cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, con
     const double *p = partial + ((int64_t)j * Kacc + k) * Lpad + l;
     double s = 0.0;
     for (int ch = 0; ch < nch; ch++) s += p[ch * stride];
-    const double v = (prefactor * degeneracy[sp]) * s;
+    double unscale;                            // the stream carried p.dsigma 2^-e: exact to put back
+    (void)pds_scale(pds_bound, &unscale);
+    const double v = (prefactor * degeneracy[sp]) * (s * unscale);
     out[idx] = accumulate ? (out[idx] + v) : v;
 }
 
 hipError_t launch_finalize(const double *partial, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
-                           int accumulate, hipStream_t stream)
+                           int accumulate, const unsigned long long *pds_bound, hipStream_t stream)
 {
     if (nout <= 0) return hipSuccess;
     int grid = (int)((nout + 255) / 256);
     hipLaunchKernelGGL(cf_finalize, dim3(grid), dim3(256), 0, stream, partial, cls, degeneracy, out, nout, npart,
-                       npT, J, Kacc, Lpad, nch, prefactor, accumulate);
+                       npT, J, Kacc, Lpad, nch, prefactor, accumulate, pds_bound);
     return hipGetLastError();
 }
 

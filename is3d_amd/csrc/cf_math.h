@@ -76,6 +76,20 @@ __device__ __forceinline__ double fma_clamp01_half(double a, double b)
     return u;
 }
 
+// a + b and a * b + c with the clamp modifier: result clamped to [0, 1]
+__device__ __forceinline__ double add_clamp01(double a, double b)
+{
+    double u;
+    asm("v_add_f64 %0, %1, %2 clamp" : "=v"(u) : "v"(a), "v"(b));
+    return u;
+}
+__device__ __forceinline__ double fma_clamp01(double a, double b, double c)
+{
+    double u;
+    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(u) : "v"(a), "v"(b), "v"(c));
+    return u;
+}
+
 // sqrt(x) for normal x > 0: v_rsq_f64 seed, one coupled Newton (Goldschmidt) step for sqrt and 1/(2 sqrt), then one
 // residual correction: relative error <= ~1.5e-16 for any seed better than 1e-5.  No range scaling: callers pass
 // x in [1e-280, 1e280].

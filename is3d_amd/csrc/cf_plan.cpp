@@ -71,6 +71,8 @@ struct is3d_plan {
     int nch_max = 1;
     size_t bytes_per_cell = 0;
     double prefactor = 0;
+    double mTmax = 0, pTmax = 0;   // over the lane table: bound of |p.dsigma| for the stream's power-of-two scale
+    double kmin = 0, kmax = 0, gw2d = 1;   // y range (3+1D) / max_k w_k cosh(eta_k) (2+1D) for the same bound
 
     DevBuf<double> d_mT, d_pT, d_sign, d_lane_b, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
     DevBuf<double> d_bilT, d_bilB, d_biltab[5];
@@ -263,6 +265,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         sg[s] = csign[c];
         lb[s] = cbar[c];
     }
+    for (int s = 0; s < P->L; s++) { P->mTmax = std::max(P->mTmax, mT[s]); P->pTmax = std::max(P->pTmax, std::fabs(pT[s])); }
     std::vector<int> lane_sp((size_t)P->npart * P->npT);
     for (int s = 0; s < P->npart; s++)
         for (int i = 0; i < P->npT; i++) lane_sp[(size_t)s * P->npT + i] = slot_of[cls[s] * P->npT + i];
@@ -273,6 +276,13 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     for (int k = 0; k < P->K; k++) {
         kgrid[k] = P->dim3 ? g->y[k] : g->eta[k];
         if (!P->dim3) kweight[k] = g->eta_w[k];
+    }
+    if (P->dim3) {
+        P->kmin = *std::min_element(kgrid.begin(), kgrid.end());
+        P->kmax = *std::max_element(kgrid.begin(), kgrid.end());
+    } else {
+        P->gw2d = 0.0;
+        for (int k = 0; k < P->K; k++) P->gw2d = std::max(P->gw2d, std::fabs(kweight[k]) * std::cosh(kgrid[k]));
     }
     HIP_TRY(P->d_mT.upload(mT));
     HIP_TRY(P->d_pT.upload(pT));
@@ -527,12 +537,19 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
     HIP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, st));
 
     int nch_used = 1;
+    // tiled delta-f stream: p.dsigma travels times 2^-e (status[6] = bits of the bound, cf_device.h)
+    const bool use_scale = !P->feqmod && P->variant != 1;
     if (n == 0) {
         // empty surface: spectrum is zero (reference: loops do not execute)
         if (!o.accumulate) HIP_TRY(hipMemsetAsync(dN_out, 0, (size_t)P->nout * sizeof(double), st));
     } else {
         // all passes use the chunk count of the first (largest) pass so that partial slots line up
         nch_used = chunks_for(P, std::min<int64_t>(n, P->pass_cells));
+        if (use_scale) {
+            is3d::CellPtrs cp{};
+            cp.tau = cells->tau; cp.eta = cells->eta; cp.dat = cells->dat; cp.dax = cells->dax; cp.day = cells->day; cp.dan = cells->dan;
+            HIP_TRY(is3d::launch_pds_bound(cp, n, P->dim3, P->kmin, P->kmax, P->gw2d, P->mTmax, P->pTmax, P->d_status.p + 6, st));
+        }
         for (int pass = 0; pass < npasses; pass++) {
             const int64_t c0 = (int64_t)pass * P->pass_cells;
             const int32_t nc = (int32_t)std::min<int64_t>(P->pass_cells, n - c0);
@@ -601,6 +618,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             pp.tiled = (P->variant != 1);
             pp.JT = P->JT; pp.R = P->KT; pp.jtiles = P->jtiles; pp.rblocks = P->rblocks;
             pp.TS = P->d_TS.p;
+            pp.pds_bound = use_scale ? P->d_status.p + 6 : nullptr;
             pp.status = P->d_status.p;
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
             HIP_TRY(is3d::launch_prep(pp, st));
@@ -628,7 +646,8 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 2], st));
         }
         HIP_TRY(is3d::launch_finalize(P->d_partial.p, P->d_cls.p, P->d_degeneracy.p, dN_out, P->nout, P->npart, P->npT, P->J,
-                                      P->Kacc, P->Lpad, nch_used, P->prefactor, o.accumulate != 0, st));
+                                      P->Kacc, P->Lpad, nch_used, P->prefactor, o.accumulate != 0,
+                                      use_scale ? P->d_status.p + 6 : nullptr, st));
         if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[npasses * 3], st));
     }
 
