@@ -45,7 +45,8 @@ extern "C" {
 #define IS3D_OK 0
 #define IS3D_EINVAL (-1)     /* bad argument / unsupported option combination            */
 #define IS3D_ENODEVICE (-2)  /* no HIP device, or a HIP runtime error (see last_error)    */
-#define IS3D_EDOMAIN (-3)    /* a non-skipped cell's T is outside the coefficient table  */
+#define IS3D_EDOMAIN (-3)    /* a non-skipped cell's T is outside the coefficient table, */
+                             /* or its flow is so fast that p.u/T can exceed 1e9         */
                              /* (reference: GSL domain error -> abort, deltafReader.cpp:339) */
 #define IS3D_ENOMEM (-4)
 #define IS3D_EIO (-5)        /* host reader/writer failure                               */

@@ -60,7 +60,8 @@ struct PrepParams {
     int32_t jtiles, rblocks;        // ceil(J/JT), ceil(K/R)
     double *TS;
     const unsigned long long *pds_bound;   // tiled stream: bits of a bound on |p.dsigma| over all lanes and cells (cf_pds_bound)
-    unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count
+    double mTmax, kmin, kmax;       // largest lane mT; range of the k grid (y in 3+1D, eta nodes in 2+1D): bound of p.u/T
+    unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count, [7] min cell whose p.u/T can exceed 1e9
 };
 
 // ---- tiled stream TS (variants >= 2): what one workgroup of the main kernel streams through LDS ----

@@ -470,7 +470,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
 #pragma unroll
             for (int jj = 0; jj < JT; jj++) {
                 const double X = sqrt_nr(X2[jj]);
-                const double z = exp_full(-X);
+                const double z = exp_full_sat(-X);   // X = |A^-1 p|/T_mod is unbounded for nearly singular A
                 const double d = __builtin_fma(sign, z, 1.0);
                 const double rr = rcp_nr1(d);
                 double pds = __builtin_fma(pTB[jj], W, mTA);

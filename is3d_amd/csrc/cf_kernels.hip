@@ -193,6 +193,16 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 valid = false;
             }
             if (valid) {
+                // exponent range of exp_core: p.u/T <= mTmax (u^tau + |tau u^eta|) cosh(max |y - eta|) / T must stay below 1e9
+                // (a Lorentz factor of several hundred at T = 0.1 GeV; the reference's exp() would return inf there)
+                const double eta0 = p.dim3 ? p.cells.eta[gi] : 0.0;
+                const double xb = p.mTmax * (ut + fabs(tau * un)) * cosh(fmax(fabs(p.kmin - eta0), fabs(p.kmax - eta0))) / T;
+                if (!(xb < 1.0e9)) {
+                    atomicMin(&p.status[7], (unsigned long long)gi);
+                    valid = false;
+                }
+            }
+            if (valid) {
                 double P = p.cells.P[gi], E = p.cells.E[gi];
                 double ux2 = ux * ux, uy2 = uy * uy, ut2 = ut * ut;
                 double utperp2 = 1.0 + ux * ux + uy * uy;                         // utperp^2, :142

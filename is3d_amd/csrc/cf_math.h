@@ -18,9 +18,15 @@ __attribute__((weak)) __constant__ double kExpC[10] = {2.76263718333300477554e-0
     1.98411702685802050468e-04, 1.38888889325031097272e-03, 8.33333338566940792780e-03,
     4.16666666665731558195e-02, 1.66666666665543999892e-01, 5.00000000000000555112e-01, 1.00000000000000666134e+00};
 
+// Domain: |v| < 1.4e9 (the shift trick below takes n from the low dword; cf_prep refuses cells that could exceed it).
+// exp_core_sat is the same with a saturating conversion, for callers without such a guarantee.
 __device__ __forceinline__ void exp_core(double v, double &f, int &n)
 {
-    double dn = __builtin_rint(v * IS3D_LOG2E);
+    // n = rint(v log2 e) by the 1.5 * 2^52 shift: the sum's low mantissa bits ARE the integer (two's complement, |n| < 2^31),
+    // so the int comes out of the low dword for free and no v_rndne_f64 / v_cvt_i32_f64 is issued
+    const double shift = 6755399441055744.0;   // 0x1.8p52
+    double t = __builtin_fma(v, IS3D_LOG2E, shift);
+    double dn = t - shift;
     double r = __builtin_fma(-dn, IS3D_LN2_HI, v);
     r = __builtin_fma(-dn, IS3D_LN2_LO, r);
     // The non-inline Taylor coefficients come from constant memory, i.e. they sit in SGPRs: the Horner steps are
@@ -37,10 +43,28 @@ __device__ __forceinline__ void exp_core(double v, double &f, int &n)
     p = __builtin_fma(p, r, kExpC[8]);
     p = __builtin_fma(p, r, kExpC[9]);
     f = __builtin_fma(p, r, 1.0);
-    n = (int)dn;
+    n = __double2loint(t);
 }
 
 __device__ __forceinline__ double ldexp_fast(double f, int n) { return __builtin_amdgcn_ldexp(f, n); }  // v_ldexp_f64
+
+__device__ __forceinline__ double exp_full_sat(double v)
+{
+    double dn = __builtin_rint(v * IS3D_LOG2E);
+    double r = __builtin_fma(-dn, IS3D_LN2_HI, v);
+    r = __builtin_fma(-dn, IS3D_LN2_LO, r);
+    double p = kExpC[0];
+    p = __builtin_fma(p, r, kExpC[1]);
+    p = __builtin_fma(p, r, kExpC[2]);
+    p = __builtin_fma(p, r, kExpC[3]);
+    p = __builtin_fma(p, r, kExpC[4]);
+    p = __builtin_fma(p, r, kExpC[5]);
+    p = __builtin_fma(p, r, kExpC[6]);
+    p = __builtin_fma(p, r, kExpC[7]);
+    p = __builtin_fma(p, r, kExpC[8]);
+    p = __builtin_fma(p, r, kExpC[9]);
+    return ldexp_fast(__builtin_fma(p, r, 1.0), (int)dn);   // v_cvt_i32_f64 saturates: e^-huge = +0, never a wrapped exponent
+}
 
 // e^v; exactly +0 for v < -745.2 (v_ldexp_f64 underflow)
 __device__ __forceinline__ double exp_full(double v)

@@ -277,10 +277,9 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         kgrid[k] = P->dim3 ? g->y[k] : g->eta[k];
         if (!P->dim3) kweight[k] = g->eta_w[k];
     }
-    if (P->dim3) {
-        P->kmin = *std::min_element(kgrid.begin(), kgrid.end());
-        P->kmax = *std::max_element(kgrid.begin(), kgrid.end());
-    } else {
+    P->kmin = *std::min_element(kgrid.begin(), kgrid.end());
+    P->kmax = *std::max_element(kgrid.begin(), kgrid.end());
+    if (!P->dim3) {
         P->gw2d = 0.0;
         for (int k = 0; k < P->K; k++) P->gw2d = std::max(P->gw2d, std::fabs(kweight[k]) * std::cosh(kgrid[k]));
     }
@@ -533,7 +532,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         }
     }
     P->last_passes = npasses;
-    unsigned long long init[8] = {~0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    unsigned long long init[8] = {~0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, ~0ULL};
     HIP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, st));
 
     int nch_used = 1;
@@ -619,6 +618,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             pp.JT = P->JT; pp.R = P->KT; pp.jtiles = P->jtiles; pp.rblocks = P->rblocks;
             pp.TS = P->d_TS.p;
             pp.pds_bound = use_scale ? P->d_status.p + 6 : nullptr;
+            pp.mTmax = P->mTmax; pp.kmin = P->kmin; pp.kmax = P->kmax;
             pp.status = P->d_status.p;
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
             HIP_TRY(is3d::launch_prep(pp, st));
@@ -664,6 +664,12 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         status->n_cells_breakdown = (int64_t)h[4];
         status->n_cells_narrow = (int64_t)h[5];
         status->bad_cell = (h[0] == ~0ULL) ? -1 : (int64_t)h[0];
+        if (h[7] != ~0ULL && (status->bad_cell < 0 || (int64_t)h[7] < status->bad_cell)) {
+            status->bad_cell = (int64_t)h[7];
+            status->code = IS3D_EDOMAIN;
+            return fail(IS3D_EDOMAIN, "cell %lld: p.u/T can exceed 1e9 for the momentum grid (flow velocity / temperature outside the "
+                        "kernel's exponent range; the reference's exp() overflows to inf there)", (long long)status->bad_cell);
+        }
         if (status->bad_cell >= 0) {
             status->code = IS3D_EDOMAIN;
             return fail(IS3D_EDOMAIN, "cell %lld: T%s outside the coefficient table (the reference aborts in gsl_spline_eval here)",

@@ -212,6 +212,18 @@ def test_skipped_cells_and_domain_error(fx):
     with pytest.raises(api.Is3dError) as e:
         api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], o)
     assert e.value.code == api.IS3D_EDOMAIN and "cell 20" in str(e.value)
+    # a Lorentz factor beyond the exponent range of the device exp (p.u/T > 1e9 possible): refused, not garbage
+    fast = synth.synth_surface(40, 3, seed=12)
+    fast["ux"][11] = 3.0e5
+    for variant in (1, 2):
+        with pytest.raises(api.Is3dError) as e:
+            api.smooth_spectra(fast, fx["pikp"], fx["grid"], fx["df"], dict(o, kernel_variant=variant))
+        assert e.value.code == api.IS3D_EDOMAIN and "cell 11" in str(e.value) and "p.u/T" in str(e.value)
+    # gamma ~ 200 is still inside: p.u/T up to ~4e8 for the 40 GeV bins, every exponential exactly 0 or finite
+    fast["ux"][11] = 200.0
+    ref = oracle.dN_pTdpTdphidy(fast, fx["pikp"], fx["grid"], fx["df"], o)
+    got, st = api.smooth_spectra(fast, fx["pikp"], fx["grid"], fx["df"], o)
+    assert relerr(got, ref) < TOL and np.isfinite(got).all()
 
 
 def test_passes_chunks_and_accumulate(fx, torch_mod):
