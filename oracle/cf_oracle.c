@@ -945,3 +945,325 @@ int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, 
     free(part); free(s); free(J); free(yValues); free(cosphi); free(sinphi);
     return err;
 }
+
+/* ==========================================================================================
+ * Particle sampler (operation = 2): SURVEY.md 8f rank 4.  Restates, for viscous hydro with a linear
+ * delta-f (df_mode 1, 2), include_baryon = 0, non-"fast" mode,
+ *   EmissionFunctionArray::sample_dN_pTdpTdphidy      src/cpp/emissionfunction_sampling_kernels.cpp:833-1225
+ *   max_particle_number (df_mode 1, 2: 2 n_eq)        :282-303
+ *   sample_momentum (light / heavy hadron branches)   :456-617, pion_thermal_weight_max :172-196
+ *   compute_df_weight                                 :361-453
+ *   Milne_Basis, Surface_Element_Vector, Shear_Stress::boost_pimunu_to_lrf   src/cpp/viscous_correction.cpp:8-115
+ *   Lab_Momentum::boost_pLRF_to_lab_frame             src/cpp/emissionfunction.cpp:40-51
+ *
+ * Random numbers.  The reference draws from five std::default_random_engine streams (seed + {0,1,2,3,4} 10^4;
+ * :846-850) consumed serially over cells, through std::poisson_distribution / std::discrete_distribution, whose
+ * outputs are implementation-defined: a bitwise reproduction is neither possible nor meaningful.
+ * What is kept is the structure -- five independent streams with the same roles (hadron number, species, momentum,
+ * keep test, rapidity) -- and every distribution; what is DEFINED HERE, and followed bit for bit by the device
+ * sampler, is a counter-based construction:
+ *   generator   Philox4x32-10 (Salmon et al., SC'11), key = the 64-bit seed, counter = (block, stream, cell, event):
+ *               every (cell, event, stream) owns an independent sequence, so cells and events can run in any order;
+ *   uniform     u = ((a >> 5) 2^26 + (b >> 6)) 2^-53 in [0, 1) from two consecutive 32-bit outputs (canonical(), :154-158);
+ *   Poisson     inversion by sequential search, in chunks of mean <= 256 (std::poisson_distribution(dn_tot), :1085-1090);
+ *   species     inversion of the cumulative dn_list (std::discrete_distribution, :1082, :1094);
+ *   K mixture   inversion over {mbar^2, 2 mbar, 2} (:541-549); cos(theta) = 2u - 1 (:539).
+ * Output order: event, then cell, then the order of draws within the cell.
+ * ========================================================================================== */
+#include <stdint.h>
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+/* exposed for the known-answer test */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox4x32_10(c, key[0], key[1]);
+    memcpy(out, c, sizeof c);
+}
+
+typedef struct { uint32_t k0, k1, stream, cell, event, blk, buf[4]; int pos; } rng_stream;
+static void rng_init(rng_stream *s, uint64_t seed, uint32_t stream, uint32_t cell, uint32_t event)
+{
+    s->k0 = (uint32_t)seed; s->k1 = (uint32_t)(seed >> 32);
+    s->stream = stream; s->cell = cell; s->event = event; s->blk = 0; s->pos = 4;
+}
+static double rng_uniform(rng_stream *s)
+{
+    if (s->pos >= 4) {
+        s->buf[0] = s->blk++; s->buf[1] = s->stream; s->buf[2] = s->cell; s->buf[3] = s->event;
+        philox4x32_10(s->buf, s->k0, s->k1);
+        s->pos = 0;
+    }
+    uint32_t a = s->buf[s->pos], b = s->buf[s->pos + 1];
+    s->pos += 2;
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+/* exposed for tests: n uniforms of stream (seed, stream, cell, event) */
+void oracle_rng_uniforms(uint64_t seed, uint32_t stream, uint32_t cell, uint32_t event, int n, double *out)
+{
+    rng_stream s;
+    rng_init(&s, seed, stream, cell, event);
+    for (int i = 0; i < n; i++) out[i] = rng_uniform(&s);
+}
+
+static long rng_poisson(rng_stream *s, double mean)
+{
+    long N = 0;
+    double remaining = mean;
+    while (remaining > 0.0) {
+        const double l = remaining < 256.0 ? remaining : 256.0;
+        remaining -= l;
+        const double u = rng_uniform(s);
+        double p = exp(-l), F = p;
+        long k = 0;
+        while (u >= F && k < 4096) { k++; p *= l / (double)k; F += p; }
+        N += k;
+    }
+    return N;
+}
+
+/* :172-196 */
+static double pion_thermal_weight_max(double x)
+{
+    double x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+    double max = (143206.88623164667 - 95956.76008684626 * x - 21341.937407169076 * x2 + 14388.446116867359 * x3 - 6083.775788504437 * x4) /
+                 (-0.3541350577684533 + 143218.69233952634 * x - 24516.803600065778 * x2 - 115811.59391199696 * x3 + 35814.36403387459 * x4);
+    return 1.00001 * max;
+}
+
+typedef struct { double E, px, py, pz; } lrf_mom;
+
+/* :456-617 with chem = 0 */
+static lrf_mom sample_momentum(rng_stream *g, long *acceptances, long *samples, double mass, double sign, double T)
+{
+    const double two_pi = 2.0 * M_PI;
+    double mbar = mass / T, mbar_squared = mbar * mbar;
+    double pbar, Ebar, phi_over_2pi, costheta;
+    if (mbar < 1.008) {
+        double weq_max = 1.0;
+        if (mbar < 0.8554 && sign == -1.0) weq_max = pion_thermal_weight_max(mbar);
+        for (;;) {
+            *samples += 1;
+            double r1 = 1.0 - rng_uniform(g), r2 = 1.0 - rng_uniform(g), r3 = 1.0 - rng_uniform(g);
+            double l1 = log(r1), l2 = log(r2), l3 = log(r3);
+            double l1_plus_l2 = l1 + l2;
+            pbar = -(l1 + l2 + l3);
+            Ebar = sqrt(pbar * pbar + mbar_squared);
+            phi_over_2pi = l1_plus_l2 * l1_plus_l2 / (pbar * pbar);
+            costheta = (l1 - l2) / l1_plus_l2;
+            double weight = 1.0 / (exp(Ebar) + sign) / weq_max / (r1 * r2 * r3);
+            if (rng_uniform(g) < weight) break;
+        }
+    } else {
+        const double K0 = mbar_squared, K1 = 2.0 * mbar, K2 = 2.0, Ksum = K0 + K1 + K2;
+        double kbar;
+        for (;;) {
+            *samples += 1;
+            const double uk = rng_uniform(g) * Ksum;
+            if (uk < K0) {
+                kbar = -log(1.0 - rng_uniform(g));
+                phi_over_2pi = rng_uniform(g);
+                costheta = 2.0 * rng_uniform(g) - 1.0;
+            } else if (uk < K0 + K1) {
+                double l1 = log(1.0 - rng_uniform(g)), l2 = log(1.0 - rng_uniform(g));
+                kbar = -(l1 + l2);
+                phi_over_2pi = -l1 / kbar;
+                costheta = 2.0 * rng_uniform(g) - 1.0;
+            } else {
+                double l1 = log(1.0 - rng_uniform(g)), l2 = log(1.0 - rng_uniform(g)), l3 = log(1.0 - rng_uniform(g));
+                double l1_plus_l2 = l1 + l2;
+                kbar = -(l1 + l2 + l3);
+                phi_over_2pi = l1_plus_l2 * l1_plus_l2 / (kbar * kbar);
+                costheta = (l1 - l2) / l1_plus_l2;
+            }
+            Ebar = kbar + mbar;
+            pbar = sqrt(Ebar * Ebar - mbar_squared);
+            double exponent = exp(Ebar);
+            double weight = pbar / Ebar * exponent / (exponent + sign);
+            if (rng_uniform(g) < weight) break;
+        }
+    }
+    *acceptances += 1;
+    double E = Ebar * T, p = pbar * T, phi = phi_over_2pi * two_pi;
+    double sintheta = sqrt(1.0 - costheta * costheta);
+    lrf_mom q = {E, p * sintheta * cos(phi), p * sintheta * sin(phi), p * costheta};
+    return q;
+}
+
+typedef struct {
+    int live;
+    double tau, x, y, eta, ut, ux, uy, un, T;
+    double Xt, Xx, Xy, Xn, Yx, Yy, Zt, Zn;
+    double dst, dsx, dsy, dsz, ds_max;
+    double pixx, pixy, pixz, piyy, piyz, pizz;     /* LRF */
+    double bulkPi, dn_tot;
+    df_coeff df;
+    double shear14_coeff;
+} sampler_cell;
+
+#define ORACLE_PARTICLE_DOUBLES 14
+/* out[i * 14 + ...] = {event, cell, species index, tau, x, y, eta, t, z, E, px, py, pz, rapidity}.
+ * first_cell: global index of cells[0] (a shard of a larger surface samples exactly the hadrons the whole surface would give
+ * its cells).  stats = {momentum samples, acceptances, hadrons drawn (before the keep test)}.  Returns the number of kept
+ * particles (all of them are counted; only the first `capacity` are stored), or < 0: -1 T outside the table,
+ * -2 df_mode, -3 dimension, -4 include_baryon. */
+long oracle_sample_particles(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
+                             const cell_arrays *a, const double *x_fo, const double *y_fo, const oracle_df_tables *t,
+                             int n_gla, const double *root1, const double *weight1, const oracle_opts *o, int n_events,
+                             uint64_t seed, double y_cut, long first_cell, double *out, long capacity, long *stats)
+{
+    if (o->dimension != 2 && o->dimension != 3) return -3;
+    if (o->df_mode != 1 && o->df_mode != 2) return -2;
+    if (o->include_baryon) return -4;
+    const double two_pi2_hbarC3 = 2.0 * pow(M_PI, 2) * pow(ORACLE_HBARC, 3);
+    double y_max = 0.5;                                                       /* :837-838 */
+    if (o->dimension == 2) y_max = y_cut;
+    const int n = t->n_T;
+    double *s = (double *)calloc((size_t)5 * n, sizeof(double));
+    init_splines(t, s);
+    sampler_cell *cs = (sampler_cell *)calloc((size_t)(FO_length > 0 ? FO_length : 1), sizeof(sampler_cell));
+    double *dn_list = (double *)malloc(sizeof(double) * (size_t)npart * (size_t)(FO_length > 0 ? FO_length : 1));
+    int err = 0;
+    for (long ic = 0; ic < FO_length && !err; ic++) {
+        sampler_cell *c = &cs[ic];
+        c->live = 0;
+        double tau = a->tau[ic], tau2 = tau * tau;
+        double dat = a->dat[ic], dax = a->dax[ic], day = a->day[ic], dan = a->dan[ic];
+        double ux = a->ux[ic], uy = a->uy[ic], un = a->un[ic];
+        double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+        double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+        if (udsigma <= 0.0) continue;                                         /* :899 */
+        double ut2 = ut * ut, ux2 = ux * ux, uy2 = uy * uy;
+        double uperp = sqrt(ux * ux + uy * uy), utperp = sqrt(1.0 + ux * ux + uy * uy);
+        double T = a->T[ic], P = a->P[ic], E = a->E[ic];
+        double pitt = 0, pitx = 0, pity = 0, pitn = 0, pixx = 0, pixy = 0, pixn = 0, piyy = 0, piyn = 0, pinn = 0;
+        if (o->include_shear_deltaf) {                                        /* :922-934 */
+            pixx = a->pixx[ic]; pixy = a->pixy[ic]; pixn = a->pixn[ic]; piyy = a->piyy[ic]; piyn = a->piyn[ic];
+            pinn = (pixx * (ux2 - ut2) + piyy * (uy2 - ut2) + 2.0 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp * utperp);
+            pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut;
+            pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut;
+            pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut;
+            pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
+        }
+        double bulkPi = o->include_bulk_deltaf ? a->bulkPi[ic] : 0.0;
+        if (eval_df(t, s, s + n, s + 2 * n, s + 3 * n, s + 4 * n, o->df_mode, T, &c->df)) { err = -1; break; }
+        c->shear14_coeff = 2.0 * T * T * (E + P);                             /* deltafReader.cpp:344 */
+        /* Milne_Basis */
+        double sinhL = tau * un / utperp, coshL = ut / utperp;
+        c->Xt = uperp * coshL; c->Zt = sinhL; c->Xn = uperp * sinhL / tau; c->Zn = coshL / tau;
+        c->Xx = 1.0; c->Yx = 0.0; c->Xy = 0.0; c->Yy = 1.0;
+        if (uperp > 1.e-5) { c->Xx = utperp * ux / uperp; c->Yx = -uy / uperp; c->Xy = utperp * uy / uperp; c->Yy = ux / uperp; }
+        const double Xt = c->Xt, Xx = c->Xx, Xy = c->Xy, Xn = c->Xn, Yx = c->Yx, Yy = c->Yy, Zt = c->Zt, Zn = c->Zn;
+        /* boost_dsigma_to_lrf, compute_dsigma_magnitude (viscous_correction.cpp:69-86) */
+        c->dst = dat * ut + dax * ux + day * uy + dan * un;
+        c->dsx = -(dat * Xt + dax * Xx + day * Xy + dan * Xn);
+        c->dsy = -(dax * Yx + day * Yy);
+        c->dsz = -(dat * Zt + dan * Zn);
+        c->ds_max = fabs(c->dst) + sqrt(c->dsx * c->dsx + c->dsy * c->dsy + c->dsz * c->dsz);
+        /* boost_pimunu_to_lrf */
+        c->pixx = pitt * Xt * Xt + pixx * Xx * Xx + piyy * Xy * Xy + tau2 * tau2 * pinn * Xn * Xn
+                + 2.0 * (-Xt * (pitx * Xx + pity * Xy) + pixy * Xx * Xy + tau2 * Xn * (pixn * Xx + piyn * Xy - pitn * Xt));
+        c->pixy = Yx * (-pitx * Xt + pixx * Xx + pixy * Xy + tau2 * pixn * Xn) + Yy * (-pity * Xt + pixy * Xx + piyy * Xy + tau2 * piyn * Xn);
+        c->pixz = Zt * (pitt * Xt - pitx * Xx - pity * Xy - tau2 * pitn * Xn) - tau2 * Zn * (pitn * Xt - pixn * Xx - piyn * Xy - tau2 * pinn * Xn);
+        c->piyy = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
+        c->piyz = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
+        c->pizz = -(c->pixx + c->piyy);
+        c->tau = tau; c->x = x_fo ? x_fo[ic] : 0.0; c->y = y_fo ? y_fo[ic] : 0.0;
+        c->eta = (o->dimension == 3) ? a->eta[ic] : 0.0;
+        c->ut = ut; c->ux = ux; c->uy = uy; c->un = un; c->T = T; c->bulkPi = bulkPi;
+        /* max_particle_number, df_mode 1 / 2: 2 n_eq (:282-303) */
+        double neq_fact = T * T * T / two_pi2_hbarC3, dn_tot = 0.0;
+        for (int ip = 0; ip < npart; ip++) {
+            double mbar = Mass[ip] / T;
+            double equilibrium_density = neq_fact * Degeneracy[ip] * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+            dn_list[(size_t)ic * npart + ip] = 2.0 * equilibrium_density;
+            dn_tot += dn_list[(size_t)ic * npart + ip];
+        }
+        dn_tot *= (2.0 * y_max * c->ds_max);                                  /* :1077 */
+        c->dn_tot = dn_tot;
+        if (dn_tot <= 0.0) continue;                                          /* :1079 */
+        c->live = 1;
+    }
+    long kept = 0, samples = 0, acceptances = 0, drawn = 0;
+    for (int ievent = 0; ievent < n_events && !err; ievent++)
+        for (long ic = 0; ic < FO_length; ic++) {
+            const sampler_cell *c = &cs[ic];
+            if (!c->live) continue;
+            rng_stream g_poisson, g_type, g_momentum, g_keep, g_rapidity;
+            const uint32_t gcell = (uint32_t)(first_cell + ic);   /* streams are keyed by the GLOBAL cell index: shard invariant */
+            rng_init(&g_poisson, seed, 0, gcell, (uint32_t)ievent);
+            rng_init(&g_type, seed, 1, gcell, (uint32_t)ievent);
+            rng_init(&g_momentum, seed, 2, gcell, (uint32_t)ievent);
+            rng_init(&g_keep, seed, 3, gcell, (uint32_t)ievent);
+            rng_init(&g_rapidity, seed, 4, gcell, (uint32_t)ievent);
+            const double *dn = dn_list + (size_t)ic * npart;
+            double dn_sum = 0.0;
+            for (int ip = 0; ip < npart; ip++) dn_sum += dn[ip];
+            long N_hadrons = rng_poisson(&g_poisson, c->dn_tot);
+            drawn += N_hadrons;
+            double sinheta = sinh(c->eta), cosheta = sqrt(1.0 + sinheta * sinheta);   /* :888-889 */
+            for (long ih = 0; ih < N_hadrons; ih++) {
+                const double ut_ = rng_uniform(&g_type) * dn_sum;
+                int chosen = npart - 1;
+                double cum = 0.0;
+                for (int ip = 0; ip < npart; ip++) { cum += dn[ip]; if (ut_ < cum) { chosen = ip; break; } }
+                double mass = Mass[chosen], mass_squared = mass * mass, sign = Sign[chosen];
+                lrf_mom p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T);
+                /* compute_df_weight :361-453 (baryon terms vanish) */
+                double pimunu_pmu_pnu = p.px * p.px * c->pixx + p.py * p.py * c->piyy + p.pz * p.pz * c->pizz
+                                      + 2.0 * (p.px * p.py * c->pixy + p.px * p.pz * c->pixz + p.py * p.pz * c->piyz);
+                double feqbar = 1.0 - sign / (exp(p.E / c->T) + sign), df_tot;
+                if (o->df_mode == 1) {
+                    double df_shear = pimunu_pmu_pnu / c->shear14_coeff;
+                    double df_bulk = ((c->df.c0 - c->df.c2) * mass_squared + ((4.0 * c->df.c2 - c->df.c0) * p.E) * p.E) * c->bulkPi;
+                    df_tot = feqbar * (df_shear + df_bulk);
+                } else {
+                    double df_shear = pimunu_pmu_pnu / (2.0 * p.E * c->df.betapi * c->T);
+                    double df_bulk = (c->df.F * p.E / c->T / c->T + (p.E - mass_squared / p.E) / (3.0 * c->T)) * c->bulkPi / c->df.betabulk;
+                    df_tot = feqbar * (df_shear + df_bulk);
+                }
+                df_tot = fmax(-1.0, fmin(df_tot, 1.0));
+                double w_visc = (1.0 + df_tot) / 2.0;
+                /* boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51) */
+                double ptau = p.E * c->ut + p.px * c->Xt + p.pz * c->Zt;
+                double plx = p.E * c->ux + p.px * c->Xx + p.py * c->Yx;
+                double ply = p.E * c->uy + p.px * c->Xy + p.py * c->Yy;
+                double pn = p.E * c->un + p.px * c->Xn + p.pz * c->Zn;
+                double w_flux = fmax(0.0, p.E * c->dst - p.px * c->dsx - p.py * c->dsy - p.pz * c->dsz) / (p.E * c->ds_max);   /* :1148 */
+                int add_particle = rng_uniform(&g_keep) < (w_flux * w_visc);
+                if (!add_particle) continue;
+                double Elab, pz, yp, eta = c->eta, sh = sinheta, ch = cosheta;
+                if (o->dimension == 2) {                                      /* :1168-1186 */
+                    yp = y_max * (2.0 * rng_uniform(&g_rapidity) - 1.0);
+                    double sinhy = sinh(yp), coshy = sqrt(1.0 + sinhy * sinhy);
+                    double tau_pn = c->tau * pn, mT = sqrt(mass_squared + plx * plx + ply * ply);
+                    sh = (ptau * sinhy - tau_pn * coshy) / mT;
+                    eta = asinh(sh);
+                    ch = sqrt(1.0 + sh * sh);
+                    pz = mT * sinhy;
+                    Elab = mT * coshy;
+                } else {
+                    pz = c->tau * pn * ch + ptau * sh;
+                    Elab = sqrt(mass_squared + plx * plx + ply * ply + pz * pz);
+                    yp = 0.5 * log((Elab + pz) / (Elab - pz));
+                }
+                if (kept < capacity) {
+                    double *q = out + (size_t)kept * ORACLE_PARTICLE_DOUBLES;
+                    q[0] = (double)ievent; q[1] = (double)(first_cell + ic); q[2] = (double)chosen; q[3] = c->tau; q[4] = c->x; q[5] = c->y; q[6] = eta;
+                    q[7] = c->tau * ch; q[8] = c->tau * sh; q[9] = Elab; q[10] = plx; q[11] = ply; q[12] = pz; q[13] = yp;
+                }
+                kept++;
+            }
+        }
+    if (stats) { stats[0] = samples; stats[1] = acceptances; stats[2] = drawn; }
+    free(cs); free(dn_list); free(s);
+    return err ? err : kept;
+}

@@ -227,3 +227,66 @@ def dN_pTdpTdphidy_feqmod(cells, species, grid, df, fq, opts, out=None):
     if rc:
         raise RuntimeError("oracle_dN_pTdpTdphidy_feqmod failed rc=%d" % rc)
     return out, int(nb.value)
+
+
+# ---- particle sampler (operation = 2) ----------------------------------------------------------------------------
+PARTICLE_FIELDS = ["event", "cell", "species", "tau", "x", "y", "eta", "t", "z", "E", "px", "py", "pz", "rapidity"]
+
+
+def philox4x32_10(ctr, key):
+    L = lib()
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    L.oracle_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def rng_uniforms(seed, stream, cell, event, n):
+    L = lib()
+    L.oracle_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _dp]
+    out = np.zeros(n)
+    L.oracle_rng_uniforms(seed, stream, cell, event, n, _p(out))
+    return out
+
+
+def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.5, capacity=None, first_cell=0):
+    """sample_dN_pTdpTdphidy (df_mode 1 | 2) with the counter-based RNG defined in cf_oracle.c.  gla: dict with root1, weight1
+    (is3d_amd.inputs.feqmod_tables() has them).  cells may carry x, y.  Returns (dict of arrays per PARTICLE_FIELDS, stats dict)."""
+    o = dict(DEFAULT_OPTS)
+    o.update(opts)
+    n = len(cells["tau"])
+    keep = {}
+    ca = _CellArrays()
+    for f in CELL_FIELDS:
+        if f in cells and cells[f] is not None:
+            keep[f] = _f64(cells[f])
+            setattr(ca, f, _p(keep[f]))
+    xs = _f64(cells["x"]) if cells.get("x") is not None else None
+    ys = _f64(cells["y"]) if cells.get("y") is not None else None
+    sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy"]}
+    npart = len(sp["mass"])
+    st, keep_df = _df_struct(df)
+    r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
+    os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
+    L = lib()
+    L.oracle_sample_particles.restype = C.c_long
+    L.oracle_sample_particles.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, C.POINTER(_CellArrays), _dp, _dp, C.POINTER(_DfTables), C.c_int,
+                                          _dp, _dp, C.POINTER(_Opts), C.c_int, C.c_uint64, C.c_double, C.c_long, _dp, C.c_long, C.POINTER(C.c_long)]
+    stats = (C.c_long * 3)()
+    cap = int(capacity) if capacity is not None else 0
+    while True:
+        out = np.zeros((max(cap, 1), len(PARTICLE_FIELDS)))
+        rc = L.oracle_sample_particles(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), C.byref(ca),
+                                       _p(xs) if xs is not None else None, _p(ys) if ys is not None else None, C.byref(st), len(r1), _p(r1),
+                                       _p(w1), C.byref(os_), int(n_events), int(seed), float(y_cut), int(first_cell), _p(out), cap, stats)
+        if rc < 0:
+            raise RuntimeError("oracle_sample_particles failed rc=%d" % rc)
+        if rc <= cap or capacity is not None:
+            break
+        cap = int(rc)
+    k = min(int(rc), cap)
+    res = {f: out[:k, i].copy() for i, f in enumerate(PARTICLE_FIELDS)}
+    for f in ("event", "cell", "species"):
+        res[f] = res[f].astype(np.int64)
+    return res, dict(n_kept=int(rc), samples=int(stats[0]), acceptances=int(stats[1]), drawn=int(stats[2]))
