@@ -225,6 +225,52 @@ int64_t is3d_plan_workspace_bytes(const is3d_plan *plan);
 void is3d_plan_destroy(is3d_plan *plan);
 
 /* ---------------------------------------------------------------------------------------------
+ * Particle sampler (operation = 2): replaces EmissionFunctionArray::sample_dN_pTdpTdphidy
+ * (src/cpp/emissionfunction.h:208-210, emissionfunction_sampling_kernels.cpp:833-1225, call sites emissionfunction.cpp:1543,
+ * :1606) for viscous hydro with a linear delta-f (df_mode 1, 2), include_baryon = 0, fast = 0.  The reference's serial
+ * std::default_random_engine streams are replaced by counter-based Philox4x32-10 streams keyed by (seed, stream, global cell
+ * index, event) -- same five stream roles and the same distributions; particle lists agree with the reference statistically,
+ * not draw by draw (construction in oracle/cf_oracle.c).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {                        /* Sampled_Particle (src/cpp/particle.h), 96 bytes */
+    int64_t cell;                       /* global cell index: first_cell + index in the call */
+    int32_t event;
+    int32_t species;                    /* index into the species list (mc_id, mass: caller's arrays) */
+    double tau, x, y, eta, t, z;        /* t = tau cosh(eta), z = tau sinh(eta) */
+    double E, px, py, pz;
+} is3d_particle;
+
+typedef struct {
+    int32_t n_events;                   /* Nevents (emissionfunction.cpp:202, :1531) */
+    int32_t n_gla;                      /* Gauss-Laguerre points */
+    uint64_t seed;                      /* sampler_seed */
+    double y_cut;                       /* 2+1D: hadrons get a uniform rapidity in +-y_cut (Y_CUT); 3+1D: unused (y_max = 0.5) */
+    int64_t first_cell;                 /* global index of cells[0]: a shard of a surface samples what the whole surface would */
+    const double *x, *y;                /* cell positions x_fo, y_fo copied into the particles; may be NULL */
+    const double *root1, *weight1;      /* Gauss-Laguerre alpha = 1 (equilibrium densities, max_particle_number) */
+} is3d_sampler_inputs;
+
+typedef struct {
+    int64_t n_cells_skipped;            /* u.dsigma <= 0 (:899) */
+    int64_t n_hadrons_drawn;            /* sum of the Poisson numbers (before the flux / viscous keep test) */
+    int64_t n_momentum_samples, n_acceptances;   /* "Momentum sampling efficiency" (:1224) */
+    int32_t n_classes, reserved;
+    double ms_h2d, ms_prep, ms_count, ms_fill;   /* device time: upload, densities + cell records, count pass + scan, fill pass */
+} is3d_sampler_stats;
+
+/* All pointers HOST memory; opts: dimension, df_mode (1 | 2), include_bulk_deltaf, include_shear_deltaf, device.  Particles
+ * come ordered by (event, cell, draw).  particles == NULL (or capacity 0): only *n_particles is computed.  If the buffer is
+ * too small the first `capacity` particles are stored, *n_particles is the full count and IS3D_ENOMEM is returned. */
+int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
+                          const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
+                          int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats);
+
+/* write_particle_list_OSC (src/cpp/emissionfunction.cpp:863-901): results/particle_list_osc.dat, "# N" per non-empty event
+ * then "mcid t x y z E px py pz" rows; particles ordered by event. */
+int is3d_write_particle_list_osc(const char *path, int32_t n_events, int64_t n_particles, const is3d_particle *particles,
+                                 const int64_t *mc_id);
+
+/* ---------------------------------------------------------------------------------------------
  * Host I/O in the reference's file formats (C++ implementation, C ABI so that tests and other
  * hosts can reach it).  All paths are explicit; the CLI driver passes the reference's hard-coded
  * CWD-relative names.

@@ -49,6 +49,29 @@ class FeqmodTables(C.Structure):
                 ("mass_pion0", C.c_double)]
 
 
+class Particle(C.Structure):
+    _fields_ = [("cell", C.c_int64), ("event", C.c_int32), ("species", C.c_int32)] + \
+               [(n, C.c_double) for n in ["tau", "x", "y", "eta", "t", "z", "E", "px", "py", "pz"]]
+
+
+PARTICLE_DTYPE = np.dtype([("cell", "<i8"), ("event", "<i4"), ("species", "<i4")] +
+                          [(n, "<f8") for n in ["tau", "x", "y", "eta", "t", "z", "E", "px", "py", "pz"]])
+
+
+class SamplerInputs(C.Structure):
+    _fields_ = [("n_events", C.c_int32), ("n_gla", C.c_int32), ("seed", C.c_uint64), ("y_cut", C.c_double), ("first_cell", C.c_int64),
+                ("x", _dp), ("y", _dp), ("root1", _dp), ("weight1", _dp)]
+
+
+class SamplerStats(C.Structure):
+    _fields_ = [("n_cells_skipped", C.c_int64), ("n_hadrons_drawn", C.c_int64), ("n_momentum_samples", C.c_int64),
+                ("n_acceptances", C.c_int64), ("n_classes", C.c_int32), ("reserved", C.c_int32), ("ms_h2d", C.c_double),
+                ("ms_prep", C.c_double), ("ms_count", C.c_double), ("ms_fill", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
                                          "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
@@ -71,7 +94,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
-           "is3d_gla_read", "is3d_write_results"]
+           "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc"]
 
 
 class Is3dError(RuntimeError):
@@ -137,6 +160,9 @@ def load():
     L.is3d_pdg_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _dp, _dp, _dp, _dp, C.c_int32]
     L.is3d_df_table_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), _dp, _dp, C.c_int32]
     L.is3d_df_table_read_full.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, C.c_int64]
+    L.is3d_sample_particles.argtypes = [C.POINTER(Cells), C.POINTER(Species), C.POINTER(DfTables), C.POINTER(SamplerInputs),
+                                        C.POINTER(Options), C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(SamplerStats)]
+    L.is3d_write_particle_list_osc.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
     L.is3d_gla_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, C.c_int64]
     L.is3d_write_results.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, _dp, _dp,
                                      C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]
@@ -367,6 +393,51 @@ def df_table_read_full(path):
     T, B, v = np.zeros(nT.value), np.zeros(nB.value), np.zeros((nB.value, nT.value))
     _check(L.is3d_df_table_read_full(path.encode(), C.byref(nT), C.byref(nB), _p(T), _p(B), _p(v), v.size))
     return T, B, v
+
+
+def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_cut=0.5, first_cell=0, capacity=None):
+    """is3d_sample_particles (the drop-in for sample_dN_pTdpTdphidy, df_mode 1 | 2).  cells: dict of host arrays (x, y optional);
+    gla: dict with root1, weight1.  Returns (numpy structured array of PARTICLE_DTYPE, stats dict); capacity = None sizes the
+    buffer from a count-only first call."""
+    L = load()
+    grid_dummy = dict(pT=[1.0], phi=[0.0], y=[0.0], eta=[0.0], eta_w=[1.0])
+    sps, _, ds, os_, _, keep = _pack_common(species, grid_dummy, df, opts)
+    n = len(cells["tau"])
+    cs = Cells()
+    cs.n_cells = n
+    held = []
+    for f in CELL_FIELDS:
+        a = cells.get(f)
+        if a is not None:
+            a = _f64(a)
+            assert a.shape == (n,), f
+            held.append(a)
+            setattr(cs, f, a.ctypes.data)
+    r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
+    xs = _f64(cells["x"]) if cells.get("x") is not None else None
+    ys = _f64(cells["y"]) if cells.get("y") is not None else None
+    si = SamplerInputs(int(n_events), len(r1), int(seed), float(y_cut), int(first_cell), _p(xs) if xs is not None else None,
+                       _p(ys) if ys is not None else None, _p(r1), _p(w1))
+    st = SamplerStats()
+    cnt = C.c_int64(0)
+    if capacity is None:
+        _check(L.is3d_sample_particles(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), None, 0, C.byref(cnt), C.byref(st)))
+        capacity = int(cnt.value)
+    out = np.zeros(max(int(capacity), 1), dtype=PARTICLE_DTYPE)
+    assert out.dtype.itemsize == C.sizeof(Particle)
+    rc = L.is3d_sample_particles(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), out.ctypes.data, int(capacity),
+                                 C.byref(cnt), C.byref(st))
+    _check(rc)
+    d = st.as_dict()
+    d["n_particles"] = int(cnt.value)
+    return out[:min(int(cnt.value), int(capacity))], d
+
+
+def write_particle_list_osc(path, n_events, particles, mc_id):
+    particles = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+    ids = np.ascontiguousarray(mc_id, dtype=np.int64)
+    _check(load().is3d_write_particle_list_osc(path.encode(), int(n_events), len(particles), particles.ctypes.data,
+                                               ids.ctypes.data_as(C.POINTER(C.c_int64))))
 
 
 def gla_read(path):

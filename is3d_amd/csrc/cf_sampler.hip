@@ -1,0 +1,608 @@
+// cf_sampler.hip -- particle sampler (operation = 2) on the device: SURVEY.md 8f rank 4.
+//
+// Device path of EmissionFunctionArray::sample_dN_pTdpTdphidy
+// (/root/reference/src/cpp/emissionfunction_sampling_kernels.cpp:833-1225) for viscous hydro with a linear delta-f
+// (df_mode 1, 2), include_baryon = 0, non-"fast" mode; helpers max_particle_number (:282-303), sample_momentum (:456-617),
+// compute_df_weight (:361-453), Milne_Basis / Surface_Element_Vector / boost_pimunu_to_lrf (viscous_correction.cpp:8-115),
+// boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51).
+//
+// The reference walks the cells serially and feeds five std::default_random_engine streams through implementation-defined
+// std:: distributions; that order dependence cannot (and need not) be reproduced.  Here every (cell, event, stream) owns a
+// counter-based Philox4x32-10 sequence keyed by the seed (the construction is spelled out in oracle/cf_oracle.c and followed
+// bit for bit), so the hadrons of a cell depend on nothing but (seed, global cell index, event): any launch geometry,
+// any cell sharding over GPUs and any event batching give the same particle list.
+//
+//   cf_sampler_density  thread <-> (cell, species class): 32-point Gauss-Laguerre equilibrium density integral
+//   cf_sampler_cells    thread <-> cell: LRF basis, dsigma and pi^{mu nu} in the LRF, delta-f coefficients, mean hadron number
+//   cf_sampler_run      thread <-> (event, cell): Poisson number, species, momentum rejection loop, viscous and flux weights,
+//                       keep test; pass 1 counts, an exclusive scan (hipCUB) turns counts into offsets, pass 2 replays the same
+//                       streams and writes the particles -- the list comes out ordered by (event, cell, draw), no atomics.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/is3d_amd.h"
+#include "cf_device.h"
+#include "cf_math.h"
+#include "errors.h"
+#include "spline.h"
+
+namespace is3d {
+
+struct SamplerCell {
+    double live;
+    double tau, x, y, eta, ut, ux, uy, un, T;
+    double Xt, Xx, Xy, Xn, Yx, Yy, Zt, Zn;
+    double dst, dsx, dsy, dsz, ds_max;
+    double pixx, pixy, pixz, piyy, piyz, pizz;     // LRF
+    double bulkPi, dn_tot, dn_sum, neq_fact;
+    double c0, c2, F, betabulk, betapi, shear14;
+};
+
+struct SamplerSpecies {       // device arrays, length npart / ncls
+    const double *mass, *sign, *degeneracy;
+    const int32_t *cls;
+    const double *cls_mass, *cls_sign;
+    int32_t npart, ncls;
+};
+
+struct SamplerParams {
+    CellPtrs cells;
+    const double *x, *y;
+    int64_t n_cells, first_cell;
+    int32_t dim3, df_mode, include_bulk, include_shear;
+    SplineDev spl;              // 14-moment: c0, c2; Chapman-Enskog: F, betabulk, betapi
+    int32_t ngl;
+    const double *gl;           // [2][ngl]: root1, weight1
+    double y_max;
+    uint64_t seed;
+    unsigned long long *status; // [0] min bad cell, [1] skipped, [2] momentum samples, [3] acceptances, [4] hadrons drawn
+};
+
+// ---- Philox4x32-10 streams (oracle/cf_oracle.c: rng_stream) ----
+struct Rng {
+    uint32_t k0, k1, stream, cell, event, blk, buf[4];
+    int pos;
+    __device__ void init(uint64_t seed, uint32_t s, uint32_t c, uint32_t e)
+    {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        stream = s; cell = c; event = e; blk = 0; pos = 4;
+    }
+    __device__ double uniform()
+    {
+        if (pos >= 4) {
+            uint32_t c0 = blk++, c1 = stream, c2 = cell, c3 = event, a = k0, b = k1;
+#pragma unroll
+            for (int r = 0; r < 10; r++) {
+                const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+                const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+                c0 = hi1 ^ c1 ^ a; c1 = lo1; c2 = hi0 ^ c3 ^ b; c3 = lo0;
+                a += 0x9E3779B9u; b += 0xBB67AE85u;
+            }
+            buf[0] = c0; buf[1] = c1; buf[2] = c2; buf[3] = c3;
+            pos = 0;
+        }
+        const uint32_t a = buf[pos], b = buf[pos + 1];
+        pos += 2;
+        return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+    }
+    __device__ long poisson(double mean)
+    {
+        long N = 0;
+        double remaining = mean;
+        while (remaining > 0.0) {
+            const double l = remaining < 256.0 ? remaining : 256.0;
+            remaining -= l;
+            const double u = uniform();
+            double p = exp(-l), F = p;
+            long k = 0;
+            while (u >= F && k < 4096) { k++; p *= l / (double)k; F += p; }
+            N += k;
+        }
+        return N;
+    }
+};
+
+// GaussThermal(neq_int, ...) at alpha_B = 0 (gaussThermal.cpp)
+__device__ __forceinline__ double gt_neq(const double *root, const double *weight, int n, double mbar, double sign)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
+        s += weight[k] * (pbar * exp(pbar) / (exp(Ebar) + sign));
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(256)
+cf_sampler_density(const double *__restrict__ T_fo, int64_t n_cells, SamplerSpecies sp, const double *__restrict__ gl, int ngl,
+                   double *__restrict__ GT)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_cells * sp.ncls) return;
+    const int64_t cell = idx / sp.ncls;
+    const int c = (int)(idx - cell * sp.ncls);
+    GT[idx] = gt_neq(gl, gl + ngl, ngl, sp.cls_mass[c] / T_fo[cell], sp.cls_sign[c]);
+}
+
+__global__ void __launch_bounds__(128)
+cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ GT, SamplerCell *__restrict__ out)
+{
+    const int64_t ic = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= p.n_cells) return;
+    SamplerCell c;
+    memset(&c, 0, sizeof c);
+    const double tau = p.cells.tau[ic], tau2 = tau * tau;
+    const double dat = p.cells.dat[ic], dax = p.cells.dax[ic], day = p.cells.day[ic], dan = p.cells.dan[ic];
+    const double ux = p.cells.ux[ic], uy = p.cells.uy[ic], un = p.cells.un[ic];
+    const double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+    const double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+    if (udsigma <= 0.0) {                                                          // :899
+        atomicAdd(&p.status[1], 1ULL);
+        out[ic] = c;
+        return;
+    }
+    const double T = p.cells.T[ic], P = p.cells.P[ic], E = p.cells.E[ic];
+    if (!(T >= p.spl.x[0] && T <= p.spl.x[p.spl.n - 1])) {                          // GSL domain error in the reference
+        atomicMin(&p.status[0], (unsigned long long)(p.first_cell + ic));
+        out[ic] = c;
+        return;
+    }
+    const double ut2 = ut * ut, ux2 = ux * ux, uy2 = uy * uy;
+    const double uperp = sqrt(ux * ux + uy * uy), utperp = sqrt(1.0 + ux * ux + uy * uy);
+    double pitt = 0, pitx = 0, pity = 0, pitn = 0, pixx = 0, pixy = 0, pixn = 0, piyy = 0, piyn = 0, pinn = 0;
+    if (p.include_shear) {                                                          // :922-934
+        pixx = p.cells.pixx[ic]; pixy = p.cells.pixy[ic]; pixn = p.cells.pixn[ic]; piyy = p.cells.piyy[ic]; piyn = p.cells.piyn[ic];
+        pinn = (pixx * (ux2 - ut2) + piyy * (uy2 - ut2) + 2.0 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp * utperp);
+        pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut;
+        pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut;
+        pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut;
+        pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
+    }
+    c.bulkPi = p.include_bulk ? p.cells.bulkPi[ic] : 0.0;
+    const double T4 = T * T * T * T;
+    const int nT = p.spl.n;
+    if (p.df_mode == 1) {                                                           // deltafReader.cpp:337-344
+        c.c0 = spline_eval_lds(nT, p.spl.x, p.spl.y[0], p.spl.c[0], T) / T4;
+        c.c2 = spline_eval_lds(nT, p.spl.x, p.spl.y[1], p.spl.c[1], T) / T4;
+    } else {                                                                        // :352-358
+        c.F = spline_eval_lds(nT, p.spl.x, p.spl.y[0], p.spl.c[0], T) * T;
+        c.betabulk = spline_eval_lds(nT, p.spl.x, p.spl.y[1], p.spl.c[1], T) * T4;
+        c.betapi = spline_eval_lds(nT, p.spl.x, p.spl.y[2], p.spl.c[2], T) * T4;
+    }
+    c.shear14 = 2.0 * T * T * (E + P);
+    // Milne_Basis (viscous_correction.cpp:8-27)
+    const double sinhL = tau * un / utperp, coshL = ut / utperp;
+    c.Xt = uperp * coshL; c.Zt = sinhL; c.Xn = uperp * sinhL / tau; c.Zn = coshL / tau;
+    c.Xx = 1.0; c.Yx = 0.0; c.Xy = 0.0; c.Yy = 1.0;
+    if (uperp > 1.e-5) { c.Xx = utperp * ux / uperp; c.Yx = -uy / uperp; c.Xy = utperp * uy / uperp; c.Yy = ux / uperp; }
+    const double Xt = c.Xt, Xx = c.Xx, Xy = c.Xy, Xn = c.Xn, Yx = c.Yx, Yy = c.Yy, Zt = c.Zt, Zn = c.Zn;
+    // boost_dsigma_to_lrf, compute_dsigma_magnitude (:69-86)
+    c.dst = dat * ut + dax * ux + day * uy + dan * un;
+    c.dsx = -(dat * Xt + dax * Xx + day * Xy + dan * Xn);
+    c.dsy = -(dax * Yx + day * Yy);
+    c.dsz = -(dat * Zt + dan * Zn);
+    c.ds_max = fabs(c.dst) + sqrt(c.dsx * c.dsx + c.dsy * c.dsy + c.dsz * c.dsz);
+    // boost_pimunu_to_lrf (:99-115)
+    c.pixx = pitt * Xt * Xt + pixx * Xx * Xx + piyy * Xy * Xy + tau2 * tau2 * pinn * Xn * Xn
+           + 2.0 * (-Xt * (pitx * Xx + pity * Xy) + pixy * Xx * Xy + tau2 * Xn * (pixn * Xx + piyn * Xy - pitn * Xt));
+    c.pixy = Yx * (-pitx * Xt + pixx * Xx + pixy * Xy + tau2 * pixn * Xn) + Yy * (-pity * Xt + pixy * Xx + piyy * Xy + tau2 * piyn * Xn);
+    c.pixz = Zt * (pitt * Xt - pitx * Xx - pity * Xy - tau2 * pitn * Xn) - tau2 * Zn * (pitn * Xt - pixn * Xx - piyn * Xy - tau2 * pinn * Xn);
+    c.piyy = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
+    c.piyz = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
+    c.pizz = -(c.pixx + c.piyy);
+    c.tau = tau; c.x = p.x ? p.x[ic] : 0.0; c.y = p.y ? p.y[ic] : 0.0;
+    c.eta = p.dim3 ? p.cells.eta[ic] : 0.0;
+    c.ut = ut; c.ux = ux; c.uy = uy; c.un = un; c.T = T;
+    // max_particle_number, df_mode 1 / 2: 2 n_eq per species (:282-303); total mean number of the cell (:1077)
+    const double two_pi2_hbarC3 = 2.0 * M_PI * M_PI * (kHbarC * kHbarC * kHbarC);
+    c.neq_fact = T * T * T / two_pi2_hbarC3;
+    const double *gt = GT + ic * sp.ncls;
+    double dn = 0.0;
+    for (int ip = 0; ip < sp.npart; ip++) dn += 2.0 * (c.neq_fact * sp.degeneracy[ip] * gt[sp.cls[ip]]);
+    c.dn_sum = dn;
+    c.dn_tot = dn * (2.0 * p.y_max * c.ds_max);
+    c.live = (c.dn_tot > 0.0) ? 1.0 : 0.0;                                          // :1079
+    out[ic] = c;
+}
+
+// :172-196
+__device__ __forceinline__ double pion_thermal_weight_max(double x)
+{
+    const double x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+    const double max = (143206.88623164667 - 95956.76008684626 * x - 21341.937407169076 * x2 + 14388.446116867359 * x3 - 6083.775788504437 * x4) /
+                       (-0.3541350577684533 + 143218.69233952634 * x - 24516.803600065778 * x2 - 115811.59391199696 * x3 + 35814.36403387459 * x4);
+    return 1.00001 * max;
+}
+
+struct LrfMom { double E, px, py, pz; };
+
+// sample_momentum (:456-617), chem = 0
+__device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, double mass, double sign, double T)
+{
+    const double two_pi = 2.0 * M_PI;
+    const double mbar = mass / T, mbar_squared = mbar * mbar;
+    double pbar, Ebar, phi_over_2pi, costheta;
+    if (mbar < 1.008) {
+        double weq_max = 1.0;
+        if (mbar < 0.8554 && sign == -1.0) weq_max = pion_thermal_weight_max(mbar);
+        for (;;) {
+            samples += 1;
+            const double r1 = 1.0 - g.uniform(), r2 = 1.0 - g.uniform(), r3 = 1.0 - g.uniform();
+            const double l1 = log(r1), l2 = log(r2), l3 = log(r3);
+            const double l1_plus_l2 = l1 + l2;
+            pbar = -(l1 + l2 + l3);
+            Ebar = sqrt(pbar * pbar + mbar_squared);
+            phi_over_2pi = l1_plus_l2 * l1_plus_l2 / (pbar * pbar);
+            costheta = (l1 - l2) / l1_plus_l2;
+            const double weight = 1.0 / (exp(Ebar) + sign) / weq_max / (r1 * r2 * r3);
+            if (g.uniform() < weight) break;
+        }
+    } else {
+        const double K0 = mbar_squared, K1 = 2.0 * mbar, K2 = 2.0, Ksum = K0 + K1 + K2;
+        double kbar;
+        for (;;) {
+            samples += 1;
+            const double uk = g.uniform() * Ksum;
+            if (uk < K0) {
+                kbar = -log(1.0 - g.uniform());
+                phi_over_2pi = g.uniform();
+                costheta = 2.0 * g.uniform() - 1.0;
+            } else if (uk < K0 + K1) {
+                const double l1 = log(1.0 - g.uniform()), l2 = log(1.0 - g.uniform());
+                kbar = -(l1 + l2);
+                phi_over_2pi = -l1 / kbar;
+                costheta = 2.0 * g.uniform() - 1.0;
+            } else {
+                const double l1 = log(1.0 - g.uniform()), l2 = log(1.0 - g.uniform()), l3 = log(1.0 - g.uniform());
+                const double l1_plus_l2 = l1 + l2;
+                kbar = -(l1 + l2 + l3);
+                phi_over_2pi = l1_plus_l2 * l1_plus_l2 / (kbar * kbar);
+                costheta = (l1 - l2) / l1_plus_l2;
+            }
+            Ebar = kbar + mbar;
+            pbar = sqrt(Ebar * Ebar - mbar_squared);
+            const double exponent = exp(Ebar);
+            const double weight = pbar / Ebar * exponent / (exponent + sign);
+            if (g.uniform() < weight) break;
+        }
+    }
+    acceptances += 1;
+    const double E = Ebar * T, pm = pbar * T, phi = phi_over_2pi * two_pi;
+    const double sintheta = sqrt(1.0 - costheta * costheta);
+    LrfMom q = {E, pm * sintheta * cos(phi), pm * sintheta * sin(phi), pm * costheta};
+    return q;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(128)
+cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict__ cellrec, const double *__restrict__ GT,
+               int event0, int n_events, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
+               is3d_particle *__restrict__ particles, int64_t capacity)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // event-major: (event - event0) * n_cells + cell
+    if (idx >= (int64_t)n_events * p.n_cells) return;
+    const int ievent = event0 + (int)(idx / p.n_cells);
+    const int64_t ic = idx % p.n_cells;
+    const SamplerCell &c = cellrec[ic];
+    if (c.live == 0.0) {
+        if (!FILL) counts[idx] = 0;
+        return;
+    }
+    const uint32_t gcell = (uint32_t)(p.first_cell + ic);
+    Rng g_poisson, g_type, g_momentum, g_keep, g_rapidity;
+    g_poisson.init(p.seed, 0, gcell, (uint32_t)ievent);
+    const long N_hadrons = g_poisson.poisson(c.dn_tot);
+    if (N_hadrons == 0) {
+        if (!FILL) counts[idx] = 0;
+        return;
+    }
+    g_type.init(p.seed, 1, gcell, (uint32_t)ievent);
+    g_momentum.init(p.seed, 2, gcell, (uint32_t)ievent);
+    g_keep.init(p.seed, 3, gcell, (uint32_t)ievent);
+    g_rapidity.init(p.seed, 4, gcell, (uint32_t)ievent);
+    const double *gt = GT + ic * sp.ncls;
+    const double sinheta = sinh(c.eta), cosheta = sqrt(1.0 + sinheta * sinheta);   // :888-889
+    long kept = 0, samples = 0, acceptances = 0;
+    int64_t slot = FILL ? base + offsets[idx] : 0;
+    for (long ih = 0; ih < N_hadrons; ih++) {
+        const double ut_ = g_type.uniform() * c.dn_sum;
+        int chosen = sp.npart - 1;
+        double cum = 0.0;
+        for (int ip = 0; ip < sp.npart; ip++) {
+            cum += 2.0 * (c.neq_fact * sp.degeneracy[ip] * gt[sp.cls[ip]]);
+            if (ut_ < cum) { chosen = ip; break; }
+        }
+        const double mass = sp.mass[chosen], mass_squared = mass * mass, sign = sp.sign[chosen];
+        const LrfMom q = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T);
+        // compute_df_weight (:361-453), baryon terms vanish
+        const double pimunu_pmu_pnu = q.px * q.px * c.pixx + q.py * q.py * c.piyy + q.pz * q.pz * c.pizz
+                                    + 2.0 * (q.px * q.py * c.pixy + q.px * q.pz * c.pixz + q.py * q.pz * c.piyz);
+        const double feqbar = 1.0 - sign / (exp(q.E / c.T) + sign);
+        double df_tot;
+        if (p.df_mode == 1) {
+            const double df_shear = pimunu_pmu_pnu / c.shear14;
+            const double df_bulk = ((c.c0 - c.c2) * mass_squared + ((4.0 * c.c2 - c.c0) * q.E) * q.E) * c.bulkPi;
+            df_tot = feqbar * (df_shear + df_bulk);
+        } else {
+            const double df_shear = pimunu_pmu_pnu / (2.0 * q.E * c.betapi * c.T);
+            const double df_bulk = (c.F * q.E / c.T / c.T + (q.E - mass_squared / q.E) / (3.0 * c.T)) * c.bulkPi / c.betabulk;
+            df_tot = feqbar * (df_shear + df_bulk);
+        }
+        df_tot = fmax(-1.0, fmin(df_tot, 1.0));
+        const double w_visc = (1.0 + df_tot) / 2.0;
+        // boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51)
+        const double ptau = q.E * c.ut + q.px * c.Xt + q.pz * c.Zt;
+        const double plx = q.E * c.ux + q.px * c.Xx + q.py * c.Yx;
+        const double ply = q.E * c.uy + q.px * c.Xy + q.py * c.Yy;
+        const double pn = q.E * c.un + q.px * c.Xn + q.pz * c.Zn;
+        const double w_flux = fmax(0.0, q.E * c.dst - q.px * c.dsx - q.py * c.dsy - q.pz * c.dsz) / (q.E * c.ds_max);   // :1148
+        if (!(g_keep.uniform() < (w_flux * w_visc))) continue;
+        double Elab, pz, eta = c.eta, sh = sinheta, ch = cosheta;
+        if (!p.dim3) {                                                              // :1168-1186
+            const double yp = p.y_max * (2.0 * g_rapidity.uniform() - 1.0);
+            const double sinhy = sinh(yp), coshy = sqrt(1.0 + sinhy * sinhy);
+            const double tau_pn = c.tau * pn, mT = sqrt(mass_squared + plx * plx + ply * ply);
+            sh = (ptau * sinhy - tau_pn * coshy) / mT;
+            eta = asinh(sh);
+            ch = sqrt(1.0 + sh * sh);
+            pz = mT * sinhy;
+            Elab = mT * coshy;
+        } else {
+            pz = c.tau * pn * ch + ptau * sh;
+            Elab = sqrt(mass_squared + plx * plx + ply * ply + pz * pz);
+        }
+        if (FILL && slot < capacity) {
+            is3d_particle o;
+            o.cell = p.first_cell + ic; o.event = ievent; o.species = chosen;
+            o.tau = c.tau; o.x = c.x; o.y = c.y; o.eta = eta; o.t = c.tau * ch; o.z = c.tau * sh;
+            o.E = Elab; o.px = plx; o.py = ply; o.pz = pz;
+            particles[slot] = o;
+        }
+        slot++;
+        kept++;
+    }
+    if (!FILL) {
+        counts[idx] = kept;
+        atomicAdd(&p.status[2], (unsigned long long)samples);
+        atomicAdd(&p.status[3], (unsigned long long)acceptances);
+        atomicAdd(&p.status[4], (unsigned long long)N_hadrons);
+    }
+}
+
+}  // namespace is3d
+
+// ------------------------------------------------------------------------------------------------
+// host entry
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+#define SMP_TRY(expr)                                                                                            \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) return is3d::set_error(IS3D_ENODEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevMem {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes)
+    {
+        release();
+        if (!bytes) return hipSuccess;
+        return hipMalloc(&p, bytes);
+    }
+    template <class T>
+    hipError_t upload(const std::vector<T> &h)
+    {
+        hipError_t e = alloc(h.size() * sizeof(T));
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    ~DevMem() { release(); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
+                                     const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
+                                     int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats)
+{
+    using is3d::set_error;
+    if (!cells || !species || !df || !in || !opts || !n_particles) return set_error(IS3D_EINVAL, "null argument");
+    *n_particles = 0;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (opts->dimension != 2 && opts->dimension != 3) return set_error(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", opts->dimension);
+    if (opts->df_mode != 1 && opts->df_mode != 2)
+        return set_error(IS3D_EINVAL, "the sampler is built for the linear delta-f modes, df_mode 1 (14-moment) or 2 (Chapman-Enskog) (got %d)", opts->df_mode);
+    if (opts->include_baryon) return set_error(IS3D_EINVAL, "the sampler with include_baryon = 1 is not on this path");
+    if (species->n < 1 || !species->mass || !species->sign || !species->degeneracy) return set_error(IS3D_EINVAL, "empty species list");
+    for (int s = 0; s < species->n; s++)
+        if (!(species->mass[s] > 0.0)) return set_error(IS3D_EINVAL, "species %d has mass 0: photons cannot be sampled with this method (reference: exit, sampling_kernels.cpp:478-482)", s);
+    if (in->n_events < 1) return set_error(IS3D_EINVAL, "n_events must be >= 1");
+    if (in->n_gla < 1 || !in->root1 || !in->weight1) return set_error(IS3D_EINVAL, "the sampler needs the Gauss-Laguerre roots and weights for alpha = 1");
+    if (df->n_T < 3 || !df->T) return set_error(IS3D_EINVAL, "coefficient table needs >= 3 temperatures");
+    if (opts->df_mode == 1 && (!df->c0 || !df->c2)) return set_error(IS3D_EINVAL, "df_mode 1 needs c0 and c2 tables");
+    if (opts->df_mode == 2 && (!df->F || !df->betabulk || !df->betapi)) return set_error(IS3D_EINVAL, "df_mode 2 needs F, betabulk, betapi tables");
+    if (particles == nullptr) capacity = 0;
+    const int64_t n = cells->n_cells;
+    if (n < 0 || n + in->first_cell > 0xffffffffLL) return set_error(IS3D_EINVAL, "cell indices must fit 32 bits for the counter-based streams");
+    const bool three_d = opts->dimension == 3;
+    if (n > 0) {
+        if (!cells->tau || !cells->dat || !cells->dax || !cells->day || !cells->dan || !cells->ux || !cells->uy || !cells->un ||
+            !cells->T || !cells->P || !cells->E || (three_d && !cells->eta))
+            return set_error(IS3D_EINVAL, "a required cell array is NULL");
+        if (opts->include_shear_deltaf && (!cells->pixx || !cells->pixy || !cells->pixn || !cells->piyy || !cells->piyn))
+            return set_error(IS3D_EINVAL, "include_shear_deltaf needs pixx, pixy, pixn, piyy, piyn");
+        if (opts->include_bulk_deltaf && !cells->bulkPi) return set_error(IS3D_EINVAL, "include_bulk_deltaf needs bulkPi");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (opts->device >= 0) SMP_TRY(hipSetDevice(opts->device));
+    if (n == 0) return IS3D_OK;
+
+    // ---- species classes (mass, sign): the density integral is per class ----
+    const int npart = species->n;
+    std::vector<int32_t> cls(npart);
+    std::vector<double> cmass, csign;
+    for (int s = 0; s < npart; s++) {
+        int found = -1;
+        for (size_t c = 0; c < cmass.size(); c++)
+            if (cmass[c] == species->mass[s] && csign[c] == species->sign[s]) { found = (int)c; break; }
+        if (found < 0) { found = (int)cmass.size(); cmass.push_back(species->mass[s]); csign.push_back(species->sign[s]); }
+        cls[s] = found;
+    }
+    const int ncls = (int)cmass.size();
+    DevMem d_mass, d_sign, d_deg, d_cls, d_cmass, d_csign, d_gl, d_splx, d_sply[3], d_splc[3], d_cell[20], d_x, d_y;
+    SMP_TRY(d_mass.upload(std::vector<double>(species->mass, species->mass + npart)));
+    SMP_TRY(d_sign.upload(std::vector<double>(species->sign, species->sign + npart)));
+    SMP_TRY(d_deg.upload(std::vector<double>(species->degeneracy, species->degeneracy + npart)));
+    SMP_TRY(d_cls.upload(cls));
+    SMP_TRY(d_cmass.upload(cmass));
+    SMP_TRY(d_csign.upload(csign));
+    std::vector<double> gl((size_t)2 * in->n_gla);
+    for (int k = 0; k < in->n_gla; k++) { gl[k] = in->root1[k]; gl[in->n_gla + k] = in->weight1[k]; }
+    SMP_TRY(d_gl.upload(gl));
+    is3d::SamplerSpecies sp{d_mass.as<double>(), d_sign.as<double>(), d_deg.as<double>(), d_cls.as<int32_t>(),
+                            d_cmass.as<double>(), d_csign.as<double>(), npart, ncls};
+    // ---- splines (deltafReader.cpp:300-322) ----
+    is3d::SamplerParams p{};
+    std::vector<double> xs(df->T, df->T + df->n_T);
+    for (int i = 1; i < df->n_T; i++)
+        if (!(xs[i] > xs[i - 1])) return set_error(IS3D_EINVAL, "coefficient table temperatures must ascend");
+    SMP_TRY(d_splx.upload(xs));
+    const double *tabs[3] = {nullptr, nullptr, nullptr};
+    int nspl;
+    if (opts->df_mode == 1) { tabs[0] = df->c0; tabs[1] = df->c2; nspl = 2; }
+    else { tabs[0] = df->F; tabs[1] = df->betabulk; tabs[2] = df->betapi; nspl = 3; }
+    p.spl.n = df->n_T; p.spl.x = d_splx.as<double>(); p.spl.nspl = nspl;
+    for (int s = 0; s < nspl; s++) {
+        std::vector<double> ys(tabs[s], tabs[s] + df->n_T), cc;
+        if (!is3d::natural_cspline_init(xs, ys, cc)) return set_error(IS3D_EINVAL, "spline construction failed");
+        SMP_TRY(d_sply[s].upload(ys));
+        SMP_TRY(d_splc[s].upload(cc));
+        p.spl.y[s] = d_sply[s].as<double>();
+        p.spl.c[s] = d_splc[s].as<double>();
+    }
+    // ---- cell arrays ----
+    const double *src[18] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
+    const double *dptr[18];
+    hipEvent_t ev[6];
+    for (auto &e : ev) SMP_TRY(hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 6; i++) (void)hipEventDestroy(e[i]); } } evg{ev};
+    SMP_TRY(hipEventRecord(ev[0], nullptr));
+    for (int a = 0; a < 18; a++) {
+        dptr[a] = nullptr;
+        const bool need = a < 12 ? (a != 1 || three_d) : (a < 17 ? opts->include_shear_deltaf != 0 : opts->include_bulk_deltaf != 0);
+        if (src[a] && need) {
+            SMP_TRY(d_cell[a].alloc((size_t)n * sizeof(double)));
+            SMP_TRY(hipMemcpyAsync(d_cell[a].p, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+            dptr[a] = d_cell[a].as<double>();
+        }
+    }
+    if (in->x) { SMP_TRY(d_x.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_x.p, in->x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
+    if (in->y) { SMP_TRY(d_y.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_y.p, in->y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
+    p.cells = {dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], dptr[9], dptr[10], dptr[11],
+               dptr[12], dptr[13], dptr[14], dptr[15], dptr[16], dptr[17]};
+    p.x = d_x.as<double>(); p.y = d_y.as<double>();
+    p.n_cells = n; p.first_cell = in->first_cell;
+    p.dim3 = three_d; p.df_mode = opts->df_mode;
+    p.include_bulk = opts->include_bulk_deltaf != 0; p.include_shear = opts->include_shear_deltaf != 0;
+    p.ngl = in->n_gla; p.gl = d_gl.as<double>();
+    p.y_max = three_d ? 0.5 : in->y_cut;                                              // :837-838
+    p.seed = in->seed;
+    DevMem d_status, d_GT, d_rec, d_counts, d_offsets, d_scan_tmp, d_particles;
+    SMP_TRY(d_status.alloc(8 * sizeof(unsigned long long)));
+    unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0, 0};
+    SMP_TRY(hipMemcpyAsync(d_status.p, init, sizeof init, hipMemcpyHostToDevice, nullptr));
+    p.status = d_status.as<unsigned long long>();
+    SMP_TRY(d_GT.alloc((size_t)n * ncls * sizeof(double)));
+    SMP_TRY(d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
+    SMP_TRY(hipEventRecord(ev[1], nullptr));
+    {
+        const int64_t tot = n * ncls;
+        hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], n, sp,
+                           d_gl.as<double>(), in->n_gla, d_GT.as<double>());
+        hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, p, sp, d_GT.as<double>(),
+                           d_rec.as<is3d::SamplerCell>());
+        SMP_TRY(hipGetLastError());
+    }
+    SMP_TRY(hipEventRecord(ev[2], nullptr));
+    // ---- events in batches of <= 2^25 (event, cell) threads: count, scan, fill ----
+    const int64_t max_threads = (int64_t)1 << 25;
+    const int eb = (int)std::max<int64_t>(1, std::min<int64_t>(in->n_events, max_threads / n));
+    const int64_t bt = (int64_t)eb * n;
+    SMP_TRY(d_counts.alloc((size_t)(bt + 1) * sizeof(int64_t)));
+    SMP_TRY(d_offsets.alloc((size_t)(bt + 1) * sizeof(int64_t)));
+    SMP_TRY(hipMemsetAsync(d_counts.p, 0, (size_t)(bt + 1) * sizeof(int64_t), nullptr));
+    size_t tmp_bytes = 0;
+    SMP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), (int)(bt + 1), nullptr));
+    SMP_TRY(d_scan_tmp.alloc(tmp_bytes));
+    if (capacity > 0) SMP_TRY(d_particles.alloc((size_t)capacity * sizeof(is3d_particle)));
+    int64_t base = 0;
+    double ms_count = 0.0, ms_fill = 0.0;
+    for (int e0 = 0; e0 < in->n_events; e0 += eb) {
+        const int ne = std::min(eb, in->n_events - e0);
+        const int64_t nt = (int64_t)ne * n;
+        const unsigned grid = (unsigned)((nt + 127) / 128);
+        SMP_TRY(hipEventRecord(ev[5], nullptr));
+        if (ne < eb) SMP_TRY(hipMemsetAsync(d_counts.p, 0, (size_t)(bt + 1) * sizeof(int64_t), nullptr));
+        hipLaunchKernelGGL((is3d::cf_sampler_run<false>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
+                           d_GT.as<double>(), e0, ne, d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0,
+                           (is3d_particle *)nullptr, (int64_t)0);
+        SMP_TRY(hipGetLastError());
+        // element bt of the scan (counts[bt] = 0) is the batch total
+        SMP_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), (int)(bt + 1), nullptr));
+        SMP_TRY(hipEventRecord(ev[3], nullptr));
+        int64_t batch_total = 0;
+        SMP_TRY(hipMemcpy(&batch_total, d_offsets.as<int64_t>() + bt, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (capacity > 0 && base < capacity && batch_total > 0) {
+            hipLaunchKernelGGL((is3d::cf_sampler_run<true>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
+                               d_GT.as<double>(), e0, ne, (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(),
+                               capacity);
+            SMP_TRY(hipGetLastError());
+        }
+        SMP_TRY(hipEventRecord(ev[4], nullptr));
+        SMP_TRY(hipEventSynchronize(ev[4]));
+        float a = 0, b = 0;
+        SMP_TRY(hipEventElapsedTime(&a, ev[5], ev[3]));
+        SMP_TRY(hipEventElapsedTime(&b, ev[3], ev[4]));
+        ms_count += a; ms_fill += b;
+        base += batch_total;
+    }
+    unsigned long long h[8];
+    SMP_TRY(hipMemcpy(h, d_status.p, sizeof h, hipMemcpyDeviceToHost));
+    *n_particles = base;
+    if (stats) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        stats->ms_h2d = a;
+        stats->ms_prep = b;
+        stats->n_cells_skipped = (int64_t)h[1];
+        stats->n_momentum_samples = (int64_t)h[2];
+        stats->n_acceptances = (int64_t)h[3];
+        stats->n_hadrons_drawn = (int64_t)h[4];
+        stats->n_classes = ncls;
+        stats->ms_count = ms_count; stats->ms_fill = ms_fill;
+    }
+    if (h[0] != ~0ULL)
+        return set_error(IS3D_EDOMAIN, "cell %lld: T outside the delta-f coefficient table (the reference aborts in gsl_spline_eval here)", (long long)h[0]);
+    const int64_t ncopy = std::min<int64_t>(base, capacity);
+    if (ncopy > 0) SMP_TRY(hipMemcpy(particles, d_particles.p, (size_t)ncopy * sizeof(is3d_particle), hipMemcpyDeviceToHost));
+    if (particles && base > capacity)
+        return set_error(IS3D_ENOMEM, "%lld particles sampled but the caller's buffer holds %lld (call with particles = NULL for the count)",
+                         (long long)base, (long long)capacity);
+    return IS3D_OK;
+}

@@ -611,3 +611,30 @@ extern "C" int is3d_write_results(const char *dir, int32_t dimension, int32_t np
     }
     return IS3D_OK;
 }
+
+// write_particle_list_OSC (src/cpp/emissionfunction.cpp:863-901): one "# N" header per non-empty event (empty events are
+// not written: the urqmd afterburner crashes on them), then rows "mcid t x y z E px py pz", scientific, setprecision(16).
+extern "C" int is3d_write_particle_list_osc(const char *path, int32_t n_events, int64_t n_particles, const is3d_particle *particles,
+                                            const int64_t *mc_id)
+{
+    if (!path || (n_particles > 0 && (!particles || !mc_id))) return io_fail(IS3D_EINVAL, "null argument");
+    std::ofstream f(path, std::ios_base::out);
+    if (!f) return io_fail(IS3D_EIO, "couldn't open %s for writing", path);
+    int64_t i = 0;
+    for (int32_t ev = 0; ev < n_events; ev++) {
+        int64_t j = i;
+        while (j < n_particles && particles[j].event == ev) j++;
+        if (j > i) {
+            f << "# " << (j - i) << "\n";
+            for (; i < j; i++) {
+                const is3d_particle &q = particles[i];
+                f << mc_id[q.species] << " " << std::scientific << std::setw(5) << std::setprecision(16) << q.t << " " << q.x << " " << q.y << " "
+                  << q.z << " " << q.E << " " << q.px << " " << q.py << " " << q.pz << "\n";
+            }
+        }
+    }
+    if (i != n_particles) return io_fail(IS3D_EINVAL, "particles are not ordered by event (entry %lld has event %d)", (long long)i, particles[i].event);
+    f.close();
+    if (!f) return io_fail(IS3D_EIO, "write error on %s", path);
+    return IS3D_OK;
+}
