@@ -230,7 +230,7 @@ void is3d_plan_destroy(is3d_plan *plan);
  * :1606) for viscous hydro with a linear delta-f (df_mode 1, 2), include_baryon = 0, fast = 0.  The reference's serial
  * std::default_random_engine streams are replaced by counter-based Philox4x32-10 streams keyed by (seed, stream, global cell
  * index, event) -- same five stream roles and the same distributions; particle lists agree with the reference statistically,
- * not draw by draw (construction in oracle/cf_oracle.c).
+ * not draw by draw (the construction is written out in cf_sampler.hip and DESIGN.md section 3c).
  * --------------------------------------------------------------------------------------------- */
 typedef struct {                        /* Sampled_Particle (src/cpp/particle.h), 96 bytes */
     int64_t cell;                       /* global cell index: first_cell + index in the call */

@@ -8,9 +8,12 @@
 //
 // The reference walks the cells serially and feeds five std::default_random_engine streams through implementation-defined
 // std:: distributions; that order dependence cannot (and need not) be reproduced.  Here every (cell, event, stream) owns a
-// counter-based Philox4x32-10 sequence keyed by the seed (the construction is spelled out in oracle/cf_oracle.c and followed
-// bit for bit), so the hadrons of a cell depend on nothing but (seed, global cell index, event): any launch geometry,
-// any cell sharding over GPUs and any event batching give the same particle list.
+// counter-based Philox4x32-10 sequence (Salmon et al., SC'11): key = the 64-bit seed, counter = (block, stream, global cell
+// index, event); streams 0..4 = hadron number, species, momentum, keep test, rapidity (the roles of the reference's five
+// engines, :846-850); u = ((a >> 5) 2^26 + (b >> 6)) 2^-53 from two consecutive 32-bit outputs; Poisson numbers by
+// sequential-search inversion in chunks of mean <= 256; species and the heavy-hadron K mixture by inversion of the cumulative
+// weights; cos(theta) = 2u - 1.  The hadrons of a cell therefore depend on nothing but (seed, global cell index, event): any
+// launch geometry, any cell sharding over GPUs and any event batching give the same particle list.
 //
 //   cf_sampler_density  thread <-> (cell, species class): 32-point Gauss-Laguerre equilibrium density integral
 //   cf_sampler_cells    thread <-> cell: LRF basis, dsigma and pi^{mu nu} in the LRF, delta-f coefficients, mean hadron number
@@ -64,7 +67,7 @@ struct SamplerParams {
     unsigned long long *status; // [0] min bad cell, [1] skipped, [2] momentum samples, [3] acceptances, [4] hadrons drawn
 };
 
-// ---- Philox4x32-10 streams (oracle/cf_oracle.c: rng_stream) ----
+// ---- Philox4x32-10 streams ----
 struct Rng {
     uint32_t k0, k1, stream, cell, event, blk, buf[4];
     int pos;

@@ -9,10 +9,13 @@
 // and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
 // (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
-// Scope: operation = 1, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2} with include_baryon in {0, 1}, df_mode in {3, 4}
+// operation = 2 (particle sampler, df_mode 1 | 2, include_baryon = 0, fast = 0, test_sampler = 0) writes
+// results/particle_list_osc.dat (write_particle_list_OSC, emissionfunction.cpp:863-901) and results/dN_dy_*.dat is skipped.
+// Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2} with include_baryon in {0, 1}, df_mode in {3, 4}
 // (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
 // averages it has just written, as the reference does) with include_baryon = 0.  Anything else is refused
 // with a message instead of silently doing something different from the reference.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,7 +93,15 @@ int main(int argc, char **argv)
     GET(regulate, "regulate_deltaf");
     GET(outflow, "outflow");
 #undef GET
-    if (operation != 1) DIE("operation = %d: only operation = 1 (smooth momentum spectra) is on this path", operation);
+    if (operation != 1 && operation != 2) DIE("operation = %d: only operation = 1 (smooth momentum spectra) and 2 (particle sampler) are on this path", operation);
+    if (operation == 2) {
+        if (df_mode != 1 && df_mode != 2) DIE("operation = 2 with df_mode = %d: the sampler is built for df_mode 1 and 2", df_mode);
+        if (include_baryon) DIE("operation = 2 with include_baryon = 1 is not on this path");
+        double fast = 0, test_sampler = 0;
+        if (get_param("fast", &fast) || get_param("test_sampler", &test_sampler)) return 1;
+        if ((int)fast) DIE("fast = 1 (densities at the average temperature) is not on this path; set fast = 0");
+        if ((int)test_sampler) DIE("test_sampler = 1 (binned test histograms) is not on this path; set test_sampler = 0");
+    }
     if (mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
         DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
     if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
@@ -189,6 +200,65 @@ int main(int argc, char **argv)
     opts.accumulate = 0; opts.device = -1; opts.kernel_variant = variant;
     const int ny_eff = (dimension == 2) ? 1 : (int)y.size();
     std::vector<double> dN(mcid.size() * pT.size() * phi.size() * (size_t)ny_eff, 0.0);
+    if (operation == 2) {
+        // ---- emissionfunction.cpp:1522-1545: number of events, sampling, OSCAR list ----
+        double oversample, min_num_hadrons, max_num_samples, sampler_seed, y_cut;
+        if (get_param("oversample", &oversample) || get_param("min_num_hadrons", &min_num_hadrons) || get_param("max_num_samples", &max_num_samples) ||
+            get_param("sampler_seed", &sampler_seed) || get_param("y_cut", &y_cut))
+            return 1;
+        // cell positions: columns 1, 2 of every supported surface format (readindata.cpp:343-346 etc.)
+        int64_t rows = 0;
+        int32_t cols = 0;
+        if (is3d_table_read("input/surface.dat", &rows, &cols, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (rows != n_cells || cols < 3) DIE("input/surface.dat: %lld rows x %d columns, expected %lld cells", (long long)rows, cols, (long long)n_cells);
+        std::vector<double> xs((size_t)n_cells), ys((size_t)n_cells);
+        {
+            std::vector<double> tab((size_t)rows * cols);
+            if (is3d_table_read("input/surface.dat", &rows, &cols, tab.data(), (int64_t)tab.size())) DIE("%s", is3d_last_error());
+            for (int64_t r = 0; r < rows; r++) { xs[r] = tab[(size_t)r * cols + 1]; ys[r] = tab[(size_t)r * cols + 2]; }
+        }
+        int32_t n_alpha = 0, n_pts = 0;
+        const char *gla_path = "tables/gla_roots_weights_32_points.txt";
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (n_alpha < 2) DIE("%s: needs alpha = 0, 1", gla_path);
+        std::vector<double> groot((size_t)n_alpha * n_pts), gweight((size_t)n_alpha * n_pts);
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, groot.data(), gweight.data(), (int64_t)groot.size())) DIE("%s", is3d_last_error());
+        is3d_sampler_inputs si{};
+        si.n_events = 1; si.n_gla = n_pts;
+        si.seed = sampler_seed < 0 ? (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() : (uint64_t)sampler_seed;   // :842-844
+        si.y_cut = y_cut; si.first_cell = 0; si.x = xs.data(); si.y = ys.data();
+        si.root1 = groot.data() + n_pts; si.weight1 = gweight.data() + n_pts;
+        printf("iS3D Sampling Seed : %llu\n", (unsigned long long)si.seed);
+        is3d_sampler_stats ss{};
+        int64_t count = 0;
+        if ((int)oversample) {
+            // The reference sizes the run from calculate_total_yield (an analytic estimate at the surface-average temperature,
+            // sampling_kernels.cpp:653-830); here the yield of one sampled event stands in for it.
+            int rc1 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
+            if (rc1) DIE("is3d_sample_particles failed (%d): %s", rc1, is3d_last_error());
+            const double Ntotal = (double)std::max<int64_t>(count, 1);
+            printf("Total particle yield: %lld (one sampled event)\n", (long long)count);
+            si.n_events = (int32_t)std::max(1.0, std::min(std::ceil(min_num_hadrons / Ntotal), max_num_samples));
+        }
+        printf("Sampling %d event(s)\n", si.n_events);
+        printf(df_mode == 1 ? "Sampling particles with Grad 14 moment df...\n" : "Sampling particles with Chapman Enskog df...\n");
+        int rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
+        if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
+        std::vector<is3d_particle> plist((size_t)std::max<int64_t>(count, 1));
+        rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, plist.data(), count, &count, &ss);
+        if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
+        double t2s = now_s();
+        printf("\nMomentum sampling efficiency = %f %%\n", 100.0 * (double)ss.n_acceptances / (double)std::max<int64_t>(ss.n_momentum_samples, 1));
+        printf("Writing sampled particles list to OSCAR File...\n");
+        if (is3d_write_particle_list_osc("results/particle_list_osc.dat", si.n_events, count, plist.data(), mcid.data())) DIE("%s", is3d_last_error());
+        double t3s = now_s();
+        printf("particles: %lld in %d event(s); hadrons drawn %lld; cells skipped (u.dsigma <= 0): %lld\n", (long long)count, si.n_events,
+               (long long)ss.n_hadrons_drawn, (long long)ss.n_cells_skipped);
+        printf("device time: prep %.3f ms, count %.3f ms, fill %.3f ms; h2d %.3f ms\n", ss.ms_prep, ss.ms_count, ss.ms_fill, ss.ms_h2d);
+        printf("wall: read %.3f s, sampling %.3f s, write %.3f s\n", t1 - t0, t2s - t1, t3s - t2s);
+        printf("Done sampling particles. Output stored in results folder. Goodbye!\n");
+        return 0;
+    }
     is3d_status st{};
     printf(feqmod ? "computing thermal spectra from vhydro with feqmod...\n" : "computing thermal spectra from vhydro with df...\n");
     int rc;

@@ -24,6 +24,13 @@ outflow 			= {outflow}	             # Theta(p.dsigma)
 
 deta_min 			= 1.e-5
 mass_pion0			= 0.138  # lightest pion mass for the feqmod breakdown test
+oversample			= {oversample}
+fast				= 0
+y_cut				= 0.7
+min_num_hadrons			= {min_num_hadrons}
+max_num_samples			= 1000
+sampler_seed			= {sampler_seed}
+test_sampler			= 0
 group_particles                 = 0
 """
 
@@ -64,7 +71,7 @@ def make_run_dir(root, cells, species_ids, params):
     for d in ("input", "PDG", "tables/eta", "deltaf_coefficients/vh/urqmd", "results/vn_continuous"):
         os.makedirs(os.path.join(root, d), exist_ok=True)
     p = dict(operation=1, mode=1, dimension=3, df_mode=1, include_bulk_deltaf=1, include_shear_deltaf=1, regulate_deltaf=1, outflow=1,
-             include_baryon=0, include_baryondiff_deltaf=0)
+             include_baryon=0, include_baryondiff_deltaf=0, oversample=0, min_num_hadrons=2000, sampler_seed=17)
     p.update(params)
     with open(os.path.join(root, "iS3D_parameters.dat"), "w") as f:
         f.write(PARAMS_TEMPLATE.format(**p))

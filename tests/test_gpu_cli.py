@@ -103,7 +103,7 @@ def test_cli_other_surface_formats(tmp_path, fx, mode):
 
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=2), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
+    for bad in (dict(operation=3), dict(operation=2, df_mode=4), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr
@@ -131,3 +131,34 @@ def test_cli_feqmod(tmp_path, fx, dim, df_mode):
     allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
     want = np.transpose(ref.reshape(ny, 24, 32, 4), (3, 0, 1, 2)).reshape(-1)
     assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8
+
+
+@pytest.mark.parametrize("dim,oversample", [(3, 0), (3, 1), (2, 0)])
+def test_cli_sampler(tmp_path, fx, dim, oversample):
+    """operation = 2 end to end: surface (with positions) + parameters in, results/particle_list_osc.dat out, the list equal to
+    the oracle's for the same seed; oversample = 1 sizes the number of events from the yield of one sampled event."""
+    ids = [211, 321, 2212, -2212]
+    cells = synth.synth_surface(5000 if dim == 3 else 3000, dim, seed=90 + dim)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(operation=2, dimension=dim, df_mode=2, oversample=oversample,
+                                                                  min_num_hadrons=300, sampler_seed=17))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "iS3D Sampling Seed : 17" in r.stdout and "Sampling particles with Chapman Enskog df..." in r.stdout
+    n_events = int(r.stdout.split(" event(s)")[0].split("Sampling ")[-1])
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    gla = inputs.feqmod_tables(0.15)
+    sp = inputs.species(ids)
+    if oversample:
+        one, _ = oracle.sample_particles(parsed, sp, fx["df"], gla, dict(dimension=dim, df_mode=2), n_events=1, seed=17, y_cut=0.7)
+        assert n_events == max(1, min(int(np.ceil(300.0 / max(len(one["E"]), 1))), 1000)) and n_events > 1
+    else:
+        assert n_events == 1
+    ref, _ = oracle.sample_particles(parsed, sp, fx["df"], gla, dict(dimension=dim, df_mode=2), n_events=n_events, seed=17, y_cut=0.7)
+    lines = [ln for ln in open(os.path.join(root, "results", "particle_list_osc.dat")).read().split("\n") if ln]
+    headers = [int(ln[2:]) for ln in lines if ln.startswith("#")]
+    rows = np.array([[float(v) for v in ln.split(" ")] for ln in lines if not ln.startswith("#")]).reshape(-1, 9)
+    assert len(rows) > 10
+    assert sum(headers) == len(rows) == len(ref["E"]) and len(headers) == len(np.unique(ref["event"]))
+    assert np.array_equal(rows[:, 0].astype(np.int64), np.array(ids)[ref["species"]])
+    for col, f in enumerate(["t", "x", "y", "z", "E", "px", "py", "pz"], start=1):
+        assert np.allclose(rows[:, col], ref[f], rtol=1e-11, atol=1e-13), f

@@ -176,6 +176,29 @@ def test_gla_reader(tmp_path):
         api.gla_read(os.path.join(root, "tables", "missing.txt"))
 
 
+def test_oscar_writer(tmp_path):
+    """write_particle_list_OSC (emissionfunction.cpp:863-901): "# N" per non-empty event, rows "mcid t x y z E px py pz" with
+    setprecision(16) scientific; empty events are not written."""
+    p = np.zeros(5, dtype=api.PARTICLE_DTYPE)
+    p["event"] = [0, 0, 2, 2, 2]
+    p["species"] = [0, 1, 1, 0, 0]
+    for i, f in enumerate(["t", "x", "y", "z", "E", "px", "py", "pz"]):
+        p[f] = np.arange(5) * 0.37 + i + 1.0 / 3.0
+    path = str(tmp_path / "particle_list_osc.dat")
+    api.write_particle_list_osc(path, 4, p, [211, -2212])
+    lines = open(path).read().split("\n")
+    assert lines[0] == "# 2" and lines[3] == "# 3" and lines[-1] == "" and len(lines) == 8
+    row = lines[1].split(" ")
+    assert row[0] == "211" and len(row) == 9 and row[1] == "%.16e" % p["t"][0] and row[8] == "%.16e" % p["pz"][0]
+    assert lines[4].split(" ")[0] == "-2212"
+    back = np.array([[float(v) for v in ln.split(" ")[1:]] for ln in lines if ln and not ln.startswith("#")])
+    assert np.array_equal(back[:, 4], p["E"]) and np.array_equal(back[:, 0], p["t"])
+    q = p.copy()
+    q["event"] = [0, 2, 0, 2, 2]           # not ordered by event
+    with pytest.raises(api.Is3dError):
+        api.write_particle_list_osc(path, 4, q, [211, -2212])
+
+
 def test_writers_format(tmp_path):
     """emissionfunction.cpp:381-450, :729-772, :1053-1136."""
     g = inputs.grid()
