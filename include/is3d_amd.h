@@ -271,6 +271,29 @@ int is3d_write_particle_list_osc(const char *path, int32_t n_events, int64_t n_p
                                  const int64_t *mc_id);
 
 /* ---------------------------------------------------------------------------------------------
+ * Driver: IS3D::run_particlization (src/cpp/iS3D.cpp:74-192; class IS3D, src/cpp/iS3D.h:19-96).  Reads iS3D_parameters.dat,
+ * PDG/, tables/, deltaf_coefficients/ from the current directory and writes results/ exactly as the command line tool does
+ * (which is this call with surface = NULL).  surface != NULL is the embedding path (read_fo_surf_from_memory +
+ * run_particlization(0), iS3D.cpp:27-72, :100-134): HOST arrays already in GeV / fm units, x and y the cell positions (may be
+ * NULL).  result may be NULL; otherwise it receives library-allocated copies -- operation 2: the sampled particles ordered
+ * by event (what the reference returns in final_particles_, :178-184); operation 1: the spectrum -- to be released with
+ * is3d_run_result_free.  include/iS3D_amd.hpp wraps this in a class with the reference's member names.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t operation, n_events, n_species, reserved;
+    int64_t n_particles;
+    is3d_particle *particles;           /* operation 2 */
+    int64_t *mc_id;                     /* [n_species] chosen particles, order of PDG/chosen_particles.dat */
+    double *mass;                       /* [n_species] */
+    int64_t n_spectrum;
+    double *spectrum;                   /* operation 1: dN_pTdpTdphidy, species fastest */
+} is3d_run_result;
+
+int is3d_run_particlization(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
+                            is3d_run_result *result);
+void is3d_run_result_free(is3d_run_result *result);
+
+/* ---------------------------------------------------------------------------------------------
  * Host I/O in the reference's file formats (C++ implementation, C ABI so that tests and other
  * hosts can reach it).  All paths are explicit; the CLI driver passes the reference's hard-coded
  * CWD-relative names.

@@ -94,7 +94,8 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
-           "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc"]
+           "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
+           "is3d_run_particlization", "is3d_run_result_free"]
 
 
 class Is3dError(RuntimeError):

@@ -1,0 +1,375 @@
+// is3d_run.cpp -- IS3D::run_particlization (/root/reference/src/cpp/iS3D.cpp:74-192) behind the C ABI: the driver layer
+// shared by the command line tool (is3d_main.cpp) and the embedding class (include/iS3D_amd.hpp).
+//
+// Runs in a directory laid out like the reference's run directory; it reads the same hard-coded
+// CWD-relative files IS3D::run_particlization reads (/root/reference/src/cpp/iS3D.cpp:74-192):
+//   iS3D_parameters.dat, input/surface.dat, PDG/pdg-urqmd_v3.3+.dat | PDG/pdg_smash.dat,
+//   PDG/chosen_particles.dat, deltaf_coefficients/vh/<eos>/{c0,c2,F,betabulk,betapi}.dat,
+//   tables/pT_gauss_legendre_table.dat, tables/phi_gauss_legendre_table.dat,
+//   tables/y_trapezoid_table_21pt.dat, tables/eta/eta_trapezoid_table_241pt.dat
+// and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
+// (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
+// average_thermodynamic_quantities.dat (readindata.cpp:464-466).
+// operation = 2 (particle sampler, df_mode 1 | 2, include_baryon = 0, fast = 0, test_sampler = 0) writes
+// results/particle_list_osc.dat (write_particle_list_OSC, emissionfunction.cpp:863-901) and results/dN_dy_*.dat is skipped.
+// Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2} with include_baryon in {0, 1}, df_mode in {3, 4}
+// (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
+// averages it has just written, as the reference does) with include_baryon = 0.  Anything else is refused
+// with a message instead of silently doing something different from the reference.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <iomanip>
+#include <string>
+#include <vector>
+
+#include <cstdarg>
+
+#include "../../include/is3d_amd.h"
+#include "errors.h"
+
+static double now_s()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// print like the reference does before exit(-1), but return a code and keep the text for is3d_last_error()
+static int die(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+static int die(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "iS3D-amd: %s\n", buf);
+    return is3d::set_error(IS3D_EINVAL, "%s", buf);
+}
+#define DIE(...) return die(__VA_ARGS__)
+
+static int get_param(const char *name, double *v, bool required = true)
+{
+    int rc = is3d_param_get("iS3D_parameters.dat", name, v);
+    if (rc && required) fprintf(stderr, "iS3D-amd: %s\n", is3d_last_error());
+    return rc;
+}
+
+static int read_table(const char *path, std::vector<double> &col1, std::vector<double> &col2)
+{
+    int64_t rows;
+    int32_t cols;
+    if (is3d_table_read(path, &rows, &cols, nullptr, 0)) return 1;
+    std::vector<double> d((size_t)rows * cols);
+    if (is3d_table_read(path, &rows, &cols, d.data(), (int64_t)d.size())) return 1;
+    col1.resize(rows);
+    col2.assign(rows, 0.0);
+    for (int64_t r = 0; r < rows; r++) {
+        col1[r] = d[r * cols];
+        if (cols > 1) col2[r] = d[r * cols + 1];
+    }
+    return 0;
+}
+
+// surface-volume weighted averages of T, E, P, muB, nB as the readers accumulate them (readindata.cpp:422-466)
+static void surface_averages(const is3d_cells *c, double avg[5])
+{
+    double num[5] = {0, 0, 0, 0, 0}, den = 0.0;
+    for (int64_t i = 0; i < c->n_cells; i++) {
+        const double tau = c->tau[i], ux = c->ux[i], uy = c->uy[i], un = c->un[i];
+        const double ut = std::sqrt(1.0 + ux * ux + uy * uy + tau * tau * un * un);
+        const double dat = c->dat[i], dax = c->dax[i], day = c->day[i], dan = c->dan[i];
+        const double uds = ut * dat + ux * dax + uy * day + un * dan;
+        const double dsds = dat * dat - dax * dax - day * day - dan * dan / (tau * tau);
+        const double w = std::fabs(uds) + std::sqrt(std::fabs(uds * uds - dsds));
+        num[0] += c->T[i] * w; num[1] += c->E[i] * w; num[2] += c->P[i] * w;
+        if (c->muB) num[3] += c->muB[i] * w;
+        if (c->nB) num[4] += c->nB[i] * w;
+        den += w;
+    }
+    for (int k = 0; k < 5; k++) avg[k] = den > 0.0 ? num[k] / den : 0.0;
+}
+
+static int run_impl(const is3d_cells *mem, const double *mem_x, const double *mem_y, int variant, is3d_run_result *res)
+{
+    printf("iS3D-amd: MI355X-native smooth Cooper-Frye spectra (%s)\n", is3d_version());
+    double v;
+    int operation, mode, hrg_eos, dimension, df_mode, include_baryon, include_bulk, include_shear, include_diff, regulate, outflow;
+#define GET(var, name)                           \
+    if (get_param(name, &v)) return IS3D_EINVAL; \
+    var = (int)v;
+    GET(operation, "operation");
+    GET(mode, "mode");
+    GET(hrg_eos, "hrg_eos");
+    GET(dimension, "dimension");
+    GET(df_mode, "df_mode");
+    GET(include_baryon, "include_baryon");
+    GET(include_bulk, "include_bulk_deltaf");
+    GET(include_shear, "include_shear_deltaf");
+    GET(include_diff, "include_baryondiff_deltaf");
+    GET(regulate, "regulate_deltaf");
+    GET(outflow, "outflow");
+#undef GET
+    if (operation != 1 && operation != 2) DIE("operation = %d: only operation = 1 (smooth momentum spectra) and 2 (particle sampler) are on this path", operation);
+    if (operation == 2) {
+        if (df_mode != 1 && df_mode != 2) DIE("operation = 2 with df_mode = %d: the sampler is built for df_mode 1 and 2", df_mode);
+        if (include_baryon) DIE("operation = 2 with include_baryon = 1 is not on this path");
+        double fast = 0, test_sampler = 0;
+        if (get_param("fast", &fast) || get_param("test_sampler", &test_sampler)) return IS3D_EINVAL;
+        if ((int)fast) DIE("fast = 1 (densities at the average temperature) is not on this path; set fast = 0");
+        if ((int)test_sampler) DIE("test_sampler = 1 (binned test histograms) is not on this path; set test_sampler = 0");
+    }
+    if (!mem && mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
+        DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
+    if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
+    const bool feqmod = df_mode == 3 || df_mode == 4;
+    if (feqmod && include_baryon) DIE("df_mode = %d with include_baryon = 1 is not on this path", df_mode);
+    const char *pdg_path, *df_dir;
+    if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
+    else if (hrg_eos == 2) { pdg_path = "PDG/pdg_smash.dat"; df_dir = "deltaf_coefficients/vh/smash/"; }
+    else DIE("hrg_eos = %d: choose 1 (urqmd) or 2 (smash)", hrg_eos);
+
+    double t0 = now_s();
+    // ---- surface (iS3D.cpp:90-98) ----
+    int64_t n_cells = 0;
+    std::vector<std::vector<double>> arr(23);
+    double *ptr[23];
+    double avg[5] = {0, 0, 0, 0, 0};
+    if (mem) {
+        // iS3D.cpp:100-134: the surface comes from the caller's vectors, already in GeV / fm units (no hbar*c conversion)
+        printf("Reading in freezeout surface from memory \n");
+        n_cells = mem->n_cells;
+        const double *src[23] = {mem->T, mem->P, mem->E, mem->tau, mem->eta, mem->ux, mem->uy, mem->un, mem->dat, mem->dax, mem->day, mem->dan,
+                                 mem->pixx, mem->pixy, mem->pixn, mem->piyy, mem->piyn, mem->bulkPi, mem->muB, mem->nB, mem->Vx, mem->Vy, mem->Vn};
+        for (int a = 0; a < 23; a++) ptr[a] = const_cast<double *>(src[a]);
+        for (int a = 0; a < 18; a++)
+            if (!ptr[a] && !(a == 4 && dimension == 2)) DIE("in-memory surface: a required array is NULL");
+        if (n_cells > 0) surface_averages(mem, avg);
+    } else {
+        if (is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
+        for (int a = 0; a < 23; a++) {
+            const bool used = a < 18 || (a == 18 && include_baryon) || (a > 18 && include_diff);
+            arr[a].assign(used ? (size_t)n_cells : 0, 0.0);
+            ptr[a] = used ? arr[a].data() : nullptr;
+        }
+        if (n_cells > 0 && is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
+    }
+    {
+        std::ofstream f("average_thermodynamic_quantities.dat", std::ios_base::out);
+        f << std::setprecision(15) << avg[0] << "\n" << avg[1] << "\n" << avg[2] << "\n" << avg[3] << "\n" << avg[4];
+    }
+    // ---- species (iS3D.cpp:138-140, 156; emissionfunction.cpp:336-351, 1293-1307) ----
+    int32_t npdg = 0;
+    if (is3d_pdg_read(pdg_path, &npdg, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+    std::vector<int64_t> pid(npdg);
+    std::vector<double> pmass(npdg), pg(npdg), pb(npdg), ps(npdg);
+    if (is3d_pdg_read(pdg_path, &npdg, pid.data(), pmass.data(), pg.data(), pb.data(), ps.data(), npdg)) DIE("%s", is3d_last_error());
+    std::vector<double> chosen, dummy;
+    if (read_table("PDG/chosen_particles.dat", chosen, dummy)) DIE("%s", is3d_last_error());
+    std::vector<int64_t> mcid;
+    std::vector<double> mass, sign, deg, bar;
+    for (double c : chosen) {
+        int id = (int)c;
+        bool found = false;
+        for (int n = 0; n < npdg; n++)
+            if (pid[n] == id) {
+                mcid.push_back(pid[n]); mass.push_back(pmass[n]); sign.push_back(ps[n]); deg.push_back(pg[n]); bar.push_back(pb[n]);
+                found = true;
+                break;
+            }
+        if (!found) DIE("chosen particle %d is not in %s", id, pdg_path);
+    }
+    // ---- grids (iS3D.cpp:161-167) ----
+    std::vector<double> pT, pTw, phi, phiw, y, yw, eta, etaw;
+    if (read_table("tables/pT_gauss_legendre_table.dat", pT, pTw) || read_table("tables/phi_gauss_legendre_table.dat", phi, phiw) ||
+        read_table("tables/y_trapezoid_table_21pt.dat", y, yw) || read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
+        DIE("%s", is3d_last_error());
+    // ---- delta-f coefficient tables (iS3D.cpp:144-145) ----
+    //      include_baryon = 0: the mu_B = 0 rows; include_baryon = 1: the full (mu_B, T) grids (deltafReader.cpp:134)
+    const char *names[10] = {"c0.dat", "c1.dat", "c2.dat", "c3.dat", "c4.dat", "F.dat", "G.dat", "betabulk.dat", "betaV.dat", "betapi.dat"};
+    std::vector<double> Tk, Bk, tab[10];
+    for (int t = 0; t < 10; t++) {
+        std::string p = std::string(df_dir) + names[t];
+        int32_t nT = 0, nB = 0;
+        const bool spline_table = (t == 0 || t == 2 || t == 5 || t == 7 || t == 9);   // c0 c2 F betabulk betapi
+        if (!include_baryon && !spline_table) continue;   // only the bilinear branch looks at c1 c3 c4 G betaV
+        if (is3d_df_table_read_full(p.c_str(), &nT, &nB, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (!include_baryon) {
+            Tk.resize(nT);
+            Bk.assign(1, 0.0);
+            tab[t].resize(nT);
+            if (is3d_df_table_read(p.c_str(), &nT, Tk.data(), tab[t].data(), nT)) DIE("%s", is3d_last_error());
+        } else {
+            Tk.resize(nT);
+            Bk.resize(nB);
+            tab[t].resize((size_t)nT * nB);
+            if (is3d_df_table_read_full(p.c_str(), &nT, &nB, Tk.data(), Bk.data(), tab[t].data(), (int64_t)tab[t].size())) DIE("%s", is3d_last_error());
+        }
+    }
+    double t1 = now_s();
+    printf("Total number of freezeout cells: %lld\nNumber of chosen particles: %zu\n", (long long)n_cells, mcid.size());
+
+    is3d_cells cells{};
+    cells.n_cells = n_cells;
+    cells.T = ptr[0]; cells.P = ptr[1]; cells.E = ptr[2]; cells.tau = ptr[3]; cells.eta = ptr[4];
+    cells.ux = ptr[5]; cells.uy = ptr[6]; cells.un = ptr[7];
+    cells.dat = ptr[8]; cells.dax = ptr[9]; cells.day = ptr[10]; cells.dan = ptr[11];
+    cells.pixx = ptr[12]; cells.pixy = ptr[13]; cells.pixn = ptr[14]; cells.piyy = ptr[15]; cells.piyn = ptr[16];
+    cells.bulkPi = ptr[17];
+    cells.muB = ptr[18]; cells.nB = ptr[19]; cells.Vx = ptr[20]; cells.Vy = ptr[21]; cells.Vn = ptr[22];
+    is3d_species sp{(int32_t)mcid.size(), mass.data(), sign.data(), deg.data(), bar.data()};
+    is3d_grid grid{(int32_t)pT.size(), pT.data(), (int32_t)phi.size(), phi.data(), (int32_t)y.size(), y.data(),
+                   (int32_t)eta.size(), eta.data(), etaw.data()};
+    is3d_df_tables df{(int32_t)Tk.size(), Tk.data(), (int32_t)Bk.size(), Bk.data(), tab[0].data(), tab[1].data(), tab[2].data(),
+                      tab[3].data(), tab[4].data(), tab[5].data(), tab[6].data(), tab[7].data(), tab[8].data(), tab[9].data()};
+    is3d_options opts{};
+    opts.dimension = dimension; opts.df_mode = df_mode; opts.include_baryon = include_baryon;
+    opts.include_bulk_deltaf = include_bulk; opts.include_shear_deltaf = include_shear; opts.include_baryondiff_deltaf = include_diff;
+    opts.regulate_deltaf = regulate; opts.outflow = outflow;
+    opts.accumulate = 0; opts.device = -1; opts.kernel_variant = variant;
+    const int ny_eff = (dimension == 2) ? 1 : (int)y.size();
+    std::vector<double> dN(mcid.size() * pT.size() * phi.size() * (size_t)ny_eff, 0.0);
+    if (operation == 2) {
+        // ---- emissionfunction.cpp:1522-1545: number of events, sampling, OSCAR list ----
+        double oversample, min_num_hadrons, max_num_samples, sampler_seed, y_cut;
+        if (get_param("oversample", &oversample) || get_param("min_num_hadrons", &min_num_hadrons) || get_param("max_num_samples", &max_num_samples) ||
+            get_param("sampler_seed", &sampler_seed) || get_param("y_cut", &y_cut))
+            return IS3D_EINVAL;
+        // cell positions: columns 1, 2 of every supported surface format (readindata.cpp:343-346 etc.)
+        std::vector<double> xs((size_t)n_cells, 0.0), ys((size_t)n_cells, 0.0);
+        if (mem) {
+            if (mem_x) xs.assign(mem_x, mem_x + n_cells);
+            if (mem_y) ys.assign(mem_y, mem_y + n_cells);
+        } else {
+            int64_t rows = 0;
+            int32_t cols = 0;
+            if (is3d_table_read("input/surface.dat", &rows, &cols, nullptr, 0)) DIE("%s", is3d_last_error());
+            if (rows != n_cells || cols < 3) DIE("input/surface.dat: %lld rows x %d columns, expected %lld cells", (long long)rows, cols, (long long)n_cells);
+            std::vector<double> tab((size_t)rows * cols);
+            if (is3d_table_read("input/surface.dat", &rows, &cols, tab.data(), (int64_t)tab.size())) DIE("%s", is3d_last_error());
+            for (int64_t r = 0; r < rows; r++) { xs[r] = tab[(size_t)r * cols + 1]; ys[r] = tab[(size_t)r * cols + 2]; }
+        }
+        int32_t n_alpha = 0, n_pts = 0;
+        const char *gla_path = "tables/gla_roots_weights_32_points.txt";
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (n_alpha < 2) DIE("%s: needs alpha = 0, 1", gla_path);
+        std::vector<double> groot((size_t)n_alpha * n_pts), gweight((size_t)n_alpha * n_pts);
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, groot.data(), gweight.data(), (int64_t)groot.size())) DIE("%s", is3d_last_error());
+        is3d_sampler_inputs si{};
+        si.n_events = 1; si.n_gla = n_pts;
+        si.seed = sampler_seed < 0 ? (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() : (uint64_t)sampler_seed;   // :842-844
+        si.y_cut = y_cut; si.first_cell = 0; si.x = xs.data(); si.y = ys.data();
+        si.root1 = groot.data() + n_pts; si.weight1 = gweight.data() + n_pts;
+        printf("iS3D Sampling Seed : %llu\n", (unsigned long long)si.seed);
+        is3d_sampler_stats ss{};
+        int64_t count = 0;
+        if ((int)oversample) {
+            // The reference sizes the run from calculate_total_yield (an analytic estimate at the surface-average temperature,
+            // sampling_kernels.cpp:653-830); here the yield of one sampled event stands in for it.
+            int rc1 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
+            if (rc1) DIE("is3d_sample_particles failed (%d): %s", rc1, is3d_last_error());
+            const double Ntotal = (double)std::max<int64_t>(count, 1);
+            printf("Total particle yield: %lld (one sampled event)\n", (long long)count);
+            si.n_events = (int32_t)std::max(1.0, std::min(std::ceil(min_num_hadrons / Ntotal), max_num_samples));
+        }
+        printf("Sampling %d event(s)\n", si.n_events);
+        printf(df_mode == 1 ? "Sampling particles with Grad 14 moment df...\n" : "Sampling particles with Chapman Enskog df...\n");
+        int rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
+        if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
+        std::vector<is3d_particle> plist((size_t)std::max<int64_t>(count, 1));
+        rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, plist.data(), count, &count, &ss);
+        if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
+        double t2s = now_s();
+        printf("\nMomentum sampling efficiency = %f %%\n", 100.0 * (double)ss.n_acceptances / (double)std::max<int64_t>(ss.n_momentum_samples, 1));
+        printf("Writing sampled particles list to OSCAR File...\n");
+        if (is3d_write_particle_list_osc("results/particle_list_osc.dat", si.n_events, count, plist.data(), mcid.data())) DIE("%s", is3d_last_error());
+        double t3s = now_s();
+        printf("particles: %lld in %d event(s); hadrons drawn %lld; cells skipped (u.dsigma <= 0): %lld\n", (long long)count, si.n_events,
+               (long long)ss.n_hadrons_drawn, (long long)ss.n_cells_skipped);
+        printf("device time: prep %.3f ms, count %.3f ms, fill %.3f ms; h2d %.3f ms\n", ss.ms_prep, ss.ms_count, ss.ms_fill, ss.ms_h2d);
+        printf("wall: read %.3f s, sampling %.3f s, write %.3f s\n", t1 - t0, t2s - t1, t3s - t2s);
+        if (res) {
+            // iS3D.cpp:178-184: the event lists go back to the caller (final_particles_)
+            res->operation = 2; res->n_events = si.n_events; res->n_species = sp.n; res->n_particles = count;
+            res->particles = (is3d_particle *)malloc(sizeof(is3d_particle) * (size_t)std::max<int64_t>(count, 1));
+            res->mc_id = (int64_t *)malloc(sizeof(int64_t) * (size_t)sp.n);
+            res->mass = (double *)malloc(sizeof(double) * (size_t)sp.n);
+            if (!res->particles || !res->mc_id || !res->mass) return is3d::set_error(IS3D_ENOMEM, "out of memory for the particle list");
+            memcpy(res->particles, plist.data(), sizeof(is3d_particle) * (size_t)count);
+            memcpy(res->mc_id, mcid.data(), sizeof(int64_t) * (size_t)sp.n);
+            memcpy(res->mass, mass.data(), sizeof(double) * (size_t)sp.n);
+        }
+        printf("Done sampling particles. Output stored in results folder. Goodbye!\n");
+        return IS3D_OK;
+    }
+    is3d_status st{};
+    printf(feqmod ? "computing thermal spectra from vhydro with feqmod...\n" : "computing thermal spectra from vhydro with df...\n");
+    int rc;
+    if (feqmod) {
+        // emissionfunction.cpp:1309-1319: Gauss-Laguerre tables, Plasma::load_thermodynamic_averages (the file written
+        // above, read back as text), parameters deta_min and mass_pion0 (:184, :188)
+        int32_t n_alpha = 0, n_pts = 0;
+        const char *gla_path = "tables/gla_roots_weights_32_points.txt";
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        if (n_alpha < 3) DIE("%s: needs alpha = 0, 1, 2", gla_path);
+        std::vector<double> groot((size_t)n_alpha * n_pts), gweight((size_t)n_alpha * n_pts);
+        if (is3d_gla_read(gla_path, &n_alpha, &n_pts, groot.data(), gweight.data(), (int64_t)groot.size())) DIE("%s", is3d_last_error());
+        double deta_min, mass_pion0, T_avg = 0.0;
+        if (get_param("deta_min", &deta_min) || get_param("mass_pion0", &mass_pion0)) return IS3D_EINVAL;
+        {
+            FILE *tf = fopen("average_thermodynamic_quantities.dat", "r");
+            if (!tf || fscanf(tf, "%lf", &T_avg) != 1) DIE("Error opening average thermodynamic file");
+            fclose(tf);
+        }
+        is3d_feqmod_tables fq{};
+        fq.n_gla = n_pts;
+        fq.root1 = groot.data() + n_pts; fq.weight1 = gweight.data() + n_pts;
+        fq.root2 = groot.data() + 2 * (size_t)n_pts; fq.weight2 = gweight.data() + 2 * (size_t)n_pts;
+        fq.n_pdg = npdg; fq.pdg_mass = pmass.data(); fq.pdg_degeneracy = pg.data(); fq.pdg_sign = ps.data();
+        fq.T_avg = T_avg; fq.deta_min = deta_min; fq.mass_pion0 = mass_pion0;
+        rc = is3d_smooth_spectra_feqmod(&cells, &sp, &grid, &df, &fq, &opts, dN.data(), &st);
+    } else {
+        rc = is3d_smooth_spectra(&cells, &sp, &grid, &df, &opts, dN.data(), &st);
+    }
+    if (rc) DIE("is3d_smooth_spectra failed (%d): %s", rc, is3d_last_error());
+    if (feqmod) printf("\nfeqmod breaks down for %lld cells\n\n", (long long)st.n_cells_breakdown);   // smooth_kernels.cpp:989
+    double t2 = now_s();
+    if (is3d_write_results("results", dimension, sp.n, mcid.data(), grid.n_pT, pT.data(), pTw.data(), grid.n_phi, phi.data(),
+                           phiw.data(), grid.n_y, y.data(), dN.data()))
+        DIE("%s", is3d_last_error());
+    double t3 = now_s();
+    printf("species classes evaluated: %d of %d; cells skipped (u.dsigma <= 0): %lld\n", st.n_classes, sp.n, (long long)st.n_cells_skipped);
+    printf("device time: prep %.3f ms, main %.3f ms (kernel variant %d), finalize %.3f ms; h2d %.3f ms, d2h %.3f ms\n", st.ms_prep,
+           st.ms_main, st.kernel_variant, st.ms_finalize, st.ms_h2d, st.ms_d2h);
+    printf("wall: read %.3f s, spectra %.3f s, write %.3f s\n", t1 - t0, t2 - t1, t3 - t2);
+    if (res) {
+        res->operation = 1; res->n_species = sp.n; res->n_spectrum = (int64_t)dN.size();
+        res->spectrum = (double *)malloc(sizeof(double) * dN.size());
+        res->mc_id = (int64_t *)malloc(sizeof(int64_t) * (size_t)sp.n);
+        res->mass = (double *)malloc(sizeof(double) * (size_t)sp.n);
+        if (!res->spectrum || !res->mc_id || !res->mass) return is3d::set_error(IS3D_ENOMEM, "out of memory for the spectrum");
+        memcpy(res->spectrum, dN.data(), sizeof(double) * dN.size());
+        memcpy(res->mc_id, mcid.data(), sizeof(int64_t) * (size_t)sp.n);
+        memcpy(res->mass, mass.data(), sizeof(double) * (size_t)sp.n);
+    }
+    printf("Done calculating particle spectra. Output stored in results folder. Goodbye!\n");
+    return IS3D_OK;
+}
+
+extern "C" int is3d_run_particlization(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
+                                       is3d_run_result *result)
+{
+    if (result) memset(result, 0, sizeof *result);
+    return run_impl(surface, x, y, kernel_variant, result);
+}
+
+extern "C" void is3d_run_result_free(is3d_run_result *r)
+{
+    if (!r) return;
+    free(r->particles); free(r->mc_id); free(r->mass); free(r->spectrum);
+    memset(r, 0, sizeof *r);
+}

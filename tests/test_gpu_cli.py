@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import refformat
-from conftest import relerr
+from conftest import ROOT, relerr
 from is3d_amd import api, inputs, synth
 from oracle import oracle  # the checker
 
@@ -162,3 +162,39 @@ def test_cli_sampler(tmp_path, fx, dim, oversample):
     assert np.array_equal(rows[:, 0].astype(np.int64), np.array(ids)[ref["species"]])
     for col, f in enumerate(["t", "x", "y", "z", "E", "px", "py", "pz"], start=1):
         assert np.allclose(rows[:, col], ref[f], rtol=1e-11, atol=1e-13), f
+
+
+@pytest.mark.parametrize("operation", [2, 1])
+def test_embedding_class(tmp_path, fx, operation):
+    """include/iS3D_amd.hpp: the reference's embedding API (class IS3D: read_fo_surf_from_memory + run_particlization(0) +
+    final_particles_, iS3D.h:19-96) from a C++ host compiled with g++ against the C ABI; surface handed over in memory, in
+    GeV units; the sampled list equals the oracle's, the spectrum the oracle's spectrum."""
+    ids = [211, 321, 2212, -2212]
+    cells = synth.synth_surface(3000, 3, seed=95)
+    root = refformat.make_run_dir(str(tmp_path / "run"), synth.synth_surface(2, 3, seed=1), ids,
+                                  dict(operation=operation, dimension=3, df_mode=2, sampler_seed=23))
+    os.remove(os.path.join(root, "input", "surface.dat"))          # the in-memory path must not need it
+    exe = str(tmp_path / "embed_main")
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "embed_main.cpp"), "-o", exe,
+                           "-L", os.path.dirname(api.LIB_PATH), "-lis3d_amd", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH)])
+    cols = ["tau", "x", "y", "eta", "dat", "dax", "day", "dan", "E", "T", "P", "ux", "uy", "un", "pixx", "pixy", "pixn", "piyy", "piyn", None, "bulkPi"]
+    tab = np.stack([cells[c] if c else np.full(3000, 7.0) for c in cols], axis=1)      # pinn: junk, must be ignored
+    np.savetxt(str(tmp_path / "surf21.txt"), tab, fmt="%.17g")
+    r = subprocess.run([exe, str(tmp_path / "surf21.txt")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    assert "Reading in freezeout surface from memory" in r.stdout
+    sp = inputs.species(ids)
+    if operation == 2:
+        ref, _ = oracle.sample_particles(cells, sp, fx["df"], inputs.feqmod_tables(0.15), dict(dimension=3, df_mode=2), n_events=1, seed=23, y_cut=0.7)
+        rows = np.array([[float(v) for v in ln.split()[1:]] for ln in r.stdout.split("\n") if ln.startswith("P ")]).reshape(-1, 14)
+        assert len(rows) == len(ref["E"]) > 5 and "EVENTS 1 SPECTRUM 0" in r.stdout
+        assert np.array_equal(rows[:, 1].astype(int), ref["species"]) and np.array_equal(rows[:, 2].astype(int), np.array(ids)[ref["species"]])
+        assert np.array_equal(rows[:, 3], sp["mass"][ref["species"]])
+        for col, f in enumerate(["tau", "x", "y", "eta", "t", "z", "E", "px", "py", "pz"], start=4):
+            assert np.allclose(rows[:, col], ref[f], rtol=1e-11, atol=1e-13), f
+        assert os.path.getsize(os.path.join(root, "results", "particle_list_osc.dat")) > 0
+    else:
+        want = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=2))
+        line = [ln for ln in r.stdout.split("\n") if ln.startswith("SUM ")][0].split()
+        assert "SPECTRUM %d" % want.size in r.stdout
+        assert abs(float(line[1]) / want.sum() - 1) < 1e-9 and abs(float(line[3]) / want[0] - 1) < 1e-9
