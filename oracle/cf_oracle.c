@@ -1099,7 +1099,7 @@ static lrf_mom sample_momentum(rng_stream *g, long *acceptances, long *samples, 
 }
 
 typedef struct {
-    int live;
+    int live, breakdown;
     double tau, x, y, eta, ut, ux, uy, un, T;
     double Xt, Xx, Xy, Xn, Yx, Yy, Zt, Zn;
     double dst, dsx, dsy, dsz, ds_max;
@@ -1107,31 +1107,90 @@ typedef struct {
     double bulkPi, dn_tot;
     df_coeff df;
     double shear14_coeff;
+    double T_mod, shear_mod, bulk_mod;             /* df_mode 3, 4 */
+    double delta_lambda, delta_z;                  /* df_mode 4 */
 } sampler_cell;
+
+typedef struct {
+    int n_events;
+    int fast;                 /* fast = 1: species densities at the surface-average temperature (:1044-1056) */
+    uint64_t seed;
+    double y_cut;
+    long first_cell;
+    double T_avg;             /* Plasma::temperature as read back from average_thermodynamic_quantities.dat (fast densities) */
+    double T_avg_switch;      /* the same after `if (SET_T_SWITCH) temperature = T_SWITCH` (:856): the fast breakdown test */
+} oracle_sampler_opts;
+
+/* rescale_momentum (:619-650), no diffusion */
+static lrf_mom rescale_momentum(lrf_mom q, double mass_squared, const sampler_cell *c)
+{
+    lrf_mom r;
+    r.px = (1.0 + c->bulk_mod) * q.px + c->shear_mod * (c->pixx * q.px + c->pixy * q.py + c->pixz * q.pz);
+    r.py = (1.0 + c->bulk_mod) * q.py + c->shear_mod * (c->pixy * q.px + c->piyy * q.py + c->piyz * q.pz);
+    r.pz = (1.0 + c->bulk_mod) * q.pz + c->shear_mod * (c->pixz * q.px + c->piyz * q.py + c->pizz * q.pz);
+    r.E = sqrt(mass_squared + r.px * r.px + r.py * r.py + r.pz * r.pz);
+    return r;
+}
 
 #define ORACLE_PARTICLE_DOUBLES 14
 /* out[i * 14 + ...] = {event, cell, species index, tau, x, y, eta, t, z, E, px, py, pz, rapidity}.
- * first_cell: global index of cells[0] (a shard of a larger surface samples exactly the hadrons the whole surface would give
- * its cells).  stats = {momentum samples, acceptances, hadrons drawn (before the keep test)}.  Returns the number of kept
- * particles (all of them are counted; only the first `capacity` are stored), or < 0: -1 T outside the table,
- * -2 df_mode, -3 dimension, -4 include_baryon. */
+ * so->first_cell: global index of cells[0] (a shard of a larger surface samples exactly the hadrons the whole surface would give
+ * its cells).  q: Gauss-Laguerre alpha = 2, PDG list, deta_min, mass_pion0 -- df_mode 3, 4 only (may be NULL otherwise).
+ * stats = {momentum samples, acceptances, hadrons drawn (before the keep test), cells where feqmod breaks down}.  Returns
+ * the number of kept particles (all of them are counted; only the first `capacity` are stored), or < 0: -1 T (or bulkPi/P)
+ * outside a table, -2 df_mode, -3 dimension, -4 include_baryon. */
 long oracle_sample_particles(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
                              const cell_arrays *a, const double *x_fo, const double *y_fo, const oracle_df_tables *t,
-                             int n_gla, const double *root1, const double *weight1, const oracle_opts *o, int n_events,
-                             uint64_t seed, double y_cut, long first_cell, double *out, long capacity, long *stats)
+                             int n_gla, const double *root1, const double *weight1, const oracle_feqmod_tables *q,
+                             const oracle_opts *o, const oracle_sampler_opts *so, double *out, long capacity, long *stats)
 {
     if (o->dimension != 2 && o->dimension != 3) return -3;
-    if (o->df_mode != 1 && o->df_mode != 2) return -2;
+    if (o->df_mode < 1 || o->df_mode > 4) return -2;
+    if (o->df_mode >= 3 && !q) return -2;
     if (o->include_baryon) return -4;
+    const int DF_MODE = o->df_mode, n_events = so->n_events;
+    const uint64_t seed = so->seed;
+    const long first_cell = so->first_cell;
     const double two_pi2_hbarC3 = 2.0 * pow(M_PI, 2) * pow(ORACLE_HBARC, 3);
     double y_max = 0.5;                                                       /* :837-838 */
-    if (o->dimension == 2) y_max = y_cut;
+    if (o->dimension == 2) y_max = so->y_cut;
     const int n = t->n_T;
     double *s = (double *)calloc((size_t)5 * n, sizeof(double));
     init_splines(t, s);
+    const double *sF = s + 2 * n, *sbb = s + 3 * n, *sbp = s + 4 * n;
+    jonah_tab *J = (jonah_tab *)malloc(sizeof(jonah_tab));
+    if (DF_MODE == 4) compute_jonah(q, J);
     sampler_cell *cs = (sampler_cell *)calloc((size_t)(FO_length > 0 ? FO_length : 1), sizeof(sampler_cell));
     double *dn_list = (double *)malloc(sizeof(double) * (size_t)npart * (size_t)(FO_length > 0 ? FO_length : 1));
     int err = 0;
+    long n_breakdown = 0;
+    /* fast mode: Deltaf_Data::compute_particle_densities at the surface-average temperature (deltafReader.cpp:536-650) */
+    double *Equilibrium_Density = (double *)calloc((size_t)npart, sizeof(double)), *Bulk_Density = (double *)calloc((size_t)npart, sizeof(double));
+    double F_avg = 0.0, betabulk_avg = 0.0;
+    if (so->fast) {
+        const double T = so->T_avg, T4 = T * T * T * T;
+        double v, F = 0.0, betabulk = 1.0;
+        if (DF_MODE == 2 || DF_MODE == 3) {
+            if (oracle_cspline_eval(n, t->T, t->F, sF, T, &v)) err = -1; else F = v * T;
+            if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, T, &v)) err = -1; else betabulk = v * T4;
+        }
+        for (int ip = 0; ip < npart && !err; ip++) {
+            double mbar = Mass[ip] / T;
+            double neq_fact = Degeneracy[ip] * pow(T, 3) / two_pi2_hbarC3;
+            double neq = neq_fact * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+            Equilibrium_Density[ip] = neq;
+            if (DF_MODE == 2 || DF_MODE == 3) {
+                double J20_fact = Degeneracy[ip] * pow(T, 4) / two_pi2_hbarC3;
+                double J20 = J20_fact * gauss_thermal(J20_int, q ? q->root2 : root1, q ? q->weight2 : weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+                Bulk_Density[ip] = (neq + (J20 * F / pow(T, 2))) / betabulk;
+            }
+        }
+        if (DF_MODE == 3 && !err) {                                           /* :862-867: df coefficients at (Tavg with T_switch) */
+            const double Ts = so->T_avg_switch, Ts4 = Ts * Ts * Ts * Ts;
+            if (oracle_cspline_eval(n, t->T, t->F, sF, Ts, &v)) err = -1; else F_avg = v * Ts;
+            if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, Ts, &v)) err = -1; else betabulk_avg = v * Ts4;
+        }
+    }
     for (long ic = 0; ic < FO_length && !err; ic++) {
         sampler_cell *c = &cs[ic];
         c->live = 0;
@@ -1154,7 +1213,28 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
             pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
         }
         double bulkPi = o->include_bulk_deltaf ? a->bulkPi[ic] : 0.0;
-        if (eval_df(t, s, s + n, s + 2 * n, s + 3 * n, s + 4 * n, o->df_mode, T, &c->df)) { err = -1; break; }
+        if (DF_MODE == 4) {                                                   /* :966-972 (<= and >= here, unlike the smooth kernel) */
+            if (bulkPi <= -P) bulkPi = -(1.0 - 1.e-5) * P;
+            else if (bulkPi / P >= J->bulkPi_over_Peq_max) bulkPi = P * (J->bulkPi_over_Peq_max - 1.e-5);
+        }
+        /* evaluate_df_coefficients (deltafReader.cpp:325-395) */
+        double lambda = 0.0, z = 0.0, v, T4 = T * T * T * T;
+        memset(&c->df, 0, sizeof c->df);
+        if (DF_MODE <= 2) {
+            if (eval_df(t, s, s + n, sF, sbb, sbp, DF_MODE, T, &c->df)) { err = -1; break; }
+        } else if (DF_MODE == 3) {
+            if (eval_df(t, s, s + n, sF, sbb, sbp, 2, T, &c->df)) { err = -1; break; }
+        } else {
+            double lambda_squared = 0.0;
+            if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->lambda_squared, J->c_lambda, bulkPi / P, &lambda_squared)) { err = -1; break; }
+            if (bulkPi < 0.0) lambda = -sqrt(lambda_squared);
+            else if (bulkPi > 0.0) lambda = sqrt(lambda_squared);
+            if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->z, J->c_z, bulkPi / P, &z)) { err = -1; break; }
+            if (oracle_cspline_eval(n, t->T, t->betapi, sbp, T, &v)) { err = -1; break; }
+            c->df.betapi = v * T4;
+            c->delta_lambda = bulkPi / (5.0 * c->df.betapi - 3.0 * P * (E + P) / E);
+            c->delta_z = -3.0 * c->delta_lambda * P / E;
+        }
         c->shear14_coeff = 2.0 * T * T * (E + P);                             /* deltafReader.cpp:344 */
         /* Milne_Basis */
         double sinhL = tau * un / utperp, coshL = ut / utperp;
@@ -1179,13 +1259,44 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
         c->tau = tau; c->x = x_fo ? x_fo[ic] : 0.0; c->y = y_fo ? y_fo[ic] : 0.0;
         c->eta = (o->dimension == 3) ? a->eta[ic] : 0.0;
         c->ut = ut; c->ux = ux; c->uy = uy; c->un = un; c->T = T; c->bulkPi = bulkPi;
-        /* max_particle_number, df_mode 1 / 2: 2 n_eq (:282-303) */
-        double neq_fact = T * T * T / two_pi2_hbarC3, dn_tot = 0.0;
+        /* modified temperature and rescaling coefficients (:1017-1036), detA, breakdown (:1038) */
+        c->T_mod = T; c->shear_mod = 0.0; c->bulk_mod = 0.0;
+        const double F = c->df.F, betabulk = c->df.betabulk, betapi = c->df.betapi;
+        if (DF_MODE == 3) { c->T_mod = T + bulkPi * F / betabulk; c->shear_mod = 0.5 / betapi; c->bulk_mod = bulkPi / (3.0 * betabulk); }
+        else if (DF_MODE == 4) { c->shear_mod = 0.5 / betapi; c->bulk_mod = lambda; }
+        c->breakdown = 0;
+        if (DF_MODE == 3) {
+            double Axx = 1.0 + c->pixx * c->shear_mod + c->bulk_mod, Axy = c->pixy * c->shear_mod, Axz = c->pixz * c->shear_mod;
+            double Ayy = 1.0 + c->piyy * c->shear_mod + c->bulk_mod, Ayz = c->piyz * c->shear_mod, Azz = 1.0 + c->pizz * c->shear_mod + c->bulk_mod;
+            double detA = Axx * (Ayy * Azz - Ayz * Ayz) - Axy * (Axy * Azz - Ayz * Axz) + Axz * (Axy * Ayz - Ayy * Axz);
+            double Tb = T, Fb = F, bbb = betabulk;
+            if (so->fast) { Tb = so->T_avg_switch; Fb = F_avg; bbb = betabulk_avg; }             /* emissionfunction.cpp:114-119 */
+            double nf = Tb * Tb * Tb / two_pi2_hbarC3, Jf = Tb * nf, mbar_pion0 = q->mass_pion0 / Tb;
+            double neq_pion0 = nf * gauss_thermal(neq_int, root1, weight1, n_gla, mbar_pion0, 0., 0., -1.);
+            double J20_pion0 = Jf * gauss_thermal(J20_int, q->root2, q->weight2, n_gla, mbar_pion0, 0., 0., -1.);
+            double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * Fb / Tb / Tb) / bbb;
+            if (detA <= q->deta_min || (neq_pion0 + dn_pion0) < 0.0) { c->breakdown = 1; n_breakdown++; }
+        }
+        /* mean number of each species: fast_max_particle_number (:239-280) / max_particle_number (:282-359) */
+        double neq_fact = T * T * T / two_pi2_hbarC3, J20_fact = T * neq_fact, dn_tot = 0.0;
         for (int ip = 0; ip < npart; ip++) {
-            double mbar = Mass[ip] / T;
-            double equilibrium_density = neq_fact * Degeneracy[ip] * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
-            dn_list[(size_t)ic * npart + ip] = 2.0 * equilibrium_density;
-            dn_tot += dn_list[(size_t)ic * npart + ip];
+            double dn;
+            if (so->fast) {
+                if (DF_MODE <= 2 || c->breakdown) dn = 2.0 * Equilibrium_Density[ip];
+                else if (DF_MODE == 3) dn = Equilibrium_Density[ip] + bulkPi * Bulk_Density[ip];
+                else dn = z * Equilibrium_Density[ip];
+            } else {
+                double mbar = Mass[ip] / T;
+                double equilibrium_density = neq_fact * Degeneracy[ip] * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+                if (DF_MODE <= 2 || c->breakdown) dn = 2.0 * equilibrium_density;
+                else if (DF_MODE == 3) {
+                    double J20 = J20_fact * Degeneracy[ip] * gauss_thermal(J20_int, q->root2, q->weight2, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+                    double bulk_density = (equilibrium_density + (J20 * F / T / T)) / betabulk;
+                    dn = equilibrium_density + bulkPi * bulk_density;
+                } else dn = z * equilibrium_density;
+            }
+            dn_list[(size_t)ic * npart + ip] = dn;
+            dn_tot += dn;
         }
         dn_tot *= (2.0 * y_max * c->ds_max);                                  /* :1077 */
         c->dn_tot = dn_tot;
@@ -1216,22 +1327,29 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
                 double cum = 0.0;
                 for (int ip = 0; ip < npart; ip++) { cum += dn[ip]; if (ut_ < cum) { chosen = ip; break; } }
                 double mass = Mass[chosen], mass_squared = mass * mass, sign = Sign[chosen];
-                lrf_mom p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T);
-                /* compute_df_weight :361-453 (baryon terms vanish) */
-                double pimunu_pmu_pnu = p.px * p.px * c->pixx + p.py * p.py * c->piyy + p.pz * p.pz * c->pizz
-                                      + 2.0 * (p.px * p.py * c->pixy + p.px * p.pz * c->pixz + p.py * p.pz * c->piyz);
-                double feqbar = 1.0 - sign / (exp(p.E / c->T) + sign), df_tot;
-                if (o->df_mode == 1) {
-                    double df_shear = pimunu_pmu_pnu / c->shear14_coeff;
-                    double df_bulk = ((c->df.c0 - c->df.c2) * mass_squared + ((4.0 * c->df.c2 - c->df.c0) * p.E) * p.E) * c->bulkPi;
-                    df_tot = feqbar * (df_shear + df_bulk);
-                } else {
-                    double df_shear = pimunu_pmu_pnu / (2.0 * p.E * c->df.betapi * c->T);
-                    double df_bulk = (c->df.F * p.E / c->T / c->T + (p.E - mass_squared / p.E) / (3.0 * c->T)) * c->bulkPi / c->df.betabulk;
-                    df_tot = feqbar * (df_shear + df_bulk);
+                lrf_mom p;
+                double w_visc = 1.0;
+                if (DF_MODE <= 2 || c->breakdown) {                           /* :1100-1110, switch_to_linear_df */
+                    p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T);
+                    /* compute_df_weight :361-453 (baryon terms vanish); df_mode 3 takes the Chapman-Enskog branch */
+                    double pimunu_pmu_pnu = p.px * p.px * c->pixx + p.py * p.py * c->piyy + p.pz * p.pz * c->pizz
+                                          + 2.0 * (p.px * p.py * c->pixy + p.px * p.pz * c->pixz + p.py * p.pz * c->piyz);
+                    double feqbar = 1.0 - sign / (exp(p.E / c->T) + sign), df_tot;
+                    if (DF_MODE == 1) {
+                        double df_shear = pimunu_pmu_pnu / c->shear14_coeff;
+                        double df_bulk = ((c->df.c0 - c->df.c2) * mass_squared + ((4.0 * c->df.c2 - c->df.c0) * p.E) * p.E) * c->bulkPi;
+                        df_tot = feqbar * (df_shear + df_bulk);
+                    } else {
+                        double df_shear = pimunu_pmu_pnu / (2.0 * p.E * c->df.betapi * c->T);
+                        double df_bulk = (c->df.F * p.E / c->T / c->T + (p.E - mass_squared / p.E) / (3.0 * c->T)) * c->bulkPi / c->df.betabulk;
+                        df_tot = feqbar * (df_shear + df_bulk);
+                    }
+                    df_tot = fmax(-1.0, fmin(df_tot, 1.0));
+                    w_visc = (1.0 + df_tot) / 2.0;
+                } else {                                                      /* :1112-1131: modified equilibrium, no viscous weight */
+                    p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T_mod);
+                    p = rescale_momentum(p, mass_squared, c);
                 }
-                df_tot = fmax(-1.0, fmin(df_tot, 1.0));
-                double w_visc = (1.0 + df_tot) / 2.0;
                 /* boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51) */
                 double ptau = p.E * c->ut + p.px * c->Xt + p.pz * c->Zt;
                 double plx = p.E * c->ux + p.px * c->Xx + p.py * c->Yx;
@@ -1256,14 +1374,14 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
                     yp = 0.5 * log((Elab + pz) / (Elab - pz));
                 }
                 if (kept < capacity) {
-                    double *q = out + (size_t)kept * ORACLE_PARTICLE_DOUBLES;
-                    q[0] = (double)ievent; q[1] = (double)(first_cell + ic); q[2] = (double)chosen; q[3] = c->tau; q[4] = c->x; q[5] = c->y; q[6] = eta;
-                    q[7] = c->tau * ch; q[8] = c->tau * sh; q[9] = Elab; q[10] = plx; q[11] = ply; q[12] = pz; q[13] = yp;
+                    double *qo = out + (size_t)kept * ORACLE_PARTICLE_DOUBLES;
+                    qo[0] = (double)ievent; qo[1] = (double)(first_cell + ic); qo[2] = (double)chosen; qo[3] = c->tau; qo[4] = c->x; qo[5] = c->y; qo[6] = eta;
+                    qo[7] = c->tau * ch; qo[8] = c->tau * sh; qo[9] = Elab; qo[10] = plx; qo[11] = ply; qo[12] = pz; qo[13] = yp;
                 }
                 kept++;
             }
         }
-    if (stats) { stats[0] = samples; stats[1] = acceptances; stats[2] = drawn; }
-    free(cs); free(dn_list); free(s);
+    if (stats) { stats[0] = samples; stats[1] = acceptances; stats[2] = drawn; stats[3] = n_breakdown; }
+    free(cs); free(dn_list); free(s); free(J); free(Equilibrium_Density); free(Bulk_Density);
     return err ? err : kept;
 }

@@ -250,9 +250,17 @@ def rng_uniforms(seed, stream, cell, event, n):
     return out
 
 
-def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.5, capacity=None, first_cell=0):
-    """sample_dN_pTdpTdphidy (df_mode 1 | 2) with the counter-based RNG defined in cf_oracle.c.  gla: dict with root1, weight1
-    (is3d_amd.inputs.feqmod_tables() has them).  cells may carry x, y.  Returns (dict of arrays per PARTICLE_FIELDS, stats dict)."""
+class _SamplerOpts(C.Structure):
+    _fields_ = [("n_events", C.c_int), ("fast", C.c_int), ("seed", C.c_uint64), ("y_cut", C.c_double), ("first_cell", C.c_long),
+                ("T_avg", C.c_double), ("T_avg_switch", C.c_double)]
+
+
+def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.5, capacity=None, first_cell=0, fq=None, fast=0,
+                     T_avg=0.0, T_avg_switch=None):
+    """sample_dN_pTdpTdphidy (df_mode 1..4) with the counter-based RNG defined in cf_oracle.c.  gla: dict with root1, weight1
+    (is3d_amd.inputs.feqmod_tables() has them); fq: the feqmod tables (df_mode 3, 4, and the alpha = 2 nodes of fast mode);
+    fast = 1: species densities at T_avg (breakdown test at T_avg_switch, default T_avg).  cells may carry x, y.
+    Returns (dict of arrays per PARTICLE_FIELDS, stats dict)."""
     o = dict(DEFAULT_OPTS)
     o.update(opts)
     n = len(cells["tau"])
@@ -268,18 +276,24 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
     npart = len(sp["mass"])
     st, keep_df = _df_struct(df)
     r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
+    if fq is None and (int(o["df_mode"]) >= 3 or fast):
+        fq = gla
+    fs, keep_fq = _feqmod_struct(fq) if fq is not None else (None, None)
     os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
+    so = _SamplerOpts(int(n_events), int(fast), int(seed), float(y_cut), int(first_cell), float(T_avg),
+                      float(T_avg if T_avg_switch is None else T_avg_switch))
     L = lib()
     L.oracle_sample_particles.restype = C.c_long
     L.oracle_sample_particles.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, C.POINTER(_CellArrays), _dp, _dp, C.POINTER(_DfTables), C.c_int,
-                                          _dp, _dp, C.POINTER(_Opts), C.c_int, C.c_uint64, C.c_double, C.c_long, _dp, C.c_long, C.POINTER(C.c_long)]
-    stats = (C.c_long * 3)()
+                                          _dp, _dp, C.POINTER(_FeqmodTables), C.POINTER(_Opts), C.POINTER(_SamplerOpts), _dp, C.c_long,
+                                          C.POINTER(C.c_long)]
+    stats = (C.c_long * 4)()
     cap = int(capacity) if capacity is not None else 0
     while True:
         out = np.zeros((max(cap, 1), len(PARTICLE_FIELDS)))
         rc = L.oracle_sample_particles(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), C.byref(ca),
                                        _p(xs) if xs is not None else None, _p(ys) if ys is not None else None, C.byref(st), len(r1), _p(r1),
-                                       _p(w1), C.byref(os_), int(n_events), int(seed), float(y_cut), int(first_cell), _p(out), cap, stats)
+                                       _p(w1), C.byref(fs) if fs is not None else None, C.byref(os_), C.byref(so), _p(out), cap, stats)
         if rc < 0:
             raise RuntimeError("oracle_sample_particles failed rc=%d" % rc)
         if rc <= cap or capacity is not None:
@@ -289,4 +303,4 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
     res = {f: out[:k, i].copy() for i, f in enumerate(PARTICLE_FIELDS)}
     for f in ("event", "cell", "species"):
         res[f] = res[f].astype(np.int64)
-    return res, dict(n_kept=int(rc), samples=int(stats[0]), acceptances=int(stats[1]), drawn=int(stats[2]))
+    return res, dict(n_kept=int(rc), samples=int(stats[0]), acceptances=int(stats[1]), drawn=int(stats[2]), breakdown=int(stats[3]))

@@ -102,4 +102,57 @@ def test_sampler_is_a_pure_function_of_seed_cell_event(fx):
     sel = (a["cell"] >= 40) & (a["cell"] < 90) & (a["event"] < 4)
     assert sel.sum() > 0 and all(np.array_equal(d[k], a[k][sel]) for k in a)
     with pytest.raises(RuntimeError):
-        oracle.sample_particles(cells, sp, fx["df"], gla, dict(dimension=3, df_mode=4), n_events=1, seed=1)
+        oracle.sample_particles(cells, sp, fx["df"], gla, dict(dimension=3, df_mode=5), n_events=1, seed=1)
+
+
+@pytest.mark.parametrize("df_mode", [4, 3])
+def test_modified_equilibrium_sampler_reproduces_the_feqmod_spectrum(fx, df_mode):
+    """df_mode 3 / 4: momenta drawn at T_mod and rescaled p = A p_mod (rescale_momentum, sampling_kernels.cpp:619-650), mean
+    numbers n_linear / z n_eq (max_particle_number :306-348), no viscous weight; cells where feqmod breaks down (df_mode 3)
+    fall back to the linear delta-f with its weight.  Yields and <pT> against the smooth feqmod restatement."""
+    ncell = 160
+    cells = synth.synth_surface(ncell, 3, seed=720 + df_mode)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["eta"] *= 0.25
+    if df_mode == 3:
+        cells["bulkPi"][::8] = -5.0 * cells["P"][::8]          # breakdown cells
+    sp = fx["pikp"]
+    o = dict(dimension=3, df_mode=df_mode)
+    fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    g = fx["grid_w"]
+    smooth, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], fx["df"], fq, o)
+    s4 = smooth.reshape(len(g["y"]), len(g["phi"]), len(g["pT"]), 3)
+    dndy = np.einsum("j,i,kjis->ks", g["phi_w"], g["pT_w"], s4)
+    pt1 = np.einsum("j,i,kjis->ks", g["phi_w"], g["pT_w"] * g["pT"], s4)
+    h = g["y"][1] - g["y"][0]
+    N_smooth, pT_smooth = dndy.sum(axis=0) * h, pt1.sum(axis=0) / dndy.sum(axis=0)
+    n_events = int(np.ceil(60000.0 / N_smooth.sum()))
+    p, st = oracle.sample_particles(cells, sp, fx["df"], fq, o, n_events=n_events, seed=20260005, fq=fq)
+    assert st["breakdown"] == nb and (nb > 0) == (df_mode == 3)
+    for s in range(3):
+        sel = p["species"] == s
+        want = N_smooth[s] * n_events
+        assert abs(sel.sum() - want) < 4.5 * np.sqrt(want), (s, sel.sum(), want)
+        pT = np.hypot(p["px"][sel], p["py"][sel])
+        assert abs(pT.mean() - pT_smooth[s]) < 4.5 * pT.std() / np.sqrt(sel.sum()), (s, pT.mean(), pT_smooth[s])
+    mass = sp["mass"][p["species"]]
+    assert np.allclose(p["E"] ** 2 - p["px"] ** 2 - p["py"] ** 2 - p["pz"] ** 2, mass ** 2, rtol=0, atol=2e-9 * p["E"] ** 2)
+
+
+@pytest.mark.parametrize("df_mode", [2, 4])
+def test_fast_mode_on_an_isothermal_surface(fx, df_mode):
+    """fast = 1 takes the species densities at the surface-average temperature (sampling_kernels.cpp:1044-1056,
+    deltafReader.cpp:536-650); on an isothermal surface that is the same number up to rounding, so the list is the one of the
+    regular mode."""
+    cells = synth.synth_surface(200, 3, seed=733)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["T"][:] = 0.151
+    sp = fx["pikp"]
+    fq = inputs.feqmod_tables(0.151)
+    o = dict(dimension=3, df_mode=df_mode)
+    a, sa = oracle.sample_particles(cells, sp, fx["df"], fq, o, n_events=200, seed=5, fq=fq)
+    b, sb = oracle.sample_particles(cells, sp, fx["df"], fq, o, n_events=200, seed=5, fq=fq, fast=1, T_avg=0.151)
+    assert sa["n_kept"] == sb["n_kept"] > 50 and all(np.array_equal(a[k], b[k]) for k in a)
+    # a different average temperature changes the mean numbers (and with them the list)
+    c, sc = oracle.sample_particles(cells, sp, fx["df"], fq, o, n_events=200, seed=5, fq=fq, fast=1, T_avg=0.140)
+    assert sc["drawn"] < sb["drawn"]
