@@ -227,7 +227,7 @@ void is3d_plan_destroy(is3d_plan *plan);
 /* ---------------------------------------------------------------------------------------------
  * Particle sampler (operation = 2): replaces EmissionFunctionArray::sample_dN_pTdpTdphidy
  * (src/cpp/emissionfunction.h:208-210, emissionfunction_sampling_kernels.cpp:833-1225, call sites emissionfunction.cpp:1543,
- * :1606) for viscous hydro with a linear delta-f (df_mode 1, 2), include_baryon = 0, fast = 0.  The reference's serial
+ * :1606) for viscous hydro, df_mode 1-4, include_baryon = 0, fast = 0 | 1.  The reference's serial
  * std::default_random_engine streams are replaced by counter-based Philox4x32-10 streams keyed by (seed, stream, global cell
  * index, event) -- same five stream roles and the same distributions; particle lists agree with the reference statistically,
  * not draw by draw (the construction is written out in cf_sampler.hip and DESIGN.md section 3c).
@@ -248,6 +248,12 @@ typedef struct {
     int64_t first_cell;                 /* global index of cells[0]: a shard of a surface samples what the whole surface would */
     const double *x, *y;                /* cell positions x_fo, y_fo copied into the particles; may be NULL */
     const double *root1, *weight1;      /* Gauss-Laguerre alpha = 1 (equilibrium densities, max_particle_number) */
+    const is3d_feqmod_tables *feqmod;   /* df_mode 3, 4 (and fast = 1 with df_mode 2): alpha = 2 nodes, PDG list, T_avg of the
+                                           Jonah tables, deta_min, mass_pion0; NULL otherwise */
+    int32_t fast, reserved;             /* FAST: species densities at the surface-average temperature (:1044-1056) */
+    double T_avg;                       /* fast: Plasma::temperature as read back from average_thermodynamic_quantities.dat */
+    double T_avg_switch;                /* fast, df_mode 3: the same after `if (SET_T_SWITCH) temperature = T_SWITCH` (:856);
+                                           0 = T_avg */
 } is3d_sampler_inputs;
 
 typedef struct {
@@ -255,10 +261,11 @@ typedef struct {
     int64_t n_hadrons_drawn;            /* sum of the Poisson numbers (before the flux / viscous keep test) */
     int64_t n_momentum_samples, n_acceptances;   /* "Momentum sampling efficiency" (:1224) */
     int32_t n_classes, reserved;
+    int64_t n_cells_breakdown;          /* df_mode 3: cells sampled with the linear delta-f instead (:1038) */
     double ms_h2d, ms_prep, ms_count, ms_fill;   /* device time: upload, densities + cell records, count pass + scan, fill pass */
 } is3d_sampler_stats;
 
-/* All pointers HOST memory; opts: dimension, df_mode (1 | 2), include_bulk_deltaf, include_shear_deltaf, device.  Particles
+/* All pointers HOST memory; opts: dimension, df_mode (1-4), include_bulk_deltaf, include_shear_deltaf, device.  Particles
  * come ordered by (event, cell, draw).  particles == NULL (or capacity 0): only *n_particles is computed.  If the buffer is
  * too small the first `capacity` particles are stored, *n_particles is the full count and IS3D_ENOMEM is returned. */
 int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
@@ -269,6 +276,17 @@ int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, 
  * then "mcid t x y z E px py pz" rows; particles ordered by event. */
 int is3d_write_particle_list_osc(const char *path, int32_t n_events, int64_t n_particles, const is3d_particle *particles,
                                  const int64_t *mc_id);
+
+/* test_sampler = 1: the binned self-consistency outputs (sample_dN_dy ... sample_dN_dX, sampling_kernels.cpp:31-152; writers
+ * emissionfunction.cpp:903-1257) from a particle list: <dir>/dN_dy/, dN_deta/, momentum_distribution/, vn/,
+ * spacetime_distribution/ (must exist), mean_yield.dat, yield_list.dat.  Bins = the parameters y_cut, y_bins, eta_cut, eta_bins,
+ * pT_lower_cut, pT_upper_cut, pT_bins, tau_min, tau_max, tau_bins, r_min, r_max, r_bins (emissionfunction.cpp:205-222). */
+typedef struct {
+    double y_cut, eta_cut, pT_lower_cut, pT_upper_cut, tau_min, tau_max, r_min, r_max;
+    int32_t y_bins, eta_bins, pT_bins, tau_bins, r_bins, reserved;
+} is3d_sampler_test_bins;
+int is3d_write_sampler_tests(const char *results_dir, const is3d_sampler_test_bins *bins, int32_t n_events, int32_t n_species,
+                             const int64_t *mc_id, int64_t n_particles, const is3d_particle *particles, double mean_yield);
 
 /* ---------------------------------------------------------------------------------------------
  * Driver: IS3D::run_particlization (src/cpp/iS3D.cpp:74-192; class IS3D, src/cpp/iS3D.h:19-96).  Reads iS3D_parameters.dat,

@@ -60,12 +60,14 @@ PARTICLE_DTYPE = np.dtype([("cell", "<i8"), ("event", "<i4"), ("species", "<i4")
 
 class SamplerInputs(C.Structure):
     _fields_ = [("n_events", C.c_int32), ("n_gla", C.c_int32), ("seed", C.c_uint64), ("y_cut", C.c_double), ("first_cell", C.c_int64),
-                ("x", _dp), ("y", _dp), ("root1", _dp), ("weight1", _dp)]
+                ("x", _dp), ("y", _dp), ("root1", _dp), ("weight1", _dp), ("feqmod", C.POINTER(FeqmodTables)), ("fast", C.c_int32),
+                ("reserved", C.c_int32), ("T_avg", C.c_double), ("T_avg_switch", C.c_double)]
 
 
 class SamplerStats(C.Structure):
     _fields_ = [("n_cells_skipped", C.c_int64), ("n_hadrons_drawn", C.c_int64), ("n_momentum_samples", C.c_int64),
-                ("n_acceptances", C.c_int64), ("n_classes", C.c_int32), ("reserved", C.c_int32), ("ms_h2d", C.c_double),
+                ("n_acceptances", C.c_int64), ("n_classes", C.c_int32), ("reserved", C.c_int32), ("n_cells_breakdown", C.c_int64),
+                ("ms_h2d", C.c_double),
                 ("ms_prep", C.c_double), ("ms_count", C.c_double), ("ms_fill", C.c_double)]
 
     def as_dict(self):
@@ -95,7 +97,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
-           "is3d_run_particlization", "is3d_run_result_free"]
+           "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests"]
 
 
 class Is3dError(RuntimeError):
@@ -396,9 +398,10 @@ def df_table_read_full(path):
     return T, B, v
 
 
-def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_cut=0.5, first_cell=0, capacity=None):
-    """is3d_sample_particles (the drop-in for sample_dN_pTdpTdphidy, df_mode 1 | 2).  cells: dict of host arrays (x, y optional);
-    gla: dict with root1, weight1.  Returns (numpy structured array of PARTICLE_DTYPE, stats dict); capacity = None sizes the
+def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_cut=0.5, first_cell=0, capacity=None, fq=None, fast=0,
+                     T_avg=0.0, T_avg_switch=0.0):
+    """is3d_sample_particles (the drop-in for sample_dN_pTdpTdphidy, df_mode 1-4).  cells: dict of host arrays (x, y optional);
+    gla: dict with root1, weight1; fq: the feqmod tables (df_mode 3, 4; fast mode with df_mode 2).  Returns (numpy structured array of PARTICLE_DTYPE, stats dict); capacity = None sizes the
     buffer from a count-only first call."""
     L = load()
     grid_dummy = dict(pT=[1.0], phi=[0.0], y=[0.0], eta=[0.0], eta_w=[1.0])
@@ -417,8 +420,10 @@ def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_c
     r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
     xs = _f64(cells["x"]) if cells.get("x") is not None else None
     ys = _f64(cells["y"]) if cells.get("y") is not None else None
+    fqs = _pack_feqmod(fq, keep) if fq is not None else None
     si = SamplerInputs(int(n_events), len(r1), int(seed), float(y_cut), int(first_cell), _p(xs) if xs is not None else None,
-                       _p(ys) if ys is not None else None, _p(r1), _p(w1))
+                       _p(ys) if ys is not None else None, _p(r1), _p(w1), C.pointer(fqs) if fqs is not None else None, int(fast), 0,
+                       float(T_avg), float(T_avg_switch))
     st = SamplerStats()
     cnt = C.c_int64(0)
     if capacity is None:
@@ -439,6 +444,25 @@ def write_particle_list_osc(path, n_events, particles, mc_id):
     ids = np.ascontiguousarray(mc_id, dtype=np.int64)
     _check(load().is3d_write_particle_list_osc(path.encode(), int(n_events), len(particles), particles.ctypes.data,
                                                ids.ctypes.data_as(C.POINTER(C.c_int64))))
+
+
+class SamplerTestBins(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ["y_cut", "eta_cut", "pT_lower_cut", "pT_upper_cut", "tau_min", "tau_max", "r_min", "r_max"]] + \
+               [(n, C.c_int32) for n in ["y_bins", "eta_bins", "pT_bins", "tau_bins", "r_bins", "reserved"]]
+
+
+def write_sampler_tests(results_dir, bins, n_events, mc_id, particles, mean_yield=0.0):
+    """is3d_write_sampler_tests: the test_sampler = 1 binned outputs from a particle list."""
+    particles = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+    ids = np.ascontiguousarray(mc_id, dtype=np.int64)
+    b = SamplerTestBins()
+    for k, v in bins.items():
+        setattr(b, k, v)
+    L = load()
+    L.is3d_write_sampler_tests.argtypes = [C.c_char_p, C.POINTER(SamplerTestBins), C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int64,
+                                           C.c_void_p, C.c_double]
+    _check(L.is3d_write_sampler_tests(results_dir.encode(), C.byref(b), int(n_events), len(ids), ids.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      len(particles), particles.ctypes.data, float(mean_yield)))
 
 
 def gla_read(path):

@@ -1,10 +1,11 @@
 // cf_sampler.hip -- particle sampler (operation = 2) on the device: SURVEY.md 8f rank 4.
 //
 // Device path of EmissionFunctionArray::sample_dN_pTdpTdphidy
-// (/root/reference/src/cpp/emissionfunction_sampling_kernels.cpp:833-1225) for viscous hydro with a linear delta-f
-// (df_mode 1, 2), include_baryon = 0, non-"fast" mode; helpers max_particle_number (:282-303), sample_momentum (:456-617),
-// compute_df_weight (:361-453), Milne_Basis / Surface_Element_Vector / boost_pimunu_to_lrf (viscous_correction.cpp:8-115),
-// boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51).
+// (/root/reference/src/cpp/emissionfunction_sampling_kernels.cpp:833-1225) for viscous hydro, df_mode 1-4 (linear delta-f with
+// its viscous weight; modified equilibrium with momentum rescaling), include_baryon = 0, regular and "fast" mode; helpers
+// max_particle_number / fast_max_particle_number (:239-359), sample_momentum (:456-617), compute_df_weight (:361-453),
+// rescale_momentum (:619-650), does_feqmod_breakdown (emissionfunction.cpp:109-150), Milne_Basis / Surface_Element_Vector /
+// boost_pimunu_to_lrf (viscous_correction.cpp:8-115), boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51).
 //
 // The reference walks the cells serially and feeds five std::default_random_engine streams through implementation-defined
 // std:: distributions; that order dependence cannot (and need not) be reproduced.  Here every (cell, event, stream) owns a
@@ -33,12 +34,14 @@
 #include "cf_device.h"
 #include "cf_math.h"
 #include "errors.h"
+#include "jonah.h"
 #include "spline.h"
 
 namespace is3d {
 
 struct SamplerCell {
-    double live;
+    double live, breakdown;
+    double T_mod, shear_mod, bulk_mod, z;          // df_mode 3, 4
     double tau, x, y, eta, ut, ux, uy, un, T;
     double Xt, Xx, Xy, Xn, Yx, Yy, Zt, Zn;
     double dst, dsx, dsy, dsz, ds_max;
@@ -61,10 +64,16 @@ struct SamplerParams {
     int32_t dim3, df_mode, include_bulk, include_shear;
     SplineDev spl;              // 14-moment: c0, c2; Chapman-Enskog: F, betabulk, betapi
     int32_t ngl;
-    const double *gl;           // [2][ngl]: root1, weight1
+    const double *gl;           // [4][ngl]: root1, weight1, root2, weight2 (alpha = 2 only for df_mode 3)
+    int32_t fast;               // species densities at the surface-average temperature (host arrays eqd, bkd)
+    const double *eqd, *bkd;    // [npart] Equilibrium_Density, Bulk_Density (deltafReader.cpp:536-650)
+    double T_sw, F_avg, betabulk_avg;   // fast breakdown test (emissionfunction.cpp:114-119)
+    int32_t nj;                 // Jonah tables (df_mode 4): abscissa, lambda^2, z and their spline c's
+    const double *jx, *jl2, *jz, *jcl, *jcz;
+    double bp_max, detA_min, mass_pion0;
     double y_max;
     uint64_t seed;
-    unsigned long long *status; // [0] min bad cell, [1] skipped, [2] momentum samples, [3] acceptances, [4] hadrons drawn
+    unsigned long long *status; // [0] min bad cell, [1] skipped, [2] momentum samples, [3] acceptances, [4] hadrons drawn, [5] breakdown cells
 };
 
 // ---- Philox4x32-10 streams ----
@@ -122,19 +131,54 @@ __device__ __forceinline__ double gt_neq(const double *root, const double *weigh
     return s;
 }
 
+__device__ __forceinline__ double gt_J20(const double *root, const double *weight, int n, double mbar, double sign)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
+        const double qstat = exp(Ebar) + sign;
+        s += weight[k] * (Ebar * exp(pbar + Ebar) / (qstat * qstat));
+    }
+    return s;
+}
+
+// GT[cell][class] = the n_eq integral; GT2 (df_mode 3, regular mode) = the J20 integral of n_linear
 __global__ void __launch_bounds__(256)
 cf_sampler_density(const double *__restrict__ T_fo, int64_t n_cells, SamplerSpecies sp, const double *__restrict__ gl, int ngl,
-                   double *__restrict__ GT)
+                   double *__restrict__ GT, double *__restrict__ GT2)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_cells * sp.ncls) return;
     const int64_t cell = idx / sp.ncls;
     const int c = (int)(idx - cell * sp.ncls);
-    GT[idx] = gt_neq(gl, gl + ngl, ngl, sp.cls_mass[c] / T_fo[cell], sp.cls_sign[c]);
+    const double mbar = sp.cls_mass[c] / T_fo[cell];
+    GT[idx] = gt_neq(gl, gl + ngl, ngl, mbar, sp.cls_sign[c]);
+    if (GT2) GT2[idx] = gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sp.cls_sign[c]);
+}
+
+// mean-number weight of species ip in a cell: fast_max_particle_number (:239-280) / max_particle_number (:282-359)
+__device__ __forceinline__ double species_dn(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell &c, const double *gt,
+                                             const double *gt2, int ip)
+{
+    const bool linear = p.df_mode <= 2 || c.breakdown != 0.0;
+    if (p.fast) {
+        if (linear) return 2.0 * p.eqd[ip];
+        if (p.df_mode == 3) return p.eqd[ip] + c.bulkPi * p.bkd[ip];
+        return c.z * p.eqd[ip];
+    }
+    const double equilibrium_density = c.neq_fact * sp.degeneracy[ip] * gt[sp.cls[ip]];
+    if (linear) return 2.0 * equilibrium_density;
+    if (p.df_mode == 3) {
+        const double J20 = (c.T * c.neq_fact) * sp.degeneracy[ip] * gt2[sp.cls[ip]];
+        const double bulk_density = (equilibrium_density + (J20 * c.F / c.T / c.T)) / c.betabulk;
+        return equilibrium_density + c.bulkPi * bulk_density;
+    }
+    return c.z * equilibrium_density;
 }
 
 __global__ void __launch_bounds__(128)
-cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ GT, SamplerCell *__restrict__ out)
+cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ GT, const double *__restrict__ GT2,
+                 SamplerCell *__restrict__ out)
 {
     const int64_t ic = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= p.n_cells) return;
@@ -167,17 +211,33 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
         pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut;
         pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut;
     }
-    c.bulkPi = p.include_bulk ? p.cells.bulkPi[ic] : 0.0;
+    double bulkPi = p.include_bulk ? p.cells.bulkPi[ic] : 0.0;
     const double T4 = T * T * T * T;
     const int nT = p.spl.n;
+    double lambda = 0.0;
     if (p.df_mode == 1) {                                                           // deltafReader.cpp:337-344
         c.c0 = spline_eval_lds(nT, p.spl.x, p.spl.y[0], p.spl.c[0], T) / T4;
         c.c2 = spline_eval_lds(nT, p.spl.x, p.spl.y[1], p.spl.c[1], T) / T4;
-    } else {                                                                        // :352-358
+    } else if (p.df_mode <= 3) {                                                    // :352-358
         c.F = spline_eval_lds(nT, p.spl.x, p.spl.y[0], p.spl.c[0], T) * T;
         c.betabulk = spline_eval_lds(nT, p.spl.x, p.spl.y[1], p.spl.c[1], T) * T4;
         c.betapi = spline_eval_lds(nT, p.spl.x, p.spl.y[2], p.spl.c[2], T) * T4;
+    } else {                                                                        // :966-972, deltafReader.cpp:364-384
+        if (bulkPi <= -P) bulkPi = -(1.0 - 1.e-5) * P;
+        else if (bulkPi / P >= p.bp_max) bulkPi = P * (p.bp_max - 1.e-5);
+        const double r = bulkPi / P;
+        if (!(r >= p.jx[0] && r <= p.jx[p.nj - 1])) {
+            atomicMin(&p.status[0], (unsigned long long)(p.first_cell + ic));
+            out[ic] = c;
+            return;
+        }
+        const double lambda_squared = spline_eval_lds(p.nj, p.jx, p.jl2, p.jcl, r);
+        if (bulkPi < 0.0) lambda = -sqrt(lambda_squared);
+        else if (bulkPi > 0.0) lambda = sqrt(lambda_squared);
+        c.z = spline_eval_lds(p.nj, p.jx, p.jz, p.jcz, r);
+        c.betapi = spline_eval_lds(nT, p.spl.x, p.spl.y[2], p.spl.c[2], T) * T4;
     }
+    c.bulkPi = bulkPi;
     c.shear14 = 2.0 * T * T * (E + P);
     // Milne_Basis (viscous_correction.cpp:8-27)
     const double sinhL = tau * un / utperp, coshL = ut / utperp;
@@ -205,9 +265,25 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
     // max_particle_number, df_mode 1 / 2: 2 n_eq per species (:282-303); total mean number of the cell (:1077)
     const double two_pi2_hbarC3 = 2.0 * M_PI * M_PI * (kHbarC * kHbarC * kHbarC);
     c.neq_fact = T * T * T / two_pi2_hbarC3;
-    const double *gt = GT + ic * sp.ncls;
+    // modified temperature and rescaling coefficients (:1017-1036), detA and the breakdown test (:1038)
+    c.T_mod = T;
+    if (p.df_mode == 3) { c.T_mod = T + bulkPi * c.F / c.betabulk; c.shear_mod = 0.5 / c.betapi; c.bulk_mod = bulkPi / (3.0 * c.betabulk); }
+    else if (p.df_mode == 4) { c.shear_mod = 0.5 / c.betapi; c.bulk_mod = lambda; }
+    if (p.df_mode == 3) {
+        const double Axx = 1.0 + c.pixx * c.shear_mod + c.bulk_mod, Axy = c.pixy * c.shear_mod, Axz = c.pixz * c.shear_mod;
+        const double Ayy = 1.0 + c.piyy * c.shear_mod + c.bulk_mod, Ayz = c.piyz * c.shear_mod, Azz = 1.0 + c.pizz * c.shear_mod + c.bulk_mod;
+        const double detA = Axx * (Ayy * Azz - Ayz * Ayz) - Axy * (Axy * Azz - Ayz * Axz) + Axz * (Axy * Ayz - Ayy * Axz);
+        double Tb = T, Fb = c.F, bbb = c.betabulk;
+        if (p.fast) { Tb = p.T_sw; Fb = p.F_avg; bbb = p.betabulk_avg; }
+        const double nf = Tb * Tb * Tb / two_pi2_hbarC3, Jf = Tb * nf, mbar_pion0 = p.mass_pion0 / Tb;
+        const double neq_pion0 = nf * gt_neq(p.gl, p.gl + p.ngl, p.ngl, mbar_pion0, -1.0);
+        const double J20_pion0 = Jf * gt_J20(p.gl + 2 * p.ngl, p.gl + 3 * p.ngl, p.ngl, mbar_pion0, -1.0);
+        const double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * Fb / Tb / Tb) / bbb;
+        if (detA <= p.detA_min || (neq_pion0 + dn_pion0) < 0.0) { c.breakdown = 1.0; atomicAdd(&p.status[5], 1ULL); }
+    }
+    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr;
     double dn = 0.0;
-    for (int ip = 0; ip < sp.npart; ip++) dn += 2.0 * (c.neq_fact * sp.degeneracy[ip] * gt[sp.cls[ip]]);
+    for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, ip);
     c.dn_sum = dn;
     c.dn_tot = dn * (2.0 * p.y_max * c.ds_max);
     c.live = (c.dn_tot > 0.0) ? 1.0 : 0.0;                                          // :1079
@@ -285,7 +361,7 @@ __device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, doub
 template <bool FILL>
 __global__ void __launch_bounds__(128)
 cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict__ cellrec, const double *__restrict__ GT,
-               int event0, int n_events, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
+               const double *__restrict__ GT2, int event0, int n_events, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
                is3d_particle *__restrict__ particles, int64_t capacity)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // event-major: (event - event0) * n_cells + cell
@@ -309,7 +385,8 @@ cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict
     g_momentum.init(p.seed, 2, gcell, (uint32_t)ievent);
     g_keep.init(p.seed, 3, gcell, (uint32_t)ievent);
     g_rapidity.init(p.seed, 4, gcell, (uint32_t)ievent);
-    const double *gt = GT + ic * sp.ncls;
+    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr;
+    const bool linear = p.df_mode <= 2 || c.breakdown != 0.0;
     const double sinheta = sinh(c.eta), cosheta = sqrt(1.0 + sinheta * sinheta);   // :888-889
     long kept = 0, samples = 0, acceptances = 0;
     int64_t slot = FILL ? base + offsets[idx] : 0;
@@ -318,27 +395,37 @@ cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict
         int chosen = sp.npart - 1;
         double cum = 0.0;
         for (int ip = 0; ip < sp.npart; ip++) {
-            cum += 2.0 * (c.neq_fact * sp.degeneracy[ip] * gt[sp.cls[ip]]);
+            cum += species_dn(p, sp, c, gt, gt2, ip);
             if (ut_ < cum) { chosen = ip; break; }
         }
         const double mass = sp.mass[chosen], mass_squared = mass * mass, sign = sp.sign[chosen];
-        const LrfMom q = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T);
-        // compute_df_weight (:361-453), baryon terms vanish
-        const double pimunu_pmu_pnu = q.px * q.px * c.pixx + q.py * q.py * c.piyy + q.pz * q.pz * c.pizz
-                                    + 2.0 * (q.px * q.py * c.pixy + q.px * q.pz * c.pixz + q.py * q.pz * c.piyz);
-        const double feqbar = 1.0 - sign / (exp(q.E / c.T) + sign);
-        double df_tot;
-        if (p.df_mode == 1) {
-            const double df_shear = pimunu_pmu_pnu / c.shear14;
-            const double df_bulk = ((c.c0 - c.c2) * mass_squared + ((4.0 * c.c2 - c.c0) * q.E) * q.E) * c.bulkPi;
-            df_tot = feqbar * (df_shear + df_bulk);
-        } else {
-            const double df_shear = pimunu_pmu_pnu / (2.0 * q.E * c.betapi * c.T);
-            const double df_bulk = (c.F * q.E / c.T / c.T + (q.E - mass_squared / q.E) / (3.0 * c.T)) * c.bulkPi / c.betabulk;
-            df_tot = feqbar * (df_shear + df_bulk);
+        LrfMom q;
+        double w_visc = 1.0;
+        if (linear) {                                                               // :1100-1110, switch_to_linear_df
+            q = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T);
+            // compute_df_weight (:361-453), baryon terms vanish; df_mode 3 takes the Chapman-Enskog branch
+            const double pimunu_pmu_pnu = q.px * q.px * c.pixx + q.py * q.py * c.piyy + q.pz * q.pz * c.pizz
+                                        + 2.0 * (q.px * q.py * c.pixy + q.px * q.pz * c.pixz + q.py * q.pz * c.piyz);
+            const double feqbar = 1.0 - sign / (exp(q.E / c.T) + sign);
+            double df_tot;
+            if (p.df_mode == 1) {
+                const double df_shear = pimunu_pmu_pnu / c.shear14;
+                const double df_bulk = ((c.c0 - c.c2) * mass_squared + ((4.0 * c.c2 - c.c0) * q.E) * q.E) * c.bulkPi;
+                df_tot = feqbar * (df_shear + df_bulk);
+            } else {
+                const double df_shear = pimunu_pmu_pnu / (2.0 * q.E * c.betapi * c.T);
+                const double df_bulk = (c.F * q.E / c.T / c.T + (q.E - mass_squared / q.E) / (3.0 * c.T)) * c.bulkPi / c.betabulk;
+                df_tot = feqbar * (df_shear + df_bulk);
+            }
+            df_tot = fmax(-1.0, fmin(df_tot, 1.0));
+            w_visc = (1.0 + df_tot) / 2.0;
+        } else {                                                                    // :1112-1131 + rescale_momentum (:619-650)
+            const LrfMom m = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T_mod);
+            q.px = (1.0 + c.bulk_mod) * m.px + c.shear_mod * (c.pixx * m.px + c.pixy * m.py + c.pixz * m.pz);
+            q.py = (1.0 + c.bulk_mod) * m.py + c.shear_mod * (c.pixy * m.px + c.piyy * m.py + c.piyz * m.pz);
+            q.pz = (1.0 + c.bulk_mod) * m.pz + c.shear_mod * (c.pixz * m.px + c.piyz * m.py + c.pizz * m.pz);
+            q.E = sqrt(mass_squared + q.px * q.px + q.py * q.py + q.pz * q.pz);
         }
-        df_tot = fmax(-1.0, fmin(df_tot, 1.0));
-        const double w_visc = (1.0 + df_tot) / 2.0;
         // boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51)
         const double ptau = q.E * c.ut + q.px * c.Xt + q.pz * c.Zt;
         const double plx = q.E * c.ux + q.px * c.Xx + q.py * c.Yx;
@@ -426,8 +513,14 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     *n_particles = 0;
     if (stats) memset(stats, 0, sizeof *stats);
     if (opts->dimension != 2 && opts->dimension != 3) return set_error(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", opts->dimension);
-    if (opts->df_mode != 1 && opts->df_mode != 2)
-        return set_error(IS3D_EINVAL, "the sampler is built for the linear delta-f modes, df_mode 1 (14-moment) or 2 (Chapman-Enskog) (got %d)", opts->df_mode);
+    if (opts->df_mode < 1 || opts->df_mode > 4) return set_error(IS3D_EINVAL, "the sampler takes df_mode 1, 2, 3 or 4 (got %d)", opts->df_mode);
+    const is3d_feqmod_tables *fq = in->feqmod;
+    const bool need_alpha2 = opts->df_mode == 3 || (in->fast && opts->df_mode == 2);
+    if ((opts->df_mode >= 3 || need_alpha2) && !fq) return set_error(IS3D_EINVAL, "df_mode 3 / 4 (and fast mode with df_mode 2) need in->feqmod");
+    if (fq && (fq->n_gla != in->n_gla || !fq->root2 || !fq->weight2)) return set_error(IS3D_EINVAL, "in->feqmod: Gauss-Laguerre alpha = 2 nodes missing or of another size");
+    if (opts->df_mode == 4 && (fq->n_pdg < 1 || !fq->pdg_mass || !fq->pdg_degeneracy || !fq->pdg_sign || !(fq->T_avg > 0.0)))
+        return set_error(IS3D_EINVAL, "df_mode 4 needs the full PDG list and the surface-averaged temperature");
+    if (in->fast && !(in->T_avg > 0.0)) return set_error(IS3D_EINVAL, "fast = 1 needs the surface-averaged temperature");
     if (opts->include_baryon) return set_error(IS3D_EINVAL, "the sampler with include_baryon = 1 is not on this path");
     if (species->n < 1 || !species->mass || !species->sign || !species->degeneracy) return set_error(IS3D_EINVAL, "empty species list");
     for (int s = 0; s < species->n; s++)
@@ -436,7 +529,9 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     if (in->n_gla < 1 || !in->root1 || !in->weight1) return set_error(IS3D_EINVAL, "the sampler needs the Gauss-Laguerre roots and weights for alpha = 1");
     if (df->n_T < 3 || !df->T) return set_error(IS3D_EINVAL, "coefficient table needs >= 3 temperatures");
     if (opts->df_mode == 1 && (!df->c0 || !df->c2)) return set_error(IS3D_EINVAL, "df_mode 1 needs c0 and c2 tables");
-    if (opts->df_mode == 2 && (!df->F || !df->betabulk || !df->betapi)) return set_error(IS3D_EINVAL, "df_mode 2 needs F, betabulk, betapi tables");
+    if ((opts->df_mode == 2 || opts->df_mode == 3) && (!df->F || !df->betabulk || !df->betapi))
+        return set_error(IS3D_EINVAL, "df_mode 2 / 3 need F, betabulk, betapi tables");
+    if (opts->df_mode == 4 && !df->betapi) return set_error(IS3D_EINVAL, "df_mode 4 needs the betapi table");
     if (particles == nullptr) capacity = 0;
     const int64_t n = cells->n_cells;
     if (n < 0 || n + in->first_cell > 0xffffffffLL) return set_error(IS3D_EINVAL, "cell indices must fit 32 bits for the counter-based streams");
@@ -473,8 +568,11 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     SMP_TRY(d_cls.upload(cls));
     SMP_TRY(d_cmass.upload(cmass));
     SMP_TRY(d_csign.upload(csign));
-    std::vector<double> gl((size_t)2 * in->n_gla);
-    for (int k = 0; k < in->n_gla; k++) { gl[k] = in->root1[k]; gl[in->n_gla + k] = in->weight1[k]; }
+    std::vector<double> gl((size_t)4 * in->n_gla, 0.0);
+    for (int k = 0; k < in->n_gla; k++) {
+        gl[k] = in->root1[k]; gl[in->n_gla + k] = in->weight1[k];
+        if (fq) { gl[2 * in->n_gla + k] = fq->root2[k]; gl[3 * in->n_gla + k] = fq->weight2[k]; }
+    }
     SMP_TRY(d_gl.upload(gl));
     is3d::SamplerSpecies sp{d_mass.as<double>(), d_sign.as<double>(), d_deg.as<double>(), d_cls.as<int32_t>(),
                             d_cmass.as<double>(), d_csign.as<double>(), npart, ncls};
@@ -487,6 +585,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     const double *tabs[3] = {nullptr, nullptr, nullptr};
     int nspl;
     if (opts->df_mode == 1) { tabs[0] = df->c0; tabs[1] = df->c2; nspl = 2; }
+    else if (opts->df_mode == 4) { tabs[0] = tabs[1] = tabs[2] = df->betapi; nspl = 3; }   // only slot 2 (betapi) is read
     else { tabs[0] = df->F; tabs[1] = df->betabulk; tabs[2] = df->betapi; nspl = 3; }
     p.spl.n = df->n_T; p.spl.x = d_splx.as<double>(); p.spl.nspl = nspl;
     for (int s = 0; s < nspl; s++) {
@@ -523,22 +622,79 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     p.dim3 = three_d; p.df_mode = opts->df_mode;
     p.include_bulk = opts->include_bulk_deltaf != 0; p.include_shear = opts->include_shear_deltaf != 0;
     p.ngl = in->n_gla; p.gl = d_gl.as<double>();
+    // ---- df_mode 4: lambda(Pi/P), z(Pi/P) tables (deltafReader.cpp:222-297) ----
+    DevMem d_jonah, d_eqd, d_bkd;
+    if (opts->df_mode == 4) {
+        std::vector<double> bp, l2, zz, cl, cz, jon;
+        is3d::jonah_tables(fq, bp, l2, zz, p.bp_max);
+        if (!is3d::natural_cspline_init(bp, l2, cl) || !is3d::natural_cspline_init(bp, zz, cz))
+            return set_error(IS3D_EINVAL, "df_mode 4: bulkPi/Peq(lambda) is not ascending at T_avg = %.6g GeV (GSL would abort here)", fq->T_avg);
+        p.nj = (int)bp.size();
+        for (const auto *v : {&bp, &l2, &zz, &cl, &cz}) jon.insert(jon.end(), v->begin(), v->end());
+        SMP_TRY(d_jonah.upload(jon));
+        p.jx = d_jonah.as<double>(); p.jl2 = p.jx + p.nj; p.jz = p.jx + 2 * p.nj; p.jcl = p.jx + 3 * p.nj; p.jcz = p.jx + 4 * p.nj;
+    }
+    if (fq) { p.detA_min = fq->deta_min; p.mass_pion0 = fq->mass_pion0; }
+    // ---- fast mode: Deltaf_Data::compute_particle_densities at the average temperature (deltafReader.cpp:536-650) ----
+    p.fast = in->fast != 0;
+    if (p.fast) {
+        const double two_pi2_hbarC3 = 2.0 * std::pow(M_PI, 2) * std::pow(is3d::kHbarC, 3);
+        auto spline_at = [&](int slot, double Tq) {   // gsl_spline_eval on the host copies of the spline slot
+            std::vector<double> ys(tabs[slot], tabs[slot] + df->n_T), cc;
+            (void)is3d::natural_cspline_init(xs, ys, cc);
+            int lo = 0, hi = df->n_T - 1;
+            while (hi > lo + 1) { int i = (hi + lo) >> 1; if (xs[i] > Tq) hi = i; else lo = i; }
+            const double dx = xs[lo + 1] - xs[lo], dy = ys[lo + 1] - ys[lo], delx = Tq - xs[lo];
+            const double b_i = (dy / dx) - dx * (cc[lo + 1] + 2.0 * cc[lo]) / 3.0, d_i = (cc[lo + 1] - cc[lo]) / (3.0 * dx);
+            return ys[lo] + delx * (b_i + delx * (cc[lo] + delx * d_i));
+        };
+        auto in_table = [&](double Tq) { return Tq >= xs.front() && Tq <= xs.back(); };
+        const double T = in->T_avg, Tsw = in->T_avg_switch > 0.0 ? in->T_avg_switch : in->T_avg;
+        if (!in_table(T) || !in_table(Tsw)) return set_error(IS3D_EDOMAIN, "fast = 1: the average temperature %.6g GeV is outside the coefficient table", T);
+        double F = 0.0, betabulk = 1.0;
+        if (opts->df_mode == 2 || opts->df_mode == 3) { F = spline_at(0, T) * T; betabulk = spline_at(1, T) * T * T * T * T; }
+        std::vector<double> eqd(npart, 0.0), bkd(npart, 0.0);
+        for (int ip = 0; ip < npart; ip++) {
+            const double mbar = species->mass[ip] / T, sign = species->sign[ip];
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < in->n_gla; k++) {
+                const double pbar = in->root1[k], Ebar = std::sqrt(pbar * pbar + mbar * mbar);
+                s1 += in->weight1[k] * (pbar * std::exp(pbar) / (std::exp(Ebar) + sign));
+            }
+            const double neq = species->degeneracy[ip] * std::pow(T, 3) / two_pi2_hbarC3 * s1;
+            eqd[ip] = neq;
+            if (opts->df_mode == 2 || opts->df_mode == 3) {
+                for (int k = 0; k < in->n_gla; k++) {
+                    const double pbar = fq->root2[k], Ebar = std::sqrt(pbar * pbar + mbar * mbar), qstat = std::exp(Ebar) + sign;
+                    s2 += fq->weight2[k] * (Ebar * std::exp(pbar + Ebar) / (qstat * qstat));
+                }
+                const double J20 = species->degeneracy[ip] * std::pow(T, 4) / two_pi2_hbarC3 * s2;
+                bkd[ip] = (neq + (J20 * F / std::pow(T, 2))) / betabulk;
+            }
+        }
+        SMP_TRY(d_eqd.upload(eqd));
+        SMP_TRY(d_bkd.upload(bkd));
+        p.eqd = d_eqd.as<double>(); p.bkd = d_bkd.as<double>();
+        p.T_sw = Tsw;
+        if (opts->df_mode == 3) { p.F_avg = spline_at(0, Tsw) * Tsw; p.betabulk_avg = spline_at(1, Tsw) * Tsw * Tsw * Tsw * Tsw; }
+    }
     p.y_max = three_d ? 0.5 : in->y_cut;                                              // :837-838
     p.seed = in->seed;
-    DevMem d_status, d_GT, d_rec, d_counts, d_offsets, d_scan_tmp, d_particles;
+    DevMem d_status, d_GT, d_GT2, d_rec, d_counts, d_offsets, d_scan_tmp, d_particles;
     SMP_TRY(d_status.alloc(8 * sizeof(unsigned long long)));
     unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0, 0};
     SMP_TRY(hipMemcpyAsync(d_status.p, init, sizeof init, hipMemcpyHostToDevice, nullptr));
     p.status = d_status.as<unsigned long long>();
     SMP_TRY(d_GT.alloc((size_t)n * ncls * sizeof(double)));
+    if (opts->df_mode == 3 && !p.fast) SMP_TRY(d_GT2.alloc((size_t)n * ncls * sizeof(double)));
     SMP_TRY(d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
     SMP_TRY(hipEventRecord(ev[1], nullptr));
     {
         const int64_t tot = n * ncls;
         hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], n, sp,
-                           d_gl.as<double>(), in->n_gla, d_GT.as<double>());
+                           d_gl.as<double>(), in->n_gla, d_GT.as<double>(), d_GT2.as<double>());
         hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, p, sp, d_GT.as<double>(),
-                           d_rec.as<is3d::SamplerCell>());
+                           d_GT2.as<double>(), d_rec.as<is3d::SamplerCell>());
         SMP_TRY(hipGetLastError());
     }
     SMP_TRY(hipEventRecord(ev[2], nullptr));
@@ -562,7 +718,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         SMP_TRY(hipEventRecord(ev[5], nullptr));
         if (ne < eb) SMP_TRY(hipMemsetAsync(d_counts.p, 0, (size_t)(bt + 1) * sizeof(int64_t), nullptr));
         hipLaunchKernelGGL((is3d::cf_sampler_run<false>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
-                           d_GT.as<double>(), e0, ne, d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0,
+                           d_GT.as<double>(), d_GT2.as<double>(), e0, ne, d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0,
                            (is3d_particle *)nullptr, (int64_t)0);
         SMP_TRY(hipGetLastError());
         // element bt of the scan (counts[bt] = 0) is the batch total
@@ -572,7 +728,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         SMP_TRY(hipMemcpy(&batch_total, d_offsets.as<int64_t>() + bt, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (capacity > 0 && base < capacity && batch_total > 0) {
             hipLaunchKernelGGL((is3d::cf_sampler_run<true>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
-                               d_GT.as<double>(), e0, ne, (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(),
+                               d_GT.as<double>(), d_GT2.as<double>(), e0, ne, (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(),
                                capacity);
             SMP_TRY(hipGetLastError());
         }
@@ -597,11 +753,13 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         stats->n_momentum_samples = (int64_t)h[2];
         stats->n_acceptances = (int64_t)h[3];
         stats->n_hadrons_drawn = (int64_t)h[4];
+        stats->n_cells_breakdown = (int64_t)h[5];
         stats->n_classes = ncls;
         stats->ms_count = ms_count; stats->ms_fill = ms_fill;
     }
     if (h[0] != ~0ULL)
-        return set_error(IS3D_EDOMAIN, "cell %lld: T outside the delta-f coefficient table (the reference aborts in gsl_spline_eval here)", (long long)h[0]);
+        return set_error(IS3D_EDOMAIN, "cell %lld: T%s outside the coefficient table (the reference aborts in gsl_spline_eval here)", (long long)h[0],
+                         opts->df_mode == 4 ? " (or bulkPi/P)" : "");
     const int64_t ncopy = std::min<int64_t>(base, capacity);
     if (ncopy > 0) SMP_TRY(hipMemcpy(particles, d_particles.p, (size_t)ncopy * sizeof(is3d_particle), hipMemcpyDeviceToHost));
     if (particles && base > capacity)

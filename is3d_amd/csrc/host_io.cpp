@@ -638,3 +638,99 @@ extern "C" int is3d_write_particle_list_osc(const char *path, int32_t n_events, 
     if (!f) return io_fail(IS3D_EIO, "write error on %s", path);
     return IS3D_OK;
 }
+
+// test_sampler = 1: the binned self-consistency outputs of the sampler (sample_dN_dy ... sample_dN_dX,
+// emissionfunction_sampling_kernels.cpp:31-152, and their writers, emissionfunction.cpp:903-1257), built from the particle
+// list on the host: results/dN_dy/dN_dy_<id>_test.dat (+ _average_test), dN_deta/dN_deta_<id>_test.dat,
+// momentum_distribution/dN_2pipTdpTdy_<id>_test.dat, vn/vn_<id>_test.dat, spacetime_distribution/dN_taudtaudy_sampled_<id>_test.dat
+// and dN_twopirdrdy_sampled_<id>_test.dat, mean_yield.dat, yield_list.dat.  The directories must exist, as for the reference.
+extern "C" int is3d_write_sampler_tests(const char *results_dir, const is3d_sampler_test_bins *b, int32_t n_events, int32_t n_species,
+                                        const int64_t *mc_id, int64_t n_particles, const is3d_particle *particles, double mean_yield)
+{
+    if (!results_dir || !b || !mc_id || (n_particles > 0 && !particles)) return io_fail(IS3D_EINVAL, "null argument");
+    if (b->y_bins < 1 || b->eta_bins < 1 || b->pT_bins < 1 || b->tau_bins < 1 || b->r_bins < 1 || n_events < 1 || n_species < 1)
+        return io_fail(IS3D_EINVAL, "sampler test bins must be positive");
+    const int K_MAX = 7;                                                     // emissionfunction.h:132
+    const double two_pi = 2.0 * M_PI;
+    const double yw = 2.0 * b->y_cut / (double)b->y_bins, ew = 2.0 * b->eta_cut / (double)b->eta_bins;
+    const double pw = (b->pT_upper_cut - b->pT_lower_cut) / (double)b->pT_bins;
+    const double tw = (b->tau_max - b->tau_min) / (double)b->tau_bins, rw = (b->r_max - b->r_min) / (double)b->r_bins;
+    std::vector<double> dy((size_t)n_species * b->y_bins, 0.0), de((size_t)n_species * b->eta_bins, 0.0), dp((size_t)n_species * b->pT_bins, 0.0);
+    std::vector<double> vc((size_t)n_species * b->pT_bins, 0.0), vr((size_t)K_MAX * n_species * b->pT_bins, 0.0), vi(vr.size(), 0.0);
+    std::vector<double> dt((size_t)n_species * b->tau_bins, 0.0), dr((size_t)n_species * b->r_bins, 0.0);
+    std::vector<int64_t> yield((size_t)n_events, 0);
+    for (int64_t i = 0; i < n_particles; i++) {
+        const is3d_particle &q = particles[i];
+        if (q.species < 0 || q.species >= n_species || q.event < 0 || q.event >= n_events) return io_fail(IS3D_EINVAL, "particle %lld: species or event out of range", (long long)i);
+        const int ip = q.species;
+        yield[q.event] += 1;
+        const double yp = 0.5 * std::log((q.E + q.pz) / (q.E - q.pz));
+        const int iyp = (int)std::floor((yp + b->y_cut) / yw);                  // sample_dN_dy
+        if (iyp >= 0 && iyp < b->y_bins) dy[(size_t)ip * b->y_bins + iyp] += 1.0;
+        const int ieta = (int)std::floor((q.eta + b->eta_cut) / ew);            // sample_dN_deta
+        if (ieta >= 0 && ieta < b->eta_bins) de[(size_t)ip * b->eta_bins + ieta] += 1.0;
+        if (std::fabs(yp) <= b->y_cut) {
+            const double pT = std::sqrt(q.px * q.px + q.py * q.py);
+            const int ipT = (int)std::floor((pT - b->pT_lower_cut) / pw);       // sample_dN_2pipTdpTdy, sample_vn
+            if (ipT >= 0 && ipT < b->pT_bins) {
+                dp[(size_t)ip * b->pT_bins + ipT] += 1.0;
+                vc[(size_t)ip * b->pT_bins + ipT] += 1.0;
+                double phi = std::atan2(q.py, q.px);
+                if (phi < 0.0) phi += 2.0 * M_PI;
+                for (int k = 0; k < K_MAX; k++) {
+                    vr[((size_t)k * n_species + ip) * b->pT_bins + ipT] += std::cos(((double)k + 1.0) * phi);
+                    vi[((size_t)k * n_species + ip) * b->pT_bins + ipT] += std::sin(((double)k + 1.0) * phi);
+                }
+            }
+            const double r = std::sqrt(q.x * q.x + q.y * q.y);                   // sample_dN_dX
+            const int itau = (int)std::floor((q.tau - b->tau_min) / tw), ir = (int)std::floor((r - b->r_min) / rw);
+            if (itau >= 0 && itau < b->tau_bins) dt[(size_t)ip * b->tau_bins + itau] += 1.0;
+            if (ir >= 0 && ir < b->r_bins) dr[(size_t)ip * b->r_bins + ir] += 1.0;
+        }
+    }
+    const std::string root(results_dir);
+    const double Nev = (double)n_events;
+    for (int ip = 0; ip < n_species; ip++) {
+        const std::string id = std::to_string((long long)mc_id[ip]);
+        std::ofstream f1(root + "/dN_dy/dN_dy_" + id + "_test.dat"), f2(root + "/dN_dy/dN_dy_" + id + "_average_test.dat");
+        std::ofstream f3(root + "/dN_deta/dN_deta_" + id + "_test.dat"), f4(root + "/momentum_distribution/dN_2pipTdpTdy_" + id + "_test.dat");
+        std::ofstream f5(root + "/vn/vn_" + id + "_test.dat"), f6(root + "/spacetime_distribution/dN_taudtaudy_sampled_" + id + "_test.dat");
+        std::ofstream f7(root + "/spacetime_distribution/dN_twopirdrdy_sampled_" + id + "_test.dat");
+        if (!f1 || !f2 || !f3 || !f4 || !f5 || !f6 || !f7)
+            return io_fail(IS3D_EIO, "couldn't open the sampler test files under %s (dN_dy/, dN_deta/, momentum_distribution/, vn/, spacetime_distribution/ must exist)", results_dir);
+        double avg = 0.0;
+        for (int i = 0; i < b->y_bins; i++) {                                    // :919-937
+            avg += dy[(size_t)ip * b->y_bins + i];
+            f1 << std::setprecision(6) << (-b->y_cut + yw * ((double)i + 0.5)) << "\t" << dy[(size_t)ip * b->y_bins + i] / (yw * Nev) << std::endl;
+        }
+        f2 << std::setprecision(6) << avg / (2.0 * b->y_cut * Nev) << std::endl;
+        for (int i = 0; i < b->eta_bins; i++)                                    // :961-972
+            f3 << std::setprecision(6) << (-b->eta_cut + ew * ((double)i + 0.5)) << "\t" << de[(size_t)ip * b->eta_bins + i] / (ew * Nev) << std::endl;
+        for (int i = 0; i < b->pT_bins; i++) {                                   // :991-1001, :1156-1177
+            const double pT_mid = b->pT_lower_cut + pw * ((double)i + 0.5);
+            f4 << std::setprecision(6) << std::scientific << pT_mid << "\t" << dp[(size_t)ip * b->pT_bins + i] / (two_pi * 2.0 * b->y_cut * pw * pT_mid * Nev) << "\n";
+            f5 << std::setprecision(6) << std::scientific << pT_mid;
+            for (int k = 0; k < K_MAX; k++) {
+                const size_t j = ((size_t)k * n_species + ip) * b->pT_bins + i;
+                double vn_abs = std::sqrt(vr[j] * vr[j] + vi[j] * vi[j]) / vc[(size_t)ip * b->pT_bins + i];
+                if (std::isnan(vn_abs) || std::isinf(vn_abs)) vn_abs = 0.0;
+                f5 << "\t" << vn_abs;
+            }
+            f5 << "\n";
+        }
+        for (int i = 0; i < b->r_bins; i++) {                                    // :1215-1221
+            const double r_mid = b->r_min + rw * ((double)i + 0.5);
+            f7 << std::setprecision(6) << std::scientific << r_mid << "\t" << dr[(size_t)ip * b->r_bins + i] / (2.0 * M_PI * r_mid * rw * Nev * 2.0 * b->y_cut) << "\n";
+        }
+        for (int i = 0; i < b->tau_bins; i++) {                                  // :1223-1229
+            const double tau_mid = b->tau_min + tw * ((double)i + 0.5);
+            f6 << std::setprecision(6) << std::scientific << tau_mid << "\t" << dt[(size_t)ip * b->tau_bins + i] / (tau_mid * tw * Nev * 2.0 * b->y_cut) << "\n";
+        }
+    }
+    std::ofstream fm(root + "/mean_yield.dat"), fl(root + "/yield_list.dat");   // :1244-1257
+    if (!fm || !fl) return io_fail(IS3D_EIO, "couldn't open %s/mean_yield.dat", results_dir);
+    fm << mean_yield << std::endl;
+    fl << "sampled particle yield\n";
+    for (int e = 0; e < n_events; e++) fl << yield[e] << std::endl;
+    return IS3D_OK;
+}

@@ -115,14 +115,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     GET(outflow, "outflow");
 #undef GET
     if (operation != 1 && operation != 2) DIE("operation = %d: only operation = 1 (smooth momentum spectra) and 2 (particle sampler) are on this path", operation);
-    if (operation == 2) {
-        if (df_mode != 1 && df_mode != 2) DIE("operation = 2 with df_mode = %d: the sampler is built for df_mode 1 and 2", df_mode);
-        if (include_baryon) DIE("operation = 2 with include_baryon = 1 is not on this path");
-        double fast = 0, test_sampler = 0;
-        if (get_param("fast", &fast) || get_param("test_sampler", &test_sampler)) return IS3D_EINVAL;
-        if ((int)fast) DIE("fast = 1 (densities at the average temperature) is not on this path; set fast = 0");
-        if ((int)test_sampler) DIE("test_sampler = 1 (binned test histograms) is not on this path; set test_sampler = 0");
-    }
+    if (operation == 2 && include_baryon) DIE("operation = 2 with include_baryon = 1 is not on this path");
     if (!mem && mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
         DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
     if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
@@ -235,10 +228,23 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     std::vector<double> dN(mcid.size() * pT.size() * phi.size() * (size_t)ny_eff, 0.0);
     if (operation == 2) {
         // ---- emissionfunction.cpp:1522-1545: number of events, sampling, OSCAR list ----
-        double oversample, min_num_hadrons, max_num_samples, sampler_seed, y_cut;
+        double oversample, min_num_hadrons, max_num_samples, sampler_seed, y_cut, fast, test_sampler, set_T, T_switch = 0.0;
         if (get_param("oversample", &oversample) || get_param("min_num_hadrons", &min_num_hadrons) || get_param("max_num_samples", &max_num_samples) ||
-            get_param("sampler_seed", &sampler_seed) || get_param("y_cut", &y_cut))
+            get_param("sampler_seed", &sampler_seed) || get_param("y_cut", &y_cut) || get_param("fast", &fast) || get_param("test_sampler", &test_sampler) ||
+            get_param("set_fo_temperature", &set_T))
             return IS3D_EINVAL;
+        if ((int)set_T && get_param("t_switch", &T_switch)) return IS3D_EINVAL;
+        is3d_sampler_test_bins bins{};
+        if ((int)test_sampler) {                                                  // emissionfunction.cpp:205-222
+            double yb, ec, eb, pl, pu, pb, t0b, t1b, tb, r0b, r1b, rb;
+            if (get_param("y_bins", &yb) || get_param("eta_cut", &ec) || get_param("eta_bins", &eb) || get_param("pt_lower_cut", &pl) ||
+                get_param("pt_upper_cut", &pu) || get_param("pt_bins", &pb) || get_param("tau_min", &t0b) || get_param("tau_max", &t1b) ||
+                get_param("tau_bins", &tb) || get_param("r_min", &r0b) || get_param("r_max", &r1b) || get_param("r_bins", &rb))
+                return IS3D_EINVAL;
+            bins.y_cut = y_cut; bins.eta_cut = ec; bins.pT_lower_cut = pl; bins.pT_upper_cut = pu; bins.tau_min = t0b; bins.tau_max = t1b;
+            bins.r_min = r0b; bins.r_max = r1b;
+            bins.y_bins = (int)yb; bins.eta_bins = (int)eb; bins.pT_bins = (int)pb; bins.tau_bins = (int)tb; bins.r_bins = (int)rb;
+        }
         // cell positions: columns 1, 2 of every supported surface format (readindata.cpp:343-346 etc.)
         std::vector<double> xs((size_t)n_cells, 0.0), ys((size_t)n_cells, 0.0);
         if (mem) {
@@ -256,7 +262,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         int32_t n_alpha = 0, n_pts = 0;
         const char *gla_path = "tables/gla_roots_weights_32_points.txt";
         if (is3d_gla_read(gla_path, &n_alpha, &n_pts, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
-        if (n_alpha < 2) DIE("%s: needs alpha = 0, 1", gla_path);
+        if (n_alpha < 3) DIE("%s: needs alpha = 0, 1, 2", gla_path);
         std::vector<double> groot((size_t)n_alpha * n_pts), gweight((size_t)n_alpha * n_pts);
         if (is3d_gla_read(gla_path, &n_alpha, &n_pts, groot.data(), gweight.data(), (int64_t)groot.size())) DIE("%s", is3d_last_error());
         is3d_sampler_inputs si{};
@@ -264,6 +270,28 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         si.seed = sampler_seed < 0 ? (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() : (uint64_t)sampler_seed;   // :842-844
         si.y_cut = y_cut; si.first_cell = 0; si.x = xs.data(); si.y = ys.data();
         si.root1 = groot.data() + n_pts; si.weight1 = gweight.data() + n_pts;
+        // df_mode 3 / 4 and fast mode: emissionfunction.cpp:1309-1321, sampling_kernels.cpp:852-869
+        double T_avg_file = 0.0;
+        {
+            FILE *tf = fopen("average_thermodynamic_quantities.dat", "r");
+            if (!tf || fscanf(tf, "%lf", &T_avg_file) != 1) DIE("Error opening average thermodynamic file");
+            fclose(tf);
+        }
+        is3d_feqmod_tables fqs{};
+        if (feqmod || (int)fast) {
+            double deta_min, mass_pion0;
+            if (get_param("deta_min", &deta_min) || get_param("mass_pion0", &mass_pion0)) return IS3D_EINVAL;
+            fqs.n_gla = n_pts;
+            fqs.root1 = si.root1; fqs.weight1 = si.weight1;
+            fqs.root2 = groot.data() + 2 * (size_t)n_pts; fqs.weight2 = gweight.data() + 2 * (size_t)n_pts;
+            fqs.n_pdg = npdg; fqs.pdg_mass = pmass.data(); fqs.pdg_degeneracy = pg.data(); fqs.pdg_sign = ps.data();
+            fqs.T_avg = T_avg_file; fqs.deta_min = deta_min; fqs.mass_pion0 = mass_pion0;
+            si.feqmod = &fqs;
+        }
+        si.fast = (int)fast != 0;
+        si.T_avg = T_avg_file;
+        si.T_avg_switch = (int)set_T ? T_switch : T_avg_file;                     // :856
+        if (si.fast) printf("Using fast mode: (Tavg, muBavg) = (%lf, %lf)\n", si.T_avg_switch, avg[3]);
         printf("iS3D Sampling Seed : %llu\n", (unsigned long long)si.seed);
         is3d_sampler_stats ss{};
         int64_t count = 0;
@@ -277,7 +305,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
             si.n_events = (int32_t)std::max(1.0, std::min(std::ceil(min_num_hadrons / Ntotal), max_num_samples));
         }
         printf("Sampling %d event(s)\n", si.n_events);
-        printf(df_mode == 1 ? "Sampling particles with Grad 14 moment df...\n" : "Sampling particles with Chapman Enskog df...\n");
+        if (df_mode == 1) printf("Sampling particles with Grad 14 moment df...\n");                    // emissionfunction.cpp:1540-1541, :1602-1603
+        if (df_mode == 2) printf("Sampling particles with Chapman Enskog df...\n");
+        if (df_mode == 3) printf("Sampling particles with Mike's modified distribution...\n");
+        if (df_mode == 4) printf("Sampling particles with Jonah's modified distribution...\n");
         int rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
         if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
         std::vector<is3d_particle> plist((size_t)std::max<int64_t>(count, 1));
@@ -285,8 +316,14 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
         double t2s = now_s();
         printf("\nMomentum sampling efficiency = %f %%\n", 100.0 * (double)ss.n_acceptances / (double)std::max<int64_t>(ss.n_momentum_samples, 1));
-        printf("Writing sampled particles list to OSCAR File...\n");
-        if (is3d_write_particle_list_osc("results/particle_list_osc.dat", si.n_events, count, plist.data(), mcid.data())) DIE("%s", is3d_last_error());
+        if (feqmod) printf("feqmod breaks down for %lld cells\n", (long long)ss.n_cells_breakdown);
+        if ((int)test_sampler) {                                                  // emissionfunction.cpp:1545-1554
+            printf("Writing the binned sampler test distributions...\n");
+            if (is3d_write_sampler_tests("results", &bins, si.n_events, sp.n, mcid.data(), count, plist.data(), 0.0)) DIE("%s", is3d_last_error());
+        } else {
+            printf("Writing sampled particles list to OSCAR File...\n");
+            if (is3d_write_particle_list_osc("results/particle_list_osc.dat", si.n_events, count, plist.data(), mcid.data())) DIE("%s", is3d_last_error());
+        }
         double t3s = now_s();
         printf("particles: %lld in %d event(s); hadrons drawn %lld; cells skipped (u.dsigma <= 0): %lld\n", (long long)count, si.n_events,
                (long long)ss.n_hadrons_drawn, (long long)ss.n_cells_skipped);

@@ -103,7 +103,7 @@ def test_cli_other_surface_formats(tmp_path, fx, mode):
 
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=3), dict(operation=2, df_mode=4), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
+    for bad in (dict(operation=3), dict(operation=2, include_baryon=1), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr
@@ -198,3 +198,32 @@ def test_embedding_class(tmp_path, fx, operation):
         line = [ln for ln in r.stdout.split("\n") if ln.startswith("SUM ")][0].split()
         assert "SPECTRUM %d" % want.size in r.stdout
         assert abs(float(line[1]) / want.sum() - 1) < 1e-9 and abs(float(line[3]) / want[0] - 1) < 1e-9
+
+
+def test_cli_shipped_default_shape(tmp_path, fx):
+    """The shape of the reference's shipped iS3D_parameters.dat: operation = 2, dimension = 2, df_mode = 4 (Jonah), fast = 1,
+    set_FO_temperature = 1, test_sampler = 1 -> binned test distributions instead of the particle list."""
+    ids = [211, 321, 2212]
+    cells = synth.synth_surface(4000, 2, seed=97)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(operation=2, dimension=2, df_mode=4, fast=1, test_sampler=1, oversample=1,
+                                                                  min_num_hadrons=20000, sampler_seed=5))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Sampling particles with Jonah's modified distribution..." in r.stdout and "Using fast mode: (Tavg, muBavg) = (0.151000" in r.stdout
+    assert not os.path.exists(os.path.join(root, "results", "particle_list_osc.dat"))
+    n_events = int(r.stdout.split(" event(s)")[0].split("Sampling ")[-1])
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    T_avg = float(open(os.path.join(root, "average_thermodynamic_quantities.dat")).read().split()[0])
+    fq = inputs.feqmod_tables(T_avg)
+    ref, _ = oracle.sample_particles(parsed, inputs.species(ids), fx["df"], fq, dict(dimension=2, df_mode=4), n_events=n_events, seed=5,
+                                     y_cut=0.7, fq=fq, fast=1, T_avg=fq["T_avg"], T_avg_switch=0.151)
+    assert len(ref["E"]) > 5000
+    got = np.loadtxt(os.path.join(root, "results", "dN_dy", "dN_dy_211_test.dat"))
+    h, _ = np.histogram(ref["rapidity"][ref["species"] == 0], bins=14, range=(-0.7, 0.7))
+    assert np.allclose(got[:, 1], h / (0.1 * n_events), rtol=6e-6)
+    got = np.loadtxt(os.path.join(root, "results", "momentum_distribution", "dN_2pipTdpTdy_2212_test.dat"))
+    sel = ref["species"] == 2
+    h, e = np.histogram(np.hypot(ref["px"], ref["py"])[sel], bins=30, range=(0, 3))
+    assert np.allclose(got[:, 1], h / (2 * np.pi * 1.4 * 0.1 * 0.5 * (e[1:] + e[:-1]) * n_events), rtol=6e-6)
+    ylist = [int(v) for v in open(os.path.join(root, "results", "yield_list.dat")).read().split()[3:]]
+    assert len(ylist) == n_events and sum(ylist) == len(ref["E"])

@@ -73,7 +73,7 @@ def test_sampler_sharding_capacity_and_errors(fx):
     assert all(np.array_equal(again[f], whole[f]) for f in whole.dtype.names)
     other, _ = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=25, seed=8)
     assert len(other) != len(whole) or not np.array_equal(other["E"], whole["E"])
-    for bad in (dict(dimension=3, df_mode=4), dict(dimension=3, df_mode=2, include_baryon=1), dict(dimension=4, df_mode=1)):
+    for bad in (dict(dimension=3, df_mode=5), dict(dimension=3, df_mode=4), dict(dimension=3, df_mode=2, include_baryon=1), dict(dimension=4, df_mode=1)):
         with pytest.raises(api.Is3dError) as e:
             api.sample_particles(cells, sp, fx["df"], gla, bad, n_events=1, seed=1)
         assert e.value.code == -1
@@ -85,6 +85,26 @@ def test_sampler_sharding_capacity_and_errors(fx):
     with pytest.raises(api.Is3dError) as e:
         api.sample_particles(hot, sp, fx["df"], gla, o, n_events=1, seed=1)
     assert e.value.code == -3 and "cell 9" in str(e.value)
+
+
+@pytest.mark.parametrize("dim,df_mode,fast", [(3, 4, 0), (3, 3, 0), (2, 4, 0), (2, 3, 1), (3, 2, 1), (3, 4, 1)])
+def test_modified_equilibrium_and_fast_lists_match_the_oracle(fx, dim, df_mode, fast):
+    """df_mode 3 / 4: momenta drawn at T_mod and rescaled with A (rescale_momentum), n_linear / z n_eq mean numbers, breakdown
+    cells on the linear delta-f; fast = 1: densities at the average temperature, breakdown test at T_switch."""
+    cells = synth.synth_surface(400, dim, seed=830 + dim + df_mode)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["bulkPi"][::9] = -5.0 * cells["P"][::9]          # df_mode 3: breakdown; df_mode 4: clamped to -(1 - 1e-5) P
+    sp = fx["pikp"]
+    T_avg = inputs.surface_average_T(cells)
+    fq = inputs.feqmod_tables(T_avg)
+    o = dict(dimension=dim, df_mode=df_mode)
+    kw = dict(n_events=150, seed=31337, y_cut=0.9, fq=fq, fast=fast, T_avg=fq["T_avg"], T_avg_switch=0.151)
+    ref, rst = oracle.sample_particles(cells, sp, fx["df"], fq, o, **kw)
+    got, st = api.sample_particles(cells, sp, fx["df"], fq, o, **kw)
+    assert len(ref["E"]) > 100
+    compare_lists(got, ref)
+    assert st["n_cells_breakdown"] == rst["breakdown"] and (rst["breakdown"] > 0) == (df_mode == 3)
+    assert st["n_hadrons_drawn"] == rst["drawn"] and st["n_momentum_samples"] == rst["samples"]
 
 
 def test_sampled_yields_follow_the_device_smooth_spectrum(fx):

@@ -199,6 +199,56 @@ def test_oscar_writer(tmp_path):
         api.write_particle_list_osc(path, 4, q, [211, -2212])
 
 
+def test_sampler_test_writers(tmp_path):
+    """test_sampler = 1 outputs (sampling_kernels.cpp:31-152, emissionfunction.cpp:903-1257) against numpy histograms."""
+    rng = np.random.default_rng(5)
+    n = 4000
+    p = np.zeros(n, dtype=api.PARTICLE_DTYPE)
+    p["event"] = np.sort(rng.integers(0, 3, n))
+    p["species"] = rng.integers(0, 2, n)
+    p["px"], p["py"], p["pz"] = rng.normal(0, 0.6, n), rng.normal(0, 0.6, n), rng.normal(0, 2.0, n)
+    m = np.array([0.138, 0.938])[p["species"]]
+    p["E"] = np.sqrt(m ** 2 + p["px"] ** 2 + p["py"] ** 2 + p["pz"] ** 2)
+    p["eta"], p["tau"] = rng.normal(0, 2.0, n), rng.uniform(0.5, 11.0, n)
+    p["x"], p["y"] = rng.normal(0, 3.0, n), rng.normal(0, 3.0, n)
+    root = str(tmp_path)
+    for d in ("dN_dy", "dN_deta", "momentum_distribution", "vn", "spacetime_distribution"):
+        os.makedirs(os.path.join(root, d))
+    bins = dict(y_cut=1.5, eta_cut=6.0, pT_lower_cut=0.0, pT_upper_cut=3.0, tau_min=0.0, tau_max=12.0, r_min=0.0, r_max=10.0,
+                y_bins=10, eta_bins=24, pT_bins=15, tau_bins=12, r_bins=10)
+    api.write_sampler_tests(root, bins, 3, [211, 2212], p, mean_yield=12.5)
+    yp = 0.5 * np.log((p["E"] + p["pz"]) / (p["E"] - p["pz"]))
+    sel = p["species"] == 1
+    got = np.loadtxt(os.path.join(root, "dN_dy", "dN_dy_2212_test.dat"))
+    h, edges = np.histogram(yp[sel], bins=10, range=(-1.5, 1.5))
+    assert np.allclose(got[:, 0], 0.5 * (edges[1:] + edges[:-1]), atol=1e-6) and np.allclose(got[:, 1], h / (0.3 * 3), rtol=6e-6)
+    avg = float(open(os.path.join(root, "dN_dy", "dN_dy_2212_average_test.dat")).read())
+    assert abs(avg - h.sum() / (3.0 * 3)) < 1e-5 * avg
+    mid = np.abs(yp) <= 1.5
+    pT = np.hypot(p["px"], p["py"])
+    got = np.loadtxt(os.path.join(root, "momentum_distribution", "dN_2pipTdpTdy_211_test.dat"))
+    h, edges = np.histogram(pT[mid & ~sel], bins=15, range=(0.0, 3.0))
+    pm = 0.5 * (edges[1:] + edges[:-1])
+    assert np.allclose(got[:, 1], h / (2 * np.pi * 3.0 * 0.2 * pm * 3), rtol=6e-6)
+    got = np.loadtxt(os.path.join(root, "vn", "vn_211_test.dat"))
+    phi = np.arctan2(p["py"], p["px"])
+    ib = np.floor(pT / 0.2).astype(int)
+    k = (mid & ~sel) & (ib == 3)
+    assert got.shape == (15, 8) and abs(got[3, 2] - abs(np.exp(2j * phi[k]).sum()) / k.sum()) < 2e-6
+    got = np.loadtxt(os.path.join(root, "dN_deta", "dN_deta_211_test.dat"))
+    h, _ = np.histogram(p["eta"][~sel], bins=24, range=(-6, 6))
+    assert np.allclose(got[:, 1], h / (0.5 * 3), rtol=6e-6)
+    got = np.loadtxt(os.path.join(root, "spacetime_distribution", "dN_taudtaudy_sampled_2212_test.dat"))
+    h, edges = np.histogram(p["tau"][mid & sel], bins=12, range=(0, 12))
+    assert np.allclose(got[:, 1], h / (0.5 * (edges[1:] + edges[:-1]) * 1.0 * 3 * 3.0), rtol=6e-6)
+    got = np.loadtxt(os.path.join(root, "spacetime_distribution", "dN_twopirdrdy_sampled_2212_test.dat"))
+    h, edges = np.histogram(np.hypot(p["x"], p["y"])[mid & sel], bins=10, range=(0, 10))
+    assert np.allclose(got[:, 1], h / (2 * np.pi * 0.5 * (edges[1:] + edges[:-1]) * 1.0 * 3 * 3.0), rtol=6e-6)
+    lines = open(os.path.join(root, "yield_list.dat")).read().split()
+    assert [int(v) for v in lines[3:]] == [int((p["event"] == e).sum()) for e in range(3)]
+    assert float(open(os.path.join(root, "mean_yield.dat")).read()) == 12.5
+
+
 def test_writers_format(tmp_path):
     """emissionfunction.cpp:381-450, :729-772, :1053-1136."""
     g = inputs.grid()
