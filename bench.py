@@ -151,8 +151,8 @@ def main():
     tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}   # resident in HBM before timing
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local)
     fq = None
-    if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, (this shard's) average temperature
-        fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, the surface-average temperature (all ranks' cells)
+        fq = inputs.feqmod_tables(idist.surface_average_T_global(cells))
     plan = api.Plan(sp, grid, df, opts, max_cells=max(n_loc, 1), fq=fq)
     plan.set_timing(True)
     out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)

@@ -250,7 +250,9 @@ typedef struct {
     const double *root1, *weight1;      /* Gauss-Laguerre alpha = 1 (equilibrium densities, max_particle_number) */
     const is3d_feqmod_tables *feqmod;   /* df_mode 3, 4 (and fast = 1 with df_mode 2): alpha = 2 nodes, PDG list, T_avg of the
                                            Jonah tables, deta_min, mass_pion0; NULL otherwise */
-    int32_t fast, reserved;             /* FAST: species densities at the surface-average temperature (:1044-1056) */
+    int32_t fast;                       /* FAST: species densities at the surface-average temperature (:1044-1056) */
+    int32_t batch_events;               /* tuning: events per count/scan/fill batch; 0 = as many as fit 2^25 (event, cell) threads.
+                                           The particle list does not depend on it. */
     double T_avg;                       /* fast: Plasma::temperature as read back from average_thermodynamic_quantities.dat */
     double T_avg_switch;                /* fast, df_mode 3: the same after `if (SET_T_SWITCH) temperature = T_SWITCH` (:856);
                                            0 = T_avg */

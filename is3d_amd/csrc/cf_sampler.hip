@@ -700,7 +700,8 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     SMP_TRY(hipEventRecord(ev[2], nullptr));
     // ---- events in batches of <= 2^25 (event, cell) threads: count, scan, fill ----
     const int64_t max_threads = (int64_t)1 << 25;
-    const int eb = (int)std::max<int64_t>(1, std::min<int64_t>(in->n_events, max_threads / n));
+    int eb = (int)std::max<int64_t>(1, std::min<int64_t>(in->n_events, max_threads / n));
+    if (in->batch_events > 0) eb = std::min(eb, in->batch_events);
     const int64_t bt = (int64_t)eb * n;
     SMP_TRY(d_counts.alloc((size_t)(bt + 1) * sizeof(int64_t)));
     SMP_TRY(d_offsets.alloc((size_t)(bt + 1) * sizeof(int64_t)));

@@ -44,3 +44,38 @@ def allreduce_spectrum(spectrum):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(spectrum, op=dist.ReduceOp.SUM)
     return spectrum
+
+
+def surface_average_T_global(cells):
+    """Surface-volume weighted temperature over ALL ranks' shards (what the reference reads back from
+    average_thermodynamic_quantities.dat, readindata.cpp:422-450): df_mode 4 builds its lambda(Pi/P), z(Pi/P) tables at this one
+    temperature, so every rank must use the same value.  One all-reduce of two scalars."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    ut = np.sqrt(1 + cells["ux"] ** 2 + cells["uy"] ** 2 + cells["tau"] ** 2 * cells["un"] ** 2)
+    uds = ut * cells["dat"] + cells["ux"] * cells["dax"] + cells["uy"] * cells["day"] + cells["un"] * cells["dan"]
+    dsds = cells["dat"] ** 2 - cells["dax"] ** 2 - cells["day"] ** 2 - cells["dan"] ** 2 / cells["tau"] ** 2
+    mag = np.abs(uds) + np.sqrt(np.abs(uds * uds - dsds))
+    t = torch.tensor([float(np.sum(cells["T"] * mag)), float(np.sum(mag))], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0].item() / t[1].item())
+
+
+def gather_particles(particles, dst=0):
+    """Sampled particle lists of all ranks (numpy structured arrays, each ordered by (event, cell, draw) with GLOBAL cell
+    indices, see is3d_sampler_inputs.first_cell) merged on rank `dst` into the order one GPU would have produced.  Other
+    ranks get None.  The sampler itself needs no collective: the streams are keyed by the global cell index."""
+    import numpy as np
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return particles
+    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(particles, parts, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    merged = np.concatenate(parts)
+    return merged[np.lexsort((merged["cell"], merged["event"]))]     # stable: the draw order within a (event, cell) survives

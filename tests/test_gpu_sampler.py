@@ -64,6 +64,12 @@ def test_sampler_sharding_capacity_and_errors(fx):
     merged = merged[np.lexsort((merged["cell"], merged["event"]))]
     # within one (event, cell) the draw order is preserved by the stable sort keys above only if lexsort is stable: it is
     assert len(merged) == len(whole) and all(np.array_equal(merged[f], whole[f]) for f in whole.dtype.names)
+    # event batching (count / scan / fill per batch of events) does not change the list
+    for be in (1, 7):
+        b, _ = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=25, seed=7, batch_events=be)
+        assert len(b) == len(whole) and all(np.array_equal(b[f], whole[f]) for f in whole.dtype.names)
+    empty, ste = api.sample_particles({k: v[:0] for k, v in cells.items()}, sp, fx["df"], gla, o, n_events=3, seed=7)
+    assert len(empty) == 0 and ste["n_particles"] == 0
     # a buffer that is too small: IS3D_ENOMEM, the count is still reported
     with pytest.raises(api.Is3dError) as e:
         api.sample_particles(cells, sp, fx["df"], gla, o, n_events=25, seed=7, capacity=10)

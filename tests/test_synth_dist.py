@@ -64,10 +64,30 @@ def _worker(rank, world, port, q):
     t = torch.from_numpy(part.copy())
     idist.allreduce_spectrum(t)
     dist.barrier()
+    # df_mode 4 needs ONE surface-average temperature for all ranks; the sampler shards by global cell index
+    T_glob = idist.surface_average_T_global(cells)
+    nn = 300
+    lo2, hi2 = idist.shard_bounds(nn, r, w)
+    shard = synth.synth_surface(hi2 - lo2, 3, seed=321, first_cell=lo2)
+    gla = inputs.feqmod_tables(0.15)
+    pl, _ = oracle.sample_particles(shard, inputs.species("pikp"), inputs.df_tables(), gla, dict(dimension=3, df_mode=2), n_events=30, seed=9,
+                                    first_cell=lo2)
+    import numpy as np
+    from is3d_amd import api
+    arr = np.zeros(len(pl["E"]), dtype=api.PARTICLE_DTYPE)
+    for f in arr.dtype.names:
+        arr[f] = pl[f]
+    merged = idist.gather_particles(arr)
     if r == 0:
         whole = oracle.dN_pTdpTdphidy(synth.synth_surface(n, 3, seed=123), inputs.species("pikp"), grid, inputs.df_tables(),
                                       dict(dimension=3, df_mode=2))
-        q.put((t.numpy().copy(), whole))
+        T_whole = inputs.surface_average_T(synth.synth_surface(n, 3, seed=123))
+        ref, _ = oracle.sample_particles(synth.synth_surface(nn, 3, seed=321), inputs.species("pikp"), inputs.df_tables(), gla,
+                                         dict(dimension=3, df_mode=2), n_events=30, seed=9)
+        same = len(merged) == len(ref["E"]) and all(np.array_equal(merged[f], ref[f]) for f in merged.dtype.names)
+        q.put((t.numpy().copy(), whole, T_glob, T_whole, bool(same), len(merged)))
+    else:
+        assert merged is None
     dist.destroy_process_group()
 
 
@@ -82,8 +102,10 @@ def test_two_rank_shards_allreduce_to_the_whole_spectrum():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, whole = q.get(timeout=300)
+    got, whole, T_glob, T_whole, same, n_sampled = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert relerr(got, whole) < 1e-13
+    assert abs(T_glob / T_whole - 1) < 1e-14
+    assert same and n_sampled > 20          # the two shards' particle lists, merged, are the one-process list
