@@ -469,7 +469,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             if (g.zskip && __all(x2min > 555400.0)) { n_dead += 1; return; }   // X > 745.25: exp(-X) == +0 for the whole wave-row
 #pragma unroll
             for (int jj = 0; jj < JT; jj++) {
-                const double X = sqrt_nr(X2[jj]);
+                const double X = sqrt_g1(X2[jj]);   // 3e-15 relative: e^-X moves by X * 3e-15
                 const double z = exp_full_sat(-X);   // X = |A^-1 p|/T_mod is unbounded for nearly singular A
                 const double d = __builtin_fma(sign, z, 1.0);
                 const double rr = rcp_nr1(d);

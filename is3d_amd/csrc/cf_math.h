@@ -128,6 +128,16 @@ __device__ __forceinline__ double sqrt_nr(double x)
     return __builtin_fma(d, h, g);
 }
 
+// sqrt(x) with one coupled Newton (Goldschmidt) step only: relative error 1.5 e0^2 for a seed of relative error e0, i.e.
+// ~3e-15 with the 4.5e-8 v_rsq_f64 seed of gfx950.  For arguments of exponentials whose result is needed to ~1e-12.
+__device__ __forceinline__ double sqrt_g1(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
+}
+
 // gsl_interp_cspline evaluation (deltafReader.cpp:339-358 call sites) on LDS-resident tables.
 __device__ __forceinline__ double spline_eval_lds(int n, const double *x, const double *y, const double *c, double xq)
 {
