@@ -31,7 +31,10 @@ def init_process_group(backend=None):
     os.environ.setdefault("MASTER_PORT", "29533")
     if backend == "nccl":
         torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        except TypeError:   # a torch without the device_id argument
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
