@@ -366,6 +366,7 @@ cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // event-major: (event - event0) * n_cells + cell
     if (idx >= (int64_t)n_events * p.n_cells) return;
+    if (FILL && offsets[idx + 1] == offsets[idx]) return;                  // pass 1 kept nothing here: nothing to replay
     const int ievent = event0 + (int)(idx / p.n_cells);
     const int64_t ic = idx % p.n_cells;
     const SamplerCell &c = cellrec[ic];
