@@ -225,6 +225,31 @@ int64_t is3d_plan_workspace_bytes(const is3d_plan *plan);
 void is3d_plan_destroy(is3d_plan *plan);
 
 /* ---------------------------------------------------------------------------------------------
+ * Anisotropic hydro (VAH, P_L matching): replaces EmissionFunctionArray::calculate_dN_pTdpTdphidy_VAH_PL
+ * (src/cpp/emissionfunction.h, src/cpp/emissionfunction_smooth_kernels.cpp:2140-2393).  The reference never calls it (call
+ * site commented out, emissionfunction.cpp:1650-1654) and src/cpp never loads the VAH coefficient tables: the per-cell
+ * 14-moment coefficients c0..c4 are inputs, as in the method's own signature.  All ten pi_perp^{mu nu} components are inputs
+ * too (this kernel does not reconstruct them); T is accepted and unused.  No outflow cut, no skipped cells.  opts: dimension,
+ * include_bulk_deltaf, include_shear_deltaf, regulate_deltaf, accumulate, device, workspace_bytes, cell_chunks, collapse_species,
+ * zero_skip.  HOST pointers; dN_out as for is3d_smooth_spectra.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t n_cells;
+    const double *tau, *eta;            /* eta unused (may be NULL) when dimension == 2 */
+    const double *ux, *uy, *un;
+    const double *dat, *dax, *day, *dan;
+    const double *T;                    /* unused (only FORCE_F0 reads it in the reference, :2295-2298); may be NULL */
+    const double *pitt, *pitx, *pity, *pitn, *pixx, *pixy, *pixn, *piyy, *piyn, *pinn;   /* pi_perp^{mu nu} */
+    const double *bulkPi;               /* residual bulk pressure */
+    const double *Wx, *Wy;              /* W_perp^mu; W^tau, W^eta reconstructed (:2244-2245) */
+    const double *Lambda, *aL;          /* anisotropic variables */
+    const double *c0, *c1, *c2, *c3, *c4;
+} is3d_vah_cells;
+
+int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                            const is3d_options *opts, double *dN_out, is3d_status *status);
+
+/* ---------------------------------------------------------------------------------------------
  * Particle sampler (operation = 2): replaces EmissionFunctionArray::sample_dN_pTdpTdphidy
  * (src/cpp/emissionfunction.h:208-210, emissionfunction_sampling_kernels.cpp:833-1225, call sites emissionfunction.cpp:1543,
  * :1606) for viscous hydro, df_mode 1-4, include_baryon = 0, fast = 0 | 1.  The reference's serial

@@ -97,7 +97,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
-           "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests"]
+           "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah"]
 
 
 class Is3dError(RuntimeError):
@@ -226,6 +226,38 @@ def _pack_common(species, grid, df, opts):
     ny_eff = 1 if o["dimension"] == 2 else len(g["y"])
     nout = len(sp["mass"]) * len(g["pT"]) * len(g["phi"]) * ny_eff
     return sps, gs, ds, os_, nout, keep
+
+
+VAH_FIELDS = ["tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan", "T", "pitt", "pitx", "pity", "pitn", "pixx", "pixy", "pixn",
+              "piyy", "piyn", "pinn", "bulkPi", "Wx", "Wy", "Lambda", "aL", "c0", "c1", "c2", "c3", "c4"]
+
+
+class VahCells(C.Structure):
+    _fields_ = [("n_cells", C.c_int64)] + [(f, _dp) for f in VAH_FIELDS]
+
+
+def smooth_spectra_vah(cells, species, grid, opts=None, out=None):
+    """is3d_smooth_spectra_vah (the drop-in for calculate_dN_pTdpTdphidy_VAH_PL).  cells: dict of host arrays per VAH_FIELDS."""
+    L = load()
+    dummy_df = dict(T=[0.1, 0.15, 0.2], c0=[0, 0, 0], c2=[0, 0, 0], F=[0, 0, 0], betabulk=[1, 1, 1], betapi=[1, 1, 1])
+    sps, gs, _, os_, nout, keep = _pack_common(species, grid, dummy_df, opts)
+    n = len(cells["tau"])
+    cs = VahCells()
+    cs.n_cells = n
+    held = []
+    for f in VAH_FIELDS:
+        a = cells.get(f)
+        if a is not None:
+            a = _f64(a)
+            assert a.shape == (n,), f
+            held.append(a)
+            setattr(cs, f, _p(a))
+    if out is None:
+        out = np.zeros(nout)
+    st = Status()
+    L.is3d_smooth_spectra_vah.argtypes = [C.POINTER(VahCells), C.POINTER(Species), C.POINTER(Grid), C.POINTER(Options), _dp, C.POINTER(Status)]
+    _check(L.is3d_smooth_spectra_vah(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(os_), _p(out), C.byref(st)))
+    return out, st.as_dict()
 
 
 def _pack_feqmod(fq, keep):

@@ -1,0 +1,503 @@
+// cf_vah.hip -- anisotropic-hydro (VAH, P_L matching) smooth Cooper-Frye kernel on the device: BASELINE config 5, SURVEY.md 8f
+// rank 4 (second half).  Device path of EmissionFunctionArray::calculate_dN_pTdpTdphidy_VAH_PL
+// (/root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:2140-2393), which the reference itself never calls
+// (emissionfunction.cpp:1650-1654): restated from the source text, with the per-cell coefficients c0..c4 as inputs, as in the
+// method's own signature.
+//
+//   f_a = 1/(exp(E_a/Lambda) + sign),  E_a^2 = (p.u)^2 + xi_L (p.z)^2,  xi_L = 1/alpha_L^2 - 1
+//   df/(f_a fbar_a) = c3 (p.z)(p.W) + c4 pi_perp^{mu nu} p_mu p_nu + (c0 m^2 + c1 (p.z)^2 + c2 (p.u)^2) Pi
+// With p.u = mT C_k - pT D_j, p.z = mT Z_k, p.W = mT V1_k - pT V2_j both the exponent and delta-f are quadratic forms in the
+// lane constants (mT, pT) with wave-uniform coefficients:
+//   (E_a/Lambda)^2 = mT^2 ax_k + mT pT bx_jk + pT^2 gx_j          df/(f_a fbar_a) = mT^2 ad_k + mT pT bd_jk + pT^2 gd_j
+// i.e. the exponent of the modified-equilibrium kernel (one sqrt + one exp per evaluation, cf_feqmod.hip) combined with the
+// delta-f of the tile kernel (cf_kernels.hip).  Unit record (JT phi's x R rows): header jj {B_j, gx_j, gd_j, 0}; row r
+// {A_k, ax_k, ad_k, W_k, bx_{j0..,k}, bd_{j0..,k}}.  No outflow cut and no skipped cells on this path; in 2+1D the eta
+// weights are the table weights times the node spacing (:2180-2188).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/is3d_amd.h"
+#include "cf_device.h"
+#include "cf_launch.h"
+#include "cf_math.h"
+#include "errors.h"
+
+namespace is3d {
+
+struct VahPtrs {
+    const double *tau, *eta, *ux, *uy, *un, *dat, *dax, *day, *dan;
+    const double *pitt, *pitx, *pity, *pitn, *pixx, *pixy, *pixn, *piyy, *piyn, *pinn;
+    const double *bulkPi, *Wx, *Wy, *Lambda, *aL, *c0, *c1, *c2, *c3, *c4;
+};
+
+struct VahPrepParams {
+    VahPtrs cells;
+    int32_t n_cells, J, K, dim3, include_bulk, include_shear;
+    const double *cosphi, *sinphi, *kgrid, *kweight;
+    int32_t JT, R, jtiles, rblocks;
+    double *TS;
+};
+
+constexpr int kVahCB = 4;
+constexpr int kVahThreads = 256;
+
+struct VahScal {
+    double dat, dax, day, dan_tau, eta, ut, ux, uy, tau_un, zt, tzn;
+    double pitt, pitx, pity, tpitn, pixx, pixy, tpixn, piyy, tpiyn, t2pinn;
+    double Wt, Wx, Wy, tWn, invL2, xi, Pi, c0, c1, c2, c3, c4;
+};
+
+__global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
+{
+    extern __shared__ double lds[];
+    const int J = p.J, K = p.K;
+    VahScal *cs = (VahScal *)lds;                     // [CB]
+    double *lk = (double *)(cs + kVahCB);             // [9][CB][K]: A, ax, ad, W, ch, sh, C, Z, V1
+    double *lj = lk + 9 * kVahCB * K;                 // [7][CB][J]: B, gx, gd, D, V2, E, F
+    const int CK = kVahCB * K, CJ = kVahCB * J;
+    double *l_A = lk, *l_ax = lk + CK, *l_ad = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK;
+    double *l_C = lk + 6 * CK, *l_Z = lk + 7 * CK, *l_V1 = lk + 8 * CK;
+    double *l_B = lj, *l_gx = lj + CJ, *l_gd = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_V2 = lj + 4 * CJ, *l_E = lj + 5 * CJ, *l_F = lj + 6 * CJ;
+    const int tid = threadIdx.x;
+    const int nbatch = (p.n_cells + kVahCB - 1) / kVahCB;
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int cbase = batch * kVahCB;
+        const int ncb = min(kVahCB, p.n_cells - cbase);
+        if (tid < ncb) {                                                          // :2208-2256
+            const int64_t gi = cbase + tid;
+            VahScal s;
+            const double tau = p.cells.tau[gi], tau2 = tau * tau;
+            const double ux = p.cells.ux[gi], uy = p.cells.uy[gi], un = p.cells.un[gi];
+            const double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+            const double u0 = sqrt(1.0 + ux * ux + uy * uy);
+            s.zt = tau * un / u0;
+            s.tzn = tau * (ut / (u0 * tau));                                        // tau * zn
+            s.dat = p.cells.dat[gi]; s.dax = p.cells.dax[gi]; s.day = p.cells.day[gi]; s.dan_tau = p.cells.dan[gi] / tau;
+            s.eta = p.dim3 ? p.cells.eta[gi] : 0.0;
+            s.ut = ut; s.ux = ux; s.uy = uy; s.tau_un = tau * un;
+            s.pitt = p.cells.pitt[gi]; s.pitx = p.cells.pitx[gi]; s.pity = p.cells.pity[gi]; s.tpitn = tau * p.cells.pitn[gi];
+            s.pixx = p.cells.pixx[gi]; s.pixy = p.cells.pixy[gi]; s.tpixn = tau * p.cells.pixn[gi];
+            s.piyy = p.cells.piyy[gi]; s.tpiyn = tau * p.cells.piyn[gi]; s.t2pinn = tau2 * p.cells.pinn[gi];
+            const double Wx = p.cells.Wx[gi], Wy = p.cells.Wy[gi];
+            const double Wt = (ux * Wx + uy * Wy) * ut / (u0 * u0);
+            s.Wt = Wt; s.Wx = Wx; s.Wy = Wy; s.tWn = tau * (Wt * un / ut);
+            const double Lambda = p.cells.Lambda[gi], aL = p.cells.aL[gi];
+            s.invL2 = 1.0 / (Lambda * Lambda);
+            s.xi = 1.0 / (aL * aL) - 1.0;
+            s.Pi = p.include_bulk ? p.cells.bulkPi[gi] : 0.0;
+            s.c0 = p.cells.c0[gi]; s.c1 = p.cells.c1[gi]; s.c2 = p.cells.c2[gi];
+            s.c3 = p.include_shear ? p.cells.c3[gi] : 0.0;
+            s.c4 = p.include_shear ? p.cells.c4[gi] : 0.0;
+            cs[tid] = s;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < ncb * K; idx += kVahThreads) {
+            const int c = idx / K, k = idx - c * K;
+            const VahScal &s = cs[c];
+            double dlt, w;
+            if (p.dim3) { dlt = p.kgrid[k] - s.eta; w = 1.0; }
+            else { dlt = 0.0 - p.kgrid[k]; w = p.kweight[k]; }                      // host passes eta_w * delta_eta
+            const double ch = cosh(dlt), sh = sinh(dlt);
+            const double C = ch * s.ut - sh * s.tau_un;                             // p.u = mT C - pT D
+            const double Z = ch * s.zt - sh * s.tzn;                                // p.z = mT Z
+            const double V1 = ch * s.Wt - sh * s.tWn;                               // p.W = mT V1 - pT V2
+            const double Q0 = s.pitt * ch * ch + s.t2pinn * sh * sh - 2.0 * s.tpitn * ch * sh;
+            l_A[idx] = w * (ch * s.dat + sh * s.dan_tau);
+            l_W[idx] = w;
+            l_ax[idx] = (C * C + s.xi * Z * Z) * s.invL2;
+            l_ad[idx] = s.c3 * Z * V1 + s.c4 * Q0 + s.Pi * (s.c0 + s.c1 * Z * Z + s.c2 * C * C);
+            l_ch[idx] = ch; l_sh[idx] = sh; l_C[idx] = C; l_Z[idx] = Z; l_V1[idx] = V1;
+        }
+        for (int idx = tid; idx < ncb * J; idx += kVahThreads) {
+            const int c = idx / J, j = idx - c * J;
+            const VahScal &s = cs[c];
+            const double cp = p.cosphi[j], sp = p.sinphi[j];
+            const double D = cp * s.ux + sp * s.uy;
+            const double Q2 = s.pixx * cp * cp + s.piyy * sp * sp + 2.0 * s.pixy * cp * sp;
+            l_B[idx] = cp * s.dax + sp * s.day;
+            l_gx[idx] = D * D * s.invL2;
+            l_gd[idx] = s.c4 * Q2 + s.Pi * (s.c2 * D * D - s.c0);
+            l_D[idx] = D;
+            l_V2[idx] = cp * s.Wx + sp * s.Wy;
+            l_E[idx] = -2.0 * (s.pitx * cp + s.pity * sp);
+            l_F[idx] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
+        }
+        __syncthreads();
+        {
+            const int JT = p.JT, R = p.R;
+            const int HDR = 4 * JT, RWD = 4 + 2 * JT, REC = HDR + R * RWD;
+            const int units_per_cell = p.jtiles * p.rblocks, per_cell = units_per_cell * REC;
+            for (int idx = tid; idx < ncb * per_cell; idx += kVahThreads) {
+                const int c = idx / per_cell;
+                const int rem = idx - c * per_cell;
+                const int ut = rem / REC, e = rem - ut * REC;
+                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
+                const VahScal &s = cs[c];
+                double v = 0.0;
+                if (e < HDR) {
+                    const int jj = e >> 2, f = e & 3;
+                    const int j = min(jt * JT + jj, J - 1);
+                    if (f == 0) v = l_B[c * J + j];
+                    else if (f == 1) v = l_gx[c * J + j];
+                    else if (f == 2) v = l_gd[c * J + j];
+                } else {
+                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
+                    const int k = rb * R + r, kc = min(k, K - 1);     // padding rows: the forms of row K-1 with p.dsigma = 0
+                    if (f == 0) v = (k < K) ? l_A[c * K + kc] : 0.0;
+                    else if (f == 1) v = l_ax[c * K + kc];
+                    else if (f == 2) v = l_ad[c * K + kc];
+                    else if (f == 3) v = (k < K) ? l_W[c * K + kc] : 0.0;
+                    else if (f < 4 + JT) {
+                        const int j = min(jt * JT + (f - 4), J - 1);
+                        v = -2.0 * l_C[c * K + kc] * l_D[c * J + j] * s.invL2;
+                    } else {
+                        const int j = min(jt * JT + (f - 4 - JT), J - 1);
+                        const double X = l_E[c * J + j] * l_ch[c * K + kc] + l_F[c * J + j] * l_sh[c * K + kc];
+                        v = s.c4 * X - s.c3 * l_Z[c * K + kc] * l_V2[c * J + j] - 2.0 * s.Pi * s.c2 * l_C[c * K + kc] * l_D[c * J + j];
+                    }
+                }
+                const int64_t cell = cbase + c;
+                int64_t unit;
+                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;
+                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
+                p.TS[unit * REC + e] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Same task decomposition, LDS staging and partial layout as cf_main_tile / cf_main_feqmod.
+template <bool DIM3, bool REG, int JT, int R>
+__global__ void __launch_bounds__(512)
+cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
+            const double *__restrict__ lane_sign, double *__restrict__ partial, MainGeom g)
+{
+    constexpr int HDR = 4 * JT;
+    constexpr int RW = 4 + 2 * JT;
+    constexpr int REC = HDR + R * RW;
+    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
+    constexpr int BUF2 = UB * REC / 2;
+    constexpr int NLD = (BUF2 + 127) / 128;
+    static_assert(REC % 2 == 0, "unit records must be 16-byte multiples");
+    __shared__ double2 lbuf[2][BUF2 + RW / 2 + 1];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int stream = (q / g.G) * 8 + xcd;
+    if (stream >= g.NT) return;
+    int sidx = stream;
+    const int jt = sidx % g.jtiles; sidx /= g.jtiles;
+    const int kt = sidx % g.ktiles; sidx /= g.ktiles;
+    const int chunk = sidx;
+    const int nthr = blockDim.x;
+    const int lw = grp * g.wpb + (tid >> 6);
+    const bool wave_active = lw * 64 < g.Lpad;
+    const int l = wave_active ? lw * 64 + (tid & 63) : 0;
+
+    const int J = g.J, K = g.K;
+    const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
+    const double hs = REG ? 0.5 : 1.0;   // u = (1 + fbar df) * hs, clamped to [0, 1] by the VOP3 clamp modifier when REG
+    const double mT2s = hs * mT2, mTpTs = hs * mTpT, pT2s = hs * pT2;
+    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    const int n_units = (c1 - c0) * g.upc;
+    const int s_tile = DIM3 ? (jt * g.ktiles + kt) : jt;
+    const double2 *src = (const double2 *)(TS + (((int64_t)s_tile * g.n_cells + c0) * g.upc) * REC);
+    const int nb = (n_units + UB - 1) / UB;
+
+    constexpr int NACC = DIM3 ? JT * R : JT;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+
+    auto process_unit = [&](const double *U) {
+        double pTB[JT], gx[JT], gd[JT];
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) {
+            pTB[jj] = pT * U[4 * jj + 0];
+            gx[jj] = pT2 * U[4 * jj + 1];
+            gd[jj] = pT2s * U[4 * jj + 2];
+        }
+        struct Row { double v[RW]; };
+        auto fetch = [&](Row &rw, const double *row) {
+#pragma unroll
+            for (int i = 0; i < RW; i++) rw.v[i] = row[i];
+        };
+        auto evals = [&](const Row &rw, int r) {
+            const double mTA = mT * rw.v[0], ax = mT2 * rw.v[1], ad = mT2s * rw.v[2], W = rw.v[3];
+            double X2[JT];
+            double x2min = 1.0e300;
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) {
+                X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], ax + gx[jj]);
+                x2min = __builtin_fmin(x2min, X2[jj]);
+            }
+            if (g.zskip && __all(x2min > 555400.0)) return;   // E_a/Lambda > 745.25: f_a == +0 for the whole wave-row
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) {
+                const double X = sqrt_g1(X2[jj]);
+                const double z = exp_full_sat(-X);
+                const double d = __builtin_fma(sign, z, 1.0);
+                const double rr = rcp_nr1(d);                                              // fbar_a
+                const double br = __builtin_fma(mTpTs, rw.v[4 + JT + jj], ad + gd[jj]);   // hs * df/(f_a fbar_a)
+                const double u = REG ? fma_clamp01_half(rr, br) : __builtin_fma(rr, br, 1.0);
+                const double pds = __builtin_fma(pTB[jj], W, mTA);
+                const double w = (z * rr) * u;
+                if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+            }
+        };
+        const double *rows = U + HDR;
+        Row cur, nxt;
+        fetch(cur, rows);
+        if (DIM3) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
+                evals(cur, r);
+                if (r + 1 < R) cur = nxt;
+            }
+        } else {
+#pragma unroll 2
+            for (int r = 0; r < R; r++) {
+                fetch(nxt, rows + (r + 1) * RW);
+                evals(cur, 0);
+                cur = nxt;
+            }
+        }
+    };
+
+    double2 pre[NLD];
+    if (nb > 0) {
+        {
+            const int n2 = min(UB, n_units) * (REC / 2);
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * nthr;
+                if (i < n2) lbuf[0][i] = src[i];
+            }
+        }
+        __syncthreads();
+        for (int ib = 0; ib < nb; ib++) {
+            const bool more = ib + 1 < nb;
+            const int n2next = more ? min(UB, n_units - (ib + 1) * UB) * (REC / 2) : 0;
+            const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * nthr;
+                pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
+            }
+            if (wave_active) {
+                const int nu = min(UB, n_units - ib * UB);
+                const double *base = (const double *)lbuf[ib & 1];
+                for (int u = 0; u < nu; u++) process_unit(base + u * REC);
+            }
+#pragma unroll
+            for (int t = 0; t < NLD; t++) {
+                const int i = tid + t * nthr;
+                if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
+            }
+            __syncthreads();
+        }
+    }
+    if (!wave_active) return;
+    const double unscale = REG ? 2.0 : 1.0;
+    const int64_t JKacc = (int64_t)J * g.Kacc;
+    double *pp = partial + (int64_t)chunk * JKacc * g.Lpad;
+#pragma unroll
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = jt * JT + jj;
+        if (j < J) {
+            if (DIM3) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int k = kt * R + r;
+                    if (k < K) pp[((int64_t)j * g.Kacc + k) * g.Lpad + l] = unscale * acc[jj * R + r];
+                }
+            } else {
+                pp[(int64_t)j * g.Lpad + l] = unscale * acc[jj];
+            }
+        }
+    }
+}
+
+}  // namespace is3d
+
+namespace {
+
+#define VAH_TRY(expr)                                                                                            \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) return is3d::set_error(IS3D_ENODEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevMem {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { release(); return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+    template <class T>
+    hipError_t upload(const std::vector<T> &h)
+    {
+        hipError_t e = alloc(h.size() * sizeof(T));
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    ~DevMem() { release(); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+constexpr int kJT3 = 6, kR3 = 7, kJT2 = 8, kR2 = 61;   // the default tile shapes of the delta-f kernel
+
+template <bool DIM3>
+void launch_vah(bool reg, const double *TS, const double *mT, const double *pT, const double *sg, double *partial, const is3d::MainGeom &g)
+{
+    const int grid = ((g.NT + 7) / 8) * 8 * g.G;
+    constexpr int JT = DIM3 ? kJT3 : kJT2, R = DIM3 ? kR3 : kR2;
+    if (reg) hipLaunchKernelGGL((is3d::cf_main_vah<DIM3, true, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, nullptr, TS, mT, pT, sg, partial, g);
+    else hipLaunchKernelGGL((is3d::cf_main_vah<DIM3, false, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, nullptr, TS, mT, pT, sg, partial, g);
+}
+
+}  // namespace
+
+extern "C" int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_species *sp, const is3d_grid *gr, const is3d_options *o,
+                                       double *dN_out, is3d_status *status)
+{
+    using is3d::set_error;
+    if (!cells || !sp || !gr || !o || !dN_out) return set_error(IS3D_EINVAL, "null argument");
+    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
+    if (o->dimension != 2 && o->dimension != 3) return set_error(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", o->dimension);
+    if (sp->n < 1 || !sp->mass || !sp->sign || !sp->degeneracy) return set_error(IS3D_EINVAL, "empty species list");
+    if (gr->n_pT < 1 || gr->n_phi < 1 || !gr->pT || !gr->phi) return set_error(IS3D_EINVAL, "empty pT/phi grid");
+    const bool three_d = o->dimension == 3;
+    if (three_d && (gr->n_y < 1 || !gr->y)) return set_error(IS3D_EINVAL, "dimension 3 needs a y grid");
+    if (!three_d && (gr->n_eta < 2 || !gr->eta || !gr->eta_w)) return set_error(IS3D_EINVAL, "dimension 2 needs an eta table of >= 2 nodes");
+    const int64_t n = cells->n_cells;
+    if (n < 0 || n > 0x7fff0000LL) return set_error(IS3D_EINVAL, "n_cells out of range");
+    const double *src[30] = {cells->tau, cells->eta, cells->ux, cells->uy, cells->un, cells->dat, cells->dax, cells->day, cells->dan, cells->T,
+                             cells->pitt, cells->pitx, cells->pity, cells->pitn, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn,
+                             cells->pinn, cells->bulkPi, cells->Wx, cells->Wy, cells->Lambda, cells->aL, cells->c0, cells->c1, cells->c2,
+                             cells->c3, cells->c4};
+    if (n > 0)
+        for (int a = 0; a < 30; a++)
+            if (!src[a] && !(a == 1 && !three_d) && a != 9) return set_error(IS3D_EINVAL, "a required VAH cell array is NULL (index %d)", a);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (o->device >= 0) VAH_TRY(hipSetDevice(o->device));
+
+    // ---- species classes and lanes sorted by mT (as cf_plan.cpp) ----
+    const int npart = sp->n, npT = gr->n_pT, J = gr->n_phi, K = three_d ? gr->n_y : gr->n_eta, Kacc = three_d ? K : 1;
+    const int64_t nout = (int64_t)npart * npT * J * Kacc;
+    std::vector<int> cls(npart);
+    std::vector<double> cmass, csign;
+    for (int s = 0; s < npart; s++) {
+        int found = -1;
+        if (o->collapse_species != 2)
+            for (size_t c = 0; c < cmass.size(); c++)
+                if (cmass[c] == sp->mass[s] && csign[c] == sp->sign[s]) { found = (int)c; break; }
+        if (found < 0) { found = (int)cmass.size(); cmass.push_back(sp->mass[s]); csign.push_back(sp->sign[s]); }
+        cls[s] = found;
+    }
+    const int ncls = (int)cmass.size(), L = ncls * npT, Lpad = ((L + 63) / 64) * 64;
+    std::vector<double> mT(Lpad, 1.0), pT(Lpad, 0.0), sg(Lpad, 1.0), mT_nat(L);
+    std::vector<int> order(L), slot_of(L), lane_sp((size_t)npart * npT);
+    for (int c = 0; c < ncls; c++)
+        for (int i = 0; i < npT; i++) { mT_nat[c * npT + i] = std::sqrt(cmass[c] * cmass[c] + gr->pT[i] * gr->pT[i]); order[c * npT + i] = c * npT + i; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mT_nat[a] < mT_nat[b]; });
+    for (int s = 0; s < L; s++) { const int nat = order[s]; slot_of[nat] = s; mT[s] = mT_nat[nat]; pT[s] = gr->pT[nat % npT]; sg[s] = csign[nat / npT]; }
+    for (int s = 0; s < npart; s++)
+        for (int i = 0; i < npT; i++) lane_sp[(size_t)s * npT + i] = slot_of[cls[s] * npT + i];
+    std::vector<double> cosphi(J), sinphi(J), kgrid(K), kweight(K, 1.0), deg(sp->degeneracy, sp->degeneracy + npart);
+    for (int j = 0; j < J; j++) { cosphi[j] = std::cos(gr->phi[j]); sinphi[j] = std::sin(gr->phi[j]); }
+    for (int k = 0; k < K; k++) {
+        kgrid[k] = three_d ? gr->y[k] : gr->eta[k];
+        if (!three_d) kweight[k] = gr->eta_w[k] * (gr->eta[1] - gr->eta[0]);          // :2178-2187
+    }
+    if (status) status->n_classes = ncls;
+    if (n == 0) {
+        if (!o->accumulate) memset(dN_out, 0, sizeof(double) * (size_t)nout);
+        return IS3D_OK;
+    }
+    DevMem d_mT, d_pT, d_sg, d_lane, d_deg, d_cos, d_sin, d_kg, d_kw, d_cell[30], d_TS, d_partial, d_out;
+    VAH_TRY(d_mT.upload(mT)); VAH_TRY(d_pT.upload(pT)); VAH_TRY(d_sg.upload(sg)); VAH_TRY(d_lane.upload(lane_sp)); VAH_TRY(d_deg.upload(deg));
+    VAH_TRY(d_cos.upload(cosphi)); VAH_TRY(d_sin.upload(sinphi)); VAH_TRY(d_kg.upload(kgrid)); VAH_TRY(d_kw.upload(kweight));
+    const double *dp[30];
+    for (int a = 0; a < 30; a++) {
+        dp[a] = nullptr;
+        if (src[a] && a != 9) {
+            VAH_TRY(d_cell[a].alloc((size_t)n * sizeof(double)));
+            VAH_TRY(hipMemcpyAsync(d_cell[a].p, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+            dp[a] = d_cell[a].as<double>();
+        }
+    }
+    const int JT = three_d ? kJT3 : kJT2, R = three_d ? kR3 : kR2;
+    const int jtiles = (J + JT - 1) / JT, rblocks = (K + R - 1) / R, ktiles = three_d ? rblocks : 1, upc = three_d ? 1 : rblocks;
+    const int REC = 4 * JT + R * (4 + 2 * JT);
+    const size_t lds = sizeof(is3d::VahScal) * is3d::kVahCB + sizeof(double) * (size_t)is3d::kVahCB * (9 * K + 7 * J);
+    if (lds > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
+    // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
+    const size_t bytes_per_cell = sizeof(double) * (size_t)jtiles * rblocks * REC;
+    const int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
+    const int64_t pass_cells = std::max<int64_t>(1, std::min<int64_t>(n, ws / (int64_t)bytes_per_cell));
+    const int lane_waves = Lpad / 64;
+    int wpb = 4, best = 1 << 30;
+    for (int w : {8, 4, 2}) { const int waste = ((lane_waves + w - 1) / w) * w - lane_waves; if (waste < best) { best = waste; wpb = w; } }
+    int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24LL * 4096 + (int64_t)lane_waves * jtiles * ktiles - 1) / ((int64_t)lane_waves * jtiles * ktiles);
+    nch = std::min<int64_t>(nch, std::max<int64_t>(1, pass_cells / 64));
+    nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)2 << 30) / ((int64_t)J * Kacc * Lpad * 8)));
+    VAH_TRY(d_TS.alloc((size_t)pass_cells * bytes_per_cell));
+    VAH_TRY(d_partial.alloc((size_t)nch * J * Kacc * Lpad * sizeof(double)));
+    VAH_TRY(d_out.alloc((size_t)nout * sizeof(double)));
+    if (o->accumulate) VAH_TRY(hipMemcpyAsync(d_out.p, dN_out, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    hipEvent_t ev[3];
+    for (auto &e : ev) VAH_TRY(hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]); } } evg{ev};
+    const int npasses = (int)((n + pass_cells - 1) / pass_cells);
+    double ms_prep = 0.0, ms_main = 0.0;
+    for (int pass = 0; pass < npasses; pass++) {
+        const int64_t c0 = (int64_t)pass * pass_cells;
+        const int32_t nc = (int32_t)std::min<int64_t>(pass_cells, n - c0);
+        is3d::VahPrepParams pp{};
+        const double *q[30];
+        for (int a = 0; a < 30; a++) q[a] = dp[a] ? dp[a] + c0 : nullptr;
+        pp.cells = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[10], q[11], q[12], q[13], q[14], q[15], q[16], q[17], q[18], q[19],
+                    q[20], q[21], q[22], q[23], q[24], q[25], q[26], q[27], q[28], q[29]};
+        pp.n_cells = nc; pp.J = J; pp.K = K; pp.dim3 = three_d;
+        pp.include_bulk = o->include_bulk_deltaf != 0; pp.include_shear = o->include_shear_deltaf != 0;
+        pp.cosphi = d_cos.as<double>(); pp.sinphi = d_sin.as<double>(); pp.kgrid = d_kg.as<double>(); pp.kweight = d_kw.as<double>();
+        pp.JT = JT; pp.R = R; pp.jtiles = jtiles; pp.rblocks = rblocks; pp.TS = d_TS.as<double>();
+        VAH_TRY(hipEventRecord(ev[0], nullptr));
+        const int nbatch = (nc + is3d::kVahCB - 1) / is3d::kVahCB;
+        hipLaunchKernelGGL(is3d::cf_prep_vah, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), lds, nullptr, pp);
+        VAH_TRY(hipGetLastError());
+        VAH_TRY(hipEventRecord(ev[1], nullptr));
+        is3d::MainGeom g{};
+        g.n_cells = nc; g.J = J; g.K = K; g.Lpad = Lpad; g.wpb = wpb; g.G = (lane_waves + wpb - 1) / wpb;
+        g.jtiles = jtiles; g.ktiles = ktiles; g.nch = (int)nch; g.NT = jtiles * ktiles * (int)nch; g.Kacc = Kacc;
+        g.first_pass = 1; g.upc = upc; g.zskip = (o->zero_skip != 2); g.baryon = 0;
+        if (three_d) launch_vah<true>(o->regulate_deltaf != 0, d_TS.as<double>(), d_mT.as<double>(), d_pT.as<double>(), d_sg.as<double>(), d_partial.as<double>(), g);
+        else launch_vah<false>(o->regulate_deltaf != 0, d_TS.as<double>(), d_mT.as<double>(), d_pT.as<double>(), d_sg.as<double>(), d_partial.as<double>(), g);
+        VAH_TRY(hipGetLastError());
+        // each pass finalises into the output (accumulating after the first): the partial slots are rewritten per pass
+        const double prefactor = 1.0 / (8.0 * (M_PI * M_PI * M_PI)) / is3d::kHbarC / is3d::kHbarC / is3d::kHbarC;   // :2147
+        VAH_TRY(is3d::launch_finalize(d_partial.as<double>(), d_lane.as<int>(), d_deg.as<double>(), d_out.as<double>(), nout, npart, npT, J, Kacc,
+                                      Lpad, (int)nch, prefactor, (pass > 0 || o->accumulate) ? 1 : 0, nullptr, nullptr));
+        VAH_TRY(hipEventRecord(ev[2], nullptr));
+        VAH_TRY(hipEventSynchronize(ev[2]));
+        float a = 0, b2 = 0;
+        VAH_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+        VAH_TRY(hipEventElapsedTime(&b2, ev[1], ev[2]));
+        ms_prep += a; ms_main += b2;
+    }
+    VAH_TRY(hipMemcpy(dN_out, d_out.p, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) { status->n_passes = npasses; status->kernel_variant = 2; status->ms_prep = ms_prep; status->ms_main = ms_main; }
+    return IS3D_OK;
+}

@@ -98,6 +98,50 @@ def synth_surface(n_cells, dimension, seed=None, first_cell=0, baryon=False):
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in s.items()}
 
 
+VAH_FIELDS = ["tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan", "T", "pitt", "pitx", "pity", "pitn", "pixx", "pixy", "pixn",
+              "piyy", "piyn", "pinn", "bulkPi", "Wx", "Wy", "Lambda", "aL", "c0", "c1", "c2", "c3", "c4"]
+
+
+def synth_vah_surface(n_cells, dimension, seed=None, first_cell=0):
+    """Anisotropic-hydro (P_L matching) cells for the VAH smooth kernel (smooth_kernels.cpp:2140-2393): the viscous-hydro
+    synthetic surface plus all ten pi_perp^{mu nu} components (orthogonal to u, traceless, as the kernel reconstructs them on
+    the viscous-hydro path), W^x, W^y, the anisotropic variables Lambda ~ T and alpha_L in [0.7, 1.2], and per-cell 14-moment
+    coefficients c0..c4 of the magnitude the viscous-hydro tables give (delta-f of order 0.1)."""
+    s = synth_surface(n_cells, dimension, seed=seed, first_cell=first_cell)
+    if seed is None:
+        seed = SEED_CONFIG2 if dimension == 2 else SEED_CONFIG3
+    c = np.arange(first_cell, first_cell + n_cells, dtype=np.uint64) * np.uint64(32)
+
+    def U(slot):
+        return _uniform(seed ^ 0x5A5A5A5A, c + np.uint64(slot))
+
+    tau, ux, uy, un = s["tau"], s["ux"], s["uy"], s["un"]
+    tau2 = tau * tau
+    ut = np.sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un)
+    utperp2 = 1.0 + ux * ux + uy * uy
+    pixx, pixy, pixn, piyy, piyn = s["pixx"], s["pixy"], s["pixn"], s["piyy"], s["piyn"]
+    pinn = (pixx * (ux * ux - ut * ut) + piyy * (uy * uy - ut * ut) + 2.0 * (pixy * ux * uy + tau2 * un * (pixn * ux + piyn * uy))) / (tau2 * utperp2)
+    pitn = (pixn * ux + piyn * uy + tau2 * pinn * un) / ut
+    pity = (pixy * ux + piyy * uy + tau2 * piyn * un) / ut
+    pitx = (pixx * ux + pixy * uy + tau2 * pixn * un) / ut
+    pitt = (pitx * ux + pity * uy + tau2 * pitn * un) / ut
+    T, P, E = s["T"], s["P"], s["E"]
+    v = {k: s[k] for k in ["tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan", "T", "pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi"]}
+    v.update(pitt=pitt, pitx=pitx, pity=pity, pitn=pitn, pinn=pinn)
+    v["Wx"] = 0.01 * (E + P) * (2.0 * U(1) - 1.0)
+    v["Wy"] = 0.01 * (E + P) * (2.0 * U(2) - 1.0)
+    v["Lambda"] = T * (0.9 + 0.25 * U(3))
+    v["aL"] = 0.7 + 0.5 * U(4)
+    shear = 0.5 / (T * T * (E + P))
+    v["c4"] = shear * (0.8 + 0.4 * U(5))
+    v["c3"] = shear * (2.0 * U(6) - 1.0)
+    v["c0"] = 4.0 / T ** 4 * (0.5 + U(7))
+    v["c1"] = -8.0 / T ** 4 * (0.5 + U(8))
+    v["c2"] = 6.0 / T ** 4 * (0.5 + U(9))
+    v["x"], v["y"] = s["x"], s["y"]
+    return {k: np.ascontiguousarray(a, dtype=np.float64) for k, a in v.items()}
+
+
 def write_surface_dat(path, s):
     """Mode-1 (`read_surf_VH`, src/cpp/readindata.cpp:320-420) text surface, 20 columns, 17 significant
     digits, thermodynamic and viscous columns in fm^-n (divided by hbar*c)."""

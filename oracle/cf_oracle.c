@@ -1385,3 +1385,113 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
     free(cs); free(dn_list); free(s); free(J); free(Equilibrium_Density); free(Bulk_Density);
     return err ? err : kept;
 }
+
+/* ==========================================================================================
+ * Anisotropic-hydro (VAH, P_L matching) smooth kernel: BASELINE config 5 / SURVEY.md 8f rank 4, second half.
+ * Restates EmissionFunctionArray::calculate_dN_pTdpTdphidy_VAH_PL
+ * (src/cpp/emissionfunction_smooth_kernels.cpp:2140-2393) from its source text.  The reference never calls it (the call
+ * site is commented out, emissionfunction.cpp:1650-1654) and src/cpp never loads the VAH coefficient tables, so there is
+ * no reference behaviour to compare with: the per-cell 14-moment coefficients c0..c4 are INPUTS here, exactly as in the
+ * kernel's own signature.  What it computes, per cell and momentum:
+ *   f_a = 1/(exp(E_a/Lambda) + sign),  E_a = sqrt((p.u)^2 + xi_L (p.z)^2),  xi_L = 1/alpha_L^2 - 1,
+ *   df/(f_a fbar_a) = c3 (-z.p)(-p.W) + c4 pi_perp^{mu nu} p_mu p_nu + (c0 m^2 + c1 (p.z)^2 + c2 (p.u)^2) Pi,
+ * no outflow cut, no skipping of cells with u.dsigma <= 0; in 2+1D the eta weights are the table weights TIMES the node
+ * spacing (:2180-2188), unlike the viscous-hydro kernel.  Same defects as there are not restated (shared etaValues[0], :2216-2219).
+ * ========================================================================================== */
+typedef struct {
+    const double *tau, *eta, *ux, *uy, *un, *dat, *dax, *day, *dan, *T;
+    const double *pitt, *pitx, *pity, *pitn, *pixx, *pixy, *pixn, *piyy, *piyn, *pinn;
+    const double *bulkPi, *Wx, *Wy, *Lambda, *aL, *c0, *c1, *c2, *c3, *c4;
+} vah_cell_arrays;
+
+int oracle_dN_pTdpTdphidy_vah(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
+                              const vah_cell_arrays *a, const oracle_grid *g, const oracle_opts *o, double *dN_pTdpTdphidy)
+{
+    if (o->dimension != 2 && o->dimension != 3) return -3;
+    const double prefactor = 1.0 / (8.0 * (M_PI * M_PI * M_PI)) / ORACLE_HBARC / ORACLE_HBARC / ORACLE_HBARC;
+    const int npT = g->pT_tab_length, nphi = g->phi_tab_length;
+    double *cosphi = (double *)malloc(sizeof(double) * nphi), *sinphi = (double *)malloc(sizeof(double) * nphi);
+    for (int i = 0; i < nphi; i++) { cosphi[i] = cos(g->phi[i]); sinphi[i] = sin(g->phi[i]); }
+    int y_pts = g->y_tab_length, eta_pts = 1;
+    if (o->dimension == 2) { y_pts = 1; eta_pts = g->eta_tab_length; }
+    double *etaW = (double *)malloc(sizeof(double) * (eta_pts > 0 ? eta_pts : 1));
+    if (o->dimension == 2) {
+        if (eta_pts < 2) { free(cosphi); free(sinphi); free(etaW); return -3; }
+        const double delta_eta = g->eta[1] - g->eta[0];                       /* :2178 */
+        for (int i = 0; i < eta_pts; i++) etaW[i] = g->eta_w[i] * delta_eta;
+    } else etaW[0] = 1.0;
+    const long long nspec = (long long)npart * npT * nphi * y_pts;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    double *part = (double *)calloc((size_t)nspec * nthreads, sizeof(double));
+#pragma omp parallel
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double *acc = part + (size_t)tid * nspec;
+#pragma omp for schedule(static)
+        for (long ic = 0; ic < FO_length; ic++) {
+            double tau = a->tau[ic], tau2 = tau * tau;
+            double eta_cell = (o->dimension == 3) ? a->eta[ic] : 0.0;
+            double dat = a->dat[ic], dax = a->dax[ic], day = a->day[ic], dan = a->dan[ic];
+            double ux = a->ux[ic], uy = a->uy[ic], un = a->un[ic];
+            double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+            double u0 = sqrt(1.0 + ux * ux + uy * uy);
+            double zt = tau * un / u0, zn = ut / (u0 * tau);
+            double pitt = a->pitt[ic], pitx = a->pitx[ic], pity = a->pity[ic], pitn = a->pitn[ic], pixx = a->pixx[ic];
+            double pixy = a->pixy[ic], pixn = a->pixn[ic], piyy = a->piyy[ic], piyn = a->piyn[ic], pinn = a->pinn[ic];
+            double bulkPi = a->bulkPi[ic];
+            double Wx = a->Wx[ic], Wy = a->Wy[ic];
+            double Wt = (ux * Wx + uy * Wy) * ut / (u0 * u0);
+            double Wn = Wt * un / ut;
+            double Lambda = a->Lambda[ic], aL = a->aL[ic];
+            double c0 = a->c0[ic], c1 = a->c1[ic], c2 = a->c2[ic], c3 = a->c3[ic], c4 = a->c4[ic];
+            for (int ipart = 0; ipart < npart; ipart++) {
+                double mass = Mass[ipart], mass2 = mass * mass, sign = Sign[ipart], degeneracy = Degeneracy[ipart];
+                for (int ipT = 0; ipT < npT; ipT++) {
+                    double pT = g->pT[ipT], mT = sqrt(mass2 + pT * pT), mT_over_tau = mT / tau;
+                    for (int iphip = 0; iphip < nphi; iphip++) {
+                        double px = pT * cosphi[iphip], py = pT * sinphi[iphip];
+                        for (int iy = 0; iy < y_pts; iy++) {
+                            double y = (o->dimension == 2) ? 0.0 : g->y[iy], sum = 0.0;
+                            for (int ieta = 0; ieta < eta_pts; ieta++) {
+                                double eta = (o->dimension == 2) ? g->eta[ieta] : eta_cell, eta_weight = etaW[ieta];
+                                double pt = mT * cosh(y - eta), pn = mT_over_tau * sinh(y - eta), tau2_pn = tau2 * pn;
+                                double pdotdsigma = pt * dat + px * dax + py * day + pn * dan;
+                                double pdotu = pt * ut - px * ux - py * uy - tau2_pn * un;
+                                double pdotz = pt * zt - tau2_pn * zn;
+                                double xiL = 1.0 / (aL * aL) - 1.0;
+                                double Ea = sqrt(pdotu * pdotu + xiL * pdotz * pdotz);
+                                double fa = 1.0 / (exp(Ea / Lambda) + sign), fabar = 1.0 - sign * fa;
+                                double df_shear = 0.0, df_bulk = 0.0;
+                                if (o->include_shear_deltaf) {
+                                    double Wmu_pmu_pz = pdotz * (Wt * pt - Wx * px - Wy * py - Wn * tau2_pn);
+                                    double pimunu_pmu_pnu = pitt * pt * pt + pixx * px * px + piyy * py * py + pinn * tau2_pn * tau2_pn
+                                        + 2.0 * (-(pitx * px + pity * py) * pt + pixy * px * py + tau2_pn * (pixn * px + piyn * py - pitn * pt));
+                                    df_shear = c3 * Wmu_pmu_pz + c4 * pimunu_pmu_pnu;
+                                }
+                                if (o->include_bulk_deltaf) df_bulk = (c0 * mass2 + c1 * pdotz * pdotz + c2 * pdotu * pdotu) * bulkPi;
+                                double df = df_shear + df_bulk;
+                                if (o->regulate_deltaf) sum += eta_weight * pdotdsigma * fa * (1.0 + fmax(-1.0, fmin(fabar * df, 1.0)));
+                                else sum += eta_weight * pdotdsigma * fa * (1.0 + fabar * df);
+                            }
+                            long long iS3D = (long long)ipart + (long long)npart * ((long long)ipT + (long long)npT * ((long long)iphip + (long long)nphi * (long long)iy));
+                            acc[iS3D] += prefactor * degeneracy * sum;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    for (long long i = 0; i < nspec; i++) {
+        double tot = 0.0;
+        for (int th = 0; th < nthreads; th++) tot += part[(size_t)th * nspec + i];
+        dN_pTdpTdphidy[i] += tot;
+    }
+    free(part); free(cosphi); free(sinphi); free(etaW);
+    return 0;
+}

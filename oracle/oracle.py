@@ -304,3 +304,38 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
     for f in ("event", "cell", "species"):
         res[f] = res[f].astype(np.int64)
     return res, dict(n_kept=int(rc), samples=int(stats[0]), acceptances=int(stats[1]), drawn=int(stats[2]), breakdown=int(stats[3]))
+
+
+# ---- anisotropic hydro (VAH, P_L matching) smooth kernel ---------------------------------------------------------
+VAH_FIELDS = ["tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan", "T", "pitt", "pitx", "pity", "pitn", "pixx", "pixy", "pixn",
+              "piyy", "piyn", "pinn", "bulkPi", "Wx", "Wy", "Lambda", "aL", "c0", "c1", "c2", "c3", "c4"]
+
+
+class _VahCells(C.Structure):
+    _fields_ = [(f, _dp) for f in VAH_FIELDS]
+
+
+def dN_pTdpTdphidy_vah(cells, species, grid, opts):
+    """calculate_dN_pTdpTdphidy_VAH_PL restated (the reference never runs it); cells: dict with VAH_FIELDS (eta optional in 2+1D)."""
+    o = dict(DEFAULT_OPTS)
+    o.update(opts)
+    n = len(cells["tau"])
+    keep = {}
+    ca = _VahCells()
+    for f in VAH_FIELDS:
+        if cells.get(f) is not None:
+            keep[f] = _f64(cells[f])
+            setattr(ca, f, _p(keep[f]))
+    sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy"]}
+    npart = len(sp["mass"])
+    g = {k: _f64(grid[k]) for k in ["pT", "phi", "y", "eta", "eta_w"]}
+    gs = _Grid(len(g["pT"]), _p(g["pT"]), len(g["phi"]), _p(g["phi"]), len(g["y"]), _p(g["y"]), len(g["eta"]), _p(g["eta"]), _p(g["eta_w"]))
+    os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
+    ny = 1 if o["dimension"] == 2 else len(g["y"])
+    out = np.zeros(npart * len(g["pT"]) * len(g["phi"]) * ny)
+    L = lib()
+    L.oracle_dN_pTdpTdphidy_vah.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, C.POINTER(_VahCells), C.POINTER(_Grid), C.POINTER(_Opts), _dp]
+    rc = L.oracle_dN_pTdpTdphidy_vah(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), C.byref(ca), C.byref(gs), C.byref(os_), _p(out))
+    if rc:
+        raise RuntimeError("oracle_dN_pTdpTdphidy_vah failed rc=%d" % rc)
+    return out
