@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Count the fp64 VALU instructions the main kernels execute per integrand evaluation, from the gfx950 ISA hipcc
-emits for is3d_amd/csrc/cf_kernels.hip and cf_feqmod.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
+emits for is3d_amd/csrc/cf_kernels.hip, cf_feqmod.hip and cf_vah.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
 fp64-VALU roofline).  Method: for every cf_main_* instantiation take the basic blocks of the innermost loop
 that contains v_rcp_f64 (exactly one v_rcp_f64 is issued per evaluation) and divide the opcode histogram of
 those blocks by their v_rcp_f64 count.  For the 3+1D tile kernel that loop is the whole unit (header + rows),
@@ -19,7 +19,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "is3d_amd", "csrc", "cf_kernels.hip"), os.path.join(ROOT, "is3d_amd", "csrc", "cf_feqmod.hip")]
+SRCS = [os.path.join(ROOT, "is3d_amd", "csrc", f) for f in ("cf_kernels.hip", "cf_feqmod.hip", "cf_vah.hip")]
 OUT = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
 
 F64_OPS = ["v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64", "v_rcp_f64", "v_ldexp_f64",
@@ -37,6 +37,8 @@ def demangle_params(sym):
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R"]
     elif name == "cf_main_feqmod":
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R"]
+    elif name == "cf_main_vah":
+        keys = ["DIM3", "REG", "JT", "R"]
     else:
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
     return name, dict(zip(keys, vals))
