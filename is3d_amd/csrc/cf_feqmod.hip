@@ -491,12 +491,15 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 if (r + 1 < R) cur = nxt;
             }
         } else {
-#pragma unroll 2
-            for (int r = 0; r < R; r++) {
-                fetch(nxt, rows + (r + 1) * RW);   // "row R" reads the head of the next unit (or the pad); never evaluated
+            // rolled, two rows per trip (see cf_main_tile); for even R the last fetch reads the head of the next unit or the pad
+#pragma clang loop unroll(disable)
+            for (int r = 0; r + 1 < R; r += 2) {
+                fetch(nxt, rows + (r + 1) * RW);
                 evals(cur, 0);
-                cur = nxt;
+                fetch(cur, rows + (r + 2) * RW);
+                evals(nxt, 0);
             }
+            if (R & 1) evals(cur, 0);
         }
     };
 

@@ -676,13 +676,19 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 if (r + 1 < R) cur = nxt;
             }
         } else {
-            // eta quadrature rows all feed the same JT accumulators: keep the loop rolled (code size).  The fetch of
-            // "row R" reads the head of the next unit (or the pad behind the buffer); it is never evaluated.
-#pragma unroll 2
-            for (int r = 0; r < R; r++) {
+            // eta quadrature rows all feed the same JT accumulators: the loop stays ROLLED, two rows per trip with the
+            // two Row registers swapping roles (code size: left to itself the compiler unrolls all R = 61 rows into 78 KB of
+            // code, more than the instruction cache).  For even R the last fetch reads the head of the next unit (or the pad
+            // behind the buffer); it is never evaluated.
+#pragma clang loop unroll(disable)
+            for (int r = 0; r + 1 < R; r += 2) {
                 fetch(nxt, rows + (r + 1) * RW);
                 if (cur.live) evals(cur, 0);
-                cur = nxt;
+                fetch(cur, rows + (r + 2) * RW);
+                if (nxt.live) evals(nxt, 0);
+            }
+            if (R & 1) {
+                if (cur.live) evals(cur, 0);
             }
         }
     };
@@ -724,7 +730,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     if (!wave_active) return;
     if ((tid & 63) == 0) {
         // the 2+1D loop fetches one row past each unit; those are not rows of the surface
-        const int fetched = DIM3 ? n_rows : n_rows - n_units;
+        const int fetched = (DIM3 || (R & 1)) ? n_rows : n_rows - n_units;
         atomicAdd(&stats[2], (unsigned long long)fetched);
         atomicAdd(&stats[3], (unsigned long long)min(n_dead, fetched));
     }

@@ -267,12 +267,15 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
                 if (r + 1 < R) cur = nxt;
             }
         } else {
-#pragma unroll 2
-            for (int r = 0; r < R; r++) {
+            // rolled, two rows per trip (see cf_main_tile)
+#pragma clang loop unroll(disable)
+            for (int r = 0; r + 1 < R; r += 2) {
                 fetch(nxt, rows + (r + 1) * RW);
                 evals(cur, 0);
-                cur = nxt;
+                fetch(cur, rows + (r + 2) * RW);
+                evals(nxt, 0);
             }
+            if (R & 1) evals(cur, 0);
         }
     };
 
