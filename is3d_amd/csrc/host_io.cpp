@@ -2,6 +2,7 @@
 //
 // Each function states the reference routine whose observable behaviour it reproduces
 // (paths relative to /root/reference).  Nothing here calls exit(): errors become IS3D_E* codes.
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdarg>
@@ -12,6 +13,7 @@
 #include <iomanip>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/is3d_amd.h"
@@ -46,21 +48,6 @@ std::string lower(std::string s)
 {
     for (char &ch : s) ch = (char)tolower((unsigned char)ch);
     return s;
-}
-
-// arsenal.cpp:378-393 stringToDoubles: numbers until the first token that does not parse
-void line_to_doubles(const char *b, const char *e, std::vector<double> &v)
-{
-    v.clear();
-    std::string tmp(b, e);
-    const char *p = tmp.c_str();
-    for (;;) {
-        char *q;
-        double x = strtod(p, &q);
-        if (q == p) break;
-        v.push_back(x);
-        p = q;
-    }
 }
 
 }  // namespace
@@ -121,26 +108,108 @@ extern "C" int is3d_param_get(const char *path, const char *name, double *value)
 //   column count = numbers on the first line; every '\n'-terminated line is a row; whatever follows
 //   the last '\n' is never stored.
 // ---------------------------------------------------------------------------------------------
-static int parse_table(const std::string &text, const char *path, int64_t *n_rows, int32_t *n_cols,
-                       std::vector<double> *store)
+// strtod with Clinger's exact fast path in front: a decimal with at most 15 significant digits... precisely, a mantissa
+// w <= 2^53 and a decimal exponent |e10| <= 22 is w * 10^e10 or w / 10^-e10 with BOTH operands exact doubles, hence correctly
+// rounded by one IEEE operation -- the same value strtod returns, at a tenth of its cost.  Hydro codes print 6-9 digits;
+// anything longer (or hex, inf, nan, ...) goes to strtod.
+static double fast_strtod(const char *p, char **endp)
 {
-    std::vector<double> v;
-    size_t pos = 0, nl = text.find('\n');
-    const char *base = text.data();
-    line_to_doubles(base, base + (nl == std::string::npos ? text.size() : nl), v);
-    if (v.empty()) return io_fail(IS3D_EIO, "%s: empty first row; no data read", path);
-    const int32_t ncol = (int32_t)v.size();
-    int64_t rows = 0;
-    while (nl != std::string::npos) {
-        // the line [pos, nl) is complete -> it is a row
-        if (rows > 0) line_to_doubles(base + pos, base + nl, v);
-        if ((int32_t)v.size() < ncol)
-            return io_fail(IS3D_EIO, "%s: row %lld has %d numbers, expected %d", path, (long long)rows + 1, (int)v.size(), ncol);
-        if (store) store->insert(store->end(), v.begin(), v.begin() + ncol);
-        rows++;
-        pos = nl + 1;
-        nl = text.find('\n', pos);
+    static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17,
+                                   1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *s = p;
+    while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r' || *s == '\v' || *s == '\f') s++;
+    const char *q = s;
+    bool neg = false;
+    if (*q == '+' || *q == '-') { neg = (*q == '-'); q++; }
+    uint64_t w = 0;
+    int nd = 0, e10 = 0;
+    bool any = false;
+    while (*q >= '0' && *q <= '9') { if (nd < 19) { w = w * 10 + (uint64_t)(*q - '0'); if (w) nd++; } else return strtod(p, endp); q++; any = true; }
+    if (*q == '.') {
+        q++;
+        while (*q >= '0' && *q <= '9') { if (nd < 19) { w = w * 10 + (uint64_t)(*q - '0'); if (w) nd++; e10--; } else return strtod(p, endp); q++; any = true; }
     }
+    if (!any) return strtod(p, endp);          // inf, nan, garbage: strtod decides (and reports "no conversion")
+    if (*q == 'e' || *q == 'E') {
+        const char *r = q + 1;
+        bool eneg = false;
+        if (*r == '+' || *r == '-') { eneg = (*r == '-'); r++; }
+        if (*r >= '0' && *r <= '9') {
+            int ex = 0;
+            while (*r >= '0' && *r <= '9') { if (ex < 10000) ex = ex * 10 + (*r - '0'); r++; }
+            e10 += eneg ? -ex : ex;
+            q = r;
+        }
+    } else if (*q == 'x' || *q == 'X' || *q == 'p' || *q == 'P') return strtod(p, endp);   // hex float
+    if (w > (1ULL << 53) || e10 < -22 || e10 > 22) return strtod(p, endp);
+    double x = (double)w;
+    x = e10 < 0 ? x / p10[-e10] : x * p10[e10];
+    *endp = const_cast<char *>(q);
+    return neg ? -x : x;
+}
+
+// arsenal.cpp:378-393 stringToDoubles.  Numbers of the line [b, e) parsed in place (strtod would run over the newline: blanks are skipped by hand), the first
+// `keep` of them stored; returns how many the line holds up to the first token that does not parse (stringToDoubles).
+static int parse_line(const char *b, const char *e, double *out, int keep)
+{
+    int n = 0;
+    const char *p = b;
+    for (;;) {
+        while (p < e && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) p++;
+        if (p >= e) break;
+        char *q;
+        const double x = fast_strtod(p, &q);
+        if (q == p || q > e) break;
+        if (n < keep) out[n] = x;
+        n++;
+        p = q;
+    }
+    return n;
+}
+
+// A 1e6-cell surface is ~0.5 GB of text: the rows are parsed by up to 16 threads (strtod is the whole cost), each writing
+// its own rows of the table.  *exact (optional) = every row holds exactly n_cols numbers, i.e. the row-major table is the
+// file's whitespace token stream (what the surface readers, which consume tokens like operator>>, rely on).
+static int parse_table(const std::string &text, const char *path, int64_t *n_rows, int32_t *n_cols,
+                       std::vector<double> *store, bool *exact = nullptr)
+{
+    const char *base = text.data();
+    std::vector<size_t> nl;
+    for (const char *p = base, *end = base + text.size(); p < end;) {
+        const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!q) break;
+        nl.push_back((size_t)(q - base));
+        p = q + 1;
+    }
+    const int32_t ncol = parse_line(base, base + (nl.empty() ? text.size() : nl[0]), nullptr, 0);
+    if (ncol == 0) return io_fail(IS3D_EIO, "%s: empty first row; no data read", path);
+    const int64_t rows = (int64_t)nl.size();   // every '\n'-terminated line is a row
+    if (store) store->assign((size_t)rows * ncol, 0.0);
+    int nthreads = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), rows / 8192 + 1);
+    std::vector<int64_t> bad_row((size_t)nthreads, -1);
+    std::vector<int> bad_cnt((size_t)nthreads, 0), inexact((size_t)nthreads, 0);
+    auto work = [&](int t) {
+        const int64_t r0 = rows * t / nthreads, r1 = rows * (t + 1) / nthreads;
+        for (int64_t r = r0; r < r1; r++) {
+            const char *b = base + (r == 0 ? 0 : nl[(size_t)r - 1] + 1), *e = base + nl[(size_t)r];
+            const int cnt = parse_line(b, e, store ? store->data() + (size_t)r * ncol : nullptr, store ? ncol : 0);
+            if (cnt < ncol && bad_row[t] < 0) { bad_row[t] = r; bad_cnt[t] = cnt; }
+            if (cnt != ncol) inexact[t] = 1;
+        }
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    bool ex = true;
+    for (int t = 0; t < nthreads; t++) {
+        if (bad_row[t] >= 0)   // threads own ascending row ranges: the first hit is the earliest bad row
+            return io_fail(IS3D_EIO, "%s: row %lld has %d numbers, expected %d", path, (long long)bad_row[t] + 1, bad_cnt[t], ncol);
+        if (inexact[t]) ex = false;
+    }
+    if (exact) *exact = ex;
     *n_rows = rows;
     *n_cols = ncol;
     return IS3D_OK;
@@ -176,7 +245,9 @@ extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, in
     if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
     int64_t rows;
     int32_t cols;
-    int rc = parse_table(text, path, &rows, &cols, nullptr);
+    std::vector<double> tab;
+    bool exact = false;
+    int rc = parse_table(text, path, &rows, &cols, A ? &tab : nullptr, &exact);
     if (rc) return rc;
     if (!A) { *n_cells = rows; return IS3D_OK; }
     if (*n_cells < rows) return io_fail(IS3D_EINVAL, "%s: arrays hold %lld cells, file has %lld", path, (long long)*n_cells, (long long)rows);
@@ -189,7 +260,12 @@ extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, in
 
     const char *p = text.c_str();
     bool short_read = false;
-    auto next = [&]() -> double {
+    size_t ti = 0;
+    auto next = [&]() -> double {   // the whitespace token stream (surfdat >> ...): the parsed table when it IS that stream
+        if (exact) {
+            if (ti >= tab.size()) { short_read = true; return 0.0; }
+            return tab[ti++];
+        }
         char *q;
         double x = strtod(p, &q);
         if (q == p) { short_read = true; return 0.0; }
@@ -265,7 +341,9 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
     if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
     int64_t rows;
     int32_t cols;
-    int rc = parse_table(text, path, &rows, &cols, nullptr);
+    std::vector<double> tab;
+    bool exact = false;
+    int rc = parse_table(text, path, &rows, &cols, A ? &tab : nullptr, &exact);
     if (rc) return rc;
     if (!A) { *n_cells = rows; return IS3D_OK; }
     if (*n_cells < rows) return io_fail(IS3D_EINVAL, "%s: arrays hold %lld cells, file has %lld", path, (long long)*n_cells, (long long)rows);
@@ -275,7 +353,12 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
         if (!A[a]) return io_fail(IS3D_EINVAL, "cell array %d is NULL", a);
     const char *p = text.c_str();
     bool short_read = false;
-    auto next = [&]() -> double {
+    size_t ti = 0;
+    auto next = [&]() -> double {   // the whitespace token stream (surfdat >> ...): the parsed table when it IS that stream
+        if (exact) {
+            if (ti >= tab.size()) { short_read = true; return 0.0; }
+            return tab[ti++];
+        }
         char *q;
         double x = strtod(p, &q);
         if (q == p) { short_read = true; return 0.0; }

@@ -45,6 +45,36 @@ def test_table_reader_drops_unterminated_last_line(tmp_path):
         api.table_read(str(p))
 
 
+def test_number_parsing_is_correctly_rounded(tmp_path):
+    """The table parser (threads + Clinger fast path in front of strtod) returns what strtod / operator>> return: the correctly
+    rounded double, for every decimal format a hydro code prints and for the edge cases that must fall through to strtod."""
+    import random
+    random.seed(3)
+    rows, vals = [], []
+    for i in range(30000):
+        kind = random.randrange(6)
+        if kind == 0:
+            s = "%.6g" % random.uniform(-1e3, 1e3)
+        elif kind == 1:
+            s = "%.9e" % (random.uniform(-1, 1) * 10 ** random.randint(-30, 30))
+        elif kind == 2:
+            s = "%d" % random.randint(-10 ** 9, 10 ** 9)
+        elif kind == 3:
+            s = "%.15g" % random.uniform(-1, 1)
+        elif kind == 4:
+            s = "%.17g" % random.uniform(-1, 1)
+        else:
+            s = random.choice(["0", "-0.0", "1e22", "1e-22", "1e23", "123456789012345678", "0.000001", "9007199254740993", "9007199254740992",
+                               "1.e5", "+.5", "5.", "1e400", "4.9e-324", "2.2250738585072011e-308", "0.1e-21", "12345678901234567890123"])
+        rows.append(s + "\t" + s)
+        vals.append(float(s))
+    p = str(tmp_path / "numbers.dat")
+    open(p, "w").write("\n".join(rows) + "\n")
+    t = api.table_read(p)
+    assert t.shape == (30000, 2) and np.array_equal(t[:, 0], np.array(vals)) and np.array_equal(t[:, 1], t[:, 0])
+    assert np.array_equal(np.signbit(t[:, 0]), np.signbit(np.array(vals)))
+
+
 def test_grid_tables_round_trip(tmp_path):
     g = inputs.grid()
     refformat.write_table(str(tmp_path / "phi.dat"), g["phi"], g["phi_w"], leading_tab=True, dangling_fragment=True)
