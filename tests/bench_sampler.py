@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the device particle sampler (is3d_sample_particles) on the BASELINE config-3 surface (1e6 synthetic 3+1D
+"""(Lives under tests/ because its CPU leg calls the oracle, which only tests, smoke() and bench.py's cpu_baseline may do.)
+Throughput of the device particle sampler (is3d_sample_particles) on the BASELINE config-3 surface (1e6 synthetic 3+1D
 cells, 305 urqmd species, Chapman-Enskog delta-f) next to the CPU restatement (serial over cells, like the reference's
 sample_dN_pTdpTdphidy) on a bounded slice of the same surface.  Not the BASELINE metric (that is bench.py); prints one JSON
 line for profiles/."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer check on a GPU box: parity of every kernel variant against the CPU oracle on small seeded
+"""(Lives under tests/ because it calls the oracle.)  Developer check on a GPU box: parity of every kernel variant against the CPU oracle on small seeded
 surfaces, then timing of a mid-size run through the device-resident plan.  (The judged artefacts are
 tests/ and bench.py; this is the quick loop.)"""
 import argparse
