@@ -90,3 +90,8 @@ def test_product_never_touches_the_oracle():
                     assert not pat.search(open(os.path.join(dp, f), errors="ignore").read()), os.path.join(dp, f)
     ldd = subprocess.check_output(["ldd", api.LIB_PATH], text=True)
     assert "oracle" not in ldd
+    # the same for helper scripts: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg call the checker
+    imp = re.compile(r"^\s*(from\s+oracle|import\s+oracle)", re.M)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            assert not imp.search(open(os.path.join(ROOT, "tools", f), errors="ignore").read()), f
