@@ -100,7 +100,8 @@ hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3,
 // ------------------------------------------------------------------------------------------------
 // cf_prep
 // ------------------------------------------------------------------------------------------------
-constexpr int kPrepCB = 4;          // cells per workgroup batch
+constexpr int kPrepCB = 4;          // cells per workgroup batch (2+1D: K = 241 rows per cell fill the LDS)
+constexpr int kPrepCB3 = 16;       // 3+1D: larger batches give longer contiguous runs per stream of the tiled output
 constexpr int kPrepThreads = 256;
 
 struct CellScal {
@@ -134,6 +135,7 @@ __device__ __forceinline__ bool bilinear5(const BilinearDev &b, double T, double
     return true;
 }
 
+template <int CB>
 __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 {
     extern __shared__ double lds[];
@@ -143,9 +145,9 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *sc = sy + nspl * nT;              // [nspl][nT]
     CellScal *cs = (CellScal *)(sc + nspl * nT);  // [CB]
     // per (cell, k): A, Cp, alpha, W, ch, sh, C ; per (cell, j): B, Dp, gamma, D, E, F
-    double *lk = (double *)(cs + kPrepCB);    // [9][CB][K]
-    double *lj = lk + 9 * kPrepCB * K;        // [8][CB][J]
-    const int CK = kPrepCB * K, CJ = kPrepCB * J;
+    double *lk = (double *)(cs + CB);    // [9][CB][K]
+    double *lj = lk + 9 * CB * K;        // [8][CB][J]
+    const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_Cp = lk + CK, *l_al = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK, *l_C = lk + 6 * CK;
     double *l_B = lj, *l_Dp = lj + CJ, *l_ga = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_E = lj + 4 * CJ, *l_F = lj + 5 * CJ;
     double *l_V1 = lk + 7 * CK, *l_Lk = lk + 8 * CK, *l_V2 = lj + 6 * CJ, *l_L2 = lj + 7 * CJ;   // include_baryon only
@@ -160,10 +162,10 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     }
     __syncthreads();
 
-    const int nbatch = (p.n_cells + kPrepCB - 1) / kPrepCB;
+    const int nbatch = (p.n_cells + CB - 1) / CB;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-        const int cbase = batch * kPrepCB;
-        const int ncb = min(kPrepCB, p.n_cells - cbase);
+        const int cbase = batch * CB;
+        const int ncb = min(CB, p.n_cells - cbase);
 
         // ---- phase 1: per-cell scalars (smooth_kernels.cpp:118-242) ----
         if (tid < ncb) {
@@ -397,18 +399,24 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     }
 }
 
+// cells per batch: 16 while (9 K + 8 J) doubles per cell stay small (3+1D grids), else 4
+static int prep_batch_cells(int K) { return K <= 32 ? kPrepCB3 : kPrepCB; }
+
 size_t prep_lds_bytes(int nT, int nspl, int J, int K)
 {
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)kPrepCB * (9 * K + 8 * J)) + sizeof(CellScal) * kPrepCB;
+    const int cb = prep_batch_cells(K);
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (9 * K + 8 * J)) + sizeof(CellScal) * cb;
 }
 
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
 {
     if (p.n_cells <= 0) return hipSuccess;
-    int nbatch = (p.n_cells + kPrepCB - 1) / kPrepCB;
+    const int cb = prep_batch_cells(p.K);
+    int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
     size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K);
-    hipLaunchKernelGGL(cf_prep, dim3(grid), dim3(kPrepThreads), lds, stream, p);
+    if (cb == kPrepCB3) hipLaunchKernelGGL(cf_prep<kPrepCB3>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
+    else hipLaunchKernelGGL(cf_prep<kPrepCB>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     return hipGetLastError();
 }
 
