@@ -797,14 +797,31 @@ cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, con
     out[idx] = accumulate ? (out[idx] + v) : v;
 }
 
-hipError_t launch_finalize(const double *partial, const int *cls, const double *degeneracy, double *out,
+// Fixed-order sum over the cell chunks, lanes <-> threads: fully coalesced reads of the partials (the species scatter of
+// cf_finalize gathers lanes and would read them at a fraction of the bandwidth).  In place: the thread that owns element
+// (jk, lane) of chunk 0 is the only one that touches it.
+__global__ void __launch_bounds__(256)
+cf_reduce_chunks(double *__restrict__ partial, int64_t n_per_chunk, int nch)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_per_chunk) return;
+    double s = 0.0;
+    for (int ch = 0; ch < nch; ch++) s += partial[ch * n_per_chunk + i];
+    partial[i] = s;
+}
+
+hipError_t launch_finalize(double *partial, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
                            int accumulate, const unsigned long long *pds_bound, hipStream_t stream)
 {
     if (nout <= 0) return hipSuccess;
+    if (nch > 1) {
+        const int64_t n_per_chunk = (int64_t)J * Kacc * Lpad;
+        hipLaunchKernelGGL(cf_reduce_chunks, dim3((unsigned)((n_per_chunk + 255) / 256)), dim3(256), 0, stream, partial, n_per_chunk, nch);
+    }
     int grid = (int)((nout + 255) / 256);
-    hipLaunchKernelGGL(cf_finalize, dim3(grid), dim3(256), 0, stream, partial, cls, degeneracy, out, nout, npart,
-                       npT, J, Kacc, Lpad, nch, prefactor, accumulate, pds_bound);
+    hipLaunchKernelGGL(cf_finalize, dim3(grid), dim3(256), 0, stream, (const double *)partial, cls, degeneracy, out, nout, npart,
+                       npT, J, Kacc, Lpad, 1, prefactor, accumulate, pds_bound);
     return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@ size_t prep_lds_bytes(int nT, int nspl, int J, int K);
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 void main_tile_shape(int variant, int dim3, int *JT, int *KT);
 hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st);  // a.g.baryon selects the B kernels
-hipError_t launch_finalize(const double *partial, const int *cls, const double *degeneracy, double *out,
+hipError_t launch_finalize(double *partial /* chunk 0 receives the sum over chunks */, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
                            int accumulate, const unsigned long long *pds_bound, hipStream_t stream);
 // *out (zeroed by the caller) = bits of a bound on |p.dsigma| over all lanes, bins and the given cells
