@@ -124,7 +124,8 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     const char *pdg_path, *df_dir;
     if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
     else if (hrg_eos == 2) { pdg_path = "PDG/pdg_smash.dat"; df_dir = "deltaf_coefficients/vh/smash/"; }
-    else DIE("hrg_eos = %d: choose 1 (urqmd) or 2 (smash)", hrg_eos);
+    else if (hrg_eos == 3) { pdg_path = "PDG/pdg_box.dat"; df_dir = "deltaf_coefficients/vh/smash_box/"; }   // readindata.h:219, deltafReader.h:29
+    else DIE("hrg_eos = %d: please choose hrg_eos = (1,2,3)", hrg_eos);
 
     double t0 = now_s();
     // ---- surface (iS3D.cpp:90-98) ----
