@@ -116,6 +116,11 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
 #undef GET
     if (operation != 1 && operation != 2) DIE("operation = %d: only operation = 1 (smooth momentum spectra) and 2 (particle sampler) are on this path", operation);
     if (operation == 2 && include_baryon) DIE("operation = 2 with include_baryon = 1 is not on this path");
+    {
+        double decays = 0.0;   // optional key here; the reference runs do_resonance_decays() after the spectra (emissionfunction.cpp:1689-1698)
+        if (get_param("do_resonance_decays", &decays, false) == IS3D_OK && (int)decays)
+            DIE("do_resonance_decays = 1: resonance decays are not on this path; set do_resonance_decays = 0");
+    }
     if (!mem && mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
         DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
     if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
