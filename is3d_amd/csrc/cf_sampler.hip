@@ -358,11 +358,12 @@ __device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, doub
     return q;
 }
 
+// one (event, cell) pair; tallies = {momentum samples, acceptances, hadrons drawn} of this thread (count pass)
 template <bool FILL>
-__global__ void __launch_bounds__(128)
-cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict__ cellrec, const double *__restrict__ GT,
-               const double *__restrict__ GT2, int event0, int n_events, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
-               is3d_particle *__restrict__ particles, int64_t capacity)
+__device__ __forceinline__ void sampler_thread(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell *__restrict__ cellrec,
+                                               const double *__restrict__ GT, const double *__restrict__ GT2, int event0, int n_events,
+                                               int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
+                                               is3d_particle *__restrict__ particles, int64_t capacity, unsigned long long (&tally)[3])
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // event-major: (event - event0) * n_cells + cell
     if (idx >= (int64_t)n_events * p.n_cells) return;
@@ -460,9 +461,27 @@ cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict
     }
     if (!FILL) {
         counts[idx] = kept;
-        atomicAdd(&p.status[2], (unsigned long long)samples);
-        atomicAdd(&p.status[3], (unsigned long long)acceptances);
-        atomicAdd(&p.status[4], (unsigned long long)N_hadrons);
+        tally[0] = (unsigned long long)samples; tally[1] = (unsigned long long)acceptances; tally[2] = (unsigned long long)N_hadrons;
+    }
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(128)
+cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict__ cellrec, const double *__restrict__ GT,
+               const double *__restrict__ GT2, int event0, int n_events, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
+               is3d_particle *__restrict__ particles, int64_t capacity)
+{
+    unsigned long long tally[3] = {0ULL, 0ULL, 0ULL};
+    sampler_thread<FILL>(p, sp, cellrec, GT, GT2, event0, n_events, counts, offsets, base, particles, capacity, tally);
+    if (!FILL) {
+        // the run-wide tallies: one global atomic per counter and workgroup instead of three per sampling thread
+        __shared__ unsigned long long blk[3];
+        if (threadIdx.x < 3) blk[threadIdx.x] = 0ULL;
+        __syncthreads();
+        for (int k = 0; k < 3; k++)
+            if (tally[k]) atomicAdd(&blk[k], tally[k]);
+        __syncthreads();
+        if (threadIdx.x < 3 && blk[threadIdx.x]) atomicAdd(&p.status[2 + threadIdx.x], blk[threadIdx.x]);
     }
 }
 
