@@ -18,9 +18,12 @@
 //
 //   cf_sampler_density  thread <-> (cell, species class): 32-point Gauss-Laguerre equilibrium density integral
 //   cf_sampler_cells    thread <-> cell: LRF basis, dsigma and pi^{mu nu} in the LRF, delta-f coefficients, mean hadron number
-//   cf_sampler_run      thread <-> (event, cell): Poisson number, species, momentum rejection loop, viscous and flux weights,
-//                       keep test; pass 1 counts, an exclusive scan (hipCUB) turns counts into offsets, pass 2 replays the same
-//                       streams and writes the particles -- the list comes out ordered by (event, cell, draw), no atomics.
+//   cf_sampler_poisson  thread <-> (event, cell): the Poisson number only.  A few per cent of the pairs emit anything, but nearly
+//                       every wave holds one that does: sampling right here would drag 64 lanes through the rejection loops
+//                       of one.  hipCUB compacts the emitting pairs into a dense, ordered list instead.
+//   cf_sampler_run      thread <-> emitting (event, cell) pair: species, momentum rejection loop, viscous and flux weights, keep
+//                       test; pass 1 counts, an exclusive scan turns counts into offsets, pass 2 replays the same streams and
+//                       writes the particles -- the list comes out ordered by (event, cell, draw), no atomics, no sort.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
@@ -358,31 +361,42 @@ __device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, doub
     return q;
 }
 
-// one (event, cell) pair; tallies = {momentum samples, acceptances, hadrons drawn} of this thread (count pass)
+// stream 0 of every (event, cell) pair of the batch: the Poisson number of hadrons (std::poisson_distribution(dn_tot), :1085-1090)
+__global__ void __launch_bounds__(256)
+cf_sampler_poisson(SamplerParams p, const SamplerCell *__restrict__ cellrec, int event0, int n_events, int32_t *__restrict__ n_drawn,
+                   uint8_t *__restrict__ emits)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_events * p.n_cells) return;
+    const int64_t ic = idx % p.n_cells;
+    long N = 0;
+    if (cellrec[ic].live != 0.0) {
+        Rng g;
+        g.init(p.seed, 0, (uint32_t)(p.first_cell + ic), (uint32_t)(event0 + (int)(idx / p.n_cells)));
+        N = g.poisson(cellrec[ic].dn_tot);
+    }
+    n_drawn[idx] = (int32_t)(N < 0x7fffffffL ? N : 0x7fffffffL);
+    emits[idx] = N > 0;
+}
+
+// one emitting (event, cell) pair; tallies = {momentum samples, acceptances, hadrons drawn} of this thread (count pass)
 template <bool FILL>
 __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell *__restrict__ cellrec,
-                                               const double *__restrict__ GT, const double *__restrict__ GT2, int event0, int n_events,
+                                               const double *__restrict__ GT, const double *__restrict__ GT2, int event0,
+                                               const int32_t *__restrict__ active, int64_t n_active, const int32_t *__restrict__ n_drawn,
                                                int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
                                                is3d_particle *__restrict__ particles, int64_t capacity, unsigned long long (&tally)[3])
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // event-major: (event - event0) * n_cells + cell
-    if (idx >= (int64_t)n_events * p.n_cells) return;
-    if (FILL && offsets[idx + 1] == offsets[idx]) return;                  // pass 1 kept nothing here: nothing to replay
+    const int64_t ia = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // position in the list of emitting (event, cell) pairs
+    if (ia >= n_active) return;
+    if (FILL && offsets[ia + 1] == offsets[ia]) return;                    // pass 1 kept nothing here: nothing to replay
+    const int64_t idx = active[ia];                                         // event-major: (event - event0) * n_cells + cell
     const int ievent = event0 + (int)(idx / p.n_cells);
     const int64_t ic = idx % p.n_cells;
     const SamplerCell &c = cellrec[ic];
-    if (c.live == 0.0) {
-        if (!FILL) counts[idx] = 0;
-        return;
-    }
     const uint32_t gcell = (uint32_t)(p.first_cell + ic);
-    Rng g_poisson, g_type, g_momentum, g_keep, g_rapidity;
-    g_poisson.init(p.seed, 0, gcell, (uint32_t)ievent);
-    const long N_hadrons = g_poisson.poisson(c.dn_tot);
-    if (N_hadrons == 0) {
-        if (!FILL) counts[idx] = 0;
-        return;
-    }
+    const long N_hadrons = n_drawn[idx];                                    // cf_sampler_poisson (stream 0)
+    Rng g_type, g_momentum, g_keep, g_rapidity;
     g_type.init(p.seed, 1, gcell, (uint32_t)ievent);
     g_momentum.init(p.seed, 2, gcell, (uint32_t)ievent);
     g_keep.init(p.seed, 3, gcell, (uint32_t)ievent);
@@ -391,7 +405,7 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
     const bool linear = p.df_mode <= 2 || c.breakdown != 0.0;
     const double sinheta = sinh(c.eta), cosheta = sqrt(1.0 + sinheta * sinheta);   // :888-889
     long kept = 0, samples = 0, acceptances = 0;
-    int64_t slot = FILL ? base + offsets[idx] : 0;
+    int64_t slot = FILL ? base + offsets[ia] : 0;
     for (long ih = 0; ih < N_hadrons; ih++) {
         const double ut_ = g_type.uniform() * c.dn_sum;
         int chosen = sp.npart - 1;
@@ -460,7 +474,7 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
         kept++;
     }
     if (!FILL) {
-        counts[idx] = kept;
+        counts[ia] = kept;
         tally[0] = (unsigned long long)samples; tally[1] = (unsigned long long)acceptances; tally[2] = (unsigned long long)N_hadrons;
     }
 }
@@ -468,11 +482,12 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
 template <bool FILL>
 __global__ void __launch_bounds__(128)
 cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict__ cellrec, const double *__restrict__ GT,
-               const double *__restrict__ GT2, int event0, int n_events, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
+               const double *__restrict__ GT2, int event0, const int32_t *__restrict__ active, int64_t n_active,
+               const int32_t *__restrict__ n_drawn, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
                is3d_particle *__restrict__ particles, int64_t capacity)
 {
     unsigned long long tally[3] = {0ULL, 0ULL, 0ULL};
-    sampler_thread<FILL>(p, sp, cellrec, GT, GT2, event0, n_events, counts, offsets, base, particles, capacity, tally);
+    sampler_thread<FILL>(p, sp, cellrec, GT, GT2, event0, active, n_active, n_drawn, counts, offsets, base, particles, capacity, tally);
     if (!FILL) {
         // the run-wide tallies: one global atomic per counter and workgroup instead of three per sampling thread
         __shared__ unsigned long long blk[3];
@@ -723,11 +738,18 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     int eb = (int)std::max<int64_t>(1, std::min<int64_t>(in->n_events, max_threads / n));
     if (in->batch_events > 0) eb = std::min(eb, in->batch_events);
     const int64_t bt = (int64_t)eb * n;
+    DevMem d_drawn, d_emits, d_active, d_nactive;
+    SMP_TRY(d_drawn.alloc((size_t)bt * sizeof(int32_t)));
+    SMP_TRY(d_emits.alloc((size_t)bt));
+    SMP_TRY(d_active.alloc((size_t)bt * sizeof(int32_t)));
+    SMP_TRY(d_nactive.alloc(sizeof(int32_t)));
     SMP_TRY(d_counts.alloc((size_t)(bt + 1) * sizeof(int64_t)));
     SMP_TRY(d_offsets.alloc((size_t)(bt + 1) * sizeof(int64_t)));
-    SMP_TRY(hipMemsetAsync(d_counts.p, 0, (size_t)(bt + 1) * sizeof(int64_t), nullptr));
-    size_t tmp_bytes = 0;
+    size_t tmp_bytes = 0, tmp2 = 0;
     SMP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), (int)(bt + 1), nullptr));
+    SMP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp2, hipcub::CountingInputIterator<int32_t>(0), d_emits.as<uint8_t>(), d_active.as<int32_t>(),
+                                          d_nactive.as<int32_t>(), (int)bt, nullptr));
+    tmp_bytes = std::max(tmp_bytes, tmp2);
     SMP_TRY(d_scan_tmp.alloc(tmp_bytes));
     if (capacity > 0) SMP_TRY(d_particles.alloc((size_t)capacity * sizeof(is3d_particle)));
     int64_t base = 0;
@@ -735,23 +757,35 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     for (int e0 = 0; e0 < in->n_events; e0 += eb) {
         const int ne = std::min(eb, in->n_events - e0);
         const int64_t nt = (int64_t)ne * n;
-        const unsigned grid = (unsigned)((nt + 127) / 128);
         SMP_TRY(hipEventRecord(ev[5], nullptr));
-        if (ne < eb) SMP_TRY(hipMemsetAsync(d_counts.p, 0, (size_t)(bt + 1) * sizeof(int64_t), nullptr));
-        hipLaunchKernelGGL((is3d::cf_sampler_run<false>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
-                           d_GT.as<double>(), d_GT2.as<double>(), e0, ne, d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0,
-                           (is3d_particle *)nullptr, (int64_t)0);
+        // Poisson numbers of all pairs, then the ordered list of the pairs that emit
+        hipLaunchKernelGGL(is3d::cf_sampler_poisson, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, nullptr, p, d_rec.as<is3d::SamplerCell>(), e0, ne,
+                           d_drawn.as<int32_t>(), d_emits.as<uint8_t>());
         SMP_TRY(hipGetLastError());
-        // element bt of the scan (counts[bt] = 0) is the batch total
-        SMP_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), (int)(bt + 1), nullptr));
-        SMP_TRY(hipEventRecord(ev[3], nullptr));
+        SMP_TRY(hipcub::DeviceSelect::Flagged(d_scan_tmp.p, tmp_bytes, hipcub::CountingInputIterator<int32_t>(0), d_emits.as<uint8_t>(),
+                                              d_active.as<int32_t>(), d_nactive.as<int32_t>(), (int)nt, nullptr));
+        int32_t n_active = 0;
+        SMP_TRY(hipMemcpy(&n_active, d_nactive.p, sizeof(int32_t), hipMemcpyDeviceToHost));
         int64_t batch_total = 0;
-        SMP_TRY(hipMemcpy(&batch_total, d_offsets.as<int64_t>() + bt, sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (capacity > 0 && base < capacity && batch_total > 0) {
-            hipLaunchKernelGGL((is3d::cf_sampler_run<true>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
-                               d_GT.as<double>(), d_GT2.as<double>(), e0, ne, (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(),
-                               capacity);
+        if (n_active > 0) {
+            const unsigned grid = (unsigned)(((int64_t)n_active + 127) / 128);
+            SMP_TRY(hipMemsetAsync(d_counts.as<int64_t>() + n_active, 0, sizeof(int64_t), nullptr));
+            hipLaunchKernelGGL((is3d::cf_sampler_run<false>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
+                               d_GT.as<double>(), d_GT2.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active, d_drawn.as<int32_t>(),
+                               d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0, (is3d_particle *)nullptr, (int64_t)0);
             SMP_TRY(hipGetLastError());
+            // element n_active of the scan (counts[n_active] = 0) is the batch total
+            SMP_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), n_active + 1, nullptr));
+            SMP_TRY(hipEventRecord(ev[3], nullptr));
+            SMP_TRY(hipMemcpy(&batch_total, d_offsets.as<int64_t>() + n_active, sizeof(int64_t), hipMemcpyDeviceToHost));
+            if (capacity > 0 && base < capacity && batch_total > 0) {
+                hipLaunchKernelGGL((is3d::cf_sampler_run<true>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
+                                   d_GT.as<double>(), d_GT2.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active, d_drawn.as<int32_t>(),
+                                   (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(), capacity);
+                SMP_TRY(hipGetLastError());
+            }
+        } else {
+            SMP_TRY(hipEventRecord(ev[3], nullptr));
         }
         SMP_TRY(hipEventRecord(ev[4], nullptr));
         SMP_TRY(hipEventSynchronize(ev[4]));
