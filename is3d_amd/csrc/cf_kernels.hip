@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "cf_launch.h"
 #include "cf_math.h"
@@ -560,7 +561,7 @@ cf_main_direct(const double *__restrict__ S1, const double *__restrict__ S2, con
 // compiler can hoist far ahead of their use, so no evaluation waits on memory.  (The first version
 // used scalar loads; each s_load sat 4 instructions in front of its s_waitcnt and the kernel ran at
 // ~60 % of its issue bound.)
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R>
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R, bool LAZY = false>
 __global__ void __launch_bounds__(512)
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, const double *__restrict__ lane_b, double *__restrict__ partial,
@@ -631,11 +632,18 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         // and on wide (y, eta) surfaces a quarter of all rows (high pT x large |y - eta|) go this way.
         const double baB = BARYON ? bq * U[4 * JT] : 0.0;   // b mu_B / T: f_eq = 1/(exp(x - b alpha_B) + sign)
         constexpr int RW = RS + JT;
-        struct Row { double v[RW]; double mTC, E1; bool live; };
+        // LAZY: a Row carries only what the exponential of the NEXT row needs (Cp -> mTC, E1) plus the row's address, and the
+        // other operands are read from LDS when the row is evaluated; otherwise the whole row is prefetched into registers.
+        struct RowE { double v[RW]; double mTC, E1; bool live; };
+        struct RowL { const double *v; double mTC, E1; bool live; };
+        using Row = typename std::conditional<LAZY, RowL, RowE>::type;
         auto fetch = [&](Row &rw, const double *row) {
+            if constexpr (LAZY) rw.v = row;
+            else {
 #pragma unroll
-            for (int i = 0; i < RW; i++) rw.v[i] = row[i];
-            rw.mTC = mT * rw.v[1];
+                for (int i = 0; i < RW; i++) rw.v[i] = row[i];
+            }
+            rw.mTC = mT * row[1];
             const double earg = BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC;
             rw.live = !(g.zskip && __all(earg < -745.2));
             n_rows += 1;
@@ -835,15 +843,15 @@ static void launch_direct_t(const MainArgs &a, hipStream_t st)
     hipLaunchKernelGGL((cf_main_direct<CE, DIM3, OUTFLOW, REG, KT>), dim3(grid), dim3(kWPB * 64), 0, st, a.S1, a.S2,
                        a.S3, a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
 }
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R>
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R, bool LAZY = false>
 static void launch_tile_t(const MainArgs &a, hipStream_t st)
 {
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
     if (a.g.baryon)
-        hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, true, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
+        hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, true, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
                            a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g);
     else
-        hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, false, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
+        hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, false, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
                            a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g);
 }
 
@@ -866,7 +874,9 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
 {
     switch (variant) {
     case 1: launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st); break;
-    case 3: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[1] : kTileJT2[1]), (DIM3 ? kTileR3[1] : kTileR2[1])>(a, st); break;
+    // 8 x 7 in 3+1D: its 56 accumulators leave no room to prefetch whole rows (54 VGPRs spill, 180 GB of scratch traffic per
+    // config-3 launch): row operands are read when the row is evaluated (LAZY) -- 8 spills, and 0.7 % faster besides
+    case 3: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[1] : kTileJT2[1]), (DIM3 ? kTileR3[1] : kTileR2[1]), DIM3>(a, st); break;
     case 4: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[2] : kTileJT2[2]), (DIM3 ? kTileR3[2] : kTileR2[2])>(a, st); break;
     default: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[0] : kTileJT2[0]), (DIM3 ? kTileR3[0] : kTileR2[0])>(a, st); break;
     }

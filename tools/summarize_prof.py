@@ -20,7 +20,8 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+# gpurun merges every call's files into the same local directory: take the newest of each kind
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 rows = list(csv.reader(open(stats)))
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
@@ -37,7 +38,7 @@ cnt = collections.Counter()
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in [max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)]:
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if not name.startswith("is3d::"):
