@@ -406,7 +406,8 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
     constexpr int BUF2 = UB * REC / 2;
     constexpr int NLD = (BUF2 + 127) / 128;
-    static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
+    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
+    static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples (JT even)");
     __shared__ double2 lbuf[2][BUF2 + RW / 2 + 1];
 
     const int tid = threadIdx.x;
@@ -467,17 +468,26 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             }
             n_rows += 1;
             if (g.zskip && __all(x2min > 555400.0)) { n_dead += 1; return; }   // X > 745.25: exp(-X) == +0 for the whole wave-row
+            // the reciprocals of RB evaluations share one v_rcp_f64 (rcp_batch, cf_math.h): d = 1 + sign z lies in (1e-3, 2]
 #pragma unroll
-            for (int jj = 0; jj < JT; jj++) {
-                const double X = sqrt_g1(X2[jj]);   // 3e-15 relative: e^-X moves by X * 3e-15
-                const double z = exp_full_sat(-X);   // X = |A^-1 p|/T_mod is unbounded for nearly singular A
-                const double d = __builtin_fma(sign, z, 1.0);
-                const double rr = rcp_nr1(d);
-                double pds = __builtin_fma(pTB[jj], W, mTA);
-                if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
-                const double w = z * rr;
-                if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
-                else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+            for (int j0 = 0; j0 < JT; j0 += RB) {
+                double zz[RB], d[RB], inv[RB];
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const double X = sqrt_g1(X2[j0 + i]);   // 3e-15 relative: e^-X moves by X * 3e-15
+                    zz[i] = exp_full_sat(-X);                 // X = |A^-1 p|/T_mod is unbounded for nearly singular A
+                    d[i] = __builtin_fma(sign, zz[i], 1.0);
+                }
+                rcp_batch<RB>(d, inv);
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int jj = j0 + i;
+                    double pds = __builtin_fma(pTB[jj], W, mTA);
+                    if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
+                    const double w = zz[i] * inv[i];
+                    if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                    else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+                }
             }
         };
         const double *rows = U + HDR;

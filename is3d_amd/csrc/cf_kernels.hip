@@ -574,6 +574,11 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;  // units per batch (about 12 KB)
     constexpr int BUF2 = UB * REC / 2;                       // double2 per buffer
     constexpr int NLD = (BUF2 + 127) / 128;                 // staging loads per thread for the smallest workgroup (2 waves)
+    constexpr bool EARLY = LAZY;   // staging order, see the batch loop (eager tiles: 664 -> 666 ms, 2+1D 40.2 -> 42.0 ms with it)
+    // evaluations per shared reciprocal (A/B on config 3 / config 2): 3+1D 8 x 7: 1 -> 685, 2 -> 651, 4 -> 637,
+    // 8 -> 716 ms (spills); 2+1D 8 x 61: 1 -> 44.1, 2 -> 41.5, 4 -> 40.7, 8 -> 40.2 ms
+    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);
+    static_assert(JT % RB == 0, "the phi tile is a whole number of reciprocal batches");
     static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
     __shared__ double2 lbuf[2][BUF2 + (RS + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
 
@@ -654,31 +659,39 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             const double mTA = mT * rw.v[0];
             const double mT2a = BARYON ? __builtin_fma(hbmT, rw.v[4], mT2s * rw.v[2]) : mT2s * rw.v[2];   // + hs b mT L_k
             const double W = rw.v[3], mTC = rw.mTC, E1 = rw.E1;
+            // The reciprocals of RB evaluations share one v_rcp_f64 (rcp_batch, cf_math.h).  q = (1 + sign z) x lies in (1e-6, 2e9)
+            // (cf_prep refuses p.u/T > 1e9), so a product of 8 neither overflows nor underflows.
 #pragma unroll
-            for (int jj = 0; jj < JT; jj++) {
-                const double beta = rw.v[RS + jj];
-                // |p.dsigma 2^-e| <= 1 (cf_device.h), so Theta(p.dsigma) p.dsigma is the clamp modifier of the instruction that forms it
-                double pds;
-                if (OUTFLOW) pds = DIM3 ? add_clamp01(mTA, pTB[jj]) : fma_clamp01(pTB[jj], W, mTA);
-                else pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
-                const double z = E1 * E2[jj];
-                const double d = __builtin_fma(sign, z, 1.0);
-                const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
-                // Chapman-Enskog: df = br / ((1 + sign z) x) with the kappa x term already inside br (cf_prep), so one
-                // reciprocal Rc = 1/((1 + sign z) x) gives df = br Rc and 1/(1 + sign z) = Rc x.
-                double rr, dfr;
-                if (CE) {
-                    const double x = mTC - pTD[jj];
-                    dfr = rcp_nr1(d * x);
-                    rr = dfr * x;
-                } else {
-                    rr = rcp_nr1(d);
-                    dfr = rr;
+            for (int j0 = 0; j0 < JT; j0 += RB) {
+                double zz[RB], xx[RB], q[RB], inv[RB];
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    zz[i] = E1 * E2[j0 + i];
+                    const double d = __builtin_fma(sign, zz[i], 1.0);
+                    // Chapman-Enskog: df = br / ((1 + sign z) x) with the kappa x term already inside br (cf_prep), so one
+                    // reciprocal Rc = 1/((1 + sign z) x) gives df = br Rc and 1/(1 + sign z) = Rc x.
+                    if (CE) {
+                        xx[i] = mTC - pTD[j0 + i];
+                        q[i] = d * xx[i];
+                    } else q[i] = d;
                 }
-                const double u = REG ? fma_clamp01_half(dfr, br) : __builtin_fma(dfr, br, 1.0);
-                const double w = (z * rr) * u;
-                if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
-                else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+                rcp_batch<RB>(q, inv);
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int jj = j0 + i;
+                    const double beta = rw.v[RS + jj];
+                    // |p.dsigma 2^-e| <= 1 (cf_device.h), so Theta(p.dsigma) p.dsigma is the clamp modifier of the instruction that forms it
+                    double pds;
+                    if (OUTFLOW) pds = DIM3 ? add_clamp01(mTA, pTB[jj]) : fma_clamp01(pTB[jj], W, mTA);
+                    else pds = DIM3 ? (mTA + pTB[jj]) : __builtin_fma(pTB[jj], W, mTA);
+                    const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
+                    const double dfr = inv[i];
+                    const double rr = CE ? dfr * xx[i] : dfr;
+                    const double u = REG ? fma_clamp01_half(dfr, br) : __builtin_fma(dfr, br, 1.0);
+                    const double w = (zz[i] * rr) * u;
+                    if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                    else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+                }
             }
         };
         const double *rows = U + HDR;
@@ -709,8 +722,9 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         }
     };
 
-    // double-buffered staging: batch ib+1 travels global -> registers while batch ib is consumed
-    double2 pre[NLD];
+    // double-buffered staging: batch ib+1 is copied global -> LDS by every wave BEFORE it consumes batch ib (the other buffer
+    // was released by the barrier that ended batch ib-1).  The copy's latency is covered by the other waves of the SIMD;
+    // holding the batch in registers across the evaluations instead costs 4 NLD VGPRs that the 8 x 7 tile does not have.
     if (nb > 0) {
         {
             const int n2 = min(UB, n_units) * (REC / 2);
@@ -725,20 +739,32 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             const bool more = ib + 1 < nb;
             const int n2next = more ? min(UB, n_units - (ib + 1) * UB) * (REC / 2) : 0;
             const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
+            if (EARLY) {
 #pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
+                for (int t = 0; t < NLD; t++) {
+                    const int i = tid + t * nthr;
+                    if (i < n2next) lbuf[(ib + 1) & 1][i] = s2[i];
+                }
+            }
+            double2 pre[NLD];
+            if (!EARLY) {
+#pragma unroll
+                for (int t = 0; t < NLD; t++) {
+                    const int i = tid + t * nthr;
+                    pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
+                }
             }
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1];
                 for (int u = 0; u < nu; u++) process_unit(base + u * REC);
             }
+            if (!EARLY) {
 #pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
+                for (int t = 0; t < NLD; t++) {
+                    const int i = tid + t * nthr;
+                    if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
+                }
             }
             __syncthreads();
         }

@@ -184,7 +184,8 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
     constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
     constexpr int BUF2 = UB * REC / 2;
     constexpr int NLD = (BUF2 + 127) / 128;
-    static_assert(REC % 2 == 0, "unit records must be 16-byte multiples");
+    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
+    static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples");
     __shared__ double2 lbuf[2][BUF2 + RW / 2 + 1];
 
     const int tid = threadIdx.x;
@@ -243,17 +244,26 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
             }
             if (g.zskip && __all(x2min > 555400.0)) return;   // E_a/Lambda > 745.25: f_a == +0 for the whole wave-row
 #pragma unroll
-            for (int jj = 0; jj < JT; jj++) {
-                const double X = sqrt_g1(X2[jj]);
-                const double z = exp_full_sat(-X);
-                const double d = __builtin_fma(sign, z, 1.0);
-                const double rr = rcp_nr1(d);                                              // fbar_a
-                const double br = __builtin_fma(mTpTs, rw.v[4 + JT + jj], ad + gd[jj]);   // hs * df/(f_a fbar_a)
-                const double u = REG ? fma_clamp01_half(rr, br) : __builtin_fma(rr, br, 1.0);
-                const double pds = __builtin_fma(pTB[jj], W, mTA);
-                const double w = (z * rr) * u;
-                if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
-                else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+            for (int j0 = 0; j0 < JT; j0 += RB) {   // one v_rcp_f64 per RB evaluations (rcp_batch, cf_math.h)
+                double zz[RB], d[RB], inv[RB];
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const double X = sqrt_g1(X2[j0 + i]);
+                    zz[i] = exp_full_sat(-X);
+                    d[i] = __builtin_fma(sign, zz[i], 1.0);
+                }
+                rcp_batch<RB>(d, inv);                                                         // fbar_a
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int jj = j0 + i;
+                    const double rr = inv[i];
+                    const double br = __builtin_fma(mTpTs, rw.v[4 + JT + jj], ad + gd[jj]);   // hs * df/(f_a fbar_a)
+                    const double u = REG ? fma_clamp01_half(rr, br) : __builtin_fma(rr, br, 1.0);
+                    const double pds = __builtin_fma(pTB[jj], W, mTA);
+                    const double w = (zz[i] * rr) * u;
+                    if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                    else acc[jj] = __builtin_fma(pds, w, acc[jj]);
+                }
             }
         };
         const double *rows = U + HDR;

@@ -3,11 +3,13 @@
 emits for is3d_amd/csrc/cf_kernels.hip, cf_feqmod.hip and cf_vah.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
 fp64-VALU roofline).  Method: for every cf_main_* instantiation take the basic blocks of the innermost loop
 that contains v_rcp_f64 (exactly one v_rcp_f64 is issued per evaluation) and divide the opcode histogram of
-those blocks by their v_rcp_f64 count.  For the 3+1D tile kernel that loop is the whole unit (header + rows),
+those blocks by the number of evaluations they cover = their v_rcp_f64 count x RB, where RB evaluations share one
+reciprocal (rcp_batch in cf_math.h; RB follows from the tile shape exactly as in the kernels; cf_main_direct: 1).
+For the 3+1D tile kernel that loop is the whole unit (header + rows),
 so the amortised exponentials are included; for 2+1D the per-unit header (<2 %) is outside the counted loop.
 
 flops: v_fma/v_fmac = 2, every other fp64 VALU op = 1 (v_rcp_f64 counts 1 although it issues at 1/4 rate).
-issue_cycles: 4 cycles per fp64-rate VALU wave-instruction, 16 for v_rcp_f64 (tools/ubench_fp64.hip measures
+issue_cycles: 4 cycles per fp64-rate VALU wave-instruction, 16 for v_rcp_f64 / v_rsq_f64 (tools/ubench_fp64.hip measures
 4.4-5.3 and 17 at the reported 2.4 GHz clock), 2 for 32-bit integer VALU ops.
 """
 import collections
@@ -88,18 +90,24 @@ def main():
         for b in blocks:
             if b["depth"] >= dmax and dmax > 0:
                 hot.update(b["ops"])
-        n_eval = hot["v_rcp_f64"]
-        if n_eval == 0:
+        if hot["v_rcp_f64"] == 0:
             continue
+        if name == "cf_main_direct":
+            rbatch = 1
+        else:
+            jt = params["JT"]
+            rbatch = (4 if jt % 4 == 0 else (3 if jt % 3 == 0 else 2)) if params["DIM3"] else (8 if jt % 8 == 0 else 4)
+        n_eval = hot["v_rcp_f64"] * rbatch
         f64 = {k: v for k, v in hot.items() if k.endswith("_f64") or k == "v_mov_b64"}
         fma = hot["v_fma_f64"] + hot["v_fmac_f64"]
         other = sum(v for k, v in f64.items() if k not in ("v_fma_f64", "v_fmac_f64", "v_mov_b64"))
         flops = 2 * fma + other
-        full_rate = sum(v for k, v in f64.items() if k != "v_rcp_f64")
+        trans = hot["v_rcp_f64"] + hot["v_rsq_f64"]
+        full_rate = sum(v for k, v in f64.items()) - trans
         int_ops = sum(v for k, v in hot.items() if k.startswith("v_") and k not in f64)
-        cycles = 4 * full_rate + 16 * hot["v_rcp_f64"] + 2 * int_ops
+        cycles = 4 * full_rate + 16 * trans + 2 * int_ops
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
-        out[key] = dict(evals_in_loop=n_eval, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
+        out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
                         histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
     with open(OUT, "w") as f:
