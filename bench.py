@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)")
     a = ap.parse_args()
@@ -191,6 +192,25 @@ def main():
         elapsed = float(tt.item())
     st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
     torch.cuda.synchronize()
+    # untimed: the shader clock the main kernel runs at (idle probe waves on a private stream while one more step executes)
+    clock_ghz = None
+    if rank == 0 and not a.no_clock_probe:
+        import threading
+        box = {}
+
+        def probe():
+            try:
+                time.sleep(float(np.mean(ms["prep"])) * 1e-3 + 0.002)   # let cf_prep pass: the probe should see cf_main only
+                box["ghz"] = api.probe_shader_clock(min(0.25, 0.6 * np.mean(ms["main"]) * 1e-3), local)
+            except Exception as e:   # diagnostic only
+                box["err"] = str(e)
+
+        th = threading.Thread(target=probe)
+        plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)   # enqueue, returns before the kernels finish
+        th.start()
+        th.join()
+        torch.cuda.synchronize()
+        clock_ghz = box.get("ghz") or None
     spectrum_ok = bool(torch.isfinite(out).all().item())
 
     if rank == 0:
@@ -226,6 +246,8 @@ def main():
                       executed_flop_per_eval=ic["flop_per_eval"], fp64_valu_instr_per_eval=ic["valu_f64_instr_per_eval"],
                       issue_cycles_per_eval=ic["issue_cycles_per_eval"],
                       issue_bound_frac_at_2p4GHz=executed_evals / 64.0 * ic["issue_cycles_per_eval"] / (1024 * 2.4e9 * ms_main * 1e-3),
+                      shader_clock_ghz=clock_ghz,
+                      frac_at_shader_clock=(tf / (FP64_VALU_PEAK_TF * clock_ghz / 2.4)) if clock_ghz else None,
                       integrands_per_launch=unique_evals, integrands_executed=executed_evals, wave_rows_culled_frac=culled,
                       note="flops and issue cycles count executed integrands only: rows whose exp(-p.u/T) is exactly +0 for a "
                            "whole wave are skipped (bitwise-identical result)")

@@ -216,6 +216,13 @@ int is3d_plan_observables(is3d_plan *plan, const double *dN_dev, const double *p
 int is3d_plan_set_timing(is3d_plan *plan, int32_t enable);
 /* Synchronises the recorded events of the last execute and fills status->ms_*. */
 int is3d_plan_timings(is3d_plan *plan, is3d_status *status);
+
+/* Diagnostic (no reference counterpart): the shader clock a kernel actually runs at.  Launches one idle wave per XCD on a
+ * private non-blocking stream of `device`; each reads the shader-clock counter (s_memtime) and the constant-rate counter
+ * (s_memrealtime) `seconds` apart and the call returns the mean ratio in GHz.  Called from a second host thread while a
+ * spectra kernel runs on another stream, it gives the clock that kernel's fp64 roofline should be priced at
+ * (bench.py: roofline_valu.shader_clock_ghz).  *ghz = 0 if the two counters tick at the same rate on this device. */
+int is3d_probe_shader_clock(int32_t device, double seconds, double *ghz);
 /* Name of the dominant kernel as it appears in rocprofv3 traces, for the variant in use. */
 const char *is3d_plan_main_kernel_name(const is3d_plan *plan);
 /* tile of the main kernel: *JT phi's x *R rows (y's in 3+1D, eta nodes in 2+1D) */

@@ -93,7 +93,7 @@ class Status(C.Structure):
 
 EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_spectra", "is3d_smooth_spectra_feqmod", "is3d_plan_create",
            "is3d_plan_create_feqmod",
-           "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
+           "is3d_probe_shader_clock", "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
@@ -143,6 +143,7 @@ def load():
                                              C.POINTER(FeqmodTables), C.POINTER(Options), _dp, C.POINTER(Status)]
     L.is3d_plan_create_feqmod.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
                                           C.POINTER(FeqmodTables), C.POINTER(Options), C.c_int64]
+    L.is3d_probe_shader_clock.argtypes = [C.c_int32, C.c_double, C.POINTER(C.c_double)]
     L.is3d_plan_output_size.restype = C.c_int64
     L.is3d_plan_output_size.argtypes = [C.c_void_p]
     L.is3d_plan_workspace_bytes.restype = C.c_int64
@@ -297,6 +298,14 @@ def smooth_spectra(cells, species, grid, df, opts=None, out=None, fq=None):
         rc = L.is3d_smooth_spectra(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(os_), _p(out), C.byref(st))
     _check(rc)
     return out, st.as_dict()
+
+
+def probe_shader_clock(seconds=0.3, device=0):
+    """Shader clock in GHz averaged over `seconds`, sampled by idle waves on a private stream (0.0: the device's two counters
+    tick at the same rate, nothing to measure).  Call it from a second thread while a kernel runs to price that kernel."""
+    ghz = C.c_double(0.0)
+    _check(load().is3d_probe_shader_clock(int(device), float(seconds), C.byref(ghz)))
+    return ghz.value
 
 
 class Plan:

@@ -917,6 +917,30 @@ static void launch_flags(int variant, bool outflow, bool reg, const MainArgs &a,
     else launch_variant<CE, DIM3, false, false>(variant, a, st);
 }
 
+// One idle wave per workgroup, 8 workgroups (one per XCD under round-robin dispatch): shader-clock ticks (s_memtime) per
+// ref_ticks of the constant-rate counter (s_memrealtime).  s_sleep keeps the wave off the issue ports of its SIMD.
+__global__ void __launch_bounds__(64) cf_clock_probe(unsigned long long ref_ticks, unsigned long long *__restrict__ out)
+{
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long c0 = clock64();
+    unsigned long long r1;
+    do {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = wall_clock64();
+    } while (r1 - r0 < ref_ticks);
+    const unsigned long long c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+hipError_t launch_clock_probe(unsigned long long ref_ticks, unsigned long long *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(cf_clock_probe, dim3(8), dim3(64), 0, st, ref_ticks, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st)
 {
     if (a.g.n_cells <= 0) return hipSuccess;

@@ -18,4 +18,5 @@ const char *main_kernel_name(int variant);
 hipError_t launch_observables(const double *dN, const double *phi_w, const double *pT_w, const double *coskphi,
                               const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
                               int ny, hipStream_t st);
+hipError_t launch_clock_probe(unsigned long long ref_ticks, unsigned long long *out /* 2 x 8 */, hipStream_t st);
 }  // namespace is3d

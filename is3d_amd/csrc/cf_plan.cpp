@@ -426,6 +426,34 @@ extern "C" int is3d_plan_create_feqmod(is3d_plan **out, const is3d_species *sp, 
     return plan_create_impl(out, sp, g, df, fq, o, max_cells);
 }
 
+extern "C" int is3d_probe_shader_clock(int32_t device, double seconds, double *ghz)
+{
+    if (!ghz || !(seconds > 0.0) || seconds > 10.0) return fail(IS3D_EINVAL, "is3d_probe_shader_clock: ghz == NULL or seconds outside (0, 10]");
+    *ghz = 0.0;
+    HIP_TRY(hipSetDevice(device));
+    int khz = 0;
+    HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+    if (khz <= 0) return fail(IS3D_ENODEVICE, "is3d_probe_shader_clock: the device reports no wall clock rate");
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    unsigned long long *d = nullptr, h[16] = {0};
+    hipError_t e = hipMalloc(&d, sizeof h);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, sizeof h, st);
+    if (e == hipSuccess) e = is3d::launch_clock_probe((unsigned long long)(seconds * khz * 1e3), d, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d) (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return fail(IS3D_ENODEVICE, "is3d_probe_shader_clock: %s", hipGetErrorString(e));
+    double sum = 0.0;
+    int n = 0;
+    for (int i = 0; i < 8; i++)
+        if (h[2 * i + 1]) { sum += (double)h[2 * i] / (double)h[2 * i + 1]; n++; }
+    const double ratio = n ? sum / n : 0.0;                 // shader ticks per reference tick
+    *ghz = (ratio > 1.001 || ratio < 0.999) ? ratio * khz * 1e-6 : 0.0;
+    return IS3D_OK;
+}
+
 extern "C" int64_t is3d_plan_output_size(const is3d_plan *P) { return P ? P->nout : 0; }
 extern "C" int64_t is3d_plan_workspace_bytes(const is3d_plan *P) { return P ? P->workspace : 0; }
 extern "C" const char *is3d_plan_main_kernel_name(const is3d_plan *P)
