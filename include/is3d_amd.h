@@ -129,7 +129,7 @@ typedef struct {
     int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
     int32_t device;                     /* HIP device ordinal; -1 = current device */
     /* tuning; 0 = library default */
-    int32_t kernel_variant;             /* 0 default (3 for the 3+1D delta-f kernel without baryon terms, else 2) | 1 direct kernel
+    int32_t kernel_variant;             /* 0 default (3 in 3+1D without baryon terms, else 2) | 1 direct kernel
                                            (flat streams, one exp per evaluation) | 2,3,4 LDS-staged tile kernel, (phi x rows)
                                            tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61 in 2+1D */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */

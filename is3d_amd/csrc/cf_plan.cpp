@@ -179,9 +179,9 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     P->ny_eff = P->Kacc;
     P->nout = (int64_t)P->npart * P->npT * P->J * P->ny_eff;
     P->prefactor = std::pow(2.0 * M_PI * is3d::kHbarC, -3);  // smooth_kernels.cpp:36
-    // default tile: 8 x 7 for the 3+1D delta-f kernel (measured 675 vs 696 ms for 6 x 7 on config 3, in spite of 54 spilled
-    // VGPRs: fewer exponentials per evaluation), 6 x 7 / 8 x 61 elsewhere
-    const int default_variant = (o->dimension == 3 && !fq && !o->include_baryon) ? 3 : 2;
+    // default tile: 8 x 7 in 3+1D (delta-f kernel, config 3: 638 vs 659 ms for 6 x 7 -- fewer exponentials per evaluation;
+    // modified-equilibrium kernel: 1005 vs 1028 ms), 6 x 7 with the baryon slots, 8 x 61 in 2+1D
+    const int default_variant = (o->dimension == 3 && !o->include_baryon) ? 3 : 2;
     P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 4) ? o->kernel_variant : default_variant;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----

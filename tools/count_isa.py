@@ -10,7 +10,7 @@ so the amortised exponentials are included; for 2+1D the per-unit header (<2 %) 
 
 flops: v_fma/v_fmac = 2, every other fp64 VALU op = 1 (v_rcp_f64 counts 1 although it issues at 1/4 rate).
 issue_cycles: 4 cycles per fp64-rate VALU wave-instruction, 16 for v_rcp_f64 / v_rsq_f64 (tools/ubench_fp64.hip measures
-4.4-5.3 and 17 at the reported 2.4 GHz clock), 2 for 32-bit integer VALU ops.
+4.36-4.57 and 16.3-16.5 in sustained runs at the probed shader clock), 2 for 32-bit integer VALU ops.
 """
 import collections
 import json

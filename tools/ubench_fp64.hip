@@ -105,6 +105,57 @@ static void run(const char *name, kern_t k, double *d_out, double clk_ghz, int w
     printf("%-10s waves/SIMD=%d  %8.3f ms  %6.2f cycles/wave-instr/SIMD (at %.2f GHz)\n", name, waves_per_simd, ms, cyc, clk_ghz);
 }
 
+// Shader clock under load: idle waves (one per XCD) read s_memtime (shader clock) and s_memrealtime (constant rate) `ref_ticks` apart.
+__global__ void __launch_bounds__(64) k_clock_probe(unsigned long long ref_ticks, unsigned long long *out)
+{
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    unsigned long long r1;
+    do { __builtin_amdgcn_s_sleep(64); r1 = wall_clock64(); } while (r1 - r0 < ref_ticks);
+    const unsigned long long c1 = clock64();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// The same instruction stream for ~0.6 s with the probe running beside it for 0.25 s: the clock the chip sustains under that
+// load, and the issue cost in cycles of THAT clock.
+static void sustained(const char *name, kern_t k, double *d_out, int waves_per_simd)
+{
+    int blocks = 256 * waves_per_simd, wall_khz = 0;
+    hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    hipStream_t sa, sb;
+    hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    unsigned long long *d_p, h_p[16];
+    hipMalloc(&d_p, sizeof h_p);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, sa, d_out, 1.0000001, 0);
+    hipStreamSynchronize(sa);
+    hipEventRecord(a, sa);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, sa, d_out, 1.0000001, 0);
+    hipEventRecord(b, sa);
+    hipEventSynchronize(b);
+    float ms1;
+    hipEventElapsedTime(&ms1, a, b);
+    const int reps = (int)(600.0 / ms1) + 1;
+    hipEventRecord(a, sa);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, sa, d_out, 1.0000001, 0);
+    hipEventRecord(b, sa);
+    hipLaunchKernelGGL(k_clock_probe, dim3(8), dim3(64), 0, sb, (unsigned long long)(0.25 * wall_khz * 1e3), d_p);
+    hipMemcpyAsync(h_p, d_p, sizeof h_p, hipMemcpyDeviceToHost, sb);
+    hipStreamSynchronize(sb);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    double ratio = 0;
+    for (int i = 0; i < 8; i++) ratio += (double)h_p[2 * i] / (double)h_p[2 * i + 1] / 8.0;
+    const double ghz = ratio * wall_khz * 1e-6;
+    const double winstr_per_simd = (double)ITER * 16 * waves_per_simd * reps;
+    printf("sustained %-10s waves/SIMD=%d  %7.1f ms  shader clock %.3f GHz  %5.2f cycles/wave-instr/SIMD at that clock\n", name,
+           waves_per_simd, ms, ghz, ms * 1e-3 * ghz * 1e9 / winstr_per_simd);
+    hipFree(d_p);
+    hipStreamDestroy(sa); hipStreamDestroy(sb);
+}
+
 int main()
 {
     double *d_out;
@@ -124,6 +175,13 @@ int main()
         run("ldexp_f64", k_ldexp, d_out, ghz, w);
         run("cvt_i32", k_cvt, d_out, ghz, w);
         run("mov_b64", k_mov, d_out, ghz, w);
+    }
+    for (int w = 2; w <= 4; w *= 2) {
+        sustained("fma_f64", k_fma, d_out, w);
+        sustained("mul_f64", k_mul, d_out, w);
+        sustained("add_f64", k_add, d_out, w);
+        sustained("rcp_f64", k_rcp, d_out, w);
+        sustained("fma_f32", k_fma32, d_out, w);
     }
     // rcp accuracy
     const int n = 1 << 16;
