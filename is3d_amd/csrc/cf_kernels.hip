@@ -360,40 +360,48 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 p.S3[(int64_t)(cbase + c) * JK + r] = beta_of(c, j, k);
             }
         } else {
-            // ---- phase 3 (tiled): unit records, consecutive threads -> consecutive doubles ----
+            // ---- phase 3 (tiled): one unit record per wave at a time, consecutive lanes -> consecutive doubles.  The (cell,
+            // tile, row block) loops are wave-uniform and the only division left, element -> (row, field), is a multiplication
+            // (q < 2^15, RWD < 64: q * ceil(2^20 / RWD) >> 20 is exact); decoding a flat index with five runtime divisions per
+            // element made this kernel VALU-bound (200 instructions per double written).
             const int JT = p.JT, R = p.R;
             const double psc = pds_scale(p.pds_bound, nullptr);
             const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
-            const int units_per_cell = p.jtiles * p.rblocks;
-            const int per_cell = units_per_cell * REC;
-            for (int idx = tid; idx < ncb * per_cell; idx += kPrepThreads) {
-                const int c = idx / per_cell;
-                int rem = idx - c * per_cell;
-                const int ut = rem / REC, e = rem - ut * REC;
-                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
-                double v;
-                if (e < 4 * JT) {
-                    const int jj = e >> 2, f = e & 3;
-                    const int j = min(jt * JT + jj, J - 1);
-                    v = f == 0 ? l_B[c * J + j] * psc : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
-                } else if (e < HDR) {
-                    v = (e == 4 * JT) ? cs[c].alphaB : 0.0;
-                } else {
-                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
-                    const int k = rb * R + r;
-                    if (k < K) {
-                        if (f < 4) v = f == 0 ? l_A[c * K + k] * psc : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
-                        else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : 0.0;
-                        else v = beta_of(c, min(jt * JT + (f - RS), J - 1), k);
-                    } else {
-                        v = (f == 1) ? l_Cp[c * K + K - 1] : 0.0;   // neutral padding row
+            const unsigned rwd_magic = ((1u << 20) + (unsigned)RWD - 1u) / (unsigned)RWD;
+            const int wave = tid >> 6, lane = tid & 63;
+            int n = 0;
+            for (int c = 0; c < ncb; c++) {
+                const int64_t cell = cbase + c;
+                for (int jt = 0; jt < p.jtiles; jt++) {
+                    for (int rb = 0; rb < p.rblocks; rb++, n++) {
+                        if ((n & (kPrepThreads / 64 - 1)) != wave) continue;
+                        int64_t unit;
+                        if (p.dim3) unit = (int64_t)(jt * p.rblocks + rb) * p.n_cells + cell;       // s = jt*rblocks + rb
+                        else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;              // s = jt
+                        double *o = p.TS + unit * REC;
+                        for (int e = lane; e < REC; e += 64) {
+                            double v;
+                            if (e < 4 * JT) {
+                                const int jj = e >> 2, f = e & 3;
+                                const int j = min(jt * JT + jj, J - 1);
+                                v = f == 0 ? l_B[c * J + j] * psc : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
+                            } else if (e < HDR) {
+                                v = (e == 4 * JT) ? cs[c].alphaB : 0.0;
+                            } else {
+                                const int q = e - HDR, r = (int)(((unsigned)q * rwd_magic) >> 20), f = q - r * RWD;
+                                const int k = rb * R + r;
+                                if (k < K) {
+                                    if (f < 4) v = f == 0 ? l_A[c * K + k] * psc : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
+                                    else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : 0.0;
+                                    else v = beta_of(c, min(jt * JT + (f - RS), J - 1), k);
+                                } else {
+                                    v = (f == 1) ? l_Cp[c * K + K - 1] : 0.0;   // neutral padding row
+                                }
+                            }
+                            o[e] = v;
+                        }
                     }
                 }
-                const int64_t cell = cbase + c;
-                int64_t unit;
-                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;                         // s = jt*rblocks + rb
-                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;              // s = jt
-                p.TS[unit * REC + e] = v;
             }
         }
         __syncthreads();
