@@ -118,7 +118,8 @@ typedef struct {
 typedef struct {
     int32_t dimension;                  /* 2 | 3                      DIMENSION  */
     int32_t df_mode;                    /* 1 14-moment | 2 Chapman-Enskog | 3 modified equilibrium (Mike) | 4 (Jonah);
-                                           3 and 4 only through the *_feqmod entries, include_baryon = 0   DF_MODE */
+                                           3 and 4 only through the *_feqmod entries; 4 needs include_baryon = 0, as in the
+                                           reference (deltafReader.cpp:470-474)                             DF_MODE */
     int32_t include_baryon;             /* 1: mu_B/T in f_eq, bilinear (T, mu_B) coefficients (muB_fo; with
                                            include_baryondiff_deltaf also nB_fo, Vx_fo, Vy_fo, Vn_fo) */
     int32_t include_bulk_deltaf;

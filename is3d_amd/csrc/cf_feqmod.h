@@ -1,6 +1,7 @@
 // cf_feqmod.h -- modified-equilibrium smooth kernel (df_mode 3 "Mike", 4 "Jonah"): shared definitions and launch entry
 // points of cf_feqmod.hip.  Device path of EmissionFunctionArray::calculate_dN_ptdptdphidy_feqmod
-// (/root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:396-996) for include_baryon = 0.
+// (/root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:396-996); include_baryon = 1 with df_mode 3 only (the reference
+// exits for df_mode 4 at nonzero mu_B, deltafReader.cpp:470-474).
 //
 // The modified momentum is linear in the lab momentum,
 //   p_LRF = mT a_k + pT b_j,  a_k = (-Xt ch + tau Xn sh, 0, -Zt ch + tau Zn sh),  b_j = (Xx cos + Xy sin, Yx cos + Yy sin, 0)
@@ -11,6 +12,8 @@
 // (m^2 = mT^2 - pT^2 folded in), and f = |renorm| / (exp(E_mod/T_mod) + sign).  cf_prep_feqmod writes these coefficients
 // into the same tiled unit-record stream the delta-f kernel uses (cf_device.h) with the slots reused:
 //   header jj : {B_j, gammaf_j, 0, 0}          row r : {A_k, alphaf_k, W_k, 0, betaf_{j0..j0+JT-1,k}}
+//   (include_baryon: header slot 2 of jj = 0 carries alpha_B,mod = alpha_B + Pi G / beta_Pi, :637; the lane's baryon number
+//   times it is added to the exponent, :742, :927; A_ij ignores the baryon diffusion, ":660 leave for future work")
 //   p.dsigma = rn (mT A_k + W_k pT B_j),  A_k = w_k ch dat + sh dan/tau  (the reference keeps dsigma_eta outside the eta
 //   weight, :905), W_k = w_k;  rn = |renorm| (df_mode 4: folded into A_k and W_k by the prep kernel; df_mode 3: a
 //   per-(cell, class) table RN read by the main kernel).
@@ -23,7 +26,7 @@
 
 namespace is3d {
 
-constexpr int kFbRec = 28;   // doubles per fallback record (cf_feqmod.hip::FbRec)
+constexpr int kFbRec = 36;   // doubles per fallback record (cf_feqmod.hip::FbRec)
 constexpr int kCrRec = 8;    // doubles per cell record of the df_mode 3 renormalisation kernel
 
 struct FqPrepParams {
@@ -32,6 +35,8 @@ struct FqPrepParams {
     int32_t n_cells, J, K;
     int32_t dim3, mode;                 // mode: 3 | 4
     int32_t include_bulk, include_shear;
+    int32_t baryon, baryondiff;         // include_baryon (df_mode 3), && include_baryondiff_deltaf: mu_B, n_B, V^mu are read (:572-584)
+    BilinearDev bil;                    // baryon: F, G, betabulk, betaV, betapi on the (mu_B, T) grid
     const double *cosphi, *sinphi, *kgrid, *kweight;
     SplineDev spl;                      // y/c[0..2] = F, betabulk, betapi (F, betabulk unused in df_mode 4)
     int32_t nj;                         // Jonah tables (df_mode 4): abscissa bulkPi/Peq, lambda^2, z and their spline c's
@@ -50,6 +55,7 @@ struct FqPrepParams {
 
 struct FqMainArgs {
     const double *TS, *lane_mT, *lane_pT, *lane_sign;
+    const double *lane_b;               // include_baryon: baryon number of each lane slot's class
     const double *RN;                   // df_mode 3: [n_cells][ncls] |renorm|
     const int32_t *lane_cls;            // df_mode 3: class of each lane slot
     int32_t ncls;
@@ -62,6 +68,7 @@ struct FqLinearArgs {
     const double *FB;
     const int32_t *list, *count;        // compacted fallback cells (ascending), *count entries
     const double *lane_mT, *lane_pT, *lane_sign, *lane_mass;
+    const double *lane_b;               // include_baryon, else NULL
     const double *cosphi, *sinphi, *kgrid, *kweight;
     double *partial;                    // chunk 0 of the partial buffer: += after the main kernel
     int32_t J, K, Kacc, Lpad, dim3, mode, outflow, regulate;
@@ -71,8 +78,9 @@ size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K);
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st);
 // RN[cell][cls] = |n_linear / n_mod| (/ detA in 3+1D), 0 where the reference skips the species (nan / inf) or the cell
 hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, const double *cls_mass, const double *cls_sign,
-                                int ncls, int n_cells, int include_bulk, int is_dim3, double *RN, hipStream_t st);
-hipError_t launch_main_feqmod(int variant, int dim3, int outflow, int mode3, const FqMainArgs &a, hipStream_t st);
+                                const double *cls_baryon /* NULL: include_baryon = 0 */, int ncls, int n_cells, int include_bulk,
+                                int is_dim3, double *RN, hipStream_t st);
+hipError_t launch_main_feqmod(int variant, int dim3, int outflow, int mode3, int baryon, const FqMainArgs &a, hipStream_t st);
 // list = indices with flag != 0 in ascending order, *count = their number; status[4] += #flag 1, status[5] += #flag 2
 hipError_t launch_feqmod_compact(const int32_t *flag, int n, int32_t *list, int32_t *count, unsigned long long *status,
                                  hipStream_t st);

@@ -33,30 +33,43 @@ struct FqScal {
     double Ai[9];                  // A^-1, row major
     double detA;
     double narrow;                 // 1: 3+1D cell with detA < 0.01: rows with |y - eta| < detA go to the linear kernel
+    double alphaB_mod;             // include_baryon: alpha_B + Pi G / beta_Pi (:637), else 0
 };
 
 enum FbIdx { FB_DAT = 0, FB_DAX, FB_DAY, FB_DAN, FB_UT, FB_UX, FB_UY, FB_UN, FB_TAU, FB_ETA, FB_T,
              FB_PITT, FB_PITX, FB_PITY, FB_PITN, FB_PIXX, FB_PIXY, FB_PIXN, FB_PIYY, FB_PIYN, FB_PINN,
-             FB_SHEAR, FB_CA, FB_CB, FB_DETA, FB_KIND, FB_END };
+             FB_SHEAR, FB_CA, FB_CB, FB_DETA, FB_KIND,
+             FB_ALPHAB, FB_B1, FB_BER, FB_IBV, FB_VT, FB_VX, FB_VY, FB_VN,   // include_baryon (df_mode 3): :838-850
+             FB_END };
 static_assert(FB_END <= kFbRec, "fallback record too small");
 
-// GaussThermal integrands at alpha_B = 0 (gaussThermal.cpp; neq_int, J20_int)
-__device__ __forceinline__ double gt_neq(const double *root, const double *weight, int n, double mbar, double sign)
+// GaussThermal integrands (gaussThermal.cpp; neq_int, J10_int, J20_int); chem = baryon * alpha_B
+__device__ __forceinline__ double gt_neq(const double *root, const double *weight, int n, double mbar, double sign, double chem = 0.0)
 {
     double s = 0.0;
     for (int k = 0; k < n; k++) {
         const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
-        s += weight[k] * (pbar * exp(pbar) / (exp(Ebar) + sign));
+        s += weight[k] * (pbar * exp(pbar) / (exp(Ebar - chem) + sign));
     }
     return s;
 }
-__device__ __forceinline__ double gt_J20(const double *root, const double *weight, int n, double mbar, double sign)
+__device__ __forceinline__ double gt_J10(const double *root, const double *weight, int n, double mbar, double sign, double chem)
 {
     double s = 0.0;
     for (int k = 0; k < n; k++) {
         const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
-        const double qstat = exp(Ebar) + sign;
-        s += weight[k] * (Ebar * exp(pbar + Ebar) / (qstat * qstat));
+        const double qstat = exp(Ebar - chem) + sign;
+        s += weight[k] * (pbar * exp(pbar + Ebar - chem) / (qstat * qstat));
+    }
+    return s;
+}
+__device__ __forceinline__ double gt_J20(const double *root, const double *weight, int n, double mbar, double sign, double chem = 0.0)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
+        const double qstat = exp(Ebar - chem) + sign;
+        s += weight[k] * (Ebar * exp(pbar + Ebar - chem) / (qstat * qstat));
     }
     return s;
 }
@@ -107,7 +120,18 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             bool valid = udsigma > 0.0;                                               // :502
             if (!valid) atomicAdd(&p.status[1], 1ULL);
             const double T = p.cells.T[gi];
-            if (valid && !(T >= sx[0] && T <= sx[nT - 1])) {                          // GSL domain error in the reference
+            double muB = 0.0, nB = 0.0, Vx = 0.0, Vy = 0.0, Vn = 0.0;
+            if (valid && p.baryon && p.baryondiff) {                                  // :572-584
+                muB = p.cells.muB[gi]; nB = p.cells.nB[gi];
+                Vx = p.cells.Vx[gi]; Vy = p.cells.Vy[gi]; Vn = p.cells.Vn[gi];
+            }
+            double bl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};                                 // F, G, betabulk, betaV, betapi / powers of T
+            if (valid && p.baryon) {
+                if (!bilinear5(p.bil, T, muB, bl)) {                                  // outside the (T, mu_B) table: exit(-1) in the reference
+                    atomicMin(&p.status[0], (unsigned long long)gi);
+                    valid = false;
+                }
+            } else if (valid && !(T >= sx[0] && T <= sx[nT - 1])) {                   // GSL domain error in the reference
                 atomicMin(&p.status[0], (unsigned long long)gi);
                 valid = false;
             }
@@ -139,9 +163,12 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                 }
                 // evaluate_df_coefficients -> cubic_spline (deltafReader.cpp:347-384)
                 const double T4 = T * T * T * T;
-                double F = 0.0, betabulk = 0.0, lambda = 0.0, z = 0.0, delta_lambda = 0.0, delta_z = 0.0;
-                const double betapi = spline_eval_lds(nT, sx, sy + 2 * nT, sc + 2 * nT, T) * T4;
-                if (p.mode == 3) {
+                double F = 0.0, G = 0.0, betabulk = 0.0, betaV = 1.0, lambda = 0.0, z = 0.0, delta_lambda = 0.0, delta_z = 0.0;
+                const double betapi = p.baryon ? bl[4] * T4 : spline_eval_lds(nT, sx, sy + 2 * nT, sc + 2 * nT, T) * T4;
+                const double alphaB = muB / T;
+                if (p.baryon) {                                                       // deltafReader.cpp:454-468 (case 2: case 3:)
+                    F = bl[0] * T; G = bl[1]; betabulk = bl[2] * T4; betaV = bl[3] * T * T * T;
+                } else if (p.mode == 3) {
                     F = spline_eval_lds(nT, sx, sy, sc, T) * T;
                     betabulk = spline_eval_lds(nT, sx, sy + nT, sc + nT, T) * T4;
                 } else {
@@ -210,11 +237,12 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                 s.Xx = Xx; s.Xy = Xy; s.Yx = Yx; s.Yy = Yy;
                 s.detA = detA;
                 s.narrow = narrow ? 1.0 : 0.0;
+                s.alphaB_mod = (p.mode == 3) ? alphaB + bulkPi * G / betabulk : alphaB;   // :632-637
                 flag = breakdown ? 1 : (narrow ? 2 : 0);
                 if (p.mode == 3) {
                     double *cr = p.CR + (int64_t)cell * kCrRec;
                     cr[0] = T; cr[1] = T_mod; cr[2] = bulkPi / betabulk; cr[3] = F; cr[4] = detA; cr[5] = s.live;
-                    cr[6] = 0.0; cr[7] = 0.0;
+                    cr[6] = alphaB; cr[7] = G;
                 }
                 if (flag) {
                     double *fb = p.FB + (int64_t)cell * kFbRec;
@@ -232,6 +260,13 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                     }
                     fb[FB_DETA] = detA;
                     fb[FB_KIND] = (double)flag;
+                    const double tau2V = tau2 * Vn;
+                    fb[FB_ALPHAB] = alphaB;
+                    fb[FB_B1] = (p.mode == 3 && p.baryon) ? (G / betabulk) * bulkPi : 0.0;        // bulk1_coeff Pi, :643, :849
+                    fb[FB_BER] = nB / (E + P);                                                     // baryon_enthalpy_ratio, :583
+                    fb[FB_IBV] = 1.0 / betaV;
+                    fb[FB_VT] = (Vx * ux + Vy * uy + tau2V * un) / ut;                             // :580
+                    fb[FB_VX] = Vx; fb[FB_VY] = Vy; fb[FB_VN] = Vn;
                 }
             } else {
                 s.live = 0.0;
@@ -248,7 +283,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                 s.Xt = s.tXn = s.Zt = s.tZn = 0.0;
                 s.Xx = s.Xy = s.Yx = s.Yy = 0.0;
                 for (int i = 0; i < 9; i++) s.Ai[i] = 0.0;
-                s.detA = 1.0; s.narrow = 0.0;
+                s.detA = 1.0; s.narrow = 0.0; s.alphaB_mod = 0.0;
             }
             p.flag[cell] = flag;
             cs[tid] = s;
@@ -302,6 +337,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                     const int j = min(jt * JT + jj, J - 1);
                     if (f == 0) v = l_B[c * J + j];
                     else if (f == 1) v = l_ga[c * J + j];
+                    else if (e == 2) v = cs[c].alphaB_mod;
                 } else {
                     const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                     const int k = rb * R + r;
@@ -346,7 +382,8 @@ hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 cf_feqmod_renorm(const double *__restrict__ CR, const double *__restrict__ gl, int ngl, const double *__restrict__ cls_mass,
-                 const double *__restrict__ cls_sign, int ncls, int n_cells, int include_bulk, int dim3, double *__restrict__ RN)
+                 const double *__restrict__ cls_sign, const double *__restrict__ cls_baryon, int ncls, int n_cells, int include_bulk,
+                 int dim3, double *__restrict__ RN)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)n_cells * ncls) return;
@@ -361,11 +398,15 @@ cf_feqmod_renorm(const double *__restrict__ CR, const double *__restrict__ gl, i
             const double neq_fact = T * T * T / two_pi2_hbarC3, J20_fact = T * neq_fact;
             const double nmod_fact = T_mod * T_mod * T_mod / two_pi2_hbarC3;
             const double mass = cls_mass[c], sign = cls_sign[c];
+            const double baryon = cls_baryon ? cls_baryon[c] : 0.0;
+            const double alphaB = cr[6], G = cr[7], alphaB_mod = alphaB + dn_fact * G;   // :637
+            const double chem = baryon * alphaB, chem_mod = baryon * alphaB_mod;
             const double mbar = mass / T, mbar_mod = mass / T_mod;
-            const double neq = neq_fact * gt_neq(gl, gl + ngl, ngl, mbar, sign);
-            const double J20 = J20_fact * gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sign);
-            const double n_linear = neq + dn_fact * (neq + J20 * F / T / T);          // G = 0 without baryon
-            const double n_mod = nmod_fact * gt_neq(gl, gl + ngl, ngl, mbar_mod, sign);
+            const double neq = neq_fact * gt_neq(gl, gl + ngl, ngl, mbar, sign, chem);
+            const double N10 = (baryon != 0.0) ? baryon * neq_fact * gt_J10(gl, gl + ngl, ngl, mbar, sign, chem) : 0.0;   // N10_fact = neq_fact, :717
+            const double J20 = J20_fact * gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sign, chem);
+            const double n_linear = neq + dn_fact * (neq + N10 * G + J20 * F / T / T);   // :760
+            const double n_mod = nmod_fact * gt_neq(gl, gl + ngl, ngl, mbar_mod, sign, chem_mod);
             renorm = n_linear / n_mod;
         }
         if (isnan(renorm) || isinf(renorm)) renorm = 0.0;                             // :768-772: species skipped in this cell
@@ -378,12 +419,13 @@ cf_feqmod_renorm(const double *__restrict__ CR, const double *__restrict__ gl, i
 }
 
 hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, const double *cls_mass, const double *cls_sign,
-                                int ncls, int n_cells, int include_bulk, int is_dim3, double *RN, hipStream_t st)
+                                const double *cls_baryon, int ncls, int n_cells, int include_bulk, int is_dim3, double *RN,
+                                hipStream_t st)
 {
     if (n_cells <= 0) return hipSuccess;
     const int64_t n = (int64_t)n_cells * ncls;
     hipLaunchKernelGGL(cf_feqmod_renorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, CR, gl, ngl, cls_mass, cls_sign,
-                       ncls, n_cells, include_bulk, is_dim3, RN);
+                       cls_baryon, ncls, n_cells, include_bulk, is_dim3, RN);
     return hipGetLastError();
 }
 
@@ -394,11 +436,12 @@ hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, con
 // tile except the row and column products.  Rows whose X exceeds 745.2 for every lane and phi of the tile (z = +0
 // exactly) are culled as in cf_main_tile.
 // ------------------------------------------------------------------------------------------------
-template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R>
+template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R, bool BARYON = false>
 __global__ void __launch_bounds__(512)
 cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
                const double *__restrict__ lane_sign, const double *__restrict__ RN, const int32_t *__restrict__ lane_cls,
-               int ncls, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g)
+               int ncls, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g,
+               const double *__restrict__ lane_b)
 {
     constexpr int HDR = 4 * JT;
     constexpr int RW = 4 + JT;
@@ -428,6 +471,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     const int J = g.J, K = g.K;
     const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
     const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
+    const double bq = BARYON ? lane_b[l] : 0.0;
     const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
     const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
     const int n_units = (c1 - c0) * g.upc;
@@ -445,6 +489,10 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     auto process_unit = [&](const double *U, double rn) {
         double pTB[JT], pT2g[JT];
         const double rpT = MODE3 ? rn * pT : pT, rmT = MODE3 ? rn * mT : mT;
+        const double cm = BARYON ? bq * U[2] : 0.0;   // chem_mod = baryon * alpha_B,mod (:742): f = |renorm| / (exp(E_mod/T_mod - chem_mod) + sign)
+        // exact-zero culling: exp(cm - X) == +0 needs X > 745.25 + cm
+        const double xcut = BARYON ? 745.25 + __builtin_fmax(cm, 0.0) : 745.25;
+        const double x2cut = BARYON ? xcut * xcut : 555400.0;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
             pTB[jj] = rpT * U[4 * jj + 0];
@@ -467,7 +515,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 x2min = __builtin_fmin(x2min, X2[jj]);
             }
             n_rows += 1;
-            if (g.zskip && __all(x2min > 555400.0)) { n_dead += 1; return; }   // X > 745.25: exp(-X) == +0 for the whole wave-row
+            if (g.zskip && __all(x2min > x2cut)) { n_dead += 1; return; }   // X > 745.25 (+ cm): exp(cm - X) == +0 for the whole wave-row
             // the reciprocals of RB evaluations share one v_rcp_f64 (rcp_batch, cf_math.h): d = 1 + sign z lies in (1e-3, 2]
 #pragma unroll
             for (int j0 = 0; j0 < JT; j0 += RB) {
@@ -475,7 +523,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const double X = sqrt_g1(X2[j0 + i]);   // 3e-15 relative: e^-X moves by X * 3e-15
-                    zz[i] = exp_full_sat(-X);                 // X = |A^-1 p|/T_mod is unbounded for nearly singular A
+                    zz[i] = exp_full_sat(BARYON ? cm - X : -X);   // X = |A^-1 p|/T_mod is unbounded for nearly singular A
                     d[i] = __builtin_fma(sign, zz[i], 1.0);
                 }
                 rcp_batch<RB>(d, inv);
@@ -590,8 +638,15 @@ template <bool DIM3, bool OF, bool M3, int JT, int R>
 static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
 {
     const int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    if constexpr (M3) {
+        if (a.lane_b) {   // include_baryon (df_mode 3 only)
+            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, true>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT,
+                               a.lane_pT, a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b);
+            return;
+        }
+    }
     hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
-                       a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g);
+                       a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b);
 }
 
 template <bool DIM3, bool OF, bool M3>
@@ -605,9 +660,10 @@ static void launch_fq_variant(int variant, const FqMainArgs &a, hipStream_t st)
     }
 }
 
-hipError_t launch_main_feqmod(int variant, int dim3, int outflow, int mode3, const FqMainArgs &a, hipStream_t st)
+hipError_t launch_main_feqmod(int variant, int dim3, int outflow, int mode3, int baryon, const FqMainArgs &a, hipStream_t st)
 {
     if (a.g.n_cells <= 0) return hipSuccess;
+    if ((baryon != 0) != (a.lane_b != nullptr) || (baryon && !mode3)) return hipErrorInvalidValue;
     const int sel = (dim3 ? 4 : 0) | (outflow ? 2 : 0) | (mode3 ? 1 : 0);
     switch (sel) {
     case 0: launch_fq_variant<false, false, false>(variant, a, st); break;
@@ -681,6 +737,7 @@ __global__ void __launch_bounds__(256) cf_feqmod_linear(FqLinearArgs a)
     const int jk = (int)(idx / a.Lpad);
     const int j = jk / a.Kacc, k = jk - j * a.Kacc;
     const double mT = a.lane_mT[l], pT = a.lane_pT[l], sign = a.lane_sign[l], mass = a.lane_mass[l];
+    const double baryon = a.lane_b ? a.lane_b[l] : 0.0;
     const double mass2 = mass * mass;
     const double px = pT * a.cosphi[j], py = pT * a.sinphi[j];
     const double y = a.dim3 ? a.kgrid[k] : 0.0;
@@ -702,10 +759,16 @@ __global__ void __launch_bounds__(256) cf_feqmod_linear(FqLinearArgs a)
             const double pdotu = pt * fb[FB_UT] - px * fb[FB_UX] - py * fb[FB_UY] - tau2_pn * fb[FB_UN];
             const double pimunu_pmu_pnu = fb[FB_PITT] * pt * pt + fb[FB_PIXX] * px * px + fb[FB_PIYY] * py * py + fb[FB_PINN] * tau2_pn * tau2_pn
                 + 2.0 * (-(fb[FB_PITX] * px + fb[FB_PITY] * py) * pt + fb[FB_PIXY] * px * py + tau2_pn * (fb[FB_PIXN] * px + fb[FB_PIYN] * py - fb[FB_PITN] * pt));
-            const double feq = 1.0 / (exp(pdotu / T) + sign), feqbar = 1.0 - sign * feq;
+            const double chem = (a.mode == 3) ? baryon * fb[FB_ALPHAB] : 0.0;                                               // :741, :838
+            const double feq = 1.0 / (exp(pdotu / T - chem) + sign), feqbar = 1.0 - sign * feq;
             const double df_shear = fb[FB_SHEAR] * pimunu_pmu_pnu / pdotu;
             double df;
-            if (a.mode == 3) df = feqbar * (df_shear + fb[FB_CA] * pdotu + fb[FB_CB] * (pdotu - mass2 / pdotu));          // :833-858
+            if (a.mode == 3) {                                                                                               // :833-858
+                const double Vmu_pmu = fb[FB_VT] * pt - fb[FB_VX] * px - fb[FB_VY] * py - fb[FB_VN] * tau2_pn;
+                const double df_bulk = fb[FB_CA] * pdotu + fb[FB_B1] * baryon + fb[FB_CB] * (pdotu - mass2 / pdotu);
+                const double df_diff = (fb[FB_BER] - baryon / pdotu) * Vmu_pmu * fb[FB_IBV];
+                df = feqbar * (df_shear + df_bulk + df_diff);
+            }
             else df = feqbar * df_shear + fb[FB_CA] + feqbar * fb[FB_CB] * (pdotu - mass2 / pdotu);                         // :859-880
             if (a.regulate) df = fmax(-1.0, fmin(df, 1.0));
             sum += pdotdsigma * (feq * (1.0 + df));

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "cf_device.h"
+
 namespace is3d {
 
 #define IS3D_LOG2E 1.44269504088896338700e+00
@@ -185,6 +187,26 @@ __device__ __forceinline__ double sqrt_g1(double x)
     double g = x * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     return __builtin_fma(g, r, g);
+}
+
+// Deltaf_Data::bilinear_interpolation (deltafReader.cpp:412-484) on the device copies of the full (mu_B, T) grids,
+// with the intended [imuB][iT] indexing (the reference's calculate_bilinear swaps the indices, :404-407).
+// Returns false outside the table (reference: printf + exit(-1), :423-427).
+__device__ __forceinline__ bool bilinear5(const BilinearDev &b, double T, double muB, double (&v)[5])
+{
+    const double T_min = b.T[0], B_min = b.muB[0];
+    const double dT = fabs(b.T[1] - b.T[0]), dB = fabs(b.muB[1] - b.muB[0]);
+    const int iTL = (int)floor((T - T_min) / dT), iTR = iTL + 1;
+    const int iBL = (int)floor((muB - B_min) / dB), iBR = iBL + 1;
+    if (!(iTL >= 0 && iTR < b.nT) || !(iBL >= 0 && iBR < b.nB)) return false;
+    const double TL = b.T[iTL], TR = b.T[iTR], BL = b.muB[iBL], BR = b.muB[iBR];
+    for (int k = 0; k < 5; k++) {
+        const double *f = b.tab[k];
+        const double f_LL = f[(size_t)iBL * b.nT + iTL], f_LR = f[(size_t)iBR * b.nT + iTL];
+        const double f_RL = f[(size_t)iBL * b.nT + iTR], f_RR = f[(size_t)iBR * b.nT + iTR];
+        v[k] = ((f_LL * (TR - T) + f_RL * (T - TL)) * (BR - muB) + (f_LR * (TR - T) + f_RR * (T - TL)) * (muB - BL)) / (dT * dB);
+    }
+    return true;
 }
 
 // gsl_interp_cspline evaluation (deltafReader.cpp:339-358 call sites) on LDS-resident tables.

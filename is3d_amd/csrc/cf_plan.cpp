@@ -92,7 +92,7 @@ struct is3d_plan {
     bool feqmod = false;
     int nj = 0, ngl = 0;
     double bp_max = 0.0, detA_min = 0.0, mass_pion0 = 0.0;
-    DevBuf<double> d_gl, d_jonah, d_cls_mass, d_cls_sign, d_lane_mass, d_RN, d_CR, d_FB;
+    DevBuf<double> d_gl, d_jonah, d_cls_mass, d_cls_sign, d_cls_baryon, d_lane_mass, d_RN, d_CR, d_FB;
     DevBuf<int32_t> d_lane_cls, d_flag, d_list, d_count;
 
     bool timing = false;
@@ -114,7 +114,8 @@ static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_ta
     if (o->dimension != 2 && o->dimension != 3) return fail(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", o->dimension);
     if (fq) {
         if (o->df_mode != 3 && o->df_mode != 4) return fail(IS3D_EINVAL, "the feqmod entries take df_mode 3 or 4 (got %d)", o->df_mode);
-        if (o->include_baryon) return fail(IS3D_EINVAL, "df_mode 3/4 with include_baryon = 1 is not supported on this path");
+        if (o->include_baryon && o->df_mode == 4)   // the reference: "Jonah df doesn't work for nonzero muB. Exiting..", deltafReader.cpp:470-474
+            return fail(IS3D_EINVAL, "df_mode 4 does not work with include_baryon = 1 (the reference exits there too)");
         if (o->kernel_variant == 1) return fail(IS3D_EINVAL, "df_mode 3/4 runs on the tile kernel only (kernel_variant 0, 2-4)");
         if (fq->n_gla < 1 || fq->n_gla > 256 || !fq->root1 || !fq->weight1 || !fq->root2 || !fq->weight2)
             return fail(IS3D_EINVAL, "df_mode 3/4 needs the Gauss-Laguerre roots and weights for alpha = 1, 2");
@@ -131,7 +132,7 @@ static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_ta
         for (int i = 1; i < df->n_muB; i++)
             if (!(df->muB[i] > df->muB[i - 1])) return fail(IS3D_EINVAL, "coefficient table muB values must ascend");
         if (o->df_mode == 1 && (!df->c1 || !df->c3 || !df->c4)) return fail(IS3D_EINVAL, "include_baryon = 1, df_mode 1 needs c0..c4 tables");
-        if (o->df_mode == 2 && (!df->G || !df->betaV)) return fail(IS3D_EINVAL, "include_baryon = 1, df_mode 2 needs F, G, betabulk, betaV, betapi tables");
+        if ((o->df_mode == 2 || o->df_mode == 3) && (!df->G || !df->betaV)) return fail(IS3D_EINVAL, "include_baryon = 1, df_mode 2 needs F, G, betabulk, betaV, betapi tables");
     }
     if (sp->n < 1 || !sp->mass || !sp->sign || !sp->degeneracy) return fail(IS3D_EINVAL, "empty species list");
     if (g->n_pT < 1 || g->n_phi < 1 || !g->pT || !g->phi) return fail(IS3D_EINVAL, "empty pT/phi grid");
@@ -292,7 +293,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if (P->baryon) {
         // full (mu_B, T) grids for the bilinear branch (deltafReader.cpp:412-484)
         const double *t5[5];
-        if (!P->ce) { t5[0] = df->c0; t5[1] = df->c1; t5[2] = df->c2; t5[3] = df->c3; t5[4] = df->c4; }
+        if (!P->ce && !fq) { t5[0] = df->c0; t5[1] = df->c1; t5[2] = df->c2; t5[3] = df->c3; t5[4] = df->c4; }
         else { t5[0] = df->F; t5[1] = df->G; t5[2] = df->betabulk; t5[3] = df->betaV; t5[4] = df->betapi; }
         std::vector<double> bs(df->muB, df->muB + df->n_muB);
         HIP_TRY(P->d_bilT.upload(xs));
@@ -336,6 +337,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_lane_cls.upload(lane_cls));
         HIP_TRY(P->d_cls_mass.upload(cmass));
         HIP_TRY(P->d_cls_sign.upload(csign));
+        if (P->baryon) HIP_TRY(P->d_cls_baryon.upload(cbar));
         if (is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K) > 160 * 1024)
             return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     } else if (is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K) > 160 * 1024)
@@ -349,7 +351,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;   // k tiles are separate tasks only in 3+1D
     P->upc = (tiled && !P->dim3) ? P->rblocks : 1;            // 2+1D: eta blocks are consecutive units of one stream
     if (tiled)
-        P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0);
+        P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0);
     else
         P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
     if (P->feqmod)   // fallback record, flag, list entry; df_mode 3: cell record + |renorm| per class
@@ -389,7 +391,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         P->nch_max = (int)nch;
     }
     if (tiled) {
-        HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0)));
+        HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0)));
     } else {
         HIP_TRY(P->d_S1.alloc((size_t)pc * P->K * is3d::kS1Rec));
         HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
@@ -541,7 +543,9 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             if (P->feqmod) {
                 is3d::FqPrepParams fp{};
                 fp.cells = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
-                            cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
+                            cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
+                            cells->muB, cells->nB, cells->Vx, cells->Vy, cells->Vn};
+                fp.baryon = P->baryon; fp.baryondiff = P->baryondiff; fp.bil = P->bil;
                 fp.cell0 = c0; fp.n_cells = nc; fp.J = P->J; fp.K = P->K;
                 fp.dim3 = P->dim3; fp.mode = o.df_mode;
                 fp.include_bulk = o.include_bulk_deltaf != 0; fp.include_shear = o.include_shear_deltaf != 0;
@@ -558,24 +562,27 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
                 HIP_TRY(is3d::launch_prep_feqmod(fp, st));
                 if (o.df_mode == 3)
-                    HIP_TRY(is3d::launch_feqmod_renorm(P->d_CR.p, P->d_gl.p, P->ngl, P->d_cls_mass.p, P->d_cls_sign.p, P->ncls, nc,
-                                                       fp.include_bulk, P->dim3, P->d_RN.p, st));
+                    HIP_TRY(is3d::launch_feqmod_renorm(P->d_CR.p, P->d_gl.p, P->ngl, P->d_cls_mass.p, P->d_cls_sign.p,
+                                                       P->baryon ? P->d_cls_baryon.p : nullptr, P->ncls, nc, fp.include_bulk, P->dim3,
+                                                       P->d_RN.p, st));
                 if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 1], st));
                 is3d::FqMainArgs a{};
                 a.TS = P->d_TS.p; a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
                 a.RN = P->d_RN.p; a.lane_cls = P->d_lane_cls.p; a.ncls = P->ncls;
+                a.lane_b = P->baryon ? P->d_lane_b.p : nullptr;
                 a.partial = P->d_partial.p; a.stats = P->d_status.p;
                 a.g.upc = P->upc; a.g.zskip = (o.zero_skip != 2); a.g.baryon = 0;
                 a.g.n_cells = nc; a.g.J = P->J; a.g.K = P->K; a.g.Lpad = P->Lpad; a.g.wpb = P->wpb;
                 a.g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
                 a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles; a.g.nch = nch_used;
                 a.g.NT = P->jtiles * P->ktiles * nch_used; a.g.Kacc = P->Kacc; a.g.first_pass = (pass == 0);
-                HIP_TRY(is3d::launch_main_feqmod(P->variant, P->dim3, o.outflow != 0, o.df_mode == 3, a, st));
+                HIP_TRY(is3d::launch_main_feqmod(P->variant, P->dim3, o.outflow != 0, o.df_mode == 3, P->baryon ? 1 : 0, a, st));
                 // flagged cells (breakdown, narrow rows): ordered list, then the linearised delta-f on top of chunk 0
                 HIP_TRY(is3d::launch_feqmod_compact(P->d_flag.p, nc, P->d_list.p, P->d_count.p, P->d_status.p, st));
                 is3d::FqLinearArgs la{};
                 la.FB = P->d_FB.p; la.list = P->d_list.p; la.count = P->d_count.p;
                 la.lane_mT = P->d_mT.p; la.lane_pT = P->d_pT.p; la.lane_sign = P->d_sign.p; la.lane_mass = P->d_lane_mass.p;
+                la.lane_b = P->baryon ? P->d_lane_b.p : nullptr;
                 la.cosphi = P->d_cosphi.p; la.sinphi = P->d_sinphi.p; la.kgrid = P->d_kgrid.p; la.kweight = P->d_kweight.p;
                 la.partial = P->d_partial.p;
                 la.J = P->J; la.K = P->K; la.Kacc = P->Kacc; la.Lpad = P->Lpad; la.dim3 = P->dim3; la.mode = o.df_mode;

@@ -12,7 +12,7 @@
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
 // operation = 2 (particle sampler, df_mode 1 | 2, include_baryon = 0, fast = 0, test_sampler = 0) writes
 // results/particle_list_osc.dat (write_particle_list_OSC, emissionfunction.cpp:863-901) and results/dN_dy_*.dat is skipped.
-// Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2} with include_baryon in {0, 1}, df_mode in {3, 4}
+// Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2, 3} with include_baryon in {0, 1}, df_mode 4
 // (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
 // averages it has just written, as the reference does) with include_baryon = 0.  Anything else is refused
 // with a message instead of silently doing something different from the reference.
@@ -125,7 +125,8 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
     if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
     const bool feqmod = df_mode == 3 || df_mode == 4;
-    if (feqmod && include_baryon) DIE("df_mode = %d with include_baryon = 1 is not on this path", df_mode);
+    if (df_mode == 4 && include_baryon)   // deltafReader.cpp:470-474
+        DIE("Bilinear interpolation error: Jonah df doesn't work for nonzero muB (df_mode = 4 with include_baryon = 1)");
     const char *pdg_path, *df_dir;
     if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
     else if (hrg_eos == 2) { pdg_path = "PDG/pdg_smash.dat"; df_dir = "deltaf_coefficients/vh/smash/"; }

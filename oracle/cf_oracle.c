@@ -202,7 +202,7 @@ static int eval_df_bilinear(const oracle_df_tables *t, int df_mode, double T, do
     double T3 = T * T * T, T4 = T3 * T, T5 = T4 * T;
     if (df_mode == 1) {                                        /* :436-452 */
         df->c0 = v[0] / T4; df->c1 = v[1] / T3; df->c2 = v[2] / T4; df->c3 = v[3] / T4; df->c4 = v[4] / T5;
-    } else if (df_mode == 2) {                                 /* :454-468 */
+    } else if (df_mode == 2 || df_mode == 3) {                 /* :454-468 (case 2: case 3:) */
         df->F = v[5] * T; df->G = v[6]; df->betabulk = v[7] * T4; df->betaV = v[8] * T3; df->betapi = v[9] * T4;
     } else {
         return -2;
@@ -717,14 +717,20 @@ static void matvec3(const double A[3][3], const double x[3], double y[3])
     for (int i = 0; i < 3; i++) y[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
 }
 
-/* Returns 0, or <0: -1 T (or bulkPi/P) outside a table, -2 df_mode, -3 dimension/grid, -4 include_baryon (not restated for feqmod). */
+/* include_baryon = 1 (df_mode 3 only; with df_mode 4 the reference exits: "Jonah df doesn't work for nonzero muB",
+ * deltafReader.cpp:470-474): coefficients by the bilinear branch; mu_B, n_B, V^mu are read only if include_baryondiff_deltaf
+ * is also set (:572-584); alpha_B,mod = alpha_B + Pi G / beta_Pi (:637) enters the modified distribution and, with N10 G, the
+ * renormalisation (:754-762); A_ij ignores the baryon diffusion (":660 leave for future work"), which only appears in the
+ * linearised fallback (df_diff, :850).
+ * Returns 0, or <0: -1 T, (T, mu_B) or bulkPi/P outside a table, -2 df_mode, -3 dimension/grid, -4 include_baryon with df_mode 4
+ * or without the full (mu_B, T) tables. */
 int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
                                  const double *Baryon, const cell_arrays *a, const oracle_df_tables *t, const oracle_feqmod_tables *q,
                                  const oracle_grid *g, const oracle_opts *o, double *dN_pTdpTdphidy, long *n_breakdown)
 {
     if (o->dimension != 2 && o->dimension != 3) return -3;
     if (o->df_mode != 3 && o->df_mode != 4) return -2;
-    if (o->include_baryon) return -4;
+    if (o->include_baryon && o->df_mode == 4) return -4;
     const int DF_MODE = o->df_mode;
     const double two_pi2_hbarC3 = 2.0 * pow(M_PI, 2) * pow(ORACLE_HBARC, 3);        /* iS3D.h:11 */
     const double prefactor = pow(2.0 * M_PI * ORACLE_HBARC, -3);
@@ -785,10 +791,26 @@ int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, 
                 else if (bulkPi / P > J->bulkPi_over_Peq_max) bulkPi = P * (J->bulkPi_over_Peq_max - 1.e-5);
             }
             /* evaluate_df_coefficients -> cubic_spline, deltafReader.cpp:347-384 */
-            double F = 0, G = 0, betabulk = 0, betapi = 0, lambda = 0, z = 0, delta_lambda = 0, delta_z = 0;
+            double F = 0, G = 0, betabulk = 0, betapi = 0, betaV = 1.0, lambda = 0, z = 0, delta_lambda = 0, delta_z = 0;
             double T4 = T * T * T * T, v;
             int bad = 0;
-            if (DF_MODE == 3) {
+            double muB = 0.0, alphaB = 0.0, nB = 0.0, Vt = 0.0, Vx = 0.0, Vy = 0.0, Vn = 0.0, baryon_enthalpy_ratio = 0.0;   /* :564-584 */
+            if (o->include_baryon && o->include_baryondiff_deltaf) {
+                muB = a->muB[ic]; nB = a->nB[ic]; Vx = a->Vx[ic]; Vy = a->Vy[ic]; Vn = a->Vn[ic];
+                Vt = (Vx * ux + Vy * uy + tau2 * Vn * un) / ut;
+                alphaB = muB / T;
+                baryon_enthalpy_ratio = nB / (E + P);
+            }
+            if (o->include_baryon) {                                                 /* evaluate_df_coefficients -> bilinear_interpolation */
+                df_coeff dfb;
+                int brc = eval_df_bilinear(t, 3, T, muB, &dfb);
+                if (brc) {
+#pragma omp atomic write
+                    err = brc == -1 ? -1 : -4;
+                    continue;
+                }
+                F = dfb.F; G = dfb.G; betabulk = dfb.betabulk; betaV = dfb.betaV; betapi = dfb.betapi;
+            } else if (DF_MODE == 3) {
                 if (oracle_cspline_eval(n, t->T, t->F, sF, T, &v)) bad = 1; else F = v * T;
                 G = 0.0;
                 if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, T, &v)) bad = 1; else betabulk = v * T4;
@@ -821,7 +843,7 @@ int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, 
             double piyy_LRF = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
             double piyz_LRF = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
             double pizz_LRF = -(pixx_LRF + piyy_LRF);
-            double T_mod = T, alphaB = 0.0, alphaB_mod = 0.0;
+            double T_mod = T, alphaB_mod = alphaB;
             if (DF_MODE == 3) { T_mod = T + bulkPi * F / betabulk; alphaB_mod = alphaB + bulkPi * G / betabulk; }   /* :627-631 */
             double shear_coeff = 0.5 / (betapi * T);
             double bulk0_coeff = F / (T * T * betabulk), bulk1_coeff = G / betabulk, bulk2_coeff = 1.0 / (3.0 * T * betabulk);
@@ -895,7 +917,9 @@ int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, 
                                         double feq = 1.0 / (exp(pdotu / T - chem) + sign), feqbar = 1.0 - sign * feq;
                                         double df_shear = shear_coeff * pimunu_pmu_pnu / pdotu;
                                         double df_bulk = (bulk0_coeff * pdotu + bulk1_coeff * baryon + bulk2_coeff * (pdotu - mass2 / pdotu)) * bulkPi;
-                                        df = feqbar * (df_shear + df_bulk);
+                                        double Vmu_pmu = Vt * pt - Vx * px - Vy * py - Vn * tau2_pn;                  /* :846 */
+                                        double df_diff = (baryon_enthalpy_ratio - baryon / pdotu) * Vmu_pmu / betaV;   /* :850 */
+                                        df = feqbar * (df_shear + df_bulk + df_diff);
                                         if (o->regulate_deltaf) df = fmax(-1.0, fmin(df, 1.0));
                                         f = feq * (1.0 + df);
                                     } else {                                             /* :859-880 */

@@ -79,6 +79,25 @@ def test_cli_include_baryon(tmp_path, fx, df_mode):
     assert 0.05 < avg[3] < 0.4 and 0.02 < avg[4] < 0.1     # mu_B and n_B averages are filled now
 
 
+def test_cli_feqmod_with_baryon(tmp_path, fx):
+    """df_mode = 3 with include_baryon = 1 end to end: 25-column surface, full (T, mu_B) coefficient files, Gauss-Laguerre file."""
+    ids = [211, 2212, -2212]
+    cells = synth.synth_surface(11, 3, seed=57, baryon=True)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["bulkPi"][4] = -5.0 * cells["P"][4]            # one breakdown cell: linearised delta-f with the baryon terms
+    o = dict(dimension=3, df_mode=3, include_baryon=1, include_baryondiff_deltaf=1)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, o)
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    T_avg = float(open(os.path.join(root, "average_thermodynamic_quantities.dat")).read().split()[0])
+    ref, nb = oracle.dN_pTdpTdphidy_feqmod(parsed, inputs.species(ids), fx["grid"], inputs.df_tables_full(), inputs.feqmod_tables(T_avg), o)
+    assert nb == 1 and "feqmod breaks down for 1 cells" in r.stdout
+    allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
+    want = np.transpose(ref.reshape(21, 24, 32, 3), (3, 0, 1, 2)).reshape(-1)
+    assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8
+
+
 @pytest.mark.parametrize("mode", [0, 4, 6, 7])
 def test_cli_other_surface_formats(tmp_path, fx, mode):
     """The other viscous-hydro surface formats end to end: 2+1D boost-invariant MUSIC /

@@ -158,6 +158,36 @@ def test_feqmod_plan_passes_accumulate_and_skipped(fx):
         plan.close()
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("flags", [dict(include_baryondiff_deltaf=1), dict(include_baryondiff_deltaf=0),
+                                   dict(include_baryondiff_deltaf=1, outflow=0, regulate_deltaf=0),
+                                   dict(include_baryondiff_deltaf=1, include_bulk_deltaf=0)])
+def test_feqmod_with_baryon_parity(fx, dim, flags):
+    """df_mode 3 with include_baryon = 1: bilinear coefficients, b (alpha_B + Pi G / beta_Pi) in the exponent, N10 G in the
+    renormalisation, baryon terms in the linearised fallback (breakdown cells and, in 3+1D, the narrow rows)."""
+    dff = inputs.df_tables_full()
+    cells = synth.synth_surface(60 if dim == 3 else 8, dim, seed=340 + dim, baryon=True)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["bulkPi"][::7] = -5.0 * cells["P"][::7]                     # breakdown cells -> linear delta-f with baryon terms
+    sp = inputs.species([211, 321, 2212, -2212, 3122, -3122, 333]) if dim == 3 else inputs.species([211, 2212, -2212])
+    fq = fq_for(cells)
+    o = dict(dimension=dim, df_mode=3, include_baryon=1, **flags)
+    ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], dff, fq, o)
+    assert (nb > 0) == bool(flags.get("include_bulk_deltaf", 1))
+    for variant in (2, 3):
+        got, st = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, kernel_variant=variant), fq=fq)
+        assert st["code"] == 0 and st["n_cells_breakdown"] == nb
+        assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
+    # protons and antiprotons are different classes here (the baryon number is part of the class key)
+    assert st["n_classes"] == len(sp["mass"])
+    if flags.get("include_baryondiff_deltaf") and dim == 3:
+        out = {k: v.copy() for k, v in cells.items()}
+        out["muB"][3] = 0.95                                           # outside the (T, mu_B) table
+        with pytest.raises(api.Is3dError) as e:
+            api.smooth_spectra(out, sp, fx["grid"], dff, o, fq=fq)
+        assert e.value.code == -3 and "cell 3" in str(e.value)
+
+
 def test_feqmod_argument_errors(fx):
     cells = synth.synth_surface(4, 3, seed=1)
     fq = fq_for(cells)

@@ -164,6 +164,50 @@ def test_feqmod_tables_and_breakdown(fx):
         oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, dict(dimension=3, df_mode=2))
 
 
+def test_feqmod_with_baryon(fx):
+    """df_mode 3 with include_baryon = 1 (smooth_kernels.cpp:564-584, :632-637, :739-762, :838-850): coefficients by the
+    bilinear branch, chem_mod = b (alpha_B + Pi G / beta_Pi) in the modified distribution, N10 G in the renormalisation,
+    baryon diffusion only in the linearised fallback.  Checks: mu_B/T raises soft protons and lowers antiprotons by about
+    exp(+-alpha_B) relative to the diffusion switch off (mu_B is read only with it on, :572-584) while mesons do not move;
+    the renormalisation keeps every species' yield at the linear (Chapman-Enskog) one to second order in the viscous
+    corrections; breakdown cells reproduce the df_mode-2 baryon spectrum exactly (3+1D); df_mode 4 is refused as in the
+    reference (deltafReader.cpp:470-474)."""
+    dff = inputs.df_tables_full()
+    cells = synth.synth_surface(6, 3, seed=43, baryon=True)
+    for k in ("pixx", "pixy", "pixn", "piyy", "piyn", "bulkPi", "Vx", "Vy", "Vn"):
+        cells[k] = 0.2 * cells[k]                                   # small corrections: second-order terms ~ 1e-3
+    sp = inputs.species([211, 2212, -2212])
+    fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    g = dict(fx["grid"], pT=fx["grid"]["pT"][::2], phi=fx["grid"]["phi"][::4])
+    o_on = dict(dimension=3, df_mode=3, include_baryon=1, include_baryondiff_deltaf=1)
+    on, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, dff, fq, o_on)
+    off, _ = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, dff, fq, dict(o_on, include_baryondiff_deltaf=0))
+    assert nb == 0 and np.isfinite(on).all() and (on >= 0).all()
+    shape = (21, len(g["phi"]), len(g["pT"]), 3)
+    r_on, r_off = on.reshape(shape), off.reshape(shape)
+    aB = (cells["muB"] / cells["T"])
+    lo, hi = np.exp(aB.min()), np.exp(aB.max())
+    y_on, y_off = r_on.sum(axis=(0, 1, 2)), r_off.sum(axis=(0, 1, 2))
+    assert 0.9 * lo < y_on[1] / y_off[1] < 1.1 * hi and 0.9 / hi < y_on[2] / y_off[2] < 1.1 / lo
+    assert abs(y_on[0] / y_off[0] - 1) < 0.02                        # pions: only through the coefficients' mu_B dependence
+    # yields against the linear delta-f at the same (T, mu_B): pT-integrated with the table's weights, summed over phi and y
+    gw = fx["grid_w"]
+    w = (gw["pT_w"][::2] * 2.0)[None, None, :, None]                 # every second node: crude, but the same rule on both sides
+    ce = oracle.dN_pTdpTdphidy(cells, sp, g, dff, dict(o_on, df_mode=2)).reshape(shape)
+    n_mod, n_lin = (r_on * w).sum(axis=(0, 1, 2)), (ce * w).sum(axis=(0, 1, 2))
+    assert np.abs(n_mod / n_lin - 1).max() < 0.02, n_mod / n_lin
+    bad = {k: v.copy() for k, v in cells.items()}
+    bad["bulkPi"][:] = -5.0 * bad["P"]
+    fb, nb = oracle.dN_pTdpTdphidy_feqmod(bad, sp, g, dff, fq, o_on)
+    assert nb == 6
+    assert relerr(fb, oracle.dN_pTdpTdphidy(bad, sp, g, dff, dict(o_on, df_mode=2))) < 1e-13
+    with pytest.raises(RuntimeError):
+        oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, dff, fq, dict(o_on, df_mode=4))
+    cells["muB"][1] = 0.9                                            # outside the (T, mu_B) table
+    with pytest.raises(RuntimeError):
+        oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, dff, fq, o_on)
+
+
 def test_golden_64cell_regression(fx, pins):
     """The committed oracle vectors are reproduced bit for bit with one thread and to rounding with many."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "golden_64cell.npz"))
