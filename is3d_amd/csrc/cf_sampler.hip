@@ -2,7 +2,8 @@
 //
 // Device path of EmissionFunctionArray::sample_dN_pTdpTdphidy
 // (/root/reference/src/cpp/emissionfunction_sampling_kernels.cpp:833-1225) for viscous hydro, df_mode 1-4 (linear delta-f with
-// its viscous weight; modified equilibrium with momentum rescaling), include_baryon = 0, regular and "fast" mode; helpers
+// its viscous weight; modified equilibrium with momentum rescaling), regular and "fast" mode, include_baryon = 1 in regular
+// mode for df_mode 1-3 (chemical potential, bulk1 / diffusion terms, diffusion in the momentum rescaling); helpers
 // max_particle_number / fast_max_particle_number (:239-359), sample_momentum (:456-617), compute_df_weight (:361-453),
 // rescale_momentum (:619-650), does_feqmod_breakdown (emissionfunction.cpp:109-150), Milne_Basis / Surface_Element_Vector /
 // boost_pimunu_to_lrf (viscous_correction.cpp:8-115), boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51).
@@ -51,6 +52,8 @@ struct SamplerCell {
     double pixx, pixy, pixz, piyy, piyz, pizz;     // LRF
     double bulkPi, dn_tot, dn_sum, neq_fact;
     double c0, c2, F, betabulk, betapi, shear14;
+    // include_baryon: alpha_B (:962), alpha_B,mod (:1022), n_B/(E+P), T/betaV (:1026), V^i in the LRF (boost_Vmu_to_lrf), c1 c3 c4 | G betaV
+    double alphaB, alphaB_mod, ber, diff_mod, Vx, Vy, Vz, c1, c3, c4, G, betaV;
 };
 
 struct SamplerSpecies {       // device arrays, length npart / ncls
@@ -58,6 +61,7 @@ struct SamplerSpecies {       // device arrays, length npart / ncls
     const int32_t *cls;
     const double *cls_mass, *cls_sign;
     int32_t npart, ncls;
+    const double *baryon, *cls_baryon;   // include_baryon, else NULL (the baryon number is part of the class key then)
 };
 
 struct SamplerParams {
@@ -65,6 +69,8 @@ struct SamplerParams {
     const double *x, *y;
     int64_t n_cells, first_cell;
     int32_t dim3, df_mode, include_bulk, include_shear;
+    int32_t baryon, baryondiff;  // include_baryon; && include_baryondiff_deltaf: mu_B, n_B, V^mu are read (:953-964)
+    BilinearDev bil;             // baryon: c0..c4 (df_mode 1) | F G betabulk betaV betapi (df_mode 2, 3) on the (mu_B, T) grid
     SplineDev spl;              // 14-moment: c0, c2; Chapman-Enskog: F, betabulk, betapi
     int32_t ngl;
     const double *gl;           // [4][ngl]: root1, weight1, root2, weight2 (alpha = 2 only for df_mode 3)
@@ -123,45 +129,61 @@ struct Rng {
     }
 };
 
-// GaussThermal(neq_int, ...) at alpha_B = 0 (gaussThermal.cpp)
-__device__ __forceinline__ double gt_neq(const double *root, const double *weight, int n, double mbar, double sign)
+// GaussThermal(neq_int | J10_int | J20_int, ...) (gaussThermal.cpp); chem = baryon * alpha_B
+__device__ __forceinline__ double gt_neq(const double *root, const double *weight, int n, double mbar, double sign, double chem = 0.0)
 {
     double s = 0.0;
     for (int k = 0; k < n; k++) {
         const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
-        s += weight[k] * (pbar * exp(pbar) / (exp(Ebar) + sign));
+        s += weight[k] * (pbar * exp(pbar) / (exp(Ebar - chem) + sign));
     }
     return s;
 }
 
-__device__ __forceinline__ double gt_J20(const double *root, const double *weight, int n, double mbar, double sign)
+__device__ __forceinline__ double gt_J10(const double *root, const double *weight, int n, double mbar, double sign, double chem)
 {
     double s = 0.0;
     for (int k = 0; k < n; k++) {
         const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
-        const double qstat = exp(Ebar) + sign;
-        s += weight[k] * (Ebar * exp(pbar + Ebar) / (qstat * qstat));
+        const double qstat = exp(Ebar - chem) + sign;
+        s += weight[k] * (pbar * exp(pbar + Ebar - chem) / (qstat * qstat));
     }
     return s;
 }
 
-// GT[cell][class] = the n_eq integral; GT2 (df_mode 3, regular mode) = the J20 integral of n_linear
+__device__ __forceinline__ double gt_J20(const double *root, const double *weight, int n, double mbar, double sign, double chem = 0.0)
+{
+    double s = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double pbar = root[k], Ebar = sqrt(pbar * pbar + mbar * mbar);
+        const double qstat = exp(Ebar - chem) + sign;
+        s += weight[k] * (Ebar * exp(pbar + Ebar - chem) / (qstat * qstat));
+    }
+    return s;
+}
+
+// GT[cell][class] = the n_eq integral; GT2 (df_mode 3, regular mode) = the J20 integral of n_linear, GT3 (with include_baryon) its
+// J10 integral; muB_fo != NULL (include_baryon && include_baryondiff_deltaf): chem = baryon mu_B / T
 __global__ void __launch_bounds__(256)
-cf_sampler_density(const double *__restrict__ T_fo, int64_t n_cells, SamplerSpecies sp, const double *__restrict__ gl, int ngl,
-                   double *__restrict__ GT, double *__restrict__ GT2)
+cf_sampler_density(const double *__restrict__ T_fo, const double *__restrict__ muB_fo, int64_t n_cells, SamplerSpecies sp,
+                   const double *__restrict__ gl, int ngl, double *__restrict__ GT, double *__restrict__ GT2, double *__restrict__ GT3)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_cells * sp.ncls) return;
     const int64_t cell = idx / sp.ncls;
     const int c = (int)(idx - cell * sp.ncls);
-    const double mbar = sp.cls_mass[c] / T_fo[cell];
-    GT[idx] = gt_neq(gl, gl + ngl, ngl, mbar, sp.cls_sign[c]);
-    if (GT2) GT2[idx] = gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sp.cls_sign[c]);
+    const double T = T_fo[cell];
+    const double mbar = sp.cls_mass[c] / T;
+    const double alphaB = muB_fo ? muB_fo[cell] / T : 0.0;
+    const double chem = sp.cls_baryon ? sp.cls_baryon[c] * alphaB : 0.0;
+    GT[idx] = gt_neq(gl, gl + ngl, ngl, mbar, sp.cls_sign[c], chem);
+    if (GT2) GT2[idx] = gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sp.cls_sign[c], chem);
+    if (GT3) GT3[idx] = gt_J10(gl, gl + ngl, ngl, mbar, sp.cls_sign[c], chem);
 }
 
 // mean-number weight of species ip in a cell: fast_max_particle_number (:239-280) / max_particle_number (:282-359)
 __device__ __forceinline__ double species_dn(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell &c, const double *gt,
-                                             const double *gt2, int ip)
+                                             const double *gt2, const double *gt3, int ip)
 {
     const bool linear = p.df_mode <= 2 || c.breakdown != 0.0;
     if (p.fast) {
@@ -173,7 +195,9 @@ __device__ __forceinline__ double species_dn(const SamplerParams &p, const Sampl
     if (linear) return 2.0 * equilibrium_density;
     if (p.df_mode == 3) {
         const double J20 = (c.T * c.neq_fact) * sp.degeneracy[ip] * gt2[sp.cls[ip]];
-        const double bulk_density = (equilibrium_density + (J20 * c.F / c.T / c.T)) / c.betabulk;
+        double bJ10G = 0.0;                                                             // baryon * J10 * G, :319-325
+        if (gt3) bJ10G = sp.baryon[ip] * (c.neq_fact * sp.degeneracy[ip] * gt3[sp.cls[ip]]) * c.G;
+        const double bulk_density = (equilibrium_density + bJ10G + (J20 * c.F / c.T / c.T)) / c.betabulk;
         return equilibrium_density + c.bulkPi * bulk_density;
     }
     return c.z * equilibrium_density;
@@ -181,7 +205,7 @@ __device__ __forceinline__ double species_dn(const SamplerParams &p, const Sampl
 
 __global__ void __launch_bounds__(128)
 cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ GT, const double *__restrict__ GT2,
-                 SamplerCell *__restrict__ out)
+                 const double *__restrict__ GT3, SamplerCell *__restrict__ out)
 {
     const int64_t ic = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= p.n_cells) return;
@@ -198,8 +222,17 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
         return;
     }
     const double T = p.cells.T[ic], P = p.cells.P[ic], E = p.cells.E[ic];
-    if (!(T >= p.spl.x[0] && T <= p.spl.x[p.spl.n - 1])) {                          // GSL domain error in the reference
+    double muB = 0.0, nB = 0.0, Vt = 0.0, Vx = 0.0, Vy = 0.0, Vn = 0.0;               // :942-964
+    if (p.baryon && p.baryondiff) {
+        muB = p.cells.muB[ic]; nB = p.cells.nB[ic]; Vx = p.cells.Vx[ic]; Vy = p.cells.Vy[ic]; Vn = p.cells.Vn[ic];
+        Vt = (Vx * ux + Vy * uy + tau2 * Vn * un) / ut;
+        c.alphaB = muB / T;
+        c.ber = nB / (E + P);
+    }
+    double bl[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (p.baryon ? !bilinear5(p.bil, T, muB, bl) : !(T >= p.spl.x[0] && T <= p.spl.x[p.spl.n - 1])) {   // exit(-1) / GSL domain error in the reference
         atomicMin(&p.status[0], (unsigned long long)(p.first_cell + ic));
+        memset(&c, 0, sizeof c);
         out[ic] = c;
         return;
     }
@@ -218,7 +251,11 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
     const double T4 = T * T * T * T;
     const int nT = p.spl.n;
     double lambda = 0.0;
-    if (p.df_mode == 1) {                                                           // deltafReader.cpp:337-344
+    if (p.baryon) {                                                                 // deltafReader.cpp:436-468 (bilinear branch)
+        const double T3 = T * T * T;
+        if (p.df_mode == 1) { c.c0 = bl[0] / T4; c.c1 = bl[1] / T3; c.c2 = bl[2] / T4; c.c3 = bl[3] / T4; c.c4 = bl[4] / (T4 * T); }
+        else { c.F = bl[0] * T; c.G = bl[1]; c.betabulk = bl[2] * T4; c.betaV = bl[3] * T3; c.betapi = bl[4] * T4; }
+    } else if (p.df_mode == 1) {                                                    // deltafReader.cpp:337-344
         c.c0 = spline_eval_lds(nT, p.spl.x, p.spl.y[0], p.spl.c[0], T) / T4;
         c.c2 = spline_eval_lds(nT, p.spl.x, p.spl.y[1], p.spl.c[1], T) / T4;
     } else if (p.df_mode <= 3) {                                                    // :352-358
@@ -262,6 +299,10 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
     c.piyy = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
     c.piyz = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
     c.pizz = -(c.pixx + c.piyy);
+    // boost_Vmu_to_lrf (viscous_correction.cpp:161-173)
+    c.Vx = -Vt * Xt + Vx * Xx + Vy * Xy + tau2 * Vn * Xn;
+    c.Vy = Vx * Yx + Vy * Yy;
+    c.Vz = -Vt * Zt + tau2 * Vn * Zn;
     c.tau = tau; c.x = p.x ? p.x[ic] : 0.0; c.y = p.y ? p.y[ic] : 0.0;
     c.eta = p.dim3 ? p.cells.eta[ic] : 0.0;
     c.ut = ut; c.ux = ux; c.uy = uy; c.un = un; c.T = T;
@@ -270,7 +311,12 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
     c.neq_fact = T * T * T / two_pi2_hbarC3;
     // modified temperature and rescaling coefficients (:1017-1036), detA and the breakdown test (:1038)
     c.T_mod = T;
-    if (p.df_mode == 3) { c.T_mod = T + bulkPi * c.F / c.betabulk; c.shear_mod = 0.5 / c.betapi; c.bulk_mod = bulkPi / (3.0 * c.betabulk); }
+    c.alphaB_mod = c.alphaB;
+    if (p.df_mode == 3) {
+        c.T_mod = T + bulkPi * c.F / c.betabulk; c.shear_mod = 0.5 / c.betapi; c.bulk_mod = bulkPi / (3.0 * c.betabulk);
+        c.alphaB_mod = c.alphaB + bulkPi * c.G / c.betabulk;
+        c.diff_mod = p.baryon ? T / c.betaV : 0.0;
+    }
     else if (p.df_mode == 4) { c.shear_mod = 0.5 / c.betapi; c.bulk_mod = lambda; }
     if (p.df_mode == 3) {
         const double Axx = 1.0 + c.pixx * c.shear_mod + c.bulk_mod, Axy = c.pixy * c.shear_mod, Axz = c.pixz * c.shear_mod;
@@ -284,9 +330,9 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
         const double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * Fb / Tb / Tb) / bbb;
         if (detA <= p.detA_min || (neq_pion0 + dn_pion0) < 0.0) { c.breakdown = 1.0; atomicAdd(&p.status[5], 1ULL); }
     }
-    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr;
+    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
     double dn = 0.0;
-    for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, ip);
+    for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
     c.dn_sum = dn;
     c.dn_tot = dn * (2.0 * p.y_max * c.ds_max);
     c.live = (c.dn_tot > 0.0) ? 1.0 : 0.0;                                          // :1079
@@ -304,8 +350,8 @@ __device__ __forceinline__ double pion_thermal_weight_max(double x)
 
 struct LrfMom { double E, px, py, pz; };
 
-// sample_momentum (:456-617), chem = 0
-__device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, double mass, double sign, double T)
+// sample_momentum (:456-617); chem = baryon * alpha_B enters the heavy-hadron weight only (:588)
+__device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, double mass, double sign, double T, double chem)
 {
     const double two_pi = 2.0 * M_PI;
     const double mbar = mass / T, mbar_squared = mbar * mbar;
@@ -349,7 +395,7 @@ __device__ LrfMom sample_momentum(Rng &g, long &acceptances, long &samples, doub
             }
             Ebar = kbar + mbar;
             pbar = sqrt(Ebar * Ebar - mbar_squared);
-            const double exponent = exp(Ebar);
+            const double exponent = exp(Ebar - chem);
             const double weight = pbar / Ebar * exponent / (exponent + sign);
             if (g.uniform() < weight) break;
         }
@@ -382,8 +428,8 @@ cf_sampler_poisson(SamplerParams p, const SamplerCell *__restrict__ cellrec, int
 // one emitting (event, cell) pair; tallies = {momentum samples, acceptances, hadrons drawn} of this thread (count pass)
 template <bool FILL>
 __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell *__restrict__ cellrec,
-                                               const double *__restrict__ GT, const double *__restrict__ GT2, int event0,
-                                               const int32_t *__restrict__ active, int64_t n_active, const int32_t *__restrict__ n_drawn,
+                                               const double *__restrict__ GT, const double *__restrict__ GT2,
+                                               const double *__restrict__ GT3, int event0, const int32_t *__restrict__ active, int64_t n_active, const int32_t *__restrict__ n_drawn,
                                                int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
                                                is3d_particle *__restrict__ particles, int64_t capacity, unsigned long long (&tally)[3])
 {
@@ -401,7 +447,7 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
     g_momentum.init(p.seed, 2, gcell, (uint32_t)ievent);
     g_keep.init(p.seed, 3, gcell, (uint32_t)ievent);
     g_rapidity.init(p.seed, 4, gcell, (uint32_t)ievent);
-    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr;
+    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
     const bool linear = p.df_mode <= 2 || c.breakdown != 0.0;
     const double sinheta = sinh(c.eta), cosheta = sqrt(1.0 + sinheta * sinheta);   // :888-889
     long kept = 0, samples = 0, acceptances = 0;
@@ -411,35 +457,43 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
         int chosen = sp.npart - 1;
         double cum = 0.0;
         for (int ip = 0; ip < sp.npart; ip++) {
-            cum += species_dn(p, sp, c, gt, gt2, ip);
+            cum += species_dn(p, sp, c, gt, gt2, gt3, ip);
             if (ut_ < cum) { chosen = ip; break; }
         }
         const double mass = sp.mass[chosen], mass_squared = mass * mass, sign = sp.sign[chosen];
+        const double baryon = sp.baryon ? sp.baryon[chosen] : 0.0;
         LrfMom q;
         double w_visc = 1.0;
         if (linear) {                                                               // :1100-1110, switch_to_linear_df
-            q = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T);
-            // compute_df_weight (:361-453), baryon terms vanish; df_mode 3 takes the Chapman-Enskog branch
+            const double chem = baryon * c.alphaB;
+            q = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T, chem);
+            // compute_df_weight (:361-453); df_mode 3 takes the Chapman-Enskog branch
             const double pimunu_pmu_pnu = q.px * q.px * c.pixx + q.py * q.py * c.piyy + q.pz * q.pz * c.pizz
                                         + 2.0 * (q.px * q.py * c.pixy + q.px * q.pz * c.pixz + q.py * q.pz * c.piyz);
-            const double feqbar = 1.0 - sign / (exp(q.E / c.T) + sign);
+            const double Vmu_pmu = -(q.px * c.Vx + q.py * c.Vy + q.pz * c.Vz);        // :384
+            const double feqbar = 1.0 - sign / (exp(q.E / c.T - chem) + sign);
             double df_tot;
             if (p.df_mode == 1) {
                 const double df_shear = pimunu_pmu_pnu / c.shear14;
-                const double df_bulk = ((c.c0 - c.c2) * mass_squared + ((4.0 * c.c2 - c.c0) * q.E) * q.E) * c.bulkPi;
-                df_tot = feqbar * (df_shear + df_bulk);
+                const double df_bulk = ((c.c0 - c.c2) * mass_squared + (baryon * c.c1 + (4.0 * c.c2 - c.c0) * q.E) * q.E) * c.bulkPi;
+                const double df_diff = (baryon * c.c3 + c.c4 * q.E) * Vmu_pmu;
+                df_tot = feqbar * (df_shear + df_bulk + df_diff);
             } else {
+                const double betaV = p.baryon ? c.betaV : 1.0;
                 const double df_shear = pimunu_pmu_pnu / (2.0 * q.E * c.betapi * c.T);
-                const double df_bulk = (c.F * q.E / c.T / c.T + (q.E - mass_squared / q.E) / (3.0 * c.T)) * c.bulkPi / c.betabulk;
-                df_tot = feqbar * (df_shear + df_bulk);
+                const double df_bulk = (baryon * c.G + c.F * q.E / c.T / c.T + (q.E - mass_squared / q.E) / (3.0 * c.T)) * c.bulkPi / c.betabulk;
+                const double df_diff = (c.ber - baryon / q.E) * Vmu_pmu / betaV;
+                df_tot = feqbar * (df_shear + df_bulk + df_diff);
             }
             df_tot = fmax(-1.0, fmin(df_tot, 1.0));
             w_visc = (1.0 + df_tot) / 2.0;
         } else {                                                                    // :1112-1131 + rescale_momentum (:619-650)
-            const LrfMom m = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T_mod);
-            q.px = (1.0 + c.bulk_mod) * m.px + c.shear_mod * (c.pixx * m.px + c.pixy * m.py + c.pixz * m.pz);
-            q.py = (1.0 + c.bulk_mod) * m.py + c.shear_mod * (c.pixy * m.px + c.piyy * m.py + c.piyz * m.pz);
-            q.pz = (1.0 + c.bulk_mod) * m.pz + c.shear_mod * (c.pixz * m.px + c.piyz * m.py + c.pizz * m.pz);
+            const bool mike = p.df_mode == 3;
+            const LrfMom m = sample_momentum(g_momentum, acceptances, samples, mass, sign, c.T_mod, mike ? baryon * c.alphaB_mod : 0.0);
+            const double diff_mod = c.diff_mod * (m.E * c.ber + (mike ? baryon : 0.0));   // :638
+            q.px = (1.0 + c.bulk_mod) * m.px + c.shear_mod * (c.pixx * m.px + c.pixy * m.py + c.pixz * m.pz) + diff_mod * c.Vx;
+            q.py = (1.0 + c.bulk_mod) * m.py + c.shear_mod * (c.pixy * m.px + c.piyy * m.py + c.piyz * m.pz) + diff_mod * c.Vy;
+            q.pz = (1.0 + c.bulk_mod) * m.pz + c.shear_mod * (c.pixz * m.px + c.piyz * m.py + c.pizz * m.pz) + diff_mod * c.Vz;
             q.E = sqrt(mass_squared + q.px * q.px + q.py * q.py + q.pz * q.pz);
         }
         // boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51)
@@ -482,12 +536,12 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
 template <bool FILL>
 __global__ void __launch_bounds__(128)
 cf_sampler_run(SamplerParams p, SamplerSpecies sp, const SamplerCell *__restrict__ cellrec, const double *__restrict__ GT,
-               const double *__restrict__ GT2, int event0, const int32_t *__restrict__ active, int64_t n_active,
+               const double *__restrict__ GT2, const double *__restrict__ GT3, int event0, const int32_t *__restrict__ active, int64_t n_active,
                const int32_t *__restrict__ n_drawn, int64_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t base,
                is3d_particle *__restrict__ particles, int64_t capacity)
 {
     unsigned long long tally[3] = {0ULL, 0ULL, 0ULL};
-    sampler_thread<FILL>(p, sp, cellrec, GT, GT2, event0, active, n_active, n_drawn, counts, offsets, base, particles, capacity, tally);
+    sampler_thread<FILL>(p, sp, cellrec, GT, GT2, GT3, event0, active, n_active, n_drawn, counts, offsets, base, particles, capacity, tally);
     if (!FILL) {
         // the run-wide tallies: one global atomic per counter and workgroup instead of three per sampling thread
         __shared__ unsigned long long blk[3];
@@ -556,7 +610,19 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     if (opts->df_mode == 4 && (fq->n_pdg < 1 || !fq->pdg_mass || !fq->pdg_degeneracy || !fq->pdg_sign || !(fq->T_avg > 0.0)))
         return set_error(IS3D_EINVAL, "df_mode 4 needs the full PDG list and the surface-averaged temperature");
     if (in->fast && !(in->T_avg > 0.0)) return set_error(IS3D_EINVAL, "fast = 1 needs the surface-averaged temperature");
-    if (opts->include_baryon) return set_error(IS3D_EINVAL, "the sampler with include_baryon = 1 is not on this path");
+    const bool baryon = opts->include_baryon != 0, baryondiff = baryon && opts->include_baryondiff_deltaf != 0;
+    if (baryon) {
+        if (opts->df_mode == 4)   // deltafReader.cpp:470-474: "Jonah df doesn't work for nonzero muB. Exiting.."
+            return set_error(IS3D_EINVAL, "df_mode 4 does not work with include_baryon = 1 (the reference exits there too)");
+        if (in->fast) return set_error(IS3D_EINVAL, "the sampler's fast mode with include_baryon = 1 is not on this path");
+        if (!species->baryon) return set_error(IS3D_EINVAL, "include_baryon = 1 needs the species' baryon numbers");
+        if (df->n_muB < 2 || !df->muB) return set_error(IS3D_EINVAL, "include_baryon = 1 needs the full (T, muB) coefficient tables");
+        for (int i = 1; i < df->n_muB; i++)
+            if (!(df->muB[i] > df->muB[i - 1])) return set_error(IS3D_EINVAL, "coefficient table muB values must ascend");
+        if (opts->df_mode == 1 && (!df->c0 || !df->c1 || !df->c2 || !df->c3 || !df->c4)) return set_error(IS3D_EINVAL, "include_baryon = 1, df_mode 1 needs c0..c4 tables");
+        if (opts->df_mode != 1 && (!df->F || !df->G || !df->betabulk || !df->betaV || !df->betapi))
+            return set_error(IS3D_EINVAL, "include_baryon = 1, df_mode 2 / 3 need F, G, betabulk, betaV, betapi tables");
+    }
     if (species->n < 1 || !species->mass || !species->sign || !species->degeneracy) return set_error(IS3D_EINVAL, "empty species list");
     for (int s = 0; s < species->n; s++)
         if (!(species->mass[s] > 0.0)) return set_error(IS3D_EINVAL, "species %d has mass 0: photons cannot be sampled with this method (reference: exit, sampling_kernels.cpp:478-482)", s);
@@ -578,25 +644,29 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         if (opts->include_shear_deltaf && (!cells->pixx || !cells->pixy || !cells->pixn || !cells->piyy || !cells->piyn))
             return set_error(IS3D_EINVAL, "include_shear_deltaf needs pixx, pixy, pixn, piyy, piyn");
         if (opts->include_bulk_deltaf && !cells->bulkPi) return set_error(IS3D_EINVAL, "include_bulk_deltaf needs bulkPi");
+        if (baryondiff && (!cells->muB || !cells->nB || !cells->Vx || !cells->Vy || !cells->Vn))
+            return set_error(IS3D_EINVAL, "include_baryon && include_baryondiff_deltaf need muB, nB, Vx, Vy, Vn");
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
     if (opts->device >= 0) SMP_TRY(hipSetDevice(opts->device));
     if (n == 0) return IS3D_OK;
 
-    // ---- species classes (mass, sign): the density integral is per class ----
+    // ---- species classes (mass, sign[, baryon number]): the density integral is per class ----
     const int npart = species->n;
     std::vector<int32_t> cls(npart);
-    std::vector<double> cmass, csign;
+    std::vector<double> cmass, csign, cbar;
     for (int s = 0; s < npart; s++) {
         int found = -1;
+        const double bs = baryon ? species->baryon[s] : 0.0;
         for (size_t c = 0; c < cmass.size(); c++)
-            if (cmass[c] == species->mass[s] && csign[c] == species->sign[s]) { found = (int)c; break; }
-        if (found < 0) { found = (int)cmass.size(); cmass.push_back(species->mass[s]); csign.push_back(species->sign[s]); }
+            if (cmass[c] == species->mass[s] && csign[c] == species->sign[s] && cbar[c] == bs) { found = (int)c; break; }
+        if (found < 0) { found = (int)cmass.size(); cmass.push_back(species->mass[s]); csign.push_back(species->sign[s]); cbar.push_back(bs); }
         cls[s] = found;
     }
     const int ncls = (int)cmass.size();
-    DevMem d_mass, d_sign, d_deg, d_cls, d_cmass, d_csign, d_gl, d_splx, d_sply[3], d_splc[3], d_cell[20], d_x, d_y;
+    DevMem d_mass, d_sign, d_deg, d_cls, d_cmass, d_csign, d_gl, d_splx, d_sply[3], d_splc[3], d_cell[23], d_x, d_y;
+    DevMem d_bar, d_cbar, d_bilT, d_bilB, d_biltab[5];
     SMP_TRY(d_mass.upload(std::vector<double>(species->mass, species->mass + npart)));
     SMP_TRY(d_sign.upload(std::vector<double>(species->sign, species->sign + npart)));
     SMP_TRY(d_deg.upload(std::vector<double>(species->degeneracy, species->degeneracy + npart)));
@@ -609,8 +679,12 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         if (fq) { gl[2 * in->n_gla + k] = fq->root2[k]; gl[3 * in->n_gla + k] = fq->weight2[k]; }
     }
     SMP_TRY(d_gl.upload(gl));
+    if (baryon) {
+        SMP_TRY(d_bar.upload(std::vector<double>(species->baryon, species->baryon + npart)));
+        SMP_TRY(d_cbar.upload(cbar));
+    }
     is3d::SamplerSpecies sp{d_mass.as<double>(), d_sign.as<double>(), d_deg.as<double>(), d_cls.as<int32_t>(),
-                            d_cmass.as<double>(), d_csign.as<double>(), npart, ncls};
+                            d_cmass.as<double>(), d_csign.as<double>(), npart, ncls, d_bar.as<double>(), d_cbar.as<double>()};
     // ---- splines (deltafReader.cpp:300-322) ----
     is3d::SamplerParams p{};
     std::vector<double> xs(df->T, df->T + df->n_T);
@@ -631,17 +705,32 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         p.spl.y[s] = d_sply[s].as<double>();
         p.spl.c[s] = d_splc[s].as<double>();
     }
+    if (baryon) {   // full (mu_B, T) grids for the bilinear branch (deltafReader.cpp:412-484)
+        const double *t5[5];
+        if (opts->df_mode == 1) { t5[0] = df->c0; t5[1] = df->c1; t5[2] = df->c2; t5[3] = df->c3; t5[4] = df->c4; }
+        else { t5[0] = df->F; t5[1] = df->G; t5[2] = df->betabulk; t5[3] = df->betaV; t5[4] = df->betapi; }
+        SMP_TRY(d_bilT.upload(xs));
+        SMP_TRY(d_bilB.upload(std::vector<double>(df->muB, df->muB + df->n_muB)));
+        p.bil.nT = df->n_T; p.bil.nB = df->n_muB;
+        p.bil.T = d_bilT.as<double>(); p.bil.muB = d_bilB.as<double>();
+        for (int k = 0; k < 5; k++) {
+            SMP_TRY(d_biltab[k].upload(std::vector<double>(t5[k], t5[k] + (size_t)df->n_T * df->n_muB)));
+            p.bil.tab[k] = d_biltab[k].as<double>();
+        }
+    }
+    p.baryon = baryon; p.baryondiff = baryondiff;
     // ---- cell arrays ----
-    const double *src[18] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
-                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi};
-    const double *dptr[18];
+    const double *src[23] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
+                             cells->muB, cells->nB, cells->Vx, cells->Vy, cells->Vn};
+    const double *dptr[23];
     hipEvent_t ev[6];
     for (auto &e : ev) SMP_TRY(hipEventCreate(&e));
     struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 6; i++) (void)hipEventDestroy(e[i]); } } evg{ev};
     SMP_TRY(hipEventRecord(ev[0], nullptr));
-    for (int a = 0; a < 18; a++) {
+    for (int a = 0; a < 23; a++) {
         dptr[a] = nullptr;
-        const bool need = a < 12 ? (a != 1 || three_d) : (a < 17 ? opts->include_shear_deltaf != 0 : opts->include_bulk_deltaf != 0);
+        const bool need = a < 12 ? (a != 1 || three_d) : (a < 17 ? opts->include_shear_deltaf != 0 : (a == 17 ? opts->include_bulk_deltaf != 0 : baryondiff));
         if (src[a] && need) {
             SMP_TRY(d_cell[a].alloc((size_t)n * sizeof(double)));
             SMP_TRY(hipMemcpyAsync(d_cell[a].p, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
@@ -651,7 +740,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     if (in->x) { SMP_TRY(d_x.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_x.p, in->x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
     if (in->y) { SMP_TRY(d_y.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_y.p, in->y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
     p.cells = {dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], dptr[9], dptr[10], dptr[11],
-               dptr[12], dptr[13], dptr[14], dptr[15], dptr[16], dptr[17]};
+               dptr[12], dptr[13], dptr[14], dptr[15], dptr[16], dptr[17], dptr[18], dptr[19], dptr[20], dptr[21], dptr[22]};
     p.x = d_x.as<double>(); p.y = d_y.as<double>();
     p.n_cells = n; p.first_cell = in->first_cell;
     p.dim3 = three_d; p.df_mode = opts->df_mode;
@@ -715,21 +804,22 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     }
     p.y_max = three_d ? 0.5 : in->y_cut;                                              // :837-838
     p.seed = in->seed;
-    DevMem d_status, d_GT, d_GT2, d_rec, d_counts, d_offsets, d_scan_tmp, d_particles;
+    DevMem d_status, d_GT, d_GT2, d_GT3, d_rec, d_counts, d_offsets, d_scan_tmp, d_particles;
     SMP_TRY(d_status.alloc(8 * sizeof(unsigned long long)));
     unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0, 0};
     SMP_TRY(hipMemcpyAsync(d_status.p, init, sizeof init, hipMemcpyHostToDevice, nullptr));
     p.status = d_status.as<unsigned long long>();
     SMP_TRY(d_GT.alloc((size_t)n * ncls * sizeof(double)));
     if (opts->df_mode == 3 && !p.fast) SMP_TRY(d_GT2.alloc((size_t)n * ncls * sizeof(double)));
+    if (opts->df_mode == 3 && baryon) SMP_TRY(d_GT3.alloc((size_t)n * ncls * sizeof(double)));
     SMP_TRY(d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
     SMP_TRY(hipEventRecord(ev[1], nullptr));
     {
         const int64_t tot = n * ncls;
-        hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], n, sp,
-                           d_gl.as<double>(), in->n_gla, d_GT.as<double>(), d_GT2.as<double>());
+        hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], dptr[18], n, sp,
+                           d_gl.as<double>(), in->n_gla, d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>());
         hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, p, sp, d_GT.as<double>(),
-                           d_GT2.as<double>(), d_rec.as<is3d::SamplerCell>());
+                           d_GT2.as<double>(), d_GT3.as<double>(), d_rec.as<is3d::SamplerCell>());
         SMP_TRY(hipGetLastError());
     }
     SMP_TRY(hipEventRecord(ev[2], nullptr));
@@ -771,8 +861,8 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
             const unsigned grid = (unsigned)(((int64_t)n_active + 127) / 128);
             SMP_TRY(hipMemsetAsync(d_counts.as<int64_t>() + n_active, 0, sizeof(int64_t), nullptr));
             hipLaunchKernelGGL((is3d::cf_sampler_run<false>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
-                               d_GT.as<double>(), d_GT2.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active, d_drawn.as<int32_t>(),
-                               d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0, (is3d_particle *)nullptr, (int64_t)0);
+                               d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active,
+                               d_drawn.as<int32_t>(), d_counts.as<int64_t>(), (const int64_t *)nullptr, (int64_t)0, (is3d_particle *)nullptr, (int64_t)0);
             SMP_TRY(hipGetLastError());
             // element n_active of the scan (counts[n_active] = 0) is the batch total
             SMP_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), n_active + 1, nullptr));
@@ -780,8 +870,8 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
             SMP_TRY(hipMemcpy(&batch_total, d_offsets.as<int64_t>() + n_active, sizeof(int64_t), hipMemcpyDeviceToHost));
             if (capacity > 0 && base < capacity && batch_total > 0) {
                 hipLaunchKernelGGL((is3d::cf_sampler_run<true>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
-                                   d_GT.as<double>(), d_GT2.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active, d_drawn.as<int32_t>(),
-                                   (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(), capacity);
+                                   d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active,
+                                   d_drawn.as<int32_t>(), (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(), capacity);
                 SMP_TRY(hipGetLastError());
             }
         } else {
@@ -814,7 +904,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     }
     if (h[0] != ~0ULL)
         return set_error(IS3D_EDOMAIN, "cell %lld: T%s outside the coefficient table (the reference aborts in gsl_spline_eval here)", (long long)h[0],
-                         opts->df_mode == 4 ? " (or bulkPi/P)" : "");
+                         opts->df_mode == 4 ? " (or bulkPi/P)" : (baryon ? " or (T, muB)" : ""));
     const int64_t ncopy = std::min<int64_t>(base, capacity);
     if (ncopy > 0) SMP_TRY(hipMemcpy(particles, d_particles.p, (size_t)ncopy * sizeof(is3d_particle), hipMemcpyDeviceToHost));
     if (particles && base > capacity)

@@ -10,7 +10,7 @@
 // and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
 // (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
-// operation = 2 (particle sampler, df_mode 1 | 2, include_baryon = 0, fast = 0, test_sampler = 0) writes
+// operation = 2 (particle sampler; df_mode 1-4, fast in {0, 1}, include_baryon = 1 with df_mode 1-3 and fast = 0) writes
 // results/particle_list_osc.dat (write_particle_list_OSC, emissionfunction.cpp:863-901) and results/dN_dy_*.dat is skipped.
 // Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2, 3} with include_baryon in {0, 1}, df_mode 4
 // (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
@@ -115,7 +115,6 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     GET(outflow, "outflow");
 #undef GET
     if (operation != 1 && operation != 2) DIE("operation = %d: only operation = 1 (smooth momentum spectra) and 2 (particle sampler) are on this path", operation);
-    if (operation == 2 && include_baryon) DIE("operation = 2 with include_baryon = 1 is not on this path");
     {
         double decays = 0.0;   // optional key here; the reference runs do_resonance_decays() after the spectra (emissionfunction.cpp:1689-1698)
         if (get_param("do_resonance_decays", &decays, false) == IS3D_OK && (int)decays)
@@ -296,6 +295,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
             si.feqmod = &fqs;
         }
         si.fast = (int)fast != 0;
+        if (si.fast && include_baryon) DIE("operation = 2 with fast = 1 and include_baryon = 1 is not on this path (set fast = 0)");
         si.T_avg = T_avg_file;
         si.T_avg_switch = (int)set_T ? T_switch : T_avg_file;                     // :856
         if (si.fast) printf("Using fast mode: (Tavg, muBavg) = (%lf, %lf)\n", si.T_avg_switch, avg[3]);

@@ -1065,8 +1065,9 @@ static double pion_thermal_weight_max(double x)
 
 typedef struct { double E, px, py, pz; } lrf_mom;
 
-/* :456-617 with chem = 0 */
-static lrf_mom sample_momentum(rng_stream *g, long *acceptances, long *samples, double mass, double sign, double T)
+/* :456-617; chem = baryon * alpha_B enters the heavy-hadron weight only (:588; the light branch, :510, ignores it, and bosons
+ * with a chemical potential make the reference exit, :466-470: they cannot occur, their baryon number is 0) */
+static lrf_mom sample_momentum(rng_stream *g, long *acceptances, long *samples, double mass, double sign, double T, double chem)
 {
     const double two_pi = 2.0 * M_PI;
     double mbar = mass / T, mbar_squared = mbar * mbar;
@@ -1110,7 +1111,7 @@ static lrf_mom sample_momentum(rng_stream *g, long *acceptances, long *samples, 
             }
             Ebar = kbar + mbar;
             pbar = sqrt(Ebar * Ebar - mbar_squared);
-            double exponent = exp(Ebar);
+            double exponent = exp(Ebar - chem);
             double weight = pbar / Ebar * exponent / (exponent + sign);
             if (rng_uniform(g) < weight) break;
         }
@@ -1132,6 +1133,7 @@ typedef struct {
     df_coeff df;
     double shear14_coeff;
     double T_mod, shear_mod, bulk_mod;             /* df_mode 3, 4 */
+    double alphaB, alphaB_mod, baryon_enthalpy_ratio, diff_mod, Vx, Vy, Vz;   /* include_baryon: V^i in the LRF (boost_Vmu_to_lrf) */
     double delta_lambda, delta_z;                  /* df_mode 4 */
 } sampler_cell;
 
@@ -1145,13 +1147,14 @@ typedef struct {
     double T_avg_switch;      /* the same after `if (SET_T_SWITCH) temperature = T_SWITCH` (:856): the fast breakdown test */
 } oracle_sampler_opts;
 
-/* rescale_momentum (:619-650), no diffusion */
-static lrf_mom rescale_momentum(lrf_mom q, double mass_squared, const sampler_cell *c)
+/* rescale_momentum (:619-650) */
+static lrf_mom rescale_momentum(lrf_mom q, double mass_squared, double baryon, const sampler_cell *c)
 {
     lrf_mom r;
-    r.px = (1.0 + c->bulk_mod) * q.px + c->shear_mod * (c->pixx * q.px + c->pixy * q.py + c->pixz * q.pz);
-    r.py = (1.0 + c->bulk_mod) * q.py + c->shear_mod * (c->pixy * q.px + c->piyy * q.py + c->piyz * q.pz);
-    r.pz = (1.0 + c->bulk_mod) * q.pz + c->shear_mod * (c->pixz * q.px + c->piyz * q.py + c->pizz * q.pz);
+    const double diff_mod = c->diff_mod * (q.E * c->baryon_enthalpy_ratio + baryon);   /* :638 */
+    r.px = (1.0 + c->bulk_mod) * q.px + c->shear_mod * (c->pixx * q.px + c->pixy * q.py + c->pixz * q.pz) + diff_mod * c->Vx;
+    r.py = (1.0 + c->bulk_mod) * q.py + c->shear_mod * (c->pixy * q.px + c->piyy * q.py + c->piyz * q.pz) + diff_mod * c->Vy;
+    r.pz = (1.0 + c->bulk_mod) * q.pz + c->shear_mod * (c->pixz * q.px + c->piyz * q.py + c->pizz * q.pz) + diff_mod * c->Vz;
     r.E = sqrt(mass_squared + r.px * r.px + r.py * r.py + r.pz * r.pz);
     return r;
 }
@@ -1162,16 +1165,17 @@ static lrf_mom rescale_momentum(lrf_mom q, double mass_squared, const sampler_ce
  * its cells).  q: Gauss-Laguerre alpha = 2, PDG list, deta_min, mass_pion0 -- df_mode 3, 4 only (may be NULL otherwise).
  * stats = {momentum samples, acceptances, hadrons drawn (before the keep test), cells where feqmod breaks down}.  Returns
  * the number of kept particles (all of them are counted; only the first `capacity` are stored), or < 0: -1 T (or bulkPi/P)
- * outside a table, -2 df_mode, -3 dimension, -4 include_baryon. */
+ * outside a table, -2 df_mode, -3 dimension, -4 include_baryon with df_mode 4 (the reference exits, deltafReader.cpp:470-474), with
+ * fast = 1 (densities at the average (T, mu_B): not restated) or without the (mu_B, T) tables.  Baryon may be NULL when include_baryon = 0. */
 long oracle_sample_particles(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
-                             const cell_arrays *a, const double *x_fo, const double *y_fo, const oracle_df_tables *t,
+                             const double *Baryon, const cell_arrays *a, const double *x_fo, const double *y_fo, const oracle_df_tables *t,
                              int n_gla, const double *root1, const double *weight1, const oracle_feqmod_tables *q,
                              const oracle_opts *o, const oracle_sampler_opts *so, double *out, long capacity, long *stats)
 {
     if (o->dimension != 2 && o->dimension != 3) return -3;
     if (o->df_mode < 1 || o->df_mode > 4) return -2;
     if (o->df_mode >= 3 && !q) return -2;
-    if (o->include_baryon) return -4;
+    if (o->include_baryon && (o->df_mode == 4 || so->fast || !Baryon)) return -4;
     const int DF_MODE = o->df_mode, n_events = so->n_events;
     const uint64_t seed = so->seed;
     const long first_cell = so->first_cell;
@@ -1241,10 +1245,21 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
             if (bulkPi <= -P) bulkPi = -(1.0 - 1.e-5) * P;
             else if (bulkPi / P >= J->bulkPi_over_Peq_max) bulkPi = P * (J->bulkPi_over_Peq_max - 1.e-5);
         }
-        /* evaluate_df_coefficients (deltafReader.cpp:325-395) */
+        double muB = 0.0, nB = 0.0, Vt = 0.0, Vx = 0.0, Vy = 0.0, Vn = 0.0;     /* :942-964 */
+        c->alphaB = 0.0; c->baryon_enthalpy_ratio = 0.0;
+        if (o->include_baryon && o->include_baryondiff_deltaf) {
+            muB = a->muB[ic]; nB = a->nB[ic]; Vx = a->Vx[ic]; Vy = a->Vy[ic]; Vn = a->Vn[ic];
+            Vt = (Vx * ux + Vy * uy + tau2 * Vn * un) / ut;
+            c->alphaB = muB / T;
+            c->baryon_enthalpy_ratio = nB / (E + P);
+        }
+        /* evaluate_df_coefficients (deltafReader.cpp:325-395; include_baryon: bilinear_interpolation :412-484) */
         double lambda = 0.0, z = 0.0, v, T4 = T * T * T * T;
         memset(&c->df, 0, sizeof c->df);
-        if (DF_MODE <= 2) {
+        if (o->include_baryon) {
+            int brc = eval_df_bilinear(t, DF_MODE, T, muB, &c->df);
+            if (brc) { err = brc == -1 ? -1 : -4; break; }
+        } else if (DF_MODE <= 2) {
             if (eval_df(t, s, s + n, sF, sbb, sbp, DF_MODE, T, &c->df)) { err = -1; break; }
         } else if (DF_MODE == 3) {
             if (eval_df(t, s, s + n, sF, sbb, sbp, 2, T, &c->df)) { err = -1; break; }
@@ -1280,13 +1295,21 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
         c->piyy = pixx * Yx * Yx + 2.0 * pixy * Yx * Yy + piyy * Yy * Yy;
         c->piyz = -Zt * (pitx * Yx + pity * Yy) + tau2 * Zn * (pixn * Yx + piyn * Yy);
         c->pizz = -(c->pixx + c->piyy);
+        /* boost_Vmu_to_lrf (viscous_correction.cpp:161-173) */
+        c->Vx = -Vt * Xt + Vx * Xx + Vy * Xy + tau2 * Vn * Xn;
+        c->Vy = Vx * Yx + Vy * Yy;
+        c->Vz = -Vt * Zt + tau2 * Vn * Zn;
         c->tau = tau; c->x = x_fo ? x_fo[ic] : 0.0; c->y = y_fo ? y_fo[ic] : 0.0;
         c->eta = (o->dimension == 3) ? a->eta[ic] : 0.0;
         c->ut = ut; c->ux = ux; c->uy = uy; c->un = un; c->T = T; c->bulkPi = bulkPi;
         /* modified temperature and rescaling coefficients (:1017-1036), detA, breakdown (:1038) */
-        c->T_mod = T; c->shear_mod = 0.0; c->bulk_mod = 0.0;
-        const double F = c->df.F, betabulk = c->df.betabulk, betapi = c->df.betapi;
-        if (DF_MODE == 3) { c->T_mod = T + bulkPi * F / betabulk; c->shear_mod = 0.5 / betapi; c->bulk_mod = bulkPi / (3.0 * betabulk); }
+        c->T_mod = T; c->shear_mod = 0.0; c->bulk_mod = 0.0; c->diff_mod = 0.0; c->alphaB_mod = c->alphaB;
+        const double F = c->df.F, G = c->df.G, betabulk = c->df.betabulk, betapi = c->df.betapi;
+        if (DF_MODE == 3) {
+            c->T_mod = T + bulkPi * F / betabulk; c->shear_mod = 0.5 / betapi; c->bulk_mod = bulkPi / (3.0 * betabulk);
+            c->alphaB_mod = c->alphaB + bulkPi * G / betabulk;
+            c->diff_mod = o->include_baryon ? T / c->df.betaV : 0.0;          /* :1026; betaV = 1 by convention without baryon, V = 0 */
+        }
         else if (DF_MODE == 4) { c->shear_mod = 0.5 / betapi; c->bulk_mod = lambda; }
         c->breakdown = 0;
         if (DF_MODE == 3) {
@@ -1311,11 +1334,14 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
                 else dn = z * Equilibrium_Density[ip];
             } else {
                 double mbar = Mass[ip] / T;
-                double equilibrium_density = neq_fact * Degeneracy[ip] * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+                const double baryon = o->include_baryon ? Baryon[ip] : 0.0, aB = c->alphaB;
+                double equilibrium_density = neq_fact * Degeneracy[ip] * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, aB, baryon, Sign[ip]);
                 if (DF_MODE <= 2 || c->breakdown) dn = 2.0 * equilibrium_density;
                 else if (DF_MODE == 3) {
-                    double J20 = J20_fact * Degeneracy[ip] * gauss_thermal(J20_int, q->root2, q->weight2, n_gla, mbar, 0.0, 0.0, Sign[ip]);
-                    double bulk_density = (equilibrium_density + (J20 * F / T / T)) / betabulk;
+                    double J10 = 0.0;                                                             /* :319-323 */
+                    if (o->include_baryon) J10 = neq_fact * Degeneracy[ip] * gauss_thermal(J10_int, root1, weight1, n_gla, mbar, aB, baryon, Sign[ip]);
+                    double J20 = J20_fact * Degeneracy[ip] * gauss_thermal(J20_int, q->root2, q->weight2, n_gla, mbar, aB, baryon, Sign[ip]);
+                    double bulk_density = (equilibrium_density + (baryon * J10 * G) + (J20 * F / T / T)) / betabulk;
                     dn = equilibrium_density + bulkPi * bulk_density;
                 } else dn = z * equilibrium_density;
             }
@@ -1351,28 +1377,34 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
                 double cum = 0.0;
                 for (int ip = 0; ip < npart; ip++) { cum += dn[ip]; if (ut_ < cum) { chosen = ip; break; } }
                 double mass = Mass[chosen], mass_squared = mass * mass, sign = Sign[chosen];
+                const double baryon = o->include_baryon ? Baryon[chosen] : 0.0;
                 lrf_mom p;
                 double w_visc = 1.0;
                 if (DF_MODE <= 2 || c->breakdown) {                           /* :1100-1110, switch_to_linear_df */
-                    p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T);
-                    /* compute_df_weight :361-453 (baryon terms vanish); df_mode 3 takes the Chapman-Enskog branch */
+                    const double chem = baryon * c->alphaB;
+                    p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T, chem);
+                    /* compute_df_weight :361-453; df_mode 3 takes the Chapman-Enskog branch */
                     double pimunu_pmu_pnu = p.px * p.px * c->pixx + p.py * p.py * c->piyy + p.pz * p.pz * c->pizz
                                           + 2.0 * (p.px * p.py * c->pixy + p.px * p.pz * c->pixz + p.py * p.pz * c->piyz);
-                    double feqbar = 1.0 - sign / (exp(p.E / c->T) + sign), df_tot;
+                    double Vmu_pmu = -(p.px * c->Vx + p.py * c->Vy + p.pz * c->Vz);                /* :384 */
+                    double feqbar = 1.0 - sign / (exp(p.E / c->T - chem) + sign), df_tot;
                     if (DF_MODE == 1) {
                         double df_shear = pimunu_pmu_pnu / c->shear14_coeff;
-                        double df_bulk = ((c->df.c0 - c->df.c2) * mass_squared + ((4.0 * c->df.c2 - c->df.c0) * p.E) * p.E) * c->bulkPi;
-                        df_tot = feqbar * (df_shear + df_bulk);
+                        double df_bulk = ((c->df.c0 - c->df.c2) * mass_squared + (baryon * c->df.c1 + (4.0 * c->df.c2 - c->df.c0) * p.E) * p.E) * c->bulkPi;
+                        double df_diff = (baryon * c->df.c3 + c->df.c4 * p.E) * Vmu_pmu;
+                        df_tot = feqbar * (df_shear + df_bulk + df_diff);
                     } else {
+                        double betaV = o->include_baryon ? c->df.betaV : 1.0;
                         double df_shear = pimunu_pmu_pnu / (2.0 * p.E * c->df.betapi * c->T);
-                        double df_bulk = (c->df.F * p.E / c->T / c->T + (p.E - mass_squared / p.E) / (3.0 * c->T)) * c->bulkPi / c->df.betabulk;
-                        df_tot = feqbar * (df_shear + df_bulk);
+                        double df_bulk = (baryon * c->df.G + c->df.F * p.E / c->T / c->T + (p.E - mass_squared / p.E) / (3.0 * c->T)) * c->bulkPi / c->df.betabulk;
+                        double df_diff = (c->baryon_enthalpy_ratio - baryon / p.E) * Vmu_pmu / betaV;
+                        df_tot = feqbar * (df_shear + df_bulk + df_diff);
                     }
                     df_tot = fmax(-1.0, fmin(df_tot, 1.0));
                     w_visc = (1.0 + df_tot) / 2.0;
                 } else {                                                      /* :1112-1131: modified equilibrium, no viscous weight */
-                    p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T_mod);
-                    p = rescale_momentum(p, mass_squared, c);
+                    p = sample_momentum(&g_momentum, &acceptances, &samples, mass, sign, c->T_mod, DF_MODE == 3 ? baryon * c->alphaB_mod : 0.0);
+                    p = rescale_momentum(p, mass_squared, DF_MODE == 3 ? baryon : 0.0, c);
                 }
                 /* boost_pLRF_to_lab_frame (emissionfunction.cpp:40-51) */
                 double ptau = p.E * c->ut + p.px * c->Xt + p.pz * c->Zt;

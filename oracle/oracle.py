@@ -273,6 +273,7 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
     xs = _f64(cells["x"]) if cells.get("x") is not None else None
     ys = _f64(cells["y"]) if cells.get("y") is not None else None
     sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy"]}
+    sp["baryon"] = _f64(species["baryon"]) if "baryon" in species else np.zeros(len(sp["mass"]))
     npart = len(sp["mass"])
     st, keep_df = _df_struct(df)
     r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
@@ -284,14 +285,14 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
                       float(T_avg if T_avg_switch is None else T_avg_switch))
     L = lib()
     L.oracle_sample_particles.restype = C.c_long
-    L.oracle_sample_particles.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, C.POINTER(_CellArrays), _dp, _dp, C.POINTER(_DfTables), C.c_int,
+    L.oracle_sample_particles.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_CellArrays), _dp, _dp, C.POINTER(_DfTables), C.c_int,
                                           _dp, _dp, C.POINTER(_FeqmodTables), C.POINTER(_Opts), C.POINTER(_SamplerOpts), _dp, C.c_long,
                                           C.POINTER(C.c_long)]
     stats = (C.c_long * 4)()
     cap = int(capacity) if capacity is not None else 0
     while True:
         out = np.zeros((max(cap, 1), len(PARTICLE_FIELDS)))
-        rc = L.oracle_sample_particles(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), C.byref(ca),
+        rc = L.oracle_sample_particles(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), _p(sp["baryon"]), C.byref(ca),
                                        _p(xs) if xs is not None else None, _p(ys) if ys is not None else None, C.byref(st), len(r1), _p(r1),
                                        _p(w1), C.byref(fs) if fs is not None else None, C.byref(os_), C.byref(so), _p(out), cap, stats)
         if rc < 0:

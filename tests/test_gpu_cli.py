@@ -122,7 +122,7 @@ def test_cli_other_surface_formats(tmp_path, fx, mode):
 
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=3), dict(operation=2, include_baryon=1), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
+    for bad in (dict(operation=3), dict(operation=2, include_baryon=1, fast=1), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr
@@ -178,6 +178,24 @@ def test_cli_sampler(tmp_path, fx, dim, oversample):
     rows = np.array([[float(v) for v in ln.split(" ")] for ln in lines if not ln.startswith("#")]).reshape(-1, 9)
     assert len(rows) > 10
     assert sum(headers) == len(rows) == len(ref["E"]) and len(headers) == len(np.unique(ref["event"]))
+    assert np.array_equal(rows[:, 0].astype(np.int64), np.array(ids)[ref["species"]])
+    for col, f in enumerate(["t", "x", "y", "z", "E", "px", "py", "pz"], start=1):
+        assert np.allclose(rows[:, col], ref[f], rtol=1e-11, atol=1e-13), f
+
+
+def test_cli_sampler_with_baryon(tmp_path, fx):
+    """operation = 2 with include_baryon = 1: 25-column surface, full (T, mu_B) coefficient files; the list equals the oracle's."""
+    ids = [211, 2212, -2212]
+    cells = synth.synth_surface(4000, 3, seed=95, baryon=True)
+    o = dict(dimension=3, df_mode=2, include_baryon=1, include_baryondiff_deltaf=1)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(o, operation=2, oversample=0, sampler_seed=19))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    ref, _ = oracle.sample_particles(parsed, inputs.species(ids), inputs.df_tables_full(), inputs.feqmod_tables(0.15), o, n_events=1, seed=19, y_cut=0.7)
+    lines = [ln for ln in open(os.path.join(root, "results", "particle_list_osc.dat")).read().split("\n") if ln]
+    rows = np.array([[float(v) for v in ln.split(" ")] for ln in lines if not ln.startswith("#")]).reshape(-1, 9)
+    assert len(rows) == len(ref["E"]) > 10
     assert np.array_equal(rows[:, 0].astype(np.int64), np.array(ids)[ref["species"]])
     for col, f in enumerate(["t", "x", "y", "z", "E", "px", "py", "pz"], start=1):
         assert np.allclose(rows[:, col], ref[f], rtol=1e-11, atol=1e-13), f

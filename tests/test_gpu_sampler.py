@@ -141,3 +141,42 @@ def test_sampled_yields_follow_the_device_smooth_spectrum(fx):
         assert abs(pT.mean() - pT_smooth[s]) < 4.5 * pT.std() / np.sqrt(sel.sum())
     m = sp["mass"][p["species"]]
     assert relerr(p["E"] ** 2, p["px"] ** 2 + p["py"] ** 2 + p["pz"] ** 2 + m ** 2) < 1e-12
+
+
+@pytest.mark.parametrize("dim,df_mode,diff", [(3, 2, 1), (3, 1, 1), (3, 3, 1), (2, 2, 1), (2, 3, 1), (3, 2, 0)])
+def test_sampler_with_baryon_lists_match_the_oracle(fx, dim, df_mode, diff):
+    """include_baryon = 1: the baryon number is part of the class key, chem = b mu_B/T in the density integrals and the momentum
+    weight, c1 c3 c4 | G betaV terms in the viscous weight, diffusion in the df_mode-3 momentum rescaling; breakdown cells
+    (df_mode 3) fall back to the linear delta-f with the baryon terms."""
+    cells = synth.synth_surface(300, dim, seed=850 + dim + df_mode, baryon=True)
+    cells = {k: v.copy() for k, v in cells.items()}
+    if df_mode == 3:
+        cells["bulkPi"][::9] = -5.0 * cells["P"][::9]
+    sp = inputs.species([211, 321, 2212, -2212, 3122, -3122])
+    dff = inputs.df_tables_full()
+    fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    o = dict(dimension=dim, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=diff)
+    kw = dict(n_events=150, seed=90210, y_cut=0.8, fq=fq if df_mode == 3 else None)
+    ref, rst = oracle.sample_particles(cells, sp, dff, fq, o, **kw)
+    got, st = api.sample_particles(cells, sp, dff, fq, o, **kw)
+    assert len(ref["E"]) > 100
+    compare_lists(got, ref)
+    assert st["n_hadrons_drawn"] == rst["drawn"] and st["n_momentum_samples"] == rst["samples"]
+    assert st["n_cells_breakdown"] == rst["breakdown"] and (rst["breakdown"] > 0) == (df_mode == 3)
+    assert st["n_classes"] == 6                                    # p / pbar and Lambda / Lambdabar are separate classes now
+    if diff:
+        n_p, n_pbar = (got["species"] == 2).sum(), (got["species"] == 3).sum()
+        assert n_p > 2 * n_pbar
+    for bad in (dict(o, df_mode=4),):
+        with pytest.raises(api.Is3dError) as e:
+            api.sample_particles(cells, sp, dff, fq, bad, n_events=1, seed=1, fq=fq)
+        assert e.value.code == -1
+    with pytest.raises(api.Is3dError) as e:
+        api.sample_particles(cells, sp, dff, fq, o, n_events=1, seed=1, fq=fq, fast=1, T_avg=0.15)
+    assert e.value.code == -1
+    if diff and dim == 3:
+        out = {k: v.copy() for k, v in cells.items()}
+        out["muB"][7] = 0.95
+        with pytest.raises(api.Is3dError) as e:
+            api.sample_particles(out, sp, dff, fq, o, n_events=1, seed=1, fq=fq if df_mode == 3 else None)
+        assert e.value.code == -3 and "cell 7" in str(e.value)

@@ -156,3 +156,40 @@ def test_fast_mode_on_an_isothermal_surface(fx, df_mode):
     # a different average temperature changes the mean numbers (and with them the list)
     c, sc = oracle.sample_particles(cells, sp, fx["df"], fq, o, n_events=200, seed=5, fq=fq, fast=1, T_avg=0.140)
     assert sc["drawn"] < sb["drawn"]
+
+
+@pytest.mark.parametrize("df_mode", [2, 1, 3])
+def test_sampler_with_baryon_reproduces_the_smooth_spectrum(fx, df_mode):
+    """include_baryon = 1 (sampling_kernels.cpp:942-964, :282-359, :361-453, :456-617, :619-650): chem = b mu_B/T in the mean
+    numbers and the momentum weights, bulk1 / diffusion terms in the viscous weight, diffusion in the momentum rescaling of
+    df_mode 3.  Proton and antiproton yields and <pT> against the smooth baryon spectra of the same surface."""
+    ncell = 160
+    cells = synth.synth_surface(ncell, 3, seed=760 + df_mode, baryon=True)
+    cells = {k: v.copy() for k, v in cells.items()}
+    cells["eta"] *= 0.25
+    sp = inputs.species([211, 2212, -2212])
+    dff = inputs.df_tables_full()
+    o = dict(dimension=3, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=1)
+    fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    g = fx["grid_w"]
+    if df_mode == 3:
+        smooth, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], dff, fq, o)
+        assert nb == 0
+    else:
+        smooth = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], dff, o)
+    s4 = smooth.reshape(len(g["y"]), len(g["phi"]), len(g["pT"]), 3)
+    dndy = np.einsum("j,i,kjis->ks", g["phi_w"], g["pT_w"], s4)
+    pt1 = np.einsum("j,i,kjis->ks", g["phi_w"], g["pT_w"] * g["pT"], s4)
+    h = g["y"][1] - g["y"][0]
+    N_smooth, pT_smooth = dndy.sum(axis=0) * h, pt1.sum(axis=0) / dndy.sum(axis=0)
+    assert N_smooth[1] > 3.0 * N_smooth[2]                             # mu_B > 0: more protons than antiprotons
+    n_events = int(np.ceil(90000.0 / N_smooth.sum()))
+    p, st = oracle.sample_particles(cells, sp, dff, fq, o, n_events=n_events, seed=20260006, fq=fq if df_mode == 3 else None)
+    for s in range(3):
+        sel = p["species"] == s
+        want = N_smooth[s] * n_events
+        assert abs(sel.sum() - want) < 4.5 * np.sqrt(want), (s, sel.sum(), want)
+        pT = np.hypot(p["px"][sel], p["py"][sel])
+        assert abs(pT.mean() - pT_smooth[s]) < 4.5 * pT.std() / np.sqrt(sel.sum()), (s, pT.mean(), pT_smooth[s])
+    with pytest.raises(RuntimeError):
+        oracle.sample_particles(cells, sp, dff, fq, dict(o, df_mode=4), n_events=1, seed=1, fq=fq)
