@@ -260,7 +260,7 @@ int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_species *spe
 /* ---------------------------------------------------------------------------------------------
  * Particle sampler (operation = 2): replaces EmissionFunctionArray::sample_dN_pTdpTdphidy
  * (src/cpp/emissionfunction.h:208-210, emissionfunction_sampling_kernels.cpp:833-1225, call sites emissionfunction.cpp:1543,
- * :1606) for viscous hydro, df_mode 1-4, fast = 0 | 1; include_baryon = 1 with df_mode 1-3 and fast = 0.  The reference's serial
+ * :1606) for viscous hydro, df_mode 1-4, fast = 0 | 1; include_baryon = 1 with df_mode 1-3.  The reference's serial
  * std::default_random_engine streams are replaced by counter-based Philox4x32-10 streams keyed by (seed, stream, global cell
  * index, event) -- same five stream roles and the same distributions; particle lists agree with the reference statistically,
  * not draw by draw (the construction is written out in cf_sampler.hip and DESIGN.md section 3c).
@@ -289,6 +289,7 @@ typedef struct {
     double T_avg;                       /* fast: Plasma::temperature as read back from average_thermodynamic_quantities.dat */
     double T_avg_switch;                /* fast, df_mode 3: the same after `if (SET_T_SWITCH) temperature = T_SWITCH` (:856);
                                            0 = T_avg */
+    double muB_avg;                     /* fast with include_baryon: Plasma::baryon_chemical_potential (deltafReader.cpp:545, :858) */
 } is3d_sampler_inputs;
 
 typedef struct {

@@ -61,7 +61,7 @@ PARTICLE_DTYPE = np.dtype([("cell", "<i8"), ("event", "<i4"), ("species", "<i4")
 class SamplerInputs(C.Structure):
     _fields_ = [("n_events", C.c_int32), ("n_gla", C.c_int32), ("seed", C.c_uint64), ("y_cut", C.c_double), ("first_cell", C.c_int64),
                 ("x", _dp), ("y", _dp), ("root1", _dp), ("weight1", _dp), ("feqmod", C.POINTER(FeqmodTables)), ("fast", C.c_int32),
-                ("batch_events", C.c_int32), ("T_avg", C.c_double), ("T_avg_switch", C.c_double)]
+                ("batch_events", C.c_int32), ("T_avg", C.c_double), ("T_avg_switch", C.c_double), ("muB_avg", C.c_double)]
 
 
 class SamplerStats(C.Structure):
@@ -440,7 +440,7 @@ def df_table_read_full(path):
 
 
 def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_cut=0.5, first_cell=0, capacity=None, fq=None, fast=0,
-                     T_avg=0.0, T_avg_switch=0.0, batch_events=0):
+                     T_avg=0.0, T_avg_switch=0.0, batch_events=0, muB_avg=0.0):
     """is3d_sample_particles (the drop-in for sample_dN_pTdpTdphidy, df_mode 1-4).  cells: dict of host arrays (x, y optional);
     gla: dict with root1, weight1; fq: the feqmod tables (df_mode 3, 4; fast mode with df_mode 2).  Returns (numpy structured array of PARTICLE_DTYPE, stats dict); capacity = None sizes the
     buffer from a count-only first call."""
@@ -464,7 +464,7 @@ def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_c
     fqs = _pack_feqmod(fq, keep) if fq is not None else None
     si = SamplerInputs(int(n_events), len(r1), int(seed), float(y_cut), int(first_cell), _p(xs) if xs is not None else None,
                        _p(ys) if ys is not None else None, _p(r1), _p(w1), C.pointer(fqs) if fqs is not None else None, int(fast), int(batch_events),
-                       float(T_avg), float(T_avg_switch))
+                       float(T_avg), float(T_avg_switch), float(muB_avg))
     st = SamplerStats()
     cnt = C.c_int64(0)
     if capacity is None:

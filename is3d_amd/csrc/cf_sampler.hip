@@ -614,7 +614,6 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     if (baryon) {
         if (opts->df_mode == 4)   // deltafReader.cpp:470-474: "Jonah df doesn't work for nonzero muB. Exiting.."
             return set_error(IS3D_EINVAL, "df_mode 4 does not work with include_baryon = 1 (the reference exits there too)");
-        if (in->fast) return set_error(IS3D_EINVAL, "the sampler's fast mode with include_baryon = 1 is not on this path");
         if (!species->baryon) return set_error(IS3D_EINVAL, "include_baryon = 1 needs the species' baryon numbers");
         if (df->n_muB < 2 || !df->muB) return set_error(IS3D_EINVAL, "include_baryon = 1 needs the full (T, muB) coefficient tables");
         for (int i = 1; i < df->n_muB; i++)
@@ -775,32 +774,68 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         auto in_table = [&](double Tq) { return Tq >= xs.front() && Tq <= xs.back(); };
         const double T = in->T_avg, Tsw = in->T_avg_switch > 0.0 ? in->T_avg_switch : in->T_avg;
         if (!in_table(T) || !in_table(Tsw)) return set_error(IS3D_EDOMAIN, "fast = 1: the average temperature %.6g GeV is outside the coefficient table", T);
-        double F = 0.0, betabulk = 1.0;
-        if (opts->df_mode == 2 || opts->df_mode == 3) { F = spline_at(0, T) * T; betabulk = spline_at(1, T) * T * T * T * T; }
+        // include_baryon: Deltaf_Data::bilinear_interpolation at (T, muB_avg) on the host (deltafReader.cpp:412-484, intended indexing)
+        auto bilinear_at = [&](double Tq, double Bq, double (&v)[5]) -> bool {
+            const double *t5[5] = {df->F, df->G, df->betabulk, df->betaV, df->betapi};
+            const int nT = df->n_T, nB = df->n_muB;
+            const double dT = std::fabs(df->T[1] - df->T[0]), dB = std::fabs(df->muB[1] - df->muB[0]);
+            const int iTL = (int)std::floor((Tq - df->T[0]) / dT), iTR = iTL + 1;
+            const int iBL = (int)std::floor((Bq - df->muB[0]) / dB), iBR = iBL + 1;
+            if (!(iTL >= 0 && iTR < nT) || !(iBL >= 0 && iBR < nB)) return false;
+            const double TL = df->T[iTL], TR = df->T[iTR], BL = df->muB[iBL], BR = df->muB[iBR];
+            for (int k = 0; k < 5; k++) {
+                const double *f = t5[k];
+                const double f_LL = f[(size_t)iBL * nT + iTL], f_LR = f[(size_t)iBR * nT + iTL];
+                const double f_RL = f[(size_t)iBL * nT + iTR], f_RR = f[(size_t)iBR * nT + iTR];
+                v[k] = ((f_LL * (TR - Tq) + f_RL * (Tq - TL)) * (BR - Bq) + (f_LR * (TR - Tq) + f_RR * (Tq - TL)) * (Bq - BL)) / (dT * dB);
+            }
+            return true;
+        };
+        const double muB_avg = baryon ? in->muB_avg : 0.0, alphaB_avg = muB_avg / T;   // deltafReader.cpp:545-551
+        double F = 0.0, G = 0.0, betabulk = 1.0;
+        if (baryon && opts->df_mode != 1) {
+            double bl[5];
+            if (!bilinear_at(T, muB_avg, bl)) return set_error(IS3D_EDOMAIN, "fast = 1: the average (T, muB) = (%.6g, %.6g) GeV is outside the coefficient table", T, muB_avg);
+            F = bl[0] * T; G = bl[1]; betabulk = bl[2] * (T * T * T * T);
+        } else if (baryon) {   // df_mode 1: only the table range is checked (the 14-moment coefficients do not enter the fast densities used here)
+            const double dB = std::fabs(df->muB[1] - df->muB[0]);
+            const int iBL = (int)std::floor((muB_avg - df->muB[0]) / dB);
+            if (!(iBL >= 0 && iBL + 1 < df->n_muB)) return set_error(IS3D_EDOMAIN, "fast = 1: the average muB = %.6g GeV is outside the coefficient table", muB_avg);
+        } else if (opts->df_mode == 2 || opts->df_mode == 3) { F = spline_at(0, T) * T; betabulk = spline_at(1, T) * T * T * T * T; }
         std::vector<double> eqd(npart, 0.0), bkd(npart, 0.0);
         for (int ip = 0; ip < npart; ip++) {
             const double mbar = species->mass[ip] / T, sign = species->sign[ip];
-            double s1 = 0.0, s2 = 0.0;
+            const double bnum = baryon ? species->baryon[ip] : 0.0, chem = bnum * alphaB_avg;
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
             for (int k = 0; k < in->n_gla; k++) {
                 const double pbar = in->root1[k], Ebar = std::sqrt(pbar * pbar + mbar * mbar);
-                s1 += in->weight1[k] * (pbar * std::exp(pbar) / (std::exp(Ebar) + sign));
+                s1 += in->weight1[k] * (pbar * std::exp(pbar) / (std::exp(Ebar - chem) + sign));
             }
             const double neq = species->degeneracy[ip] * std::pow(T, 3) / two_pi2_hbarC3 * s1;
             eqd[ip] = neq;
             if (opts->df_mode == 2 || opts->df_mode == 3) {
                 for (int k = 0; k < in->n_gla; k++) {
-                    const double pbar = fq->root2[k], Ebar = std::sqrt(pbar * pbar + mbar * mbar), qstat = std::exp(Ebar) + sign;
-                    s2 += fq->weight2[k] * (Ebar * std::exp(pbar + Ebar) / (qstat * qstat));
+                    const double pbar = fq->root2[k], Ebar = std::sqrt(pbar * pbar + mbar * mbar), qstat = std::exp(Ebar - chem) + sign;
+                    s2 += fq->weight2[k] * (Ebar * std::exp(pbar + Ebar - chem) / (qstat * qstat));
                 }
+                for (int k = 0; k < in->n_gla; k++) {
+                    const double pbar = in->root1[k], Ebar = std::sqrt(pbar * pbar + mbar * mbar), qstat = std::exp(Ebar - chem) + sign;
+                    s3 += in->weight1[k] * (pbar * std::exp(pbar + Ebar - chem) / (qstat * qstat));
+                }
+                const double J10 = species->degeneracy[ip] * std::pow(T, 3) / two_pi2_hbarC3 * s3;
                 const double J20 = species->degeneracy[ip] * std::pow(T, 4) / two_pi2_hbarC3 * s2;
-                bkd[ip] = (neq + (J20 * F / std::pow(T, 2))) / betabulk;
+                bkd[ip] = (neq + (bnum * J10 * G) + (J20 * F / std::pow(T, 2))) / betabulk;
             }
         }
         SMP_TRY(d_eqd.upload(eqd));
         SMP_TRY(d_bkd.upload(bkd));
         p.eqd = d_eqd.as<double>(); p.bkd = d_bkd.as<double>();
         p.T_sw = Tsw;
-        if (opts->df_mode == 3) { p.F_avg = spline_at(0, Tsw) * Tsw; p.betabulk_avg = spline_at(1, Tsw) * Tsw * Tsw * Tsw * Tsw; }
+        if (opts->df_mode == 3 && baryon) {                                            // :862-867 at (Tavg with T_switch, muBavg)
+            double bl[5];
+            if (!bilinear_at(Tsw, muB_avg, bl)) return set_error(IS3D_EDOMAIN, "fast = 1: (T_switch, muB_avg) = (%.6g, %.6g) GeV is outside the coefficient table", Tsw, muB_avg);
+            p.F_avg = bl[0] * Tsw; p.betabulk_avg = bl[2] * (Tsw * Tsw * Tsw * Tsw);
+        } else if (opts->df_mode == 3) { p.F_avg = spline_at(0, Tsw) * Tsw; p.betabulk_avg = spline_at(1, Tsw) * Tsw * Tsw * Tsw * Tsw; }
     }
     p.y_max = three_d ? 0.5 : in->y_cut;                                              // :837-838
     p.seed = in->seed;

@@ -10,7 +10,7 @@
 // and writes what EmissionFunctionArray::calculate_spectra writes for operation = 1
 // (emissionfunction.cpp:1678-1686) into results/ (which must exist, README.md:34) plus
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
-// operation = 2 (particle sampler; df_mode 1-4, fast in {0, 1}, include_baryon = 1 with df_mode 1-3 and fast = 0) writes
+// operation = 2 (particle sampler; df_mode 1-4, fast in {0, 1}, include_baryon = 1 with df_mode 1-3) writes
 // results/particle_list_osc.dat (write_particle_list_OSC, emissionfunction.cpp:863-901) and results/dN_dy_*.dat is skipped.
 // Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2, 3} with include_baryon in {0, 1}, df_mode 4
 // (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
@@ -277,10 +277,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         si.y_cut = y_cut; si.first_cell = 0; si.x = xs.data(); si.y = ys.data();
         si.root1 = groot.data() + n_pts; si.weight1 = gweight.data() + n_pts;
         // df_mode 3 / 4 and fast mode: emissionfunction.cpp:1309-1321, sampling_kernels.cpp:852-869
-        double T_avg_file = 0.0;
+        double T_avg_file = 0.0, E_avg_file = 0.0, P_avg_file = 0.0, muB_avg_file = 0.0;   // Plasma::load_thermodynamic_averages
         {
             FILE *tf = fopen("average_thermodynamic_quantities.dat", "r");
-            if (!tf || fscanf(tf, "%lf", &T_avg_file) != 1) DIE("Error opening average thermodynamic file");
+            if (!tf || fscanf(tf, "%lf %lf %lf %lf", &T_avg_file, &E_avg_file, &P_avg_file, &muB_avg_file) != 4) DIE("Error opening average thermodynamic file");
             fclose(tf);
         }
         is3d_feqmod_tables fqs{};
@@ -295,10 +295,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
             si.feqmod = &fqs;
         }
         si.fast = (int)fast != 0;
-        if (si.fast && include_baryon) DIE("operation = 2 with fast = 1 and include_baryon = 1 is not on this path (set fast = 0)");
+        si.muB_avg = muB_avg_file;                                                // Plasma::baryon_chemical_potential, :858
         si.T_avg = T_avg_file;
         si.T_avg_switch = (int)set_T ? T_switch : T_avg_file;                     // :856
-        if (si.fast) printf("Using fast mode: (Tavg, muBavg) = (%lf, %lf)\n", si.T_avg_switch, avg[3]);
+        if (si.fast) printf("Using fast mode: (Tavg, muBavg) = (%lf, %lf)\n", si.T_avg_switch, muB_avg_file);
         printf("iS3D Sampling Seed : %llu\n", (unsigned long long)si.seed);
         is3d_sampler_stats ss{};
         int64_t count = 0;

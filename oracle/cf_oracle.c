@@ -1145,6 +1145,7 @@ typedef struct {
     long first_cell;
     double T_avg;             /* Plasma::temperature as read back from average_thermodynamic_quantities.dat (fast densities) */
     double T_avg_switch;      /* the same after `if (SET_T_SWITCH) temperature = T_SWITCH` (:856): the fast breakdown test */
+    double muB_avg;           /* Plasma::baryon_chemical_potential (fast densities with include_baryon, deltafReader.cpp:545) */
 } oracle_sampler_opts;
 
 /* rescale_momentum (:619-650) */
@@ -1165,8 +1166,8 @@ static lrf_mom rescale_momentum(lrf_mom q, double mass_squared, double baryon, c
  * its cells).  q: Gauss-Laguerre alpha = 2, PDG list, deta_min, mass_pion0 -- df_mode 3, 4 only (may be NULL otherwise).
  * stats = {momentum samples, acceptances, hadrons drawn (before the keep test), cells where feqmod breaks down}.  Returns
  * the number of kept particles (all of them are counted; only the first `capacity` are stored), or < 0: -1 T (or bulkPi/P)
- * outside a table, -2 df_mode, -3 dimension, -4 include_baryon with df_mode 4 (the reference exits, deltafReader.cpp:470-474), with
- * fast = 1 (densities at the average (T, mu_B): not restated) or without the (mu_B, T) tables.  Baryon may be NULL when include_baryon = 0. */
+ * outside a table, -2 df_mode, -3 dimension, -4 include_baryon with df_mode 4 (the reference exits, deltafReader.cpp:470-474) or
+ * without the (mu_B, T) tables.  Baryon may be NULL when include_baryon = 0. */
 long oracle_sample_particles(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy,
                              const double *Baryon, const cell_arrays *a, const double *x_fo, const double *y_fo, const oracle_df_tables *t,
                              int n_gla, const double *root1, const double *weight1, const oracle_feqmod_tables *q,
@@ -1175,7 +1176,7 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
     if (o->dimension != 2 && o->dimension != 3) return -3;
     if (o->df_mode < 1 || o->df_mode > 4) return -2;
     if (o->df_mode >= 3 && !q) return -2;
-    if (o->include_baryon && (o->df_mode == 4 || so->fast || !Baryon)) return -4;
+    if (o->include_baryon && (o->df_mode == 4 || !Baryon)) return -4;
     const int DF_MODE = o->df_mode, n_events = so->n_events;
     const uint64_t seed = so->seed;
     const long first_cell = so->first_cell;
@@ -1197,26 +1198,42 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
     double F_avg = 0.0, betabulk_avg = 0.0;
     if (so->fast) {
         const double T = so->T_avg, T4 = T * T * T * T;
-        double v, F = 0.0, betabulk = 1.0;
-        if (DF_MODE == 2 || DF_MODE == 3) {
+        double v, F = 0.0, G = 0.0, betabulk = 1.0;
+        const double muB_avg = o->include_baryon ? so->muB_avg : 0.0, alphaB_avg = muB_avg / T;   /* deltafReader.cpp:545-551 */
+        if (o->include_baryon) {                                              /* evaluate_df_coefficients(T, muB, ...) -> bilinear */
+            df_coeff dfa;
+            int brc = eval_df_bilinear(t, DF_MODE, T, muB_avg, &dfa);
+            if (brc) err = brc == -1 ? -1 : -4;
+            F = dfa.F; G = dfa.G; betabulk = (DF_MODE == 1) ? 1.0 : dfa.betabulk;
+        } else if (DF_MODE == 2 || DF_MODE == 3) {
             if (oracle_cspline_eval(n, t->T, t->F, sF, T, &v)) err = -1; else F = v * T;
             if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, T, &v)) err = -1; else betabulk = v * T4;
         }
         for (int ip = 0; ip < npart && !err; ip++) {
             double mbar = Mass[ip] / T;
+            const double baryon = o->include_baryon ? Baryon[ip] : 0.0;
             double neq_fact = Degeneracy[ip] * pow(T, 3) / two_pi2_hbarC3;
-            double neq = neq_fact * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
+            double neq = neq_fact * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, alphaB_avg, baryon, Sign[ip]);
             Equilibrium_Density[ip] = neq;
-            if (DF_MODE == 2 || DF_MODE == 3) {
+            if (DF_MODE == 2 || DF_MODE == 3) {                                /* :615-629 */
+                double J10_fact = Degeneracy[ip] * pow(T, 3) / two_pi2_hbarC3;
                 double J20_fact = Degeneracy[ip] * pow(T, 4) / two_pi2_hbarC3;
-                double J20 = J20_fact * gauss_thermal(J20_int, q ? q->root2 : root1, q ? q->weight2 : weight1, n_gla, mbar, 0.0, 0.0, Sign[ip]);
-                Bulk_Density[ip] = (neq + (J20 * F / pow(T, 2))) / betabulk;
+                double J10 = J10_fact * gauss_thermal(J10_int, root1, weight1, n_gla, mbar, alphaB_avg, baryon, Sign[ip]);
+                double J20 = J20_fact * gauss_thermal(J20_int, q ? q->root2 : root1, q ? q->weight2 : weight1, n_gla, mbar, alphaB_avg, baryon, Sign[ip]);
+                Bulk_Density[ip] = (neq + (baryon * J10 * G) + (J20 * F / pow(T, 2))) / betabulk;
             }
         }
-        if (DF_MODE == 3 && !err) {                                           /* :862-867: df coefficients at (Tavg with T_switch) */
+        if (DF_MODE == 3 && !err) {                                           /* :862-867: df coefficients at (Tavg with T_switch, muBavg) */
             const double Ts = so->T_avg_switch, Ts4 = Ts * Ts * Ts * Ts;
-            if (oracle_cspline_eval(n, t->T, t->F, sF, Ts, &v)) err = -1; else F_avg = v * Ts;
-            if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, Ts, &v)) err = -1; else betabulk_avg = v * Ts4;
+            if (o->include_baryon) {
+                df_coeff dfa;
+                int brc = eval_df_bilinear(t, 3, Ts, muB_avg, &dfa);
+                if (brc) err = brc == -1 ? -1 : -4;
+                F_avg = dfa.F; betabulk_avg = dfa.betabulk;
+            } else {
+                if (oracle_cspline_eval(n, t->T, t->F, sF, Ts, &v)) err = -1; else F_avg = v * Ts;
+                if (oracle_cspline_eval(n, t->T, t->betabulk, sbb, Ts, &v)) err = -1; else betabulk_avg = v * Ts4;
+            }
         }
     }
     for (long ic = 0; ic < FO_length && !err; ic++) {

@@ -252,11 +252,11 @@ def rng_uniforms(seed, stream, cell, event, n):
 
 class _SamplerOpts(C.Structure):
     _fields_ = [("n_events", C.c_int), ("fast", C.c_int), ("seed", C.c_uint64), ("y_cut", C.c_double), ("first_cell", C.c_long),
-                ("T_avg", C.c_double), ("T_avg_switch", C.c_double)]
+                ("T_avg", C.c_double), ("T_avg_switch", C.c_double), ("muB_avg", C.c_double)]
 
 
 def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.5, capacity=None, first_cell=0, fq=None, fast=0,
-                     T_avg=0.0, T_avg_switch=None):
+                     T_avg=0.0, T_avg_switch=None, muB_avg=0.0):
     """sample_dN_pTdpTdphidy (df_mode 1..4) with the counter-based RNG defined in cf_oracle.c.  gla: dict with root1, weight1
     (is3d_amd.inputs.feqmod_tables() has them); fq: the feqmod tables (df_mode 3, 4, and the alpha = 2 nodes of fast mode);
     fast = 1: species densities at T_avg (breakdown test at T_avg_switch, default T_avg).  cells may carry x, y.
@@ -282,7 +282,7 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
     fs, keep_fq = _feqmod_struct(fq) if fq is not None else (None, None)
     os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
     so = _SamplerOpts(int(n_events), int(fast), int(seed), float(y_cut), int(first_cell), float(T_avg),
-                      float(T_avg if T_avg_switch is None else T_avg_switch))
+                      float(T_avg if T_avg_switch is None else T_avg_switch), float(muB_avg))
     L = lib()
     L.oracle_sample_particles.restype = C.c_long
     L.oracle_sample_particles.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_CellArrays), _dp, _dp, C.POINTER(_DfTables), C.c_int,

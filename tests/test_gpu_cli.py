@@ -122,7 +122,7 @@ def test_cli_other_surface_formats(tmp_path, fx, mode):
 
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=3), dict(operation=2, include_baryon=1, fast=1), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
+    for bad in (dict(operation=3), dict(operation=2, include_baryon=1, df_mode=4), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr

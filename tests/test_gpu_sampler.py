@@ -171,9 +171,17 @@ def test_sampler_with_baryon_lists_match_the_oracle(fx, dim, df_mode, diff):
         with pytest.raises(api.Is3dError) as e:
             api.sample_particles(cells, sp, dff, fq, bad, n_events=1, seed=1, fq=fq)
         assert e.value.code == -1
-    with pytest.raises(api.Is3dError) as e:
-        api.sample_particles(cells, sp, dff, fq, o, n_events=1, seed=1, fq=fq, fast=1, T_avg=0.15)
-    assert e.value.code == -1
+    if df_mode >= 2:
+        # fast = 1: species densities at the surface-average (T, mu_B) (deltafReader.cpp:536-650), breakdown test at T_switch
+        fkw = dict(kw, fq=fq, fast=1, T_avg=fq["T_avg"], T_avg_switch=0.1505, muB_avg=float(np.mean(cells["muB"])))
+        fref, frst = oracle.sample_particles(cells, sp, dff, fq, o, **fkw)
+        fgot, fst = api.sample_particles(cells, sp, dff, fq, o, **fkw)
+        assert len(fref["E"]) > 100 and len(fref["E"]) != len(ref["E"])
+        compare_lists(fgot, fref)
+        assert fst["n_hadrons_drawn"] == frst["drawn"] and fst["n_cells_breakdown"] == frst["breakdown"]
+        with pytest.raises(api.Is3dError) as e:                       # average mu_B outside the table
+            api.sample_particles(cells, sp, dff, fq, o, **dict(fkw, muB_avg=0.9))
+        assert e.value.code == -3
     if diff and dim == 3:
         out = {k: v.copy() for k, v in cells.items()}
         out["muB"][7] = 0.95
