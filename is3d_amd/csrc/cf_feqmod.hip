@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     FqScal *cs = (FqScal *)(gl + 4 * ngl);     // [CB]
     double *lk = (double *)(cs + kFqCB);       // [6][CB][K]: A, alphaf, W, a'x, a'y, a'z
     double *lj = lk + 6 * kFqCB * K;           // [5][CB][J]: B, gammaf, b'x, b'y, b'z
+    double *l_bm = lj + 5 * kFqCB * J;         // [CB][K][jtiles]: min over a phi tile of betaf_jk
     const int CK = kFqCB * K, CJ = kFqCB * J;
     double *l_A = lk, *l_al = lk + CK, *l_W = lk + 2 * CK, *l_ax = lk + 3 * CK, *l_ay = lk + 4 * CK, *l_az = lk + 5 * CK;
     double *l_B = lj, *l_ga = lj + CJ, *l_bx = lj + 2 * CJ, *l_by = lj + 3 * CJ, *l_bz = lj + 4 * CJ;
@@ -320,6 +321,18 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
         }
         __syncthreads();
 
+        // ---- phase 2c: (cell, k, phi tile): min_j betaf_jk, the main kernel's lower bound on X^2 for the exact-zero cull ----
+        for (int idx = tid; p.dim3 && idx < ncb * K * p.jtiles; idx += kFqThreads) {   // 3+1D only (2+1D: minimum per evaluation, below)
+            const int c = idx / (K * p.jtiles), rem = idx - c * (K * p.jtiles), k = rem / p.jtiles, jt = rem - k * p.jtiles;
+            const double ax = l_ax[c * K + k], ay = l_ay[c * K + k], az = l_az[c * K + k], s2 = 2.0 * cs[c].invTm2;
+            double v = 1.0e300;
+            for (int q2 = 0; q2 < p.JT; q2++) {
+                const int j = min(jt * p.JT + q2, J - 1);
+                v = fmin(v, (ax * l_bx[c * J + j] + ay * l_by[c * J + j] + az * l_bz[c * J + j]) * s2);
+            }
+            l_bm[idx] = v;
+        }
+        __syncthreads();
         // ---- phase 3: unit records (layout of cf_device.h, slots as in cf_feqmod.h) ----
         {
             const int JT = p.JT, R = p.R;
@@ -345,6 +358,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                     if (f == 0) v = (k < K) ? l_A[c * K + kc] : 0.0;
                     else if (f == 1) v = l_al[c * K + kc];
                     else if (f == 2) v = (k < K) ? l_W[c * K + kc] : 0.0;
+                    else if (f == 3) v = p.dim3 ? l_bm[(c * K + kc) * p.jtiles + jt] : 0.0;
                     else if (f >= 4) {
                         const int j = min(jt * JT + (f - 4), J - 1);
                         v = 2.0 * (l_ax[c * K + kc] * l_bx[c * J + j] + l_ay[c * K + kc] * l_by[c * J + j] + l_az[c * K + kc] * l_bz[c * J + j]) * cs[c].invTm2;
@@ -361,9 +375,9 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     }
 }
 
-size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K)
+size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles /* 0 in 2+1D: no beta-min table */)
 {
-    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J)) + sizeof(FqScal) * kFqCB;
+    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J + K * jtiles)) + sizeof(FqScal) * kFqCB;
 }
 
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
@@ -371,7 +385,7 @@ hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
     if (p.n_cells <= 0) return hipSuccess;
     const int nbatch = (p.n_cells + kFqCB - 1) / kFqCB;
     const int grid = nbatch < 4096 ? nbatch : 4096;
-    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K);
+    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K, p.dim3 ? p.jtiles : 0);
     hipLaunchKernelGGL(cf_prep_feqmod, dim3(grid), dim3(kFqThreads), lds, st, p);
     return hipGetLastError();
 }
@@ -493,10 +507,12 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
         // exact-zero culling: exp(cm - X) == +0 needs X > 745.25 + cm
         const double xcut = BARYON ? 745.25 + __builtin_fmax(cm, 0.0) : 745.25;
         const double x2cut = BARYON ? xcut * xcut : 555400.0;
+        double g_min = 1.0e300;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
             pTB[jj] = rpT * U[4 * jj + 0];
             pT2g[jj] = pT2 * U[4 * jj + 1];
+            if (DIM3) g_min = __builtin_fmin(g_min, pT2g[jj]);
         }
         struct Row { double v[RW]; };
         auto fetch = [&](Row &rw, const double *row) {
@@ -507,15 +523,25 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             const double mTA = rmT * rw.v[0];
             const double a = mT2 * rw.v[1];
             const double W = rw.v[2];
-            double X2[JT];
-            double x2min = 1.0e300;
-#pragma unroll
-            for (int jj = 0; jj < JT; jj++) {
-                X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
-                x2min = __builtin_fmin(x2min, X2[jj]);
-            }
             n_rows += 1;
-            if (g.zskip && __all(x2min > x2cut)) { n_dead += 1; return; }   // X > 745.25 (+ cm): exp(cm - X) == +0 for the whole wave-row
+            double X2[JT];
+            if constexpr (DIM3) {
+                // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + pT^2 min_j gammaf_j (mT pT >= 0; the row carries min_j betaf_jk):
+                // two instructions per row instead of a minimum per evaluation, and a culled row forms no X^2 at all
+                const double x2lb = __builtin_fma(mTpT, rw.v[3], a + g_min);
+                if (g.zskip && __all(x2lb > x2cut)) { n_dead += 1; return; }   // X > 745.25 (+ cm): exp(cm - X) == +0 for the whole wave-row
+#pragma unroll
+                for (int jj = 0; jj < JT; jj++) X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
+            } else {
+                // 2+1D: 241 eta rows per cell would need a 70 KB beta-min table in cf_prep_feqmod (its occupancy, +6 ms per 1e5 cells)
+                double x2min = 1.0e300;
+#pragma unroll
+                for (int jj = 0; jj < JT; jj++) {
+                    X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
+                    x2min = __builtin_fmin(x2min, X2[jj]);
+                }
+                if (g.zskip && __all(x2min > x2cut)) { n_dead += 1; return; }
+            }
             // the reciprocals of RB evaluations share one v_rcp_f64 (rcp_batch, cf_math.h): d = 1 + sign z lies in (1e-3, 2]
 #pragma unroll
             for (int j0 = 0; j0 < JT; j0 += RB) {
