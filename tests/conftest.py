@@ -14,6 +14,11 @@ REFERENCE = "/root/reference"   # present only in the build container; never rea
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: reads data files under /root/reference (container only)")
+    # a fresh checkout has no built library (build products are git-ignored): build it once, as __graft_entry__.build() does
+    lib = os.path.join(ROOT, "is3d_amd", "lib", "libis3d_amd.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "is3d_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
 
 
 def pytest_collection_modifyitems(config, items):
