@@ -345,3 +345,12 @@ def test_full_size_config2_properties_and_spot_checks(fx, torch_mod):
     ipT, iphi = [0, 9, 20], [0, 7, 23]
     ref = _subset_oracle(fx, cells, [211, 321, 2212], ipT, iphi, o).reshape(1, 3, 3, 3)
     assert relerr(w4[:, iphi][:, :, ipT], ref) < TOL
+
+
+def test_shader_clock_probe():
+    """is3d_probe_shader_clock (diagnostic used by bench.py): idle waves read s_memtime against s_memrealtime; an MI355X runs
+    between 1 and 2.5 GHz, or the call reports 0 when the two counters are the same clock."""
+    ghz = api.probe_shader_clock(0.05)
+    assert ghz == 0.0 or 1.0 < ghz < 2.6, ghz
+    with pytest.raises(api.Is3dError):
+        api.probe_shader_clock(0.0)
