@@ -137,8 +137,10 @@ typedef struct {
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
     int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per
                                            distinct (mass, sign) and scale by degeneracy */
-    int32_t zero_skip;                  /* 0 default(on) | 1 on | 2 off: wave-level culling of rows whose
-                                           exp(-p.u/T) is exactly +0 (bitwise-identical result) */
+    int32_t zero_skip;                  /* wave-level culling of rows that cannot change the result (bitwise-identical spectra
+                                           in all three settings): 1: rows whose exp(-p.u/T) is exactly +0; 0 (default): also
+                                           rows whose every term is below half an ulp of every accumulator it would be added to
+                                           (delta-f tile kernel with outflow && regulate_deltaf); 2: off */
     int32_t waves_per_group;            /* 0 default | 2, 4, 8: lane-waves per workgroup of the tile kernel (they share
                                            one LDS-staged coefficient stream) */
     int32_t reserved[5];

@@ -90,7 +90,8 @@ struct MainGeom {
     int32_t Kacc;      // accumulator slots along k: K (3+1D) or 1 (2+1D)
     int32_t first_pass;  // 1: store partials, 0: add to them
     int32_t upc;       // tiled stream: units per cell within a stream (1 in 3+1D, rblocks in 2+1D)
-    int32_t zskip;     // 1: skip rows whose exponential is exactly zero for the whole wave
+    int32_t zskip;     // 1: skip rows whose exponential is exactly zero for the whole wave; 2: also rows that cannot change a bit
+                       // of any accumulator (tile delta-f kernel with outflow && regulate_deltaf; cf_kernels.hip)
     int32_t wpb;       // lane-waves (= waves) per workgroup of the tile kernel: 2, 4 or 8
     int32_t baryon;    // 1: "B" unit records, lanes carry a baryon number
 };

@@ -604,6 +604,14 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
     int n_rows = 0, n_dead = 0;   // wave-uniform bookkeeping for the executed-work accounting of bench.py
+    // Row culling threshold on earg = log E1.  Always: exp(earg) == +0 below -745.2.  With OUTFLOW && REG (g.zskip == 2) also
+    // relative to the accumulators: every term of a row is pds w with 0 <= pds <= 1 (clamped, scaled stream), 0 <= u <= 1 and
+    // z r <= 2 z <= 2 E1 (E2 <= 1; 1/(1 + sign z) <= 2 for z <= 1/2), the accumulators only grow, and fma(pds, w, acc) == acc
+    // exactly whenever pds w < ulp(acc)/2.  So a row with 2 E1 < 2^-55 min(acc) for all 64 lanes changes no bit of any
+    // accumulator and is skipped; min(acc) >= 2^(e-1) with e the frexp exponent of a (stale, hence still valid) minimum over
+    // the lane's accumulators, refreshed once per batch.  On config 3 this culls 62 % of the wave-rows instead of 27 %.
+    constexpr bool RELCULL = OUTFLOW && REG;
+    double cull_thr = -745.2;
     auto process_unit = [&](const double *U) {
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
         double bmax = -1.0e300;
@@ -638,7 +646,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             }
             rw.mTC = mT * row[1];
             const double earg = BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC;
-            rw.live = !(g.zskip && __all(earg < -745.2));
+            rw.live = !(g.zskip && __all(earg < cull_thr));
             n_rows += 1;
             n_dead += rw.live ? 0 : 1;
             rw.E1 = exp_full(earg);
@@ -746,6 +754,13 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1];
                 for (int u = 0; u < nu; u++) process_unit(base + u * REC);
+                if (RELCULL && g.zskip == 2) {
+                    double m = acc[0];
+#pragma unroll
+                    for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
+                    const int e = __builtin_amdgcn_frexp_exp(m);                     // m = f 2^e, f in [0.5, 1)
+                    cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58) * 0.6931471805599453) : -745.2;
+                }
             }
             if (!EARLY) {
 #pragma unroll

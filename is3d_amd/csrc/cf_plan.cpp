@@ -620,7 +620,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             is3d::MainArgs a{};
             a.S1 = P->d_S1.p; a.S2 = P->d_S2.p; a.S3 = P->d_S3.p; a.TS = P->d_TS.p;
             a.g.upc = P->upc;
-            a.g.zskip = (o.zero_skip != 2);
+            a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2);   // 0 default: exact-zero + accumulator-relative culling
             a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p; a.lane_b = P->d_lane_b.p;
             a.g.baryon = P->baryon;
             a.partial = P->d_partial.p;

@@ -245,6 +245,30 @@ def test_passes_chunks_and_accumulate(fx, torch_mod):
     assert relerr(acc, 2.0 * base) < 1e-15
 
 
+@pytest.mark.parametrize("dim,df_mode,species", [(3, 2, "urqmd"), (3, 1, "pikp"), (2, 1, "pikp"), (2, 2, "urqmd")])
+def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
+    """zero_skip: 2 evaluates every row; 1 skips wave-rows whose exp(-p.u/T) is exactly +0; 0 (default) also skips rows whose
+    every term is below half an ulp of every accumulator it would be added to (outflow && regulate_deltaf).  All three give the
+    same bits; the default culls most (the y / eta range of the surface is several units wide here, as in config 3)."""
+    n = 3000 if dim == 3 else 150
+    cells = synth.synth_surface(n, dim, seed=77 + dim)
+    sp = inputs.species(species)
+    o = dict(dimension=dim, df_mode=df_mode, cell_chunks=3)
+    full, st2 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2))
+    exact, st1 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=1))
+    rel, st0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0))
+    assert np.array_equal(exact, full) and np.array_equal(rel, full)
+    assert st2["n_wave_rows_culled"] == 0 and st0["n_wave_rows_culled"] >= st1["n_wave_rows_culled"]
+    if dim == 3 and species == "urqmd":
+        assert st0["n_wave_rows_culled"] > 1.5 * st1["n_wave_rows_culled"] > 0
+    # without the outflow clamp the accumulators are not monotone: only the exact-zero rule applies, and it is still bit-exact
+    o2 = dict(o, outflow=0)
+    a, sa = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o2, zero_skip=0))
+    b, sb = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o2, zero_skip=2))
+    assert np.array_equal(a, b) and sa["n_wave_rows_culled"] == st1["n_wave_rows_culled"]
+    assert relerr(rel, oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], dict(dimension=dim, df_mode=df_mode))) < TOL
+
+
 @pytest.mark.parametrize("dim", [3, 2])
 def test_device_observables(fx, torch_mod, dim):
     """dN/dy, dN/(2 pi pT dpT dy) and v_n on the device == the reductions of the reference's
