@@ -345,6 +345,24 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             // (q < 2^15, RWD < 64: q * ceil(2^20 / RWD) >> 20 is exact); decoding a flat index with five runtime divisions per
             // element made this kernel VALU-bound (200 instructions per double written).
             const int JT = p.JT, R = p.R;
+            // 3+1D records without baryon slots carry the bounds of the main kernel's unit-level cull in two free header slots;
+            // they are formed here, in the LDS slots that only include_baryon uses
+            const bool unit_bounds = !p.baryon && p.dim3 && JT >= 2;
+            if (unit_bounds) {
+                for (int idx = tid; idx < ncb * p.jtiles; idx += kPrepThreads) {
+                    const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
+                    double v = -1.0e300;
+                    for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_Dp[c * J + min(jt * JT + q2, J - 1)]);
+                    l_V2[idx] = v;
+                }
+                for (int idx = tid; idx < ncb * p.rblocks; idx += kPrepThreads) {
+                    const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
+                    double v = 1.0e300;
+                    for (int q2 = 0; q2 < R; q2++) v = fmin(v, l_Cp[c * K + min(rb * R + q2, K - 1)]);   // padding rows repeat row K-1
+                    l_V1[idx] = v;
+                }
+                __syncthreads();
+            }
             const double psc = pds_scale(p.pds_bound, nullptr);
             const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
             const unsigned rwd_magic = ((1u << 20) + (unsigned)RWD - 1u) / (unsigned)RWD;
@@ -365,6 +383,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                                 const int jj = e >> 2, f = e & 3;
                                 const int j = min(jt * JT + jj, J - 1);
                                 v = f == 0 ? l_B[c * J + j] * psc : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
+                                if (unit_bounds && e == 3) v = l_V2[c * p.jtiles + jt];         // max_j D'_j of the tile: bmax = pT Dmax
+                                else if (unit_bounds && e == 7) v = l_V1[c * p.rblocks + rb];   // min_k C'_k of the unit's rows
                             } else if (e < HDR) {
                                 v = (e == 4 * JT) ? cs[c].alphaB : 0.0;
                             } else {
@@ -613,6 +633,13 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr bool RELCULL = OUTFLOW && REG;
     double cull_thr = -745.2;
     auto process_unit = [&](const double *U) {
+        if constexpr (!BARYON && DIM3 && JT >= 2) {
+            // unit-level cull: earg_k = bmax - mT C'_k <= pT Dmax - mT Cmin for every row of the unit (both from cf_prep; the
+            // roundings are monotone), so if that bound is below the threshold for the whole wave every row would be culled:
+            // skip the unit's header work (JT exponentials) and its R row exponentials as well
+            const double eu = __dsub_rn(__dmul_rn(pT, U[3]), __dmul_rn(mT, U[7]));   // the roundings of the row test, no contraction
+            if (g.zskip && __all(eu < cull_thr)) { n_rows += R; n_dead += R; return; }
+        }
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
         double bmax = -1.0e300;
 #pragma unroll

