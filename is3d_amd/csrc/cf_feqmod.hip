@@ -500,6 +500,12 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
     int n_rows = 0, n_dead = 0;
+    // Accumulator-relative row cull (3+1D with the outflow clamp, g.zskip == 2), as in cf_main_tile: every term of a row is
+    // pds w with 0 <= pds <= pmax = |mT A_k| + max_j |pT B_j| |W_k| and w = z/(1 + sign z) <= 2 z for z <= 1/2,
+    // z = e^(cm - X) <= e^(cm - sqrt(x2lb)); the accumulators only grow and fma(pds, w, acc) == acc when pds w < ulp(acc)/2.
+    // With pmax < 2^ep and min(acc) >= 2^(acc_e - 1): X > cm + (ep - acc_e + 58) ln 2 leaves every accumulator unchanged.
+    constexpr bool RELCULL = DIM3 && OUTFLOW;
+    int acc_e = -100000;   // frexp exponent of a (stale) minimum over the lane's accumulators; refreshed once per batch
     auto process_unit = [&](const double *U, double rn) {
         double pTB[JT], pT2g[JT];
         const double rpT = MODE3 ? rn * pT : pT, rmT = MODE3 ? rn * mT : mT;
@@ -507,12 +513,13 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
         // exact-zero culling: exp(cm - X) == +0 needs X > 745.25 + cm
         const double xcut = BARYON ? 745.25 + __builtin_fmax(cm, 0.0) : 745.25;
         const double x2cut = BARYON ? xcut * xcut : 555400.0;
-        double g_min = 1.0e300;
+        double g_min = 1.0e300, pb_max = 0.0;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
             pTB[jj] = rpT * U[4 * jj + 0];
             pT2g[jj] = pT2 * U[4 * jj + 1];
             if (DIM3) g_min = __builtin_fmin(g_min, pT2g[jj]);
+            if (RELCULL) pb_max = __builtin_fmax(pb_max, __builtin_fabs(pTB[jj]));
         }
         struct Row { double v[RW]; };
         auto fetch = [&](Row &rw, const double *row) {
@@ -529,7 +536,15 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + pT^2 min_j gammaf_j (mT pT >= 0; the row carries min_j betaf_jk):
                 // two instructions per row instead of a minimum per evaluation, and a culled row forms no X^2 at all
                 const double x2lb = __builtin_fma(mTpT, rw.v[3], a + g_min);
-                if (g.zskip && __all(x2lb > x2cut)) { n_dead += 1; return; }   // X > 745.25 (+ cm): exp(cm - X) == +0 for the whole wave-row
+                double x2c = x2cut;                                                 // X > 745.25 (+ cm): exp(cm - X) == +0
+                if (RELCULL && g.zskip == 2) {
+                    const double pmax = __builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA));
+                    const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
+                    const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
+                    const double xcp = __builtin_fmax(xc, 0.0);
+                    x2c = __builtin_fmin(x2cut, xcp * xcp);
+                }
+                if (g.zskip && __all(x2lb > x2c)) { n_dead += 1; return; }
 #pragma unroll
                 for (int jj = 0; jj < JT; jj++) X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
             } else {
@@ -621,6 +636,12 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                     }
                     process_unit(base + u * REC, rn);
                     rn = rn_next;
+                }
+                if (RELCULL && g.zskip == 2) {
+                    double m = acc[0];
+#pragma unroll
+                    for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
+                    acc_e = (m > 1.0e-290) ? __builtin_amdgcn_frexp_exp(m) : -100000;
                 }
             }
 #pragma unroll

@@ -571,7 +571,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 a.RN = P->d_RN.p; a.lane_cls = P->d_lane_cls.p; a.ncls = P->ncls;
                 a.lane_b = P->baryon ? P->d_lane_b.p : nullptr;
                 a.partial = P->d_partial.p; a.stats = P->d_status.p;
-                a.g.upc = P->upc; a.g.zskip = (o.zero_skip != 2); a.g.baryon = 0;
+                a.g.upc = P->upc; a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2); a.g.baryon = 0;
                 a.g.n_cells = nc; a.g.J = P->J; a.g.K = P->K; a.g.Lpad = P->Lpad; a.g.wpb = P->wpb;
                 a.g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
                 a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles; a.g.nch = nch_used;

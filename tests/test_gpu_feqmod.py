@@ -188,6 +188,24 @@ def test_feqmod_with_baryon_parity(fx, dim, flags):
         assert e.value.code == -3 and "cell 3" in str(e.value)
 
 
+@pytest.mark.parametrize("df_mode", [4, 3])
+def test_feqmod_row_culling_changes_no_bit(fx, df_mode):
+    """zero_skip 2 (every row), 1 (rows whose distribution is exactly +0) and 0 (default: also rows that cannot change a bit of
+    any accumulator, 3+1D with the outflow clamp) give the same bits; the default culls most."""
+    cells = synth.synth_surface(2500, 3, seed=88)
+    sp = inputs.species(SP6)
+    fq = fq_for(cells)
+    o = dict(dimension=3, df_mode=df_mode, cell_chunks=3)
+    full, st2 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2), fq=fq)
+    exact, st1 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=1), fq=fq)
+    rel, st0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0), fq=fq)
+    assert np.array_equal(exact, full) and np.array_equal(rel, full)
+    assert st2["n_wave_rows_culled"] == 0 and st0["n_wave_rows_culled"] > 1.5 * st1["n_wave_rows_culled"] > 0
+    a, sa = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0, outflow=0), fq=fq)
+    b, sb = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2, outflow=0), fq=fq)
+    assert np.array_equal(a, b)
+
+
 def test_feqmod_argument_errors(fx):
     cells = synth.synth_surface(4, 3, seed=1)
     fq = fq_for(cells)
