@@ -500,11 +500,11 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
     int n_rows = 0, n_dead = 0;
-    // Accumulator-relative row cull (3+1D with the outflow clamp, g.zskip == 2), as in cf_main_tile: every term of a row is
+    // Accumulator-relative row cull (with the outflow clamp, g.zskip == 2), as in cf_main_tile: every term of a row is
     // pds w with 0 <= pds <= pmax = |mT A_k| + max_j |pT B_j| |W_k| and w = z/(1 + sign z) <= 2 z for z <= 1/2,
     // z = e^(cm - X) <= e^(cm - sqrt(x2lb)); the accumulators only grow and fma(pds, w, acc) == acc when pds w < ulp(acc)/2.
     // With pmax < 2^ep and min(acc) >= 2^(acc_e - 1): X > cm + (ep - acc_e + 58) ln 2 leaves every accumulator unchanged.
-    constexpr bool RELCULL = DIM3 && OUTFLOW;
+    constexpr bool RELCULL = OUTFLOW;
     int acc_e = -100000;   // frexp exponent of a (stale) minimum over the lane's accumulators; refreshed once per batch
     auto process_unit = [&](const double *U, double rn) {
         double pTB[JT], pT2g[JT];
@@ -532,18 +532,18 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             const double W = rw.v[2];
             n_rows += 1;
             double X2[JT];
+            double x2c = x2cut;                                                     // X > 745.25 (+ cm): exp(cm - X) == +0
+            if (RELCULL && g.zskip == 2) {
+                const double pmax = __builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA));
+                const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
+                const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
+                const double xcp = __builtin_fmax(xc, 0.0);
+                x2c = __builtin_fmin(x2cut, xcp * xcp);
+            }
             if constexpr (DIM3) {
                 // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + pT^2 min_j gammaf_j (mT pT >= 0; the row carries min_j betaf_jk):
                 // two instructions per row instead of a minimum per evaluation, and a culled row forms no X^2 at all
                 const double x2lb = __builtin_fma(mTpT, rw.v[3], a + g_min);
-                double x2c = x2cut;                                                 // X > 745.25 (+ cm): exp(cm - X) == +0
-                if (RELCULL && g.zskip == 2) {
-                    const double pmax = __builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA));
-                    const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
-                    const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
-                    const double xcp = __builtin_fmax(xc, 0.0);
-                    x2c = __builtin_fmin(x2cut, xcp * xcp);
-                }
                 if (g.zskip && __all(x2lb > x2c)) { n_dead += 1; return; }
 #pragma unroll
                 for (int jj = 0; jj < JT; jj++) X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
@@ -555,7 +555,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                     X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
                     x2min = __builtin_fmin(x2min, X2[jj]);
                 }
-                if (g.zskip && __all(x2min > x2cut)) { n_dead += 1; return; }
+                if (g.zskip && __all(x2min > x2c)) { n_dead += 1; return; }
             }
             // the reciprocals of RB evaluations share one v_rcp_f64 (rcp_batch, cf_math.h): d = 1 + sign z lies in (1e-3, 2]
 #pragma unroll

@@ -188,6 +188,18 @@ def test_feqmod_with_baryon_parity(fx, dim, flags):
         assert e.value.code == -3 and "cell 3" in str(e.value)
 
 
+def test_feqmod_row_culling_changes_no_bit_2d(fx):
+    cells = synth.synth_surface(120, 2, seed=89)
+    sp = inputs.species("urqmd")
+    fq = fq_for(cells)
+    o = dict(dimension=2, df_mode=4, cell_chunks=2)
+    full, st2 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2), fq=fq)
+    rel, st0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0), fq=fq)
+    exact, st1 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=1), fq=fq)
+    assert np.array_equal(rel, full) and np.array_equal(exact, full)
+    assert st0["n_wave_rows_culled"] > st1["n_wave_rows_culled"] >= 0 == st2["n_wave_rows_culled"]
+
+
 @pytest.mark.parametrize("df_mode", [4, 3])
 def test_feqmod_row_culling_changes_no_bit(fx, df_mode):
     """zero_skip 2 (every row), 1 (rows whose distribution is exactly +0) and 0 (default: also rows that cannot change a bit of
