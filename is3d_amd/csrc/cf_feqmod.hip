@@ -637,7 +637,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                     process_unit(base + u * REC, rn);
                     rn = rn_next;
                 }
-                if (RELCULL && g.zskip == 2) {
+                if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 31) == 31)) {   // as in cf_main_tile: log2(acc) moves slowly
                     double m = acc[0];
 #pragma unroll
                     for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);

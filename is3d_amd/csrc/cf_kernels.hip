@@ -781,7 +781,9 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1];
                 for (int u = 0; u < nu; u++) process_unit(base + u * REC);
-                if (RELCULL && g.zskip == 2) {
+                // the threshold follows log2 of the accumulators, which grow about linearly with the cells seen: refresh after batches
+                // 0, 1, 3, 7, 15, ... and every 32nd
+                if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 31) == 31)) {
                     double m = acc[0];
 #pragma unroll
                     for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
