@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true")
+    ap.add_argument("--no-cull-check", action="store_true", help="skip the untimed bitwise comparison with culling off")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)")
     a = ap.parse_args()
@@ -192,6 +193,17 @@ def main():
         elapsed = float(tt.item())
     st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
     torch.cuda.synchronize()
+    # untimed: the row / unit culling skips only work that cannot change a bit of the spectrum -- check it here against the same
+    # kernels with culling off (zero_skip = 2) on the same resident surface
+    cull_identical = None
+    if world == 1 and not a.no_cull_check:
+        plan2 = api.Plan(sp, grid, df, dict(opts, zero_skip=2), max_cells=max(n_loc, 1), fq=fq)
+        out2 = torch.zeros(plan2.output_size, dtype=torch.float64, device=dev)
+        plan2.execute(n_loc, ptrs, out2.data_ptr(), stream, want_status=False)
+        torch.cuda.synchronize()
+        cull_identical = bool(torch.equal(out, out2))
+        plan2.close()
+        del out2
     # untimed: the shader clock the main kernel runs at (idle probe waves on a private stream while one more step executes)
     clock_ghz = None
     if rank == 0 and not a.no_clock_probe:
@@ -257,7 +269,8 @@ def main():
                    config=dict(workload=wl["text"], cells_total=n_total, cells_per_gpu=n_loc, species=nsp, species_classes_evaluated=st["n_classes"],
                                bins=nbins, evals_per_step=evals_step, kernel=plan.main_kernel_name, kernel_variant=st["kernel_variant"],
                                parallelism="cell-axis shards x%d, one all-reduce of the spectrum" % world if world > 1 else "1 GPU",
-                               workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok),
+                               workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok,
+                               culled_rows_change_no_bit=cull_identical),
                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"]))),
                    roofline=roofline, roofline_valu=rv)
         if world == 1 and not a.no_cpu_baseline:

@@ -7,9 +7,9 @@ OUT=$R/gpurun_out/prof_r01
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-clock-probe"
+BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-clock-probe --no-cull-check"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err || exit 1
-BENCH1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-clock-probe"
+BENCH1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-clock-probe --no-cull-check"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 2
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 3
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $BENCH1 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err || exit 4
