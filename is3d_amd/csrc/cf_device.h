@@ -66,7 +66,8 @@ struct PrepParams {
 
 // ---- tiled stream TS (variants >= 2): what one workgroup of the main kernel streams through LDS ----
 // unit record (REC = 4*JT + R*(4+JT) doubles) for tile (jt, rb) of one cell:
-//   header  jj < JT : {B_j, Dp_j, gamma_j, kappa}                 j = jt*JT + jj (clamped to J-1)
+//   header  jj < JT : {B_j, Dp_j, gamma_j, x}                     j = jt*JT + jj (clamped to J-1); x: 3+1D records without baryon
+//                     slots carry max_j Dp_j of the tile in x of jj = 0 and min_k Cp_k of the unit's rows in x of jj = 1 (unit-level cull)
 //   row     r  < R  : {A_k, Cp_k, alpha_k, W_k, beta_{j0..j0+JT-1,k}}   k = rb*R + r; rows past K are
 //                     neutral padding (A = W = 0, Cp copied from row K-1, alpha = beta = 0)
 // 3+1D: stream s = jt*rblocks + rb, one unit per cell:        TS[(s*n_cells + cell)*REC]
