@@ -102,6 +102,7 @@ struct MainArgs {
     double *partial;
     unsigned long long *stats;   // [2] += wave-rows visited, [3] += wave-rows culled as exactly zero
     MainGeom g;
+    const int32_t *lane_pe = nullptr;   // per lane: exponent pe with max(mT/mTmax, pT/pTmax) < 2^pe (accumulator-relative cull)
 };
 
 }  // namespace is3d

@@ -576,7 +576,7 @@ template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R
 __global__ void __launch_bounds__(512)
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, const double *__restrict__ lane_b, double *__restrict__ partial,
-             unsigned long long *__restrict__ stats, MainGeom g)
+             unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe)
 {
     // unit record layout (cf_device.h); BARYON records carry alpha_B after the header and L_k in every row
     constexpr int HDR = 4 * JT + (BARYON ? 2 : 0);
@@ -635,6 +635,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     // the lane's accumulators, refreshed once per batch.  On config 3 this culls 62 % of the wave-rows instead of 27 %.
     constexpr bool RELCULL = OUTFLOW && REG;
     double cull_thr = -745.2;
+    // the lane's own bound on the scaled p.dsigma: pds <= max(mT/mTmax, pT/pTmax) < 2^pe (pe <= 0, from the plan), in place of pds <= 1
+    const int pe = (RELCULL && lane_pe) ? lane_pe[l] : 0;
     auto process_unit = [&](const double *U) {
         if constexpr (!BARYON && DIM3 && JT >= 2) {
             // unit-level cull: earg_k = bmax - mT C'_k <= pT Dmax - mT Cmin for every row of the unit (both from cf_prep; the
@@ -791,7 +793,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 #pragma unroll
                     for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
                     const int e = __builtin_amdgcn_frexp_exp(m);                     // m = f 2^e, f in [0.5, 1)
-                    cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58) * 0.6931471805599453) : -745.2;
+                    cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
                 }
             }
             if (!EARLY) {
@@ -910,10 +912,10 @@ static void launch_tile_t(const MainArgs &a, hipStream_t st)
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
     if (a.g.baryon)
         hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, true, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
-                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g);
+                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe);
     else
         hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, false, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
-                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g);
+                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe);
 }
 
 // Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.

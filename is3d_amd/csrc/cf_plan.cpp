@@ -81,6 +81,7 @@ struct is3d_plan {
     is3d::BilinearDev bil{};
     bool baryon = false, baryondiff = false;
     DevBuf<int> d_cls;
+    DevBuf<int32_t> d_lane_pe;      // per lane: max(mT/mTmax, pT/pTmax) < 2^pe
     DevBuf<double> d_splx, d_sply[3], d_splc[3];
     DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
     int rblocks = 1, upc = 1;   // row blocks of the tiled stream; units per cell within a stream
@@ -248,6 +249,17 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     HIP_TRY(P->d_lane_b.upload(lb));
     HIP_TRY(P->d_degeneracy.upload(deg));
     HIP_TRY(P->d_cls.upload(lane_sp));
+    {
+        // scaled p.dsigma of a lane: mT |A| + pT |B W| <= max(mT/mTmax, pT/pTmax) (mTmax |A| + pTmax |B W|) <= that factor (cf_pds_bound)
+        std::vector<int32_t> pe(P->Lpad, 0);
+        for (int s = 0; s < P->L; s++) {
+            const double f = std::max(P->mTmax > 0.0 ? mT[s] / P->mTmax : 1.0, P->pTmax > 0.0 ? std::fabs(pT[s]) / P->pTmax : 0.0);
+            int e = 0;
+            (void)std::frexp(f * (1.0 + 1.0e-12), &e);     // f (1 + eps) = m 2^e, m in [0.5, 1): f < 2^e with room for the roundings
+            pe[s] = std::min(e, 0);                        // the clamp keeps the scaled p.dsigma in [0, 1] whatever the lane
+        }
+        HIP_TRY(P->d_lane_pe.upload(pe));
+    }
     HIP_TRY(P->d_cosphi.upload(cosphi));
     HIP_TRY(P->d_sinphi.upload(sinphi));
     HIP_TRY(P->d_kgrid.upload(kgrid));
@@ -623,6 +635,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2);   // 0 default: exact-zero + accumulator-relative culling
             a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p; a.lane_b = P->d_lane_b.p;
             a.g.baryon = P->baryon;
+            a.lane_pe = P->d_lane_pe.p;
             a.partial = P->d_partial.p;
             a.stats = P->d_status.p;
             a.g.n_cells = nc;
