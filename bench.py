@@ -16,8 +16,14 @@ One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   roofline        the contract's object for the dominant kernel, HBM view: algorithmic bytes / kernel time
   roofline_valu   the roofline that actually binds this kernel: fp64 VALU
   cpu_baseline    the CPU oracle (a port of the reference loop) timed on this host, bounded sample
-evals are counted as the reference would execute them (every species); the kernel evaluates one
-representative per distinct (mass, sign) class (75 of 305) -- both counts are in `config`.
+  executed_evals_per_s        `value` counts evals as the reference would execute them (every species, every row); the kernel
+                              evaluates one representative per distinct (mass, sign) class (75 of 305) and skips rows that
+                              cannot change a bit of the result -- this is the rate of integrands actually executed
+  value_incl_transfers, ms_per_step_incl_transfers   the same steps with the H->D upload of the cell arrays and the D->H
+                              download of the spectrum inside the timed region (SURVEY.md 8d's t_kernel), N = 1 only
+  kernel_ms.main_no_cull      the dominant kernel with all culling off (zero_skip = 2): the data-independent floor
+N > 1: the all-reduce is the library's own RCCL call (is3d_plan_execute_allreduce over an is3d_comm); torch.distributed
+only launches the ranks, ships the ncclUniqueId and provides the barrier.
 """
 import argparse
 import json
@@ -134,9 +140,25 @@ def main():
     local = local % torch.cuda.device_count()   # ranks may share a GPU only in a --backend gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm, allreduce_by = None, None
     if world > 1:
         idist.init_process_group(a.backend)
         import torch.distributed as dist
+        if a.backend == "nccl":
+            # the data-path collective is the library's: an is3d_comm (RCCL) built from an id made through the C ABI
+            try:
+                comm = idist.library_comm(local)
+                allreduce_by = "is3d_plan_execute_allreduce (librccl ncclAllReduce called by libis3d_amd.so)"
+            except Exception as e:   # keep the scaling run alive: torch's RCCL group does the same sum
+                print("bench.py rank %d: library communicator unavailable (%s); falling back to torch.distributed.all_reduce" % (rank, e),
+                      file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if comm is not None else 0], device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            allreduce_by = "torch.distributed.all_reduce (%s)" % a.backend
 
     wl = workload(a.workload)
     if a.df_mode:
@@ -164,9 +186,12 @@ def main():
     ms = dict(prep=[], main=[], finalize=[])
 
     def step(record):
-        plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
-        if world > 1:
-            idist.allreduce_spectrum(out)
+        if comm is not None:
+            plan.execute_allreduce(n_loc, ptrs, out.data_ptr(), comm, stream, want_status=False)
+        else:
+            plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
+            if world > 1:
+                idist.allreduce_spectrum(out)
         if record:
             t = plan.timings()   # HIP events recorded on `stream` around each kernel of this step
             ms["prep"].append(t["ms_prep"])
@@ -193,14 +218,44 @@ def main():
         elapsed = float(tt.item())
     st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
     torch.cuda.synchronize()
+    # SURVEY.md 8d's t_kernel: the same steps with the upload of the cell arrays and the download of the spectrum inside the timed
+    # region (pinned host buffers, as a host that cares would hold them); N = 1 only
+    incl = None
+    if world == 1:
+        used = [k for k in synth.CELL_FIELDS if k in ptrs and (k != "eta" or wl["dimension"] == 3)]
+        hpin = {k: torch.from_numpy(cells[k]).pin_memory() for k in used}
+        hout = torch.empty(plan.output_size, dtype=torch.float64).pin_memory()
+
+        def step_incl():
+            for k in used:
+                tens[k].copy_(hpin[k], non_blocking=True)
+            plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
+            hout.copy_(out, non_blocking=True)
+            torch.cuda.synchronize()   # the spectrum is resident on the host
+
+        step_incl()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step_incl()
+        incl = (time.perf_counter() - t1) / a.steps
+        # and the one-shot host entry a maintainer would call from calculate_dN_pTdpTdphidy: pageable host arrays, plan creation and
+        # workspace allocation included
+        t1 = time.perf_counter()
+        _, st_host = api.smooth_spectra(cells, sp, grid, df, opts, fq=fq)
+        host_entry = dict(ms=(time.perf_counter() - t1) * 1e3, ms_h2d=st_host["ms_h2d"], ms_d2h=st_host["ms_d2h"],
+                          ms_kernels=st_host["ms_prep"] + st_host["ms_main"] + st_host["ms_finalize"],
+                          note="is3d_smooth_spectra, one call: plan creation + workspace hipMalloc + pageable H->D + kernels + D->H")
+        del hpin, hout
     # untimed: the row / unit culling skips only work that cannot change a bit of the spectrum -- check it here against the same
     # kernels with culling off (zero_skip = 2) on the same resident surface
-    cull_identical = None
+    cull_identical, ms_no_cull = None, None
     if world == 1 and not a.no_cull_check:
         plan2 = api.Plan(sp, grid, df, dict(opts, zero_skip=2), max_cells=max(n_loc, 1), fq=fq)
+        plan2.set_timing(True)
         out2 = torch.zeros(plan2.output_size, dtype=torch.float64, device=dev)
         plan2.execute(n_loc, ptrs, out2.data_ptr(), stream, want_status=False)
         torch.cuda.synchronize()
+        ms_no_cull = plan2.timings()["ms_main"]   # untimed w.r.t. the metric: the data-independent floor of the dominant kernel
         cull_identical = bool(torch.equal(out, out2))
         plan2.close()
         del out2
@@ -234,14 +289,17 @@ def main():
         # ---- roofline (contract form, HBM): algorithmic bytes of the launch = cell arrays read once + spectrum written once
         ncell_arrays = 18 if wl["dimension"] == 3 else 17
         b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tp):
-            tj = json.load(open(tp)).get(wl["name"])
-            if tj and tj.get("cells") == n_loc:
-                traffic = tj["hbm_bytes_per_launch"]
+        traffic, traffic_source = None, None
+        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC counters need their own rocprofv3 passes: not this run
+            tp = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tp):
+                tj = json.load(open(tp)).get(wl["name"])
+                if tj and tj.get("cells") == n_loc and not a.df_mode and not a.variant:
+                    traffic = tj["hbm_bytes_per_launch"]
+                    traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, not measured in this run)" % tname
+                    break
         roofline = dict(bound="hbm", achieved=b_alg / (ms_main * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=b_alg / (ms_main * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, kernel=plan.main_kernel_name,
+                        frac=b_alg / (ms_main * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, kernel=plan.main_kernel_name,
                         kernel_ms=ms_main, algorithmic_bytes=b_alg,
                         note="not the binding roofline: 1e6 flop/byte; see roofline_valu and DESIGN.md section 5")
         # ---- the binding roofline: fp64 VALU
@@ -263,21 +321,34 @@ def main():
                       integrands_per_launch=unique_evals, integrands_executed=executed_evals, wave_rows_culled_frac=culled,
                       note="flops and issue cycles count executed integrands only: rows whose exp(-p.u/T) is exactly +0 for a "
                            "whole wave are skipped (bitwise-identical result)")
+        # integrands the kernels actually executed per second (rank 0's executed fraction stands for every rank's: same surface statistics)
+        executed_per_s = executed_evals * world * a.steps / elapsed
         res = dict(metric="FO-cell x momentum-bin x species evals/sec", value=value, unit="evals/s", n_gpus=world, steps=a.steps,
                    warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling, vs_baseline=None,
                    dtype="f64", data="synthetic",
+                   value_note="reference-equivalent evals (cells x bins x all %d species, every row) per second; the kernel executes %d species "
+                              "classes and %.1f %% of their rows: executed_evals_per_s" % (nsp, st["n_classes"], 100.0 * (1.0 - culled)),
+                   executed_evals_per_s=executed_per_s, executed_fraction_of_value=executed_per_s / value,
+                   transfers_included=False,
+                   value_incl_transfers=(evals_step / incl) if incl else None,
+                   ms_per_step_incl_transfers=(incl * 1e3) if incl else None,
+                   host_entry=host_entry if incl else None,
+                   allreduce=allreduce_by,
                    config=dict(workload=wl["text"], cells_total=n_total, cells_per_gpu=n_loc, species=nsp, species_classes_evaluated=st["n_classes"],
                                bins=nbins, evals_per_step=evals_step, kernel=plan.main_kernel_name, kernel_variant=st["kernel_variant"],
                                parallelism="cell-axis shards x%d, one all-reduce of the spectrum" % world if world > 1 else "1 GPU",
                                workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok,
                                culled_rows_change_no_bit=cull_identical),
-                   kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"]))),
+                   kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"])), main_no_cull=ms_no_cull),
                    roofline=roofline, roofline_valu=rv)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, fq=fq)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+            res["gpu_over_cpu_executed"] = executed_per_s / res["cpu_baseline"]["value"]   # the CPU port executes every eval
         print(json.dumps(res), flush=True)
     plan.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -235,6 +235,52 @@ int64_t is3d_plan_workspace_bytes(const is3d_plan *plan);
 void is3d_plan_destroy(is3d_plan *plan);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU.  The reference is single-process; its spectrum is a plain sum over freezeout cells
+ * (src/cpp/emissionfunction_smooth_kernels.cpp:363-375: dN_pTdpTdphidy[iS3D] += chunk sum), so the cell axis shards:
+ * contiguous blocks of cells per GPU, no data-path collective, one sum of the n_species x n_bins spectrum at the end.
+ * Two forms:
+ *   (1) one process, several devices: is3d_smooth_spectra_multi -- one host thread + stream per shard;
+ *   (2) one process per GPU (MPI / torchrun style hosts): an is3d_comm (RCCL communicator) + is3d_plan_execute_allreduce.
+ * RCCL (librccl.so.1) is loaded on first use; a host that never asks for it does not need it installed.
+ * --------------------------------------------------------------------------------------------- */
+#define IS3D_REDUCE_ORDERED 0   /* shard spectra are copied to the first shard's device (hipMemcpyPeer) and added in shard order
+                                   by a device kernel: ((s0 + s1) + s2) + ... -- bitwise reproducible for a given shard count,
+                                   whatever the devices; a device may be listed more than once */
+#define IS3D_REDUCE_RCCL 1      /* ncclAllReduce(ncclDouble, ncclSum) over a communicator of the listed devices (distinct) */
+
+/* Host entry over several devices: what is3d_smooth_spectra / is3d_smooth_spectra_feqmod (fq != NULL: df_mode 3, 4) compute,
+ * with the cells split into n_devices contiguous shards (sizes differ by at most one cell), shard s on devices[s].
+ *   devices == NULL: ordinals 0 .. n_devices-1;  n_devices <= 0: every visible device.  opts->device is ignored.
+ *   status (may be NULL): counters summed over the shards, bad_cell = lowest global cell index, ms_prep / ms_main / ms_finalize /
+ *   ms_h2d = the slowest shard's, ms_d2h = reduction + download;  shard_status (may be NULL): n_devices entries, one per shard
+ *   (bad_cell is shard-local there).
+ * All shards run concurrently.  With one shard and IS3D_REDUCE_ORDERED this is is3d_smooth_spectra on devices[0]. */
+int is3d_smooth_spectra_multi(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                              const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts,
+                              const int32_t *devices, int32_t n_devices, int32_t reduce, double *dN_out,
+                              is3d_status *status, is3d_status *shard_status);
+/* shard [*lo, *hi) of `rank` among n_ranks contiguous shards of n_cells cells (the split is3d_smooth_spectra_multi uses) */
+int is3d_shard_bounds(int64_t n_cells, int32_t rank, int32_t n_ranks, int64_t *lo, int64_t *hi);
+
+/* RCCL communicator for one-process-per-GPU hosts.  Rank 0 calls is3d_comm_unique_id and ships the 128 bytes to the other
+ * ranks by whatever the host already has (MPI_Bcast, a torch.distributed store, a file); then every rank calls
+ * is3d_comm_create (collective: ncclCommInitRank) with its HIP device. */
+typedef struct is3d_comm is3d_comm;
+#define IS3D_COMM_ID_BYTES 128
+int is3d_comm_unique_id(uint8_t id[IS3D_COMM_ID_BYTES]);
+int is3d_comm_create(is3d_comm **comm, const uint8_t id[IS3D_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int32_t device);
+int is3d_comm_rank(const is3d_comm *comm, int32_t *rank, int32_t *n_ranks);
+/* in-place sum over all ranks of n doubles at dN_dev (DEVICE pointer on the communicator's device), asynchronous on hip_stream:
+ * the "+=" of smooth_kernels.cpp:375 across shards (ncclAllReduce, ncclDouble, ncclSum). */
+int is3d_comm_allreduce(is3d_comm *comm, double *dN_dev, int64_t n, void *hip_stream);
+void is3d_comm_destroy(is3d_comm *comm);
+/* is3d_plan_execute on this rank's shard of the cells, then is3d_comm_allreduce of dN_out on the same stream: every rank ends
+ * with the spectrum of the whole surface.  comm == NULL: plain is3d_plan_execute.  opts.accumulate must be 0 with a
+ * communicator (the old contents would be summed n_ranks times). */
+int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *shard, double *dN_out, is3d_comm *comm, void *hip_stream,
+                                is3d_status *status);
+
+/* ---------------------------------------------------------------------------------------------
  * Anisotropic hydro (VAH, P_L matching): replaces EmissionFunctionArray::calculate_dN_pTdpTdphidy_VAH_PL
  * (src/cpp/emissionfunction.h, src/cpp/emissionfunction_smooth_kernels.cpp:2140-2393).  The reference never calls it (call
  * site commented out, emissionfunction.cpp:1650-1654) and src/cpp never loads the VAH coefficient tables: the per-cell
@@ -347,6 +393,12 @@ typedef struct {
 
 int is3d_run_particlization(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
                             is3d_run_result *result);
+/* The same on an explicit device list (operation 1: the cells are sharded over the devices as is3d_smooth_spectra_multi does;
+ * operation 2 samples on devices[0]).  devices == NULL && n_devices > 0: ordinals 0 .. n_devices-1.  n_devices <= 0 is what
+ * is3d_run_particlization and the command line tool do: the environment decides -- IS3D_DEVICES = "0,2,3" | "all" (default:
+ * every visible device), IS3D_REDUCE = "ordered" (default) | "rccl". */
+int is3d_run_particlization_on(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
+                               const int32_t *devices, int32_t n_devices, int32_t reduce, is3d_run_result *result);
 void is3d_run_result_free(is3d_run_result *result);
 
 /* ---------------------------------------------------------------------------------------------

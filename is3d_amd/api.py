@@ -97,7 +97,12 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
            "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
-           "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah"]
+           "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
+           "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
+           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on"]
+
+REDUCE_ORDERED, REDUCE_RCCL = 0, 1
+COMM_ID_BYTES = 128
 
 
 class Is3dError(RuntimeError):
@@ -170,6 +175,17 @@ def load():
     L.is3d_gla_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, C.c_int64]
     L.is3d_write_results.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, _dp, _dp,
                                      C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]
+    L.is3d_smooth_spectra_multi.argtypes = [C.POINTER(Cells), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
+                                            C.POINTER(FeqmodTables), C.POINTER(Options), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                            _dp, C.POINTER(Status), C.POINTER(Status)]
+    L.is3d_shard_bounds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.is3d_comm_unique_id.argtypes = [C.c_char_p]
+    L.is3d_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+    L.is3d_comm_rank.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.is3d_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.is3d_comm_destroy.argtypes = [C.c_void_p]
+    L.is3d_comm_destroy.restype = None
+    L.is3d_plan_execute_allreduce.argtypes = [C.c_void_p, C.POINTER(Cells), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Status)]
     _LIB = L
     return L
 
@@ -300,6 +316,74 @@ def smooth_spectra(cells, species, grid, df, opts=None, out=None, fq=None):
     return out, st.as_dict()
 
 
+def shard_bounds(n_cells, rank, n_ranks):
+    """is3d_shard_bounds: the contiguous cell shard [lo, hi) of `rank` (what is3d_smooth_spectra_multi uses)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    _check(load().is3d_shard_bounds(int(n_cells), int(rank), int(n_ranks), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def smooth_spectra_multi(cells, species, grid, df, opts=None, devices=None, reduce=REDUCE_ORDERED, out=None, fq=None):
+    """is3d_smooth_spectra_multi: the host entry with the cells sharded over `devices` (list of HIP ordinals, one shard per
+    entry, an ordinal may repeat; None = every visible device).  Returns (dN, aggregate status dict, [per-shard status dicts])."""
+    L = load()
+    sps, gs, ds, os_, nout, keep = _pack_common(species, grid, df, opts)
+    n = len(cells["tau"])
+    cs = Cells()
+    cs.n_cells = n
+    held = []
+    for f in CELL_FIELDS:
+        a = cells.get(f)
+        if a is not None:
+            a = _f64(a)
+            assert a.shape == (n,), f
+            held.append(a)
+            setattr(cs, f, a.ctypes.data)
+    if out is None:
+        out = np.zeros(nout)
+    assert out.dtype == np.float64 and out.size == nout and out.flags.c_contiguous
+    nd = len(devices) if devices is not None else 0
+    dv = (C.c_int32 * nd)(*[int(d) for d in devices]) if nd else None
+    st = Status()
+    sst = (Status * max(nd, L.is3d_device_count(), 1))()
+    fqs = _pack_feqmod(fq, keep) if fq is not None else None
+    rc = L.is3d_smooth_spectra_multi(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(fqs) if fqs is not None else None,
+                                     C.byref(os_), dv, nd, int(reduce), _p(out), C.byref(st), sst)
+    _check(rc)
+    return out, st.as_dict(), [sst[i].as_dict() for i in range(nd or L.is3d_device_count())]
+
+
+class Comm:
+    """is3d_comm: the library's RCCL communicator for one-process-per-GPU hosts.  Rank 0 makes the id (Comm.unique_id()),
+    the host ships the 128 bytes to the other ranks, every rank constructs Comm(id, n_ranks, rank, device)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(load().is3d_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, n_ranks, rank, device=-1):
+        assert len(uid) == COMM_ID_BYTES
+        self._h = C.c_void_p()
+        _check(load().is3d_comm_create(C.byref(self._h), C.create_string_buffer(uid, COMM_ID_BYTES), int(n_ranks), int(rank), int(device)))
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def allreduce(self, dev_ptr, n, stream=0):
+        _check(load().is3d_comm_allreduce(self._h, C.c_void_p(int(dev_ptr)), int(n), C.c_void_p(int(stream or 0))))
+
+    def close(self):
+        if self._h:
+            load().is3d_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def probe_shader_clock(seconds=0.3, device=0):
     """Shader clock in GHz averaged over `seconds`, sampled by idle waves on a private stream (0.0: the device's two counters
     tick at the same rate, nothing to measure).  Call it from a second thread while a kernel runs to price that kernel."""
@@ -343,6 +427,21 @@ class Plan:
         st = Status()
         rc = load().is3d_plan_execute(self._h, C.byref(cs), C.c_void_p(int(out_ptr)), C.c_void_p(int(stream or 0)),
                                       C.byref(st) if want_status else None)
+        _check(rc)
+        return st.as_dict() if want_status else None
+
+    def execute_allreduce(self, n_cells, cell_ptrs, out_ptr, comm=None, stream=0, want_status=True):
+        """is3d_plan_execute_allreduce: execute on this rank's shard, then the RCCL all-reduce of the spectrum over `comm`
+        (a Comm, or None for a single rank) on the same stream."""
+        cs = Cells()
+        cs.n_cells = int(n_cells)
+        for f in CELL_FIELDS:
+            p = cell_ptrs.get(f)
+            if p:
+                setattr(cs, f, int(p))
+        st = Status()
+        rc = load().is3d_plan_execute_allreduce(self._h, C.byref(cs), C.c_void_p(int(out_ptr)), comm._h if comm is not None else None,
+                                                C.c_void_p(int(stream or 0)), C.byref(st) if want_status else None)
         _check(rc)
         return st.as_dict() if want_status else None
 

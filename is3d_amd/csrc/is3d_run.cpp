@@ -94,7 +94,46 @@ static void surface_averages(const is3d_cells *c, double avg[5])
     for (int k = 0; k < 5; k++) avg[k] = den > 0.0 ? num[k] / den : 0.0;
 }
 
-static int run_impl(const is3d_cells *mem, const double *mem_x, const double *mem_y, int variant, is3d_run_result *res)
+// devices of the run: an explicit list, else the environment (IS3D_DEVICES = "0,2,3" | "all"; IS3D_REDUCE = "ordered" | "rccl"),
+// else every visible device
+struct RunDevices {
+    std::vector<int32_t> list;   // empty: all visible
+    int32_t reduce = IS3D_REDUCE_ORDERED;
+};
+
+static int parse_run_devices(const int32_t *devices, int32_t n_devices, int32_t reduce, RunDevices &rd)
+{
+    rd.reduce = reduce;
+    if (devices && n_devices > 0) {
+        rd.list.assign(devices, devices + n_devices);
+        return IS3D_OK;
+    }
+    if (n_devices > 0) {
+        for (int32_t i = 0; i < n_devices; i++) rd.list.push_back(i);
+        return IS3D_OK;
+    }
+    if (const char *e = getenv("IS3D_REDUCE")) {
+        if (!strcmp(e, "rccl")) rd.reduce = IS3D_REDUCE_RCCL;
+        else if (!strcmp(e, "ordered")) rd.reduce = IS3D_REDUCE_ORDERED;
+        else return die("IS3D_REDUCE = %s: ordered | rccl", e);
+    }
+    if (const char *e = getenv("IS3D_DEVICES")) {
+        if (strcmp(e, "all") && *e) {
+            const char *p = e;
+            while (*p) {
+                char *end = nullptr;
+                long v = strtol(p, &end, 10);
+                if (end == p || v < 0) return die("IS3D_DEVICES = %s: a comma separated list of HIP device ordinals, or all", e);
+                rd.list.push_back((int32_t)v);
+                p = (*end == ',') ? end + 1 : end;
+                if (*end && *end != ',') return die("IS3D_DEVICES = %s: a comma separated list of HIP device ordinals, or all", e);
+            }
+        }
+    }
+    return IS3D_OK;
+}
+
+static int run_impl(const is3d_cells *mem, const double *mem_x, const double *mem_y, int variant, const RunDevices &rd, is3d_run_result *res)
 {
     printf("iS3D-amd: MI355X-native smooth Cooper-Frye spectra (%s)\n", is3d_version());
     double v;
@@ -229,7 +268,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     opts.dimension = dimension; opts.df_mode = df_mode; opts.include_baryon = include_baryon;
     opts.include_bulk_deltaf = include_bulk; opts.include_shear_deltaf = include_shear; opts.include_baryondiff_deltaf = include_diff;
     opts.regulate_deltaf = regulate; opts.outflow = outflow;
-    opts.accumulate = 0; opts.device = -1; opts.kernel_variant = variant;
+    opts.accumulate = 0; opts.device = rd.list.empty() ? -1 : rd.list[0]; opts.kernel_variant = variant;
     const int ny_eff = (dimension == 2) ? 1 : (int)y.size();
     std::vector<double> dN(mcid.size() * pT.size() * phi.size() * (size_t)ny_eff, 0.0);
     if (operation == 2) {
@@ -375,11 +414,21 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         fq.root2 = groot.data() + 2 * (size_t)n_pts; fq.weight2 = gweight.data() + 2 * (size_t)n_pts;
         fq.n_pdg = npdg; fq.pdg_mass = pmass.data(); fq.pdg_degeneracy = pg.data(); fq.pdg_sign = ps.data();
         fq.T_avg = T_avg; fq.deta_min = deta_min; fq.mass_pion0 = mass_pion0;
-        rc = is3d_smooth_spectra_feqmod(&cells, &sp, &grid, &df, &fq, &opts, dN.data(), &st);
+        rc = is3d_smooth_spectra_multi(&cells, &sp, &grid, &df, &fq, &opts, rd.list.empty() ? nullptr : rd.list.data(), (int32_t)rd.list.size(),
+                                       rd.reduce, dN.data(), &st, nullptr);
     } else {
-        rc = is3d_smooth_spectra(&cells, &sp, &grid, &df, &opts, dN.data(), &st);
+        rc = is3d_smooth_spectra_multi(&cells, &sp, &grid, &df, nullptr, &opts, rd.list.empty() ? nullptr : rd.list.data(), (int32_t)rd.list.size(),
+                                       rd.reduce, dN.data(), &st, nullptr);
     }
-    if (rc) DIE("is3d_smooth_spectra failed (%d): %s", rc, is3d_last_error());
+    {
+        const int nd = rd.list.empty() ? is3d_device_count() : (int)rd.list.size();
+        printf("devices: %d (cell-axis shards of ~%lld cells%s)\n", nd, (long long)((n_cells + nd - 1) / std::max(nd, 1)),
+               nd > 1 ? (rd.reduce == IS3D_REDUCE_RCCL ? ", RCCL all-reduce of the spectrum" : ", shard-ordered device sum of the spectrum") : "");
+    }
+    if (rc) {
+        const std::string msg = is3d_last_error();
+        DIE("is3d_smooth_spectra failed (%d): %s", rc, msg.c_str());
+    }
     if (feqmod) printf("\nfeqmod breaks down for %lld cells\n\n", (long long)st.n_cells_breakdown);   // smooth_kernels.cpp:989
     double t2 = now_s();
     if (is3d_write_results("results", dimension, sp.n, mcid.data(), grid.n_pT, pT.data(), pTw.data(), grid.n_phi, phi.data(),
@@ -407,8 +456,16 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
 extern "C" int is3d_run_particlization(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
                                        is3d_run_result *result)
 {
+    return is3d_run_particlization_on(surface, x, y, kernel_variant, nullptr, 0, IS3D_REDUCE_ORDERED, result);
+}
+
+extern "C" int is3d_run_particlization_on(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
+                                          const int32_t *devices, int32_t n_devices, int32_t reduce, is3d_run_result *result)
+{
     if (result) memset(result, 0, sizeof *result);
-    return run_impl(surface, x, y, kernel_variant, result);
+    RunDevices rd;
+    if (int rc = parse_run_devices(devices, n_devices, reduce, rd)) return rc;
+    return run_impl(surface, x, y, kernel_variant, rd, result);
 }
 
 extern "C" void is3d_run_result_free(is3d_run_result *r)

@@ -40,6 +40,19 @@ def init_process_group(backend=None):
     return rank, world, local
 
 
+def library_comm(device):
+    """The library's own RCCL communicator (is3d_comm_*, include/is3d_amd.h) over the ranks of the job torchrun started:
+    rank 0 makes the ncclUniqueId through the C ABI, the 128 bytes travel through the already-initialised torch.distributed
+    group (any backend: this is rendezvous plumbing, not the data path), every rank joins with its HIP device.  After this
+    the spectrum all-reduce is is3d_plan_execute_allreduce / Comm.allreduce -- RCCL called by the library, no torch involved."""
+    import torch.distributed as dist
+    from . import api
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [api.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return api.Comm(box[0], world, rank, device)
+
+
 def allreduce_spectrum(spectrum):
     """In-place sum of the flat fp64 spectrum over all ranks (a no-op for a single process).
     All terms are >= 0 when outflow = 1, so the reduction order only moves the last bits."""

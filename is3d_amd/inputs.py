@@ -1,13 +1,13 @@
 """Input bundles for tests/bench on boxes without the reference tree: grids, the mu_B = 0 rows of the
-urqmd delta-f coefficient tables and the hadron list, from tests/golden/inputs_urqmd.json (built by
-tests/golden/make_inputs.py from the reference's data files)."""
+urqmd delta-f coefficient tables and the hadron list, from is3d_amd/data/inputs_urqmd.json (package data, built by
+tools/make_inputs.py from the reference's data files)."""
 import json
 import os
 
 import numpy as np
 
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIXTURE = os.path.join(_ROOT, "tests", "golden", "inputs_urqmd.json")
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+FIXTURE = os.path.join(_DATA, "inputs_urqmd.json")
 _CACHE = None
 
 
@@ -38,7 +38,7 @@ DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "bet
 def df_tables_full():
     """df_tables() plus the full (mu_B, T) grids of all ten coefficient tables (include_baryon = 1):
     keys T, muB and one [n_muB][n_T] array per name in DF_NAMES_2D under key "2d"."""
-    z = np.load(os.path.join(_ROOT, "tests", "golden", "df_urqmd_full.npz"))
+    z = np.load(os.path.join(_DATA, "df_urqmd_full.npz"))
     d = df_tables()
     assert np.array_equal(d["T"], z["T"])
     d["muB"] = z["muB"].copy()

@@ -95,3 +95,26 @@ def test_product_never_touches_the_oracle():
     for f in os.listdir(os.path.join(ROOT, "tools")):
         if f.endswith((".py", ".sh")):
             assert not imp.search(open(os.path.join(ROOT, "tools", f), errors="ignore").read()), f
+
+
+def test_shard_bounds_and_multi_entry_argument_checks(fx):
+    """is3d_shard_bounds is the split bench.py / is3d_amd.dist use; the multi-device entry validates before touching a device
+    and, like every compute entry, has no CPU path."""
+    from is3d_amd import dist as idist
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            assert [api.shard_bounds(n, r, w) for r in range(w)] == [idist.shard_bounds(n, r, w) for r in range(w)]
+    with pytest.raises(api.Is3dError):
+        api.shard_bounds(10, 2, 2)
+    cells = synth.synth_surface(4, 3)
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], dict(dimension=3, df_mode=1), devices=[0], reduce=7)
+    assert e.value.code == api.IS3D_EINVAL
+    if api.load().is3d_device_count() == 0:
+        with pytest.raises(api.Is3dError) as e:
+            api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], dict(dimension=3, df_mode=1), devices=[0, 0])
+        assert e.value.code == api.IS3D_ENODEVICE
+    else:
+        with pytest.raises(api.Is3dError) as e:
+            api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], dict(dimension=3, df_mode=1), devices=[0, 99])
+        assert e.value.code == api.IS3D_EINVAL

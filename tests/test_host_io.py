@@ -324,7 +324,7 @@ def test_writers_format(tmp_path):
 
 @pytest.mark.reference
 def test_readers_on_the_reference_files():
-    """The shipped data files parse to the fixture the GPU box uses (tests/golden/inputs_urqmd.json)."""
+    """The shipped data files parse to the fixture the GPU box uses (is3d_amd/data/inputs_urqmd.json)."""
     g = inputs.grid()
     for key, rel in [("pT", "tables/pT_gauss_legendre_table.dat"), ("phi", "tables/phi_gauss_legendre_table.dat"),
                      ("y", "tables/y_trapezoid_table_21pt.dat"), ("eta", "tables/eta/eta_trapezoid_table_241pt.dat")]:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build tests/golden/inputs_urqmd.json -- the INPUT DATA the hot path needs on a box that has no
+"""Build is3d_amd/data/inputs_urqmd.json (+ df_urqmd_full.npz) -- the INPUT DATA the hot path needs on a box that has no
 /root/reference (GPU box, bench.py, smoke()).
 
 It is data only: quadrature nodes/weights, the mu_B = 0 rows of the delta-f coefficient tables and
@@ -11,14 +11,14 @@ with small independent Python parsers that follow the reference readers' semanti
   deltaf_coefficients/vh/urqmd/*.dat        Deltaf_Data::load_df_coefficient_data (src/cpp/deltafReader.cpp:120-197)
   PDG/pdg-urqmd_v3.3+.dat                   PDG_Data::read_resonances_conventional (src/cpp/readindata.cpp:1440-1568)
 
-Run here (container) only:  python tests/golden/make_inputs.py
+Run here (container) only:  python tools/make_inputs.py
 """
 import json
 import os
 import sys
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "inputs_urqmd.json")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "is3d_amd", "data", "inputs_urqmd.json")
 
 
 def read_block(path):
@@ -79,7 +79,7 @@ def read_pdg(path):
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (run in the build container)")
-    d = {"source": "derekeverett/iS3D data files (MIT), parsed by tests/golden/make_inputs.py", "hbarC": 0.197327053}
+    d = {"source": "derekeverett/iS3D data files (MIT), parsed by tools/make_inputs.py", "hbarC": 0.197327053}
     grids = {}
     for key, rel in [("pT", "tables/pT_gauss_legendre_table.dat"), ("phi", "tables/phi_gauss_legendre_table.dat"),
                      ("y", "tables/y_trapezoid_table_21pt.dat"), ("eta", "tables/eta/eta_trapezoid_table_241pt.dat")]:
