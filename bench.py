@@ -216,6 +216,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    plan.check(stream)   # the timed steps ran without status read-back: any cell outside the coefficient table surfaces here
     st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
     torch.cuda.synchronize()
     # SURVEY.md 8d's t_kernel: the same steps with the upload of the cell arrays and the download of the spectrum inside the timed

@@ -143,7 +143,13 @@ typedef struct {
                                            (delta-f tile kernel with outflow && regulate_deltaf); 2: off */
     int32_t waves_per_group;            /* 0 default | 2, 4, 8: lane-waves per workgroup of the tile kernel (they share
                                            one LDS-staged coefficient stream) */
-    int32_t reserved[5];
+    int32_t reference_bilinear_indexing; /* include_baryon = 1 only.  0 (default): the (T, mu_B) coefficient tables are read [imuB][iT], as they
+                                           are stored.  1: bug-compatible with the reference's calculate_bilinear, which reads f_data[iT][imuB]
+                                           (deltafReader.cpp:404-407) from arrays allocated [points_muB][points_T] (:36-61): the value at
+                                           (mu_B row iT, T column imuB).  Reproduced wherever that read is inside the allocation
+                                           (iT + 1 < n_muB, i.e. T < T[n_muB - 1] = 0.18 GeV on the shipped 101 x 81 grids); a live cell
+                                           beyond it gives IS3D_EDOMAIN (the reference reads past its row pointers there: undefined) */
+    int32_t reserved[4];
 } is3d_options;
 
 typedef struct {
@@ -205,6 +211,12 @@ int64_t is3d_plan_output_size(const is3d_plan *plan);
  * when status != NULL (then the stream is synchronised). */
 int is3d_plan_execute(is3d_plan *plan, const is3d_cells *cells, double *dN_out, void *hip_stream,
                       is3d_status *status);
+/* Domain errors of executes that ran with status == NULL (fully asynchronous: nothing is read back, a cell whose T leaves the
+ * coefficient table is left out of the spectrum and the call returns IS3D_OK).  The plan keeps the lowest offending cell index of
+ * all executes since the last check; this call synchronises hip_stream, returns IS3D_EDOMAIN (and *bad_cell, index within its
+ * execute's cells; may be NULL) if there was one, and clears the record.  The reference aborts on such a cell (GSL domain error /
+ * exit(-1)): a caller that skips the status must ask here before trusting the spectrum. */
+int is3d_plan_check(is3d_plan *plan, void *hip_stream, int64_t *bad_cell);
 /* Derived observables from a device-resident spectrum of this plan's shape (what the reference's writers reduce on
  * the host: emissionfunction.cpp:639-677, :729-772, :1053-1136).  pT_w / phi_w: HOST arrays of the quadrature weights
  * (column 2 of the pT / phi tables).  Outputs are DEVICE arrays, any may be NULL:
@@ -355,6 +367,21 @@ typedef struct {
 int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
                           const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
                           int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats);
+
+/* EmissionFunctionArray::calculate_total_yield (src/cpp/emissionfunction_sampling_kernels.cpp:653-830; call sites
+ * emissionfunction.cpp:1527, :1591): the mean particle yield of the surface, from which an oversampled run takes its number of
+ * events, Nevents = min(ceil(min_num_hadrons / |yield|), max_num_samples) (emissionfunction.cpp:1524-1533).  Species densities
+ * as Deltaf_Data::compute_particle_densities forms them at the surface averages (deltafReader.cpp:536-650), per-cell terms as
+ * estimate_mean_particle_number (:200-236); 2+1D: times 2 y_cut (:822-826).  Deterministic (no random numbers).
+ * in: n_gla, root1, weight1, y_cut and feqmod (the alpha = 2 nodes for every df_mode; df_mode 4 also the PDG list and T_avg of
+ * the Jonah tables).  opts: dimension, df_mode, include_bulk_deltaf, include_baryon, include_baryondiff_deltaf, device.
+ * densities (may be NULL): 3 * species->n doubles {Equilibrium_Density, Bulk_Density, Diffusion_Density} (emissionfunction.cpp:1289-1306). */
+typedef struct {
+    double T, E, P, muB, nB;            /* Plasma::load_thermodynamic_averages: the five lines of average_thermodynamic_quantities.dat */
+    const double *root3, *weight3;      /* Gauss-Laguerre alpha = 3 (df_mode 1: J30, J31, deltafReader.cpp:596-600); NULL otherwise */
+} is3d_yield_inputs;
+int is3d_total_yield(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df, const is3d_sampler_inputs *in,
+                     const is3d_yield_inputs *avg, const is3d_options *opts, double *mean_yield, double *densities);
 
 /* write_particle_list_OSC (src/cpp/emissionfunction.cpp:863-901): results/particle_list_osc.dat, "# N" per non-empty event
  * then "mcid t x y z E px py pz" rows; particles ordered by event. */

@@ -78,7 +78,8 @@ class Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
                                          "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
                                          "accumulate", "device", "kernel_variant", "cell_chunks"]] + \
-               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("zero_skip", C.c_int32), ("waves_per_group", C.c_int32), ("reserved", C.c_int32 * 5)]
+               [("workspace_bytes", C.c_int64), ("collapse_species", C.c_int32), ("zero_skip", C.c_int32), ("waves_per_group", C.c_int32), ("reference_bilinear_indexing", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class Status(C.Structure):
@@ -99,7 +100,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
            "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
-           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on"]
+           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
 COMM_ID_BYTES = 128
@@ -207,7 +208,8 @@ DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "bet
 
 DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
                     include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1, accumulate=0, device=-1,
-                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0, zero_skip=0, waves_per_group=0)
+                    kernel_variant=0, cell_chunks=0, workspace_bytes=0, collapse_species=0, zero_skip=0, waves_per_group=0,
+                    reference_bilinear_indexing=0)
 
 
 def _pack_common(species, grid, df, opts):
@@ -451,6 +453,13 @@ class Plan:
         _check(load().is3d_plan_observables(self._h, C.c_void_p(int(dN_ptr)), _p(pw), _p(fw), C.c_void_p(int(dndy_ptr or 0)),
                                             C.c_void_p(int(spec2pi_ptr or 0)), C.c_void_p(int(vn_ptr or 0)), C.c_void_p(int(stream or 0))))
 
+    def check(self, stream=0):
+        """is3d_plan_check: raises Is3dError(IS3D_EDOMAIN) if an execute since the last check (status-less ones included) met a
+        cell outside the coefficient table; synchronises the stream."""
+        bad = C.c_int64(-1)
+        load().is3d_plan_check.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        _check(load().is3d_plan_check(self._h, C.c_void_p(int(stream or 0)), C.byref(bad)))
+
     def timings(self):
         st = Status()
         _check(load().is3d_plan_timings(self._h, C.byref(st)))
@@ -577,6 +586,44 @@ def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_c
     d = st.as_dict()
     d["n_particles"] = int(cnt.value)
     return out[:min(int(cnt.value), int(capacity))], d
+
+
+class YieldInputs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ["T", "E", "P", "muB", "nB"]] + [("root3", _dp), ("weight3", _dp)]
+
+
+def total_yield(cells, species, df, gla, avg5, opts=None, y_cut=0.5, fq=None):
+    """is3d_total_yield (the drop-in for calculate_total_yield): mean particle yield of the surface.  gla: dict with root1, weight1,
+    root2, weight2 (+ root3, weight3 for df_mode 1), e.g. is3d_amd.inputs.feqmod_tables(); avg5 = (T, E, P, muB, nB) surface
+    averages; fq: the feqmod tables for df_mode 4 (defaults to gla).  Returns (yield, densities[3][n_species])."""
+    L = load()
+    grid_dummy = dict(pT=[1.0], phi=[0.0], y=[0.0], eta=[0.0], eta_w=[1.0])
+    sps, _, ds, os_, _, keep = _pack_common(species, grid_dummy, df, opts)
+    n = len(cells["tau"])
+    cs = Cells()
+    cs.n_cells = n
+    held = []
+    for f in CELL_FIELDS:
+        a = cells.get(f)
+        if a is not None:
+            a = _f64(a)
+            assert a.shape == (n,), f
+            held.append(a)
+            setattr(cs, f, a.ctypes.data)
+    r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
+    fqs = _pack_feqmod(fq if fq is not None else dict(gla, T_avg=gla.get("T_avg", avg5[0]), deta_min=gla.get("deta_min", 1e-5),
+                                                      mass_pion0=gla.get("mass_pion0", 0.138)), keep)
+    si = SamplerInputs(1, len(r1), 0, float(y_cut), 0, None, None, _p(r1), _p(w1), C.pointer(fqs), 0, 0, 0.0, 0.0, 0.0)
+    r3 = _f64(gla["root3"]) if "root3" in gla else None
+    w3 = _f64(gla["weight3"]) if "weight3" in gla else None
+    yi = YieldInputs(float(avg5[0]), float(avg5[1]), float(avg5[2]), float(avg5[3]), float(avg5[4]), _p(r3) if r3 is not None else None,
+                     _p(w3) if w3 is not None else None)
+    out = C.c_double(0.0)
+    dens = np.zeros((3, sps.n))
+    L.is3d_total_yield.argtypes = [C.POINTER(Cells), C.POINTER(Species), C.POINTER(DfTables), C.POINTER(SamplerInputs), C.POINTER(YieldInputs),
+                                   C.POINTER(Options), C.POINTER(C.c_double), _dp]
+    _check(L.is3d_total_yield(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(yi), C.byref(os_), C.byref(out), _p(dens)))
+    return out.value, dens
 
 
 def write_particle_list_osc(path, n_events, particles, mc_id):

@@ -36,6 +36,7 @@ struct BilinearDev {     // full (mu_B, T) coefficient grids for include_baryon 
     int nT, nB;
     const double *T, *muB;
     const double *tab[5];  // df_mode 1: c0 c1 c2 c3 c4 ; df_mode 2: F G betabulk betaV betapi ; each [nB][nT]
+    int swap;              // opts.reference_bilinear_indexing: read tab[iT][imuB] like the reference's calculate_bilinear (deltafReader.cpp:404-407)
 };
 
 struct PrepParams {

@@ -972,6 +972,23 @@ __global__ void __launch_bounds__(64) cf_clock_probe(unsigned long long ref_tick
     }
 }
 
+// Domain-error flags of an execute (status[0]: first cell outside the coefficient table, status[7]: first cell whose p.u/T can
+// exceed 1e9) folded into the plan's sticky pair, so that a caller that passes status == NULL still learns of them at the next
+// is3d_plan_check (the reference aborts on such a cell; neutralising it silently would return an incomplete spectrum).
+__global__ void cf_fold_status(const unsigned long long *__restrict__ status, unsigned long long *__restrict__ sticky)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (status[0] < sticky[0]) sticky[0] = status[0];
+        if (status[7] < sticky[1]) sticky[1] = status[7];
+    }
+}
+
+hipError_t launch_fold_status(const unsigned long long *status, unsigned long long *sticky, hipStream_t st)
+{
+    hipLaunchKernelGGL(cf_fold_status, dim3(1), dim3(64), 0, st, status, sticky);
+    return hipGetLastError();
+}
+
 hipError_t launch_clock_probe(unsigned long long ref_ticks, unsigned long long *out, hipStream_t st)
 {
     hipLaunchKernelGGL(cf_clock_probe, dim3(8), dim3(64), 0, st, ref_ticks, out);

@@ -19,4 +19,5 @@ hipError_t launch_observables(const double *dN, const double *phi_w, const doubl
                               const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
                               int ny, hipStream_t st);
 hipError_t launch_clock_probe(unsigned long long ref_ticks, unsigned long long *out /* 2 x 8 */, hipStream_t st);
+hipError_t launch_fold_status(const unsigned long long *status /* [8] */, unsigned long long *sticky /* [2] */, hipStream_t st);
 }  // namespace is3d

@@ -189,21 +189,32 @@ __device__ __forceinline__ double sqrt_g1(double x)
     return __builtin_fma(g, r, g);
 }
 
-// Deltaf_Data::bilinear_interpolation (deltafReader.cpp:412-484) on the device copies of the full (mu_B, T) grids,
-// with the intended [imuB][iT] indexing (the reference's calculate_bilinear swaps the indices, :404-407).
+// Deltaf_Data::bilinear_interpolation (deltafReader.cpp:412-484) on copies of the full (mu_B, T) grids (device pointers in the
+// kernels, host pointers in the host-side evaluations at the surface averages), with the intended [imuB][iT] indexing.
+// The reference's calculate_bilinear swaps the indices: it reads f_data[iT][imuB] (:404-407) from arrays allocated
+// [points_muB][points_T] (:36-61), i.e. the table value at (mu_B row iT, T column imuB).  b.swap (opts.reference_bilinear_indexing)
+// reproduces that read wherever it stays inside the allocation (iTR < points_muB; the column imuBR < points_T always holds) and
+// reports the cell as outside the table where the reference reads past its row pointers (undefined behaviour there).
 // Returns false outside the table (reference: printf + exit(-1), :423-427).
-__device__ __forceinline__ bool bilinear5(const BilinearDev &b, double T, double muB, double (&v)[5])
+__host__ __device__ __forceinline__ bool bilinear5(const BilinearDev &b, double T, double muB, double (&v)[5])
 {
     const double T_min = b.T[0], B_min = b.muB[0];
     const double dT = fabs(b.T[1] - b.T[0]), dB = fabs(b.muB[1] - b.muB[0]);
     const int iTL = (int)floor((T - T_min) / dT), iTR = iTL + 1;
     const int iBL = (int)floor((muB - B_min) / dB), iBR = iBL + 1;
     if (!(iTL >= 0 && iTR < b.nT) || !(iBL >= 0 && iBR < b.nB)) return false;
+    if (b.swap && !(iTR < b.nB && iBR < b.nT)) return false;
     const double TL = b.T[iTL], TR = b.T[iTR], BL = b.muB[iBL], BR = b.muB[iBR];
     for (int k = 0; k < 5; k++) {
         const double *f = b.tab[k];
-        const double f_LL = f[(size_t)iBL * b.nT + iTL], f_LR = f[(size_t)iBR * b.nT + iTL];
-        const double f_RL = f[(size_t)iBL * b.nT + iTR], f_RR = f[(size_t)iBR * b.nT + iTR];
+        double f_LL, f_LR, f_RL, f_RR;
+        if (b.swap) {
+            f_LL = f[(size_t)iTL * b.nT + iBL]; f_LR = f[(size_t)iTL * b.nT + iBR];
+            f_RL = f[(size_t)iTR * b.nT + iBL]; f_RR = f[(size_t)iTR * b.nT + iBR];
+        } else {
+            f_LL = f[(size_t)iBL * b.nT + iTL]; f_LR = f[(size_t)iBR * b.nT + iTL];
+            f_RL = f[(size_t)iBL * b.nT + iTR]; f_RR = f[(size_t)iBR * b.nT + iTR];
+        }
         v[k] = ((f_LL * (TR - T) + f_RL * (T - TL)) * (BR - muB) + (f_LR * (TR - T) + f_RR * (T - TL)) * (muB - BL)) / (dT * dB);
     }
     return true;

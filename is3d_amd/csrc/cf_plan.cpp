@@ -86,7 +86,7 @@ struct is3d_plan {
     DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
     int rblocks = 1, upc = 1;   // row blocks of the tiled stream; units per cell within a stream
     int wpb = 4;                // waves per workgroup of the main kernel
-    DevBuf<unsigned long long> d_status;
+    DevBuf<unsigned long long> d_status, d_sticky;   // d_sticky: {min bad cell, min fast cell} over the executes since the last is3d_plan_check
     is3d::SplineDev spl{};
 
     // modified equilibrium (df_mode 3, 4)
@@ -311,6 +311,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_bilT.upload(xs));
         HIP_TRY(P->d_bilB.upload(bs));
         P->bil.nT = df->n_T; P->bil.nB = df->n_muB;
+        P->bil.swap = o->reference_bilinear_indexing != 0;
         P->bil.T = P->d_bilT.p; P->bil.muB = P->d_bilB.p;
         for (int k = 0; k < 5; k++) {
             std::vector<double> tv(t5[k], t5[k] + (size_t)df->n_T * df->n_muB);
@@ -411,6 +412,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     }
     HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
     HIP_TRY(P->d_status.alloc(8));
+    HIP_TRY(P->d_sticky.upload(std::vector<unsigned long long>{~0ULL, ~0ULL}));
     if (P->feqmod) {
         HIP_TRY(P->d_FB.alloc((size_t)pc * is3d::kFbRec));
         HIP_TRY(P->d_flag.alloc((size_t)pc));
@@ -657,6 +659,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[npasses * 3], st));
     }
 
+    if (n > 0) HIP_TRY(is3d::launch_fold_status(P->d_status.p, P->d_sticky.p, st));
     if (status) {
         unsigned long long h[8];
         HIP_TRY(hipMemcpyAsync(h, P->d_status.p, sizeof h, hipMemcpyDeviceToHost, st));
@@ -683,6 +686,26 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         }
     }
     return IS3D_OK;
+}
+
+extern "C" int is3d_plan_check(is3d_plan *P, void *hip_stream, int64_t *bad_cell)
+{
+    if (!P) return fail(IS3D_EINVAL, "null plan");
+    if (bad_cell) *bad_cell = -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(P->device));
+    unsigned long long h[2], reset[2] = {~0ULL, ~0ULL};
+    HIP_TRY(hipMemcpyAsync(h, P->d_sticky.p, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(P->d_sticky.p, reset, sizeof reset, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const unsigned long long first = std::min(h[0], h[1]);
+    if (first == ~0ULL) return IS3D_OK;
+    if (bad_cell) *bad_cell = (int64_t)first;
+    if (h[1] <= h[0])
+        return fail(IS3D_EDOMAIN, "cell %llu (of an execute since the last check): p.u/T can exceed 1e9 for the momentum grid; the cell was left "
+                    "out of the spectrum (the reference's exp() overflows to inf there)", first);
+    return fail(IS3D_EDOMAIN, "cell %llu (of an execute since the last check): T%s outside the coefficient table; the cell was left out of the "
+                "spectrum (the reference aborts in gsl_spline_eval here)", first, (P->feqmod && P->opts.df_mode == 4) ? " (or bulkPi/P)" : "");
 }
 
 extern "C" int is3d_plan_observables(is3d_plan *P, const double *dN_dev, const double *pT_w, const double *phi_w, double *dNdy_dev,

@@ -711,6 +711,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         SMP_TRY(d_bilT.upload(xs));
         SMP_TRY(d_bilB.upload(std::vector<double>(df->muB, df->muB + df->n_muB)));
         p.bil.nT = df->n_T; p.bil.nB = df->n_muB;
+        p.bil.swap = opts->reference_bilinear_indexing != 0;
         p.bil.T = d_bilT.as<double>(); p.bil.muB = d_bilB.as<double>();
         for (int k = 0; k < 5; k++) {
             SMP_TRY(d_biltab[k].upload(std::vector<double>(t5[k], t5[k] + (size_t)df->n_T * df->n_muB)));
@@ -774,22 +775,14 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         auto in_table = [&](double Tq) { return Tq >= xs.front() && Tq <= xs.back(); };
         const double T = in->T_avg, Tsw = in->T_avg_switch > 0.0 ? in->T_avg_switch : in->T_avg;
         if (!in_table(T) || !in_table(Tsw)) return set_error(IS3D_EDOMAIN, "fast = 1: the average temperature %.6g GeV is outside the coefficient table", T);
-        // include_baryon: Deltaf_Data::bilinear_interpolation at (T, muB_avg) on the host (deltafReader.cpp:412-484, intended indexing)
+        // include_baryon: Deltaf_Data::bilinear_interpolation at (T, muB_avg) on the host (deltafReader.cpp:412-484; cf_math.h::bilinear5 on the
+        // host tables, same indexing option as the kernels)
         auto bilinear_at = [&](double Tq, double Bq, double (&v)[5]) -> bool {
-            const double *t5[5] = {df->F, df->G, df->betabulk, df->betaV, df->betapi};
-            const int nT = df->n_T, nB = df->n_muB;
-            const double dT = std::fabs(df->T[1] - df->T[0]), dB = std::fabs(df->muB[1] - df->muB[0]);
-            const int iTL = (int)std::floor((Tq - df->T[0]) / dT), iTR = iTL + 1;
-            const int iBL = (int)std::floor((Bq - df->muB[0]) / dB), iBR = iBL + 1;
-            if (!(iTL >= 0 && iTR < nT) || !(iBL >= 0 && iBR < nB)) return false;
-            const double TL = df->T[iTL], TR = df->T[iTR], BL = df->muB[iBL], BR = df->muB[iBR];
-            for (int k = 0; k < 5; k++) {
-                const double *f = t5[k];
-                const double f_LL = f[(size_t)iBL * nT + iTL], f_LR = f[(size_t)iBR * nT + iTL];
-                const double f_RL = f[(size_t)iBL * nT + iTR], f_RR = f[(size_t)iBR * nT + iTR];
-                v[k] = ((f_LL * (TR - Tq) + f_RL * (Tq - TL)) * (BR - Bq) + (f_LR * (TR - Tq) + f_RR * (Tq - TL)) * (Bq - BL)) / (dT * dB);
-            }
-            return true;
+            is3d::BilinearDev hb{};
+            hb.nT = df->n_T; hb.nB = df->n_muB; hb.T = df->T; hb.muB = df->muB;
+            hb.tab[0] = df->F; hb.tab[1] = df->G; hb.tab[2] = df->betabulk; hb.tab[3] = df->betaV; hb.tab[4] = df->betapi;
+            hb.swap = opts->reference_bilinear_indexing != 0;
+            return is3d::bilinear5(hb, Tq, Bq, v);
         };
         const double muB_avg = baryon ? in->muB_avg : 0.0, alphaB_avg = muB_avg / T;   // deltafReader.cpp:545-551
         double F = 0.0, G = 0.0, betabulk = 1.0;

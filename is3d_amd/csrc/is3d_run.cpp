@@ -341,14 +341,36 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         printf("iS3D Sampling Seed : %llu\n", (unsigned long long)si.seed);
         is3d_sampler_stats ss{};
         int64_t count = 0;
+        double mean_yield = 0.0;   // calculate_total_yield's member mean_yield (:828), written by write_yield_list_toFile
         if ((int)oversample) {
-            // The reference sizes the run from calculate_total_yield (an analytic estimate at the surface-average temperature,
-            // sampling_kernels.cpp:653-830); here the yield of one sampled event stands in for it.
-            int rc1 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
-            if (rc1) DIE("is3d_sample_particles failed (%d): %s", rc1, is3d_last_error());
-            const double Ntotal = (double)std::max<int64_t>(count, 1);
-            printf("Total particle yield: %lld (one sampled event)\n", (long long)count);
-            si.n_events = (int32_t)std::max(1.0, std::min(std::ceil(min_num_hadrons / Ntotal), max_num_samples));
+            // emissionfunction.cpp:1524-1533: the analytic mean yield (calculate_total_yield) sizes the run
+            double E_avg = 0.0, P_avg = 0.0, nB_avg = 0.0;
+            {
+                FILE *tf = fopen("average_thermodynamic_quantities.dat", "r");
+                double t_, m_;
+                if (!tf || fscanf(tf, "%lf %lf %lf %lf %lf", &t_, &E_avg, &P_avg, &m_, &nB_avg) != 5) DIE("Error opening average thermodynamic file");
+                fclose(tf);
+            }
+            if (n_alpha < 4) DIE("%s: the yield estimate needs alpha = 0, 1, 2, 3", gla_path);
+            is3d_feqmod_tables fqy = fqs;
+            if (!si.feqmod) {   // the alpha = 2 nodes enter every df_mode's bulk density (J20)
+                fqy.n_gla = n_pts;
+                fqy.root1 = si.root1; fqy.weight1 = si.weight1;
+                fqy.root2 = groot.data() + 2 * (size_t)n_pts; fqy.weight2 = gweight.data() + 2 * (size_t)n_pts;
+            }
+            is3d_sampler_inputs sy = si;
+            sy.feqmod = &fqy;
+            is3d_yield_inputs yi{T_avg_file, E_avg, P_avg, muB_avg_file, nB_avg, groot.data() + 3 * (size_t)n_pts, gweight.data() + 3 * (size_t)n_pts};
+            double Ntotal = 0.0;
+            printf("Total particle yield: ");
+            int rc1 = is3d_total_yield(&cells, &sp, &df, &sy, &yi, &opts, &Ntotal, nullptr);
+            if (rc1) DIE("is3d_total_yield failed (%d): %s", rc1, is3d_last_error());
+            if (dimension == 2) printf("dN_dy ~ %lf\n\n", Ntotal / (2.0 * y_cut));
+            printf("%lf\n", Ntotal);
+            mean_yield = Ntotal;
+            Ntotal = (double)fabsf((float)Ntotal);                                  // "prevent overflow", :1528
+            // Nevents = min((int)ceil(MIN_NUM_HADRONS / Ntotal), MAX_NUM_SAMPLES); at least one event is sampled here
+            si.n_events = (int32_t)std::max(1.0, std::min(std::ceil(min_num_hadrons / Ntotal), (double)(int)max_num_samples));
         }
         printf("Sampling %d event(s)\n", si.n_events);
         if (df_mode == 1) printf("Sampling particles with Grad 14 moment df...\n");                    // emissionfunction.cpp:1540-1541, :1602-1603
@@ -365,7 +387,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (feqmod) printf("feqmod breaks down for %lld cells\n", (long long)ss.n_cells_breakdown);
         if ((int)test_sampler) {                                                  // emissionfunction.cpp:1545-1554
             printf("Writing the binned sampler test distributions...\n");
-            if (is3d_write_sampler_tests("results", &bins, si.n_events, sp.n, mcid.data(), count, plist.data(), 0.0)) DIE("%s", is3d_last_error());
+            if (is3d_write_sampler_tests("results", &bins, si.n_events, sp.n, mcid.data(), count, plist.data(), mean_yield)) DIE("%s", is3d_last_error());
         } else {
             printf("Writing sampled particles list to OSCAR File...\n");
             if (is3d_write_particle_list_osc("results/particle_list_osc.dat", si.n_events, count, plist.data(), mcid.data())) DIE("%s", is3d_last_error());

@@ -68,6 +68,7 @@ def feqmod_tables(T_avg, deta_min=1.e-5, mass_pion0=0.138):
     g = fx["gla_32"]
     pdg = np.array(fx["pdg_urqmd"], dtype=np.float64)
     return dict(root1=np.array(g["root1"]), weight1=np.array(g["weight1"]), root2=np.array(g["root2"]), weight2=np.array(g["weight2"]),
+                root3=np.array(g["root3"]), weight3=np.array(g["weight3"]),
                 pdg_mass=pdg[:, 1].copy(), pdg_degeneracy=pdg[:, 2].copy(), pdg_sign=pdg[:, 4].copy(),
                 T_avg=float("%.15g" % T_avg), deta_min=float(deta_min), mass_pion0=float(mass_pion0))
 
@@ -79,3 +80,17 @@ def surface_average_T(cells):
     dsds = cells["dat"] ** 2 - cells["dax"] ** 2 - cells["day"] ** 2 - cells["dan"] ** 2 / cells["tau"] ** 2
     mag = np.abs(uds) + np.sqrt(np.abs(uds * uds - dsds))
     return float(np.sum(cells["T"] * mag) / np.sum(mag))
+
+
+def surface_averages(cells):
+    """(T, E, P, muB, nB) surface-volume weighted averages as the readers accumulate them (readindata.cpp:422-466) and as
+    Plasma::load_thermodynamic_averages reads them back from average_thermodynamic_quantities.dat (15 significant digits)."""
+    ut = np.sqrt(1 + cells["ux"] ** 2 + cells["uy"] ** 2 + cells["tau"] ** 2 * cells["un"] ** 2)
+    uds = ut * cells["dat"] + cells["ux"] * cells["dax"] + cells["uy"] * cells["day"] + cells["un"] * cells["dan"]
+    dsds = cells["dat"] ** 2 - cells["dax"] ** 2 - cells["day"] ** 2 - cells["dan"] ** 2 / cells["tau"] ** 2
+    mag = np.abs(uds) + np.sqrt(np.abs(uds * uds - dsds))
+    out = []
+    for k in ("T", "E", "P", "muB", "nB"):
+        v = cells.get(k)
+        out.append(float("%.15g" % (np.sum(v * mag) / np.sum(mag))) if v is not None else 0.0)
+    return tuple(out)

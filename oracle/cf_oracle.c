@@ -140,6 +140,8 @@ typedef struct {
     int dimension, df_mode;
     int include_baryon, include_bulk_deltaf, include_shear_deltaf, include_baryondiff_deltaf;
     int regulate_deltaf, outflow;
+    int reference_bilinear_indexing;   /* 1: read the (T, mu_B) tables as the reference's calculate_bilinear does, f_data[iT][imuB]
+                                          (deltafReader.cpp:404-407); -1 from the evaluation where that read leaves the allocation */
 } oracle_opts;
 
 typedef struct {
@@ -180,7 +182,10 @@ static int eval_df(const oracle_df_tables *t, const double *sc0, const double *s
  * calculate_bilinear reads f_data[iT][imuB] (:404-407) although the tables are stored [imuB][iT]
  * (:168-196) -- a transposed-index defect (out of bounds for T > 0.18 GeV); the restatement uses
  * f_data[imuB][iT].  Returns -1 outside the table (reference: printf + exit(-1), :423-427). */
-static int eval_df_bilinear(const oracle_df_tables *t, int df_mode, double T, double muB, df_coeff *df)
+/* reference_indexing = 1: calculate_bilinear AS WRITTEN, f_data[iTL][imuBL] ... on arrays allocated [points_muB][points_T]
+ * (deltafReader.cpp:36-61, :404-407), i.e. the stored value at (mu_B row iT, T column imuB); defined only while iTR < points_muB
+ * (beyond that the reference dereferences row pointers past the allocation) -- there the restatement returns -1. */
+static int eval_df_bilinear_ix(const oracle_df_tables *t, int df_mode, double T, double muB, df_coeff *df, int reference_indexing)
 {
     memset(df, 0, sizeof(*df));
     const int nT = t->n_T, nB = t->n_muB;
@@ -190,6 +195,7 @@ static int eval_df_bilinear(const oracle_df_tables *t, int df_mode, double T, do
     int iTL = (int)floor((T - T_min) / dT), iTR = iTL + 1;
     int iBL = (int)floor((muB - muB_min) / dmuB), iBR = iBL + 1;
     if (!(iTL >= 0 && iTR < nT) || !(iBL >= 0 && iBR < nB)) return -1;
+    if (reference_indexing && !(iTR < nB && iBR < nT)) return -1;
     const double TL = t->T[iTL], TR = t->T[iTR], BL = t->muB[iBL], BR = t->muB[iBR];
     double v[10];
     for (int k = 0; k < 10; k++) {
@@ -197,6 +203,10 @@ static int eval_df_bilinear(const oracle_df_tables *t, int df_mode, double T, do
         if (!f) return -4;
         double f_LL = f[(size_t)iBL * nT + iTL], f_LR = f[(size_t)iBR * nT + iTL];
         double f_RL = f[(size_t)iBL * nT + iTR], f_RR = f[(size_t)iBR * nT + iTR];
+        if (reference_indexing) {                              /* :404-407 as written: rows are mu_B rows, indexed by iT */
+            f_LL = f[(size_t)iTL * nT + iBL]; f_LR = f[(size_t)iTL * nT + iBR];
+            f_RL = f[(size_t)iTR * nT + iBL]; f_RR = f[(size_t)iTR * nT + iBR];
+        }
         v[k] = ((f_LL * (TR - T) + f_RL * (T - TL)) * (BR - muB) + (f_LR * (TR - T) + f_RR * (T - TL)) * (muB - BL)) / (dT * dmuB);
     }
     double T3 = T * T * T, T4 = T3 * T, T5 = T4 * T;
@@ -214,7 +224,9 @@ static int eval_df_bilinear(const oracle_df_tables *t, int df_mode, double T, do
 int oracle_df_coefficients_bilinear(const oracle_df_tables *t, int df_mode, double T, double muB, double *out10)
 {
     df_coeff df;
-    int rc = eval_df_bilinear(t, df_mode, T, muB, &df);
+    const int reference_indexing = df_mode >= 100;             /* df_mode + 100: the reference's indexing (tests) */
+    if (reference_indexing) df_mode -= 100;
+    int rc = eval_df_bilinear_ix(t, df_mode, T, muB, &df, reference_indexing);
     out10[0] = df.c0; out10[1] = df.c1; out10[2] = df.c2; out10[3] = df.c3; out10[4] = df.c4;
     out10[5] = df.F; out10[6] = df.G; out10[7] = df.betabulk; out10[8] = df.betaV; out10[9] = df.betapi;
     return rc;
@@ -304,7 +316,7 @@ static int load_cell(const cell_arrays *a, long ic, const oracle_opts *o, const 
 
     df_coeff df;                                               /* :200, deltafReader.cpp:486-504 */
     if (o->include_baryon) {
-        int brc = eval_df_bilinear(t, o->df_mode, T, muB, &df);
+        int brc = eval_df_bilinear_ix(t, o->df_mode, T, muB, &df, o->reference_bilinear_indexing);
         if (brc) return brc;
     } else if (eval_df(t, sc0, sc2, sF, sbb, sbp, o->df_mode, T, &df)) return -1;
     c->c3 = df.c3; c->c4 = df.c4; c->betaV = df.betaV;
@@ -380,7 +392,7 @@ static int check_inputs(const oracle_opts *o, const oracle_grid *g)
 {
     if (o->dimension != 2 && o->dimension != 3) return -3;
     if (o->df_mode != 1 && o->df_mode != 2) return -2;
-    /* include_baryon = 1 needs the full (mu_B, T) tables: checked in eval_df_bilinear (-4 when absent) */
+    /* include_baryon = 1 needs the full (mu_B, T) tables: checked in eval_df_bilinear_ix (-4 when absent) */
     if (g->pT_tab_length < 1 || g->phi_tab_length < 1) return -3;
     return 0;
 }
@@ -803,7 +815,7 @@ int oracle_dN_pTdpTdphidy_feqmod(long FO_length, int npart, const double *Mass, 
             }
             if (o->include_baryon) {                                                 /* evaluate_df_coefficients -> bilinear_interpolation */
                 df_coeff dfb;
-                int brc = eval_df_bilinear(t, 3, T, muB, &dfb);
+                int brc = eval_df_bilinear_ix(t, 3, T, muB, &dfb, o->reference_bilinear_indexing);
                 if (brc) {
 #pragma omp atomic write
                     err = brc == -1 ? -1 : -4;
@@ -1202,7 +1214,7 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
         const double muB_avg = o->include_baryon ? so->muB_avg : 0.0, alphaB_avg = muB_avg / T;   /* deltafReader.cpp:545-551 */
         if (o->include_baryon) {                                              /* evaluate_df_coefficients(T, muB, ...) -> bilinear */
             df_coeff dfa;
-            int brc = eval_df_bilinear(t, DF_MODE, T, muB_avg, &dfa);
+            int brc = eval_df_bilinear_ix(t, DF_MODE, T, muB_avg, &dfa, o->reference_bilinear_indexing);
             if (brc) err = brc == -1 ? -1 : -4;
             F = dfa.F; G = dfa.G; betabulk = (DF_MODE == 1) ? 1.0 : dfa.betabulk;
         } else if (DF_MODE == 2 || DF_MODE == 3) {
@@ -1227,7 +1239,7 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
             const double Ts = so->T_avg_switch, Ts4 = Ts * Ts * Ts * Ts;
             if (o->include_baryon) {
                 df_coeff dfa;
-                int brc = eval_df_bilinear(t, 3, Ts, muB_avg, &dfa);
+                int brc = eval_df_bilinear_ix(t, 3, Ts, muB_avg, &dfa, o->reference_bilinear_indexing);
                 if (brc) err = brc == -1 ? -1 : -4;
                 F_avg = dfa.F; betabulk_avg = dfa.betabulk;
             } else {
@@ -1274,7 +1286,7 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
         double lambda = 0.0, z = 0.0, v, T4 = T * T * T * T;
         memset(&c->df, 0, sizeof c->df);
         if (o->include_baryon) {
-            int brc = eval_df_bilinear(t, DF_MODE, T, muB, &c->df);
+            int brc = eval_df_bilinear_ix(t, DF_MODE, T, muB, &c->df, o->reference_bilinear_indexing);
             if (brc) { err = brc == -1 ? -1 : -4; break; }
         } else if (DF_MODE <= 2) {
             if (eval_df(t, s, s + n, sF, sbb, sbp, DF_MODE, T, &c->df)) { err = -1; break; }
@@ -1457,6 +1469,174 @@ long oracle_sample_particles(long FO_length, int npart, const double *Mass, cons
     if (stats) { stats[0] = samples; stats[1] = acceptances; stats[2] = drawn; stats[3] = n_breakdown; }
     free(cs); free(dn_list); free(s); free(J); free(Equilibrium_Density); free(Bulk_Density);
     return err ? err : kept;
+}
+
+/* ==========================================================================================
+ * Mean particle yield of the surface (oversample = 1): restates
+ *   EmissionFunctionArray::calculate_total_yield      src/cpp/emissionfunction_sampling_kernels.cpp:653-830
+ *   estimate_mean_particle_number                     :200-236
+ *   Deltaf_Data::compute_particle_densities           src/cpp/deltafReader.cpp:536-650  (Equilibrium_Density, Bulk_Density,
+ *                                                     Diffusion_Density of the chosen species, emissionfunction.cpp:1289-1306)
+ *   J11_int, J30_int, J31_int                         src/cpp/gaussThermal.cpp:54-85
+ * and its use, Nevents = min(ceil(MIN_NUM_HADRONS / |Ntotal|), MAX_NUM_SAMPLES) (emissionfunction.cpp:1524-1533).
+ * The species densities are evaluated once, at the surface AVERAGES {T, E, P, muB, nB} (Plasma::load_thermodynamic_averages
+ * reads them back from average_thermodynamic_quantities.dat) with the df coefficients at (T, muB) and bulkPi = 0; per cell only
+ * the LRF surface element, bulkPi, V.dsigma and (df_mode 4) z(bulkPi / P) enter.  does_feqmod_breakdown returns false for
+ * df_mode 4 (emissionfunction.cpp:138-146), so the (1 + delta_z) branch of estimate_mean_particle_number is never taken.
+ * ========================================================================================== */
+static double J11_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return pbar * pbar * pbar / (Ebar * Ebar) * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);
+}
+static double J30_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return Ebar * Ebar / pbar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);
+}
+static double J31_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return pbar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);
+}
+
+/* avg5 = {T, E, P, muB, nB} surface averages; root3 / weight3 (Gauss-Laguerre alpha = 3) only for df_mode 1;
+ * densities (may be NULL): 3 * npart doubles {Equilibrium_Density, Bulk_Density, Diffusion_Density}.
+ * Returns 0, or -1 T (or bulkPi/P) outside a table, -2 df_mode, -3 dimension, -4 include_baryon with df_mode 4. */
+int oracle_total_yield(long FO_length, int npart, const double *Mass, const double *Sign, const double *Degeneracy, const double *Baryon,
+                       const cell_arrays *a, const oracle_df_tables *t, int n_gla, const double *root1, const double *weight1,
+                       const double *root2, const double *weight2, const double *root3, const double *weight3,
+                       const oracle_feqmod_tables *q, const oracle_opts *o, const double *avg5, double y_cut, double *Ntot_out,
+                       double *densities)
+{
+    if (o->dimension != 2 && o->dimension != 3) return -3;
+    const int DF_MODE = o->df_mode;
+    if (DF_MODE < 1 || DF_MODE > 4) return -2;
+    if (o->include_baryon && (DF_MODE == 4 || !Baryon)) return -4;
+    if (DF_MODE == 4 && !q) return -2;
+    const double two_pi2_hbarC3 = 2.0 * pow(M_PI, 2) * pow(ORACLE_HBARC, 3);
+    const int n = t->n_T;
+    double *s = (double *)calloc((size_t)5 * n, sizeof(double));
+    init_splines(t, s);
+    const double *sF = s + 2 * n, *sbb = s + 3 * n, *sbp = s + 4 * n;
+    jonah_tab *J = (jonah_tab *)malloc(sizeof(jonah_tab));
+    if (DF_MODE == 4) compute_jonah(q, J);
+    double *Equilibrium_Density = (double *)calloc((size_t)npart, sizeof(double));
+    double *Bulk_Density = (double *)calloc((size_t)npart, sizeof(double));
+    double *Diffusion_Density = (double *)calloc((size_t)npart, sizeof(double));
+    int err = 0;
+    /* ---- compute_particle_densities (deltafReader.cpp:536-650) ---- */
+    {
+        const double T = avg5[0], E = avg5[1], P = avg5[2];
+        const double muB = o->include_baryon ? avg5[3] : 0.0, nB = o->include_baryon ? avg5[4] : 0.0;
+        df_coeff df;
+        memset(&df, 0, sizeof df);
+        if (o->include_baryon) {
+            int brc = eval_df_bilinear_ix(t, DF_MODE, T, muB, &df, o->reference_bilinear_indexing);
+            if (brc) err = brc == -1 ? -1 : -4;
+        } else if (DF_MODE <= 3) {
+            if (eval_df(t, s, s + n, sF, sbb, sbp, DF_MODE == 3 ? 2 : DF_MODE, T, &df)) err = -1;
+        } else {   /* cubic_spline case 4 at bulkPi = 0: the Jonah splines at 0 and betapi(T); only their domain matters here */
+            double v;
+            if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->z, J->c_z, 0.0, &v)) err = -1;
+            if (oracle_cspline_eval(n, t->T, t->betapi, sbp, T, &v)) err = -1;
+        }
+        const double alphaB = muB / T;                                                       /* :551 */
+        const double baryon_enthalpy_ratio = nB / (E + P);                                   /* :552 */
+        for (int i = 0; i < npart && !err; i++) {
+            const double mass = Mass[i], degeneracy = Degeneracy[i], sign = Sign[i];
+            const double baryon = Baryon ? Baryon[i] : 0.0;
+            const double mbar = mass / T;
+            const double neq_fact = degeneracy * pow(T, 3) / two_pi2_hbarC3;
+            const double neq = neq_fact * gauss_thermal(neq_int, root1, weight1, n_gla, mbar, alphaB, baryon, sign);
+            double dn_bulk = 0.0, dn_diff = 0.0;
+            if (DF_MODE == 1) {                                                              /* :587-612 */
+                if (!root3 || !weight3) { err = -2; break; }
+                const double J10_fact = degeneracy * pow(T, 3) / two_pi2_hbarC3;
+                const double J20_fact = degeneracy * pow(T, 4) / two_pi2_hbarC3;
+                const double J30_fact = degeneracy * pow(T, 5) / two_pi2_hbarC3;
+                const double J31_fact = degeneracy * pow(T, 5) / two_pi2_hbarC3 / 3.0;
+                const double J10 = J10_fact * gauss_thermal(J10_int, root1, weight1, n_gla, mbar, alphaB, baryon, sign);
+                const double J20 = J20_fact * gauss_thermal(J20_int, root2, weight2, n_gla, mbar, alphaB, baryon, sign);
+                const double J30 = J30_fact * gauss_thermal(J30_int, root3, weight3, n_gla, mbar, alphaB, baryon, sign);
+                const double J31 = J31_fact * gauss_thermal(J31_int, root3, weight3, n_gla, mbar, alphaB, baryon, sign);
+                dn_bulk = ((df.c0 - df.c2) * mass * mass * J10 + df.c1 * baryon * J20 + (4.0 * df.c2 - df.c0) * J30);
+                dn_diff = baryon * df.c3 * neq * T + df.c4 * J31;
+            } else if (DF_MODE == 2 || DF_MODE == 3) {                                       /* :613-632 */
+                const double J10_fact = degeneracy * pow(T, 3) / two_pi2_hbarC3;
+                const double J11_fact = degeneracy * pow(T, 3) / two_pi2_hbarC3 / 3.0;
+                const double J20_fact = degeneracy * pow(T, 4) / two_pi2_hbarC3;
+                const double J10 = J10_fact * gauss_thermal(J10_int, root1, weight1, n_gla, mbar, alphaB, baryon, sign);
+                const double J11 = J11_fact * gauss_thermal(J11_int, root1, weight1, n_gla, mbar, alphaB, baryon, sign);
+                const double J20 = J20_fact * gauss_thermal(J20_int, root2, weight2, n_gla, mbar, alphaB, baryon, sign);
+                dn_bulk = (neq + (baryon * J10 * df.G) + (J20 * df.F / pow(T, 2))) / df.betabulk;
+                dn_diff = (neq * T * baryon_enthalpy_ratio - baryon * J11) / df.betaV;
+            }
+            Equilibrium_Density[i] = neq; Bulk_Density[i] = dn_bulk; Diffusion_Density[i] = dn_diff;
+        }
+    }
+    /* ---- calculate_total_yield (:653-830), serial over cells and species as the reference ---- */
+    double Ntot = 0.0;
+    for (long icell = 0; icell < FO_length && !err; icell++) {
+        double tau = a->tau[icell], tau2 = tau * tau;
+        double dat = a->dat[icell], dax = a->dax[icell], day = a->day[icell], dan = a->dan[icell];
+        double ux = a->ux[icell], uy = a->uy[icell], un = a->un[icell];
+        double ut = sqrt(1.0 + ux * ux + uy * uy + tau2 * un * un);
+        double uperp = sqrt(ux * ux + uy * uy), utperp = sqrt(1.0 + ux * ux + uy * uy);
+        double udsigma = ut * dat + ux * dax + uy * day + un * dan;
+        if (udsigma <= 0.0) continue;                                                        /* :689 */
+        double T = a->T[icell], P = a->P[icell];
+        double bulkPi = o->include_bulk_deltaf ? a->bulkPi[icell] : 0.0;                     /* :722-724 */
+        double muB = 0.0, Vt = 0.0, Vx = 0.0, Vy = 0.0, Vn = 0.0, Vdsigma = 0.0;
+        if (o->include_baryon && o->include_baryondiff_deltaf) {                             /* :736-748 */
+            muB = a->muB[icell];
+            Vx = a->Vx[icell]; Vy = a->Vy[icell]; Vn = a->Vn[icell];
+            Vt = (Vx * ux + Vy * uy + tau2 * Vn * un) / ut;
+            Vdsigma = Vt * dat + Vx * dax + Vy * day + Vn * dan;
+        }
+        if (DF_MODE == 4) {                                                                  /* :752-758 */
+            if (bulkPi <= -P) bulkPi = -(1.0 - 1.e-5) * P;
+            else if (bulkPi / P >= J->bulkPi_over_Peq_max) bulkPi = P * (J->bulkPi_over_Peq_max - 1.e-5);
+        }
+        /* evaluate_df_coefficients (:761): only z is used below, but a temperature outside the table aborts the reference here */
+        double z = 0.0, v;
+        df_coeff dfc;
+        if (o->include_baryon) {
+            int brc = eval_df_bilinear_ix(t, DF_MODE, T, muB, &dfc, o->reference_bilinear_indexing);
+            if (brc) { err = brc == -1 ? -1 : -4; break; }
+        } else if (DF_MODE <= 3) {
+            if (eval_df(t, s, s + n, sF, sbb, sbp, DF_MODE == 3 ? 2 : DF_MODE, T, &dfc)) { err = -1; break; }
+        } else {
+            if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->lambda_squared, J->c_lambda, bulkPi / P, &v)) { err = -1; break; }
+            if (oracle_cspline_eval(JONAH_POINTS, J->bulkPi_over_Peq, J->z, J->c_z, bulkPi / P, &z)) { err = -1; break; }
+            if (oracle_cspline_eval(n, t->T, t->betapi, sbp, T, &v)) { err = -1; break; }
+        }
+        /* Milne_Basis + Surface_Element_Vector::boost_dsigma_to_lrf (viscous_correction.cpp:8-27, :69-86) */
+        double sinhL = tau * un / utperp, coshL = ut / utperp;
+        double Xt = uperp * coshL, Zt = sinhL, Xn = uperp * sinhL / tau, Zn = coshL / tau;
+        double Xx = 1.0, Yx = 0.0, Xy = 0.0, Yy = 1.0;
+        if (uperp > 1.e-5) { Xx = utperp * ux / uperp; Yx = -uy / uperp; Xy = utperp * uy / uperp; Yy = ux / uperp; }
+        double ds_time = dat * ut + dax * ux + day * uy + dan * un;
+        double dsx = -(dat * Xt + dax * Xx + day * Xy + dan * Xn);
+        double dsy = -(dax * Yx + day * Yy);
+        double dsz = -(dat * Zt + dan * Zn);
+        double ds_space = sqrt(dsx * dsx + dsy * dsy + dsz * dsz);
+        for (int ipart = 0; ipart < npart; ipart++) {                                        /* :812-819, :200-236 */
+            double particle_number;
+            if (DF_MODE <= 3) particle_number = ds_time * (Equilibrium_Density[ipart] + bulkPi * Bulk_Density[ipart]) - ds_space * Vdsigma * Diffusion_Density[ipart];
+            else particle_number = ds_time * z * Equilibrium_Density[ipart];
+            Ntot += particle_number;
+        }
+    }
+    if (o->dimension == 2) Ntot *= (2.0 * y_cut);                                            /* :822-826 */
+    if (Ntot_out) *Ntot_out = Ntot;
+    if (densities)
+        for (int i = 0; i < npart; i++) { densities[i] = Equilibrium_Density[i]; densities[npart + i] = Bulk_Density[i]; densities[2 * npart + i] = Diffusion_Density[i]; }
+    free(s); free(J); free(Equilibrium_Density); free(Bulk_Density); free(Diffusion_Density);
+    return err;
 }
 
 /* ==========================================================================================

@@ -31,7 +31,8 @@ DF_NAMES_2D = ["c0", "c1", "c2", "c3", "c4", "F", "G", "betabulk", "betaV", "bet
 
 class _Opts(C.Structure):
     _fields_ = [(n, C.c_int) for n in ["dimension", "df_mode", "include_baryon", "include_bulk_deltaf",
-                                       "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow"]]
+                                       "include_shear_deltaf", "include_baryondiff_deltaf", "regulate_deltaf", "outflow",
+                                       "reference_bilinear_indexing"]]
 
 
 class _Grid(C.Structure):
@@ -110,19 +111,20 @@ def df_coefficients(df, df_mode, T):
     return dict(zip(["c0", "c2", "F", "betabulk", "betapi"], out))
 
 
-def df_coefficients_bilinear(df, df_mode, T, muB):
-    """-> dict of the ten coefficients by the (intended) bilinear branch, temperature scaling undone."""
+def df_coefficients_bilinear(df, df_mode, T, muB, reference_indexing=False):
+    """-> dict of the ten coefficients by the bilinear branch, temperature scaling undone.  reference_indexing: read the tables
+    as the reference's calculate_bilinear does (f_data[iT][imuB], deltafReader.cpp:404-407) instead of the intended [imuB][iT]."""
     st, keep = _df_struct(df)
     out = np.zeros(10)
     lib().oracle_df_coefficients_bilinear.argtypes = [C.POINTER(_DfTables), C.c_int, C.c_double, C.c_double, _dp]
-    rc = lib().oracle_df_coefficients_bilinear(C.byref(st), int(df_mode), float(T), float(muB), _p(out))
+    rc = lib().oracle_df_coefficients_bilinear(C.byref(st), int(df_mode) + (100 if reference_indexing else 0), float(T), float(muB), _p(out))
     if rc:
         raise ValueError("(T, muB) outside the coefficient table (rc=%d)" % rc)
     return dict(zip(DF_NAMES_2D, out))
 
 
 DEFAULT_OPTS = dict(dimension=3, df_mode=1, include_baryon=0, include_bulk_deltaf=1, include_shear_deltaf=1,
-                    include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1)
+                    include_baryondiff_deltaf=0, regulate_deltaf=1, outflow=1, reference_bilinear_indexing=0)
 
 
 def dN_pTdpTdphidy(cells, species, grid, df, opts, chunked=False, FO_chunk=10000, out=None):
@@ -305,6 +307,43 @@ def sample_particles(cells, species, df, gla, opts, n_events=1, seed=1, y_cut=0.
     for f in ("event", "cell", "species"):
         res[f] = res[f].astype(np.int64)
     return res, dict(n_kept=int(rc), samples=int(stats[0]), acceptances=int(stats[1]), drawn=int(stats[2]), breakdown=int(stats[3]))
+
+
+def total_yield(cells, species, df, gla, avg5, opts, y_cut=0.5, fq=None):
+    """calculate_total_yield restated (oracle_total_yield).  gla: dict with root1, weight1, root2, weight2 (+ root3, weight3 for
+    df_mode 1); avg5 = (T, E, P, muB, nB) surface averages; fq: feqmod tables (df_mode 4; defaults to gla).
+    Returns (yield, densities[3][n_species])."""
+    o = dict(DEFAULT_OPTS)
+    o.update(opts)
+    n = len(cells["tau"])
+    keep = {}
+    ca = _CellArrays()
+    for f in CELL_FIELDS:
+        if f in cells and cells[f] is not None:
+            keep[f] = _f64(cells[f])
+            setattr(ca, f, _p(keep[f]))
+    sp = {k: _f64(species[k]) for k in ["mass", "sign", "degeneracy"]}
+    sp["baryon"] = _f64(species["baryon"]) if "baryon" in species else np.zeros(len(sp["mass"]))
+    npart = len(sp["mass"])
+    st, keep_df = _df_struct(df)
+    r = {k: _f64(gla[k]) for k in ["root1", "weight1", "root2", "weight2"]}
+    r3 = _f64(gla["root3"]) if "root3" in gla else None
+    w3 = _f64(gla["weight3"]) if "weight3" in gla else None
+    fs, keep_fq = _feqmod_struct(fq if fq is not None else gla) if int(o["df_mode"]) == 4 else (None, None)
+    os_ = _Opts(*[int(o[k]) for k, _ in _Opts._fields_])
+    a5 = _f64(avg5)
+    L = lib()
+    L.oracle_total_yield.argtypes = [C.c_long, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_CellArrays), C.POINTER(_DfTables), C.c_int,
+                                     _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(_FeqmodTables), C.POINTER(_Opts), _dp, C.c_double, _dp, _dp]
+    out = np.zeros(1)
+    dens = np.zeros((3, npart))
+    rc = L.oracle_total_yield(n, npart, _p(sp["mass"]), _p(sp["sign"]), _p(sp["degeneracy"]), _p(sp["baryon"]), C.byref(ca), C.byref(st),
+                              len(r["root1"]), _p(r["root1"]), _p(r["weight1"]), _p(r["root2"]), _p(r["weight2"]),
+                              _p(r3) if r3 is not None else None, _p(w3) if w3 is not None else None,
+                              C.byref(fs) if fs is not None else None, C.byref(os_), _p(a5), float(y_cut), _p(out), _p(dens))
+    if rc:
+        raise RuntimeError("oracle_total_yield failed rc=%d" % rc)
+    return float(out[0]), dens
 
 
 # ---- anisotropic hydro (VAH, P_L matching) smooth kernel ---------------------------------------------------------

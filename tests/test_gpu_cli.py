@@ -155,7 +155,8 @@ def test_cli_feqmod(tmp_path, fx, dim, df_mode):
 @pytest.mark.parametrize("dim,oversample", [(3, 0), (3, 1), (2, 0)])
 def test_cli_sampler(tmp_path, fx, dim, oversample):
     """operation = 2 end to end: surface (with positions) + parameters in, results/particle_list_osc.dat out, the list equal to
-    the oracle's for the same seed; oversample = 1 sizes the number of events from the yield of one sampled event."""
+    the oracle's for the same seed; oversample = 1 sizes the number of events from the analytic mean yield
+    (calculate_total_yield, emissionfunction.cpp:1524-1533)."""
     ids = [211, 321, 2212, -2212]
     cells = synth.synth_surface(5000 if dim == 3 else 3000, dim, seed=90 + dim)
     root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(operation=2, dimension=dim, df_mode=2, oversample=oversample,
@@ -168,8 +169,11 @@ def test_cli_sampler(tmp_path, fx, dim, oversample):
     gla = inputs.feqmod_tables(0.15)
     sp = inputs.species(ids)
     if oversample:
-        one, _ = oracle.sample_particles(parsed, sp, fx["df"], gla, dict(dimension=dim, df_mode=2), n_events=1, seed=17, y_cut=0.7)
-        assert n_events == max(1, min(int(np.ceil(300.0 / max(len(one["E"]), 1))), 1000)) and n_events > 1
+        avg = [float(v) for v in open(os.path.join(root, "average_thermodynamic_quantities.dat")).read().split()]
+        Ntot, _ = oracle.total_yield(parsed, sp, fx["df"], gla, avg, dict(dimension=dim, df_mode=2), y_cut=0.7)
+        max_samples = int(api.param_get(os.path.join(root, "iS3D_parameters.dat"), "max_num_samples"))
+        assert n_events == max(1, min(int(np.ceil(300.0 / float(np.float32(abs(Ntot))))), max_samples)) and n_events > 1
+        assert abs(float(r.stdout.split("Total particle yield: ")[1].split()[0]) / Ntot - 1) < 1e-6
     else:
         assert n_events == 1
     ref, _ = oracle.sample_particles(parsed, sp, fx["df"], gla, dict(dimension=dim, df_mode=2), n_events=n_events, seed=17, y_cut=0.7)

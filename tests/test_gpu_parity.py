@@ -311,6 +311,51 @@ def test_device_observables(fx, torch_mod, dim):
     plan.close()
 
 
+@pytest.mark.parametrize("dim,df_mode", [(3, 2), (3, 1), (2, 2)])
+def test_reference_bilinear_indexing_option(fx, dim, df_mode):
+    """opts.reference_bilinear_indexing = 1: the (T, mu_B) tables read as the reference's calculate_bilinear reads them
+    (f_data[iT][imuB], deltafReader.cpp:404-407), against the oracle with the same option; results differ from the intended
+    indexing; a live cell with T >= T[n_muB - 1] (0.18 GeV: the reference reads past its row pointers) is IS3D_EDOMAIN."""
+    dff = inputs.df_tables_full()
+    cells = synth.synth_surface(60 if dim == 3 else 6, dim, seed=500 + dim, baryon=True)
+    sp = inputs.species([211, 2212, -2212, 3122])
+    o = dict(dimension=dim, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=1, reference_bilinear_indexing=1)
+    ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], dff, o)
+    got, st = api.smooth_spectra(cells, sp, fx["grid"], dff, o)
+    assert relerr(got, ref) < TOL
+    intended, _ = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, reference_bilinear_indexing=0))
+    assert relerr(intended, ref) > 1e-4
+    cells["T"][5] = 0.1815                      # inside the table, outside what the reference's read can reach
+    api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, reference_bilinear_indexing=0))
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra(cells, sp, fx["grid"], dff, o)
+    assert e.value.code == api.IS3D_EDOMAIN and "cell 5" in str(e.value)
+
+
+def test_status_less_executes_keep_their_domain_errors(fx, torch_mod):
+    """is3d_plan_execute with status == NULL is fully asynchronous and neutralises a cell outside the coefficient table; the
+    plan keeps the lowest such cell until is3d_plan_check (the reference aborts there: deltafReader.cpp:339)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    cells = synth.synth_surface(300, 3, seed=8)
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    plan = api.Plan(fx["pikp"], fx["grid"], fx["df"], dict(dimension=3, df_mode=2), max_cells=300)
+    out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan.execute(300, ptrs, out.data_ptr(), stream, want_status=False)
+    plan.check(stream)                                   # clean surface: nothing to report
+    tens["T"][[41, 207]] = 0.25
+    plan.execute(300, ptrs, out.data_ptr(), stream, want_status=False)
+    tens["T"][[41, 207]] = 0.15
+    plan.execute(300, ptrs, out.data_ptr(), stream, want_status=False)   # a later clean execute does not erase the record
+    with pytest.raises(api.Is3dError) as e:
+        plan.check(stream)
+    assert e.value.code == api.IS3D_EDOMAIN and "cell 41" in str(e.value)
+    plan.check(stream)                                   # cleared
+    plan.close()
+
+
 def _subset_oracle(fx, cells, sp_ids, ipT, iphi, opts):
     g = fx["grid"]
     sub = dict(g, pT=g["pT"][ipT], phi=g["phi"][iphi])

@@ -188,3 +188,25 @@ def test_sampler_with_baryon_lists_match_the_oracle(fx, dim, df_mode, diff):
         with pytest.raises(api.Is3dError) as e:
             api.sample_particles(out, sp, dff, fq, o, n_events=1, seed=1, fq=fq if df_mode == 3 else None)
         assert e.value.code == -3 and "cell 7" in str(e.value)
+
+
+@pytest.mark.parametrize("dim,df_mode,baryon", [(3, 1, 0), (3, 2, 0), (2, 3, 0), (3, 4, 0), (2, 4, 0), (3, 1, 1), (3, 2, 1), (2, 3, 1)])
+def test_total_yield_matches_the_oracle(fx, dim, df_mode, baryon):
+    """is3d_total_yield (calculate_total_yield, sampling_kernels.cpp:653-830): species densities at the surface averages on the
+    host, per-cell weights and the reduction on the device; against the oracle's serial restatement."""
+    cells = synth.synth_surface(20000, dim, seed=400 + dim, baryon=bool(baryon))
+    cells["dat"][::7] *= -1.0                          # some cells with u.dsigma <= 0 (skipped, :689)
+    sp = inputs.species([211, 321, 2212, -2212, 3122, -3122, 333])
+    df = inputs.df_tables_full() if baryon else fx["df"]
+    avg = inputs.surface_averages(cells)
+    gla = inputs.feqmod_tables(avg[0])
+    o = dict(dimension=dim, df_mode=df_mode, include_baryon=baryon, include_baryondiff_deltaf=baryon)
+    want, wdens = oracle.total_yield(cells, sp, df, gla, avg, o, y_cut=0.8)
+    got, gdens = api.total_yield(cells, sp, df, gla, avg, o, y_cut=0.8)
+    assert np.allclose(gdens, wdens, rtol=1e-13, atol=0)
+    assert abs(got / want - 1) < 1e-11 and want > 0
+    # a temperature outside the table aborts the reference in evaluate_df_coefficients (:761)
+    cells["T"][123] = 0.31
+    with pytest.raises(api.Is3dError) as e:
+        api.total_yield(cells, sp, df, gla, avg, o, y_cut=0.8)
+    assert e.value.code == api.IS3D_EDOMAIN and "cell 123" in str(e.value)

@@ -109,6 +109,37 @@ def test_against_longdouble_restatement(fx, pins):
     assert worst < 5e-10, worst
 
 
+def test_bilinear_indexing_is_pinned_on_a_non_square_asymmetric_grid():
+    """A 7 (T) x 4 (muB) grid with f = 100 iB + iT: the intended indexing reads [imuB][iT]; the reference's calculate_bilinear
+    reads [iT][imuB] from the same [points_muB][points_T] storage (deltafReader.cpp:36-61, :404-407) -- the option
+    reference_bilinear_indexing reproduces that where the read stays inside the allocation (iT + 1 < points_muB) and refuses
+    it beyond.  A later "match the reference" edit cannot silently turn one into the other."""
+    nT, nB = 7, 4
+    T = 0.10 + 0.01 * np.arange(nT)
+    B = 0.05 * np.arange(nB)
+    tab = (100.0 * np.arange(nB)[:, None] + np.arange(nT)[None, :]).astype(np.float64)          # [iB][iT]
+    dff = dict(T=T, muB=B, c0=tab[0].copy(), c2=tab[0].copy(), F=tab[0].copy(), betabulk=tab[0].copy() + 1, betapi=tab[0].copy() + 1,
+               **{"2d": {k: tab.copy() for k in inputs.DF_NAMES_2D}})
+    Tq, Bq = T[1] + 0.004, B[2] + 0.01                              # iT = 1, iB = 2; fractions 0.4, 0.2
+    want_intended = 100.0 * 2.2 + 1.4                                # f is linear: the bilinear value is exact
+    want_reference = 100.0 * 1.4 + 2.2                               # rows indexed by iT, columns by imuB
+    got = oracle.df_coefficients_bilinear(dff, 2, Tq, Bq)
+    assert abs(got["G"] - want_intended) < 1e-10
+    ref = oracle.df_coefficients_bilinear(dff, 2, Tq, Bq, reference_indexing=True)
+    assert abs(ref["G"] - want_reference) < 1e-10
+    assert abs(ref["G"] - got["G"]) > 50                             # the two conventions cannot be confused
+    # iT + 1 = 4 = points_muB: the reference dereferences f_data[4], one past its 4 row pointers
+    with pytest.raises(ValueError):
+        oracle.df_coefficients_bilinear(dff, 2, T[3] + 0.004, Bq, reference_indexing=True)
+    assert oracle.df_coefficients_bilinear(dff, 2, T[3] + 0.004, Bq)["G"] == pytest.approx(100.0 * 2.2 + 3.4, abs=1e-10)
+    # on the shipped 101 x 81 grids: defined below T[80] = 0.180 GeV only
+    full = inputs.df_tables_full()
+    v = oracle.df_coefficients_bilinear(full, 2, full["T"][30], full["muB"][12], reference_indexing=True)
+    assert abs(v["G"] - full["2d"]["G"][30, 12]) < 1e-13 * max(1.0, abs(full["2d"]["G"][30, 12]))
+    with pytest.raises(ValueError):
+        oracle.df_coefficients_bilinear(full, 2, 0.1805, 0.1, reference_indexing=True)
+
+
 def test_bilinear_branch(fx):
     """include_baryon = 1: bilinear (T, muB) interpolation with the INTENDED [imuB][iT] indexing (the reference swaps
     the indices, deltafReader.cpp:404-407); nodes are reproduced, outside the table is an error, and at muB = 0 with

@@ -97,13 +97,13 @@ def main():
     d["pdg_urqmd_columns"] = ["mc_id", "mass", "gspin", "baryon", "sign"]
     for key, rel in [("chosen_pikp", "PDG/chosen_particles_pikp.dat"), ("chosen_urqmd", "PDG/chosen_particles_urqmd_v3.3+.dat")]:
         d[key] = [int(r[0]) for r in read_block(os.path.join(REF, rel))]
-    # generalized Gauss-Laguerre roots/weights for alpha = 1, 2 (Gauss_Laguerre::load_roots_and_weights,
+    # generalized Gauss-Laguerre roots/weights for alpha = 1, 2, 3 (Gauss_Laguerre::load_roots_and_weights,
     # src/cpp/readindata.cpp:24-53): first line "n_alpha n_points", then rows "alpha root weight"
     with open(os.path.join(REF, "tables/gla_roots_weights_32_points.txt")) as f:
         n_alpha, n_pts = (int(x) for x in f.readline().split())
         rows = [f.readline().split() for _ in range(n_alpha * n_pts)]
     gla = {}
-    for al in (1, 2):
+    for al in (1, 2, 3):
         sel = rows[al * n_pts:(al + 1) * n_pts]
         assert all(int(r[0]) == al for r in sel)
         gla["root%d" % al] = [float(r[1]) for r in sel]
