@@ -52,7 +52,7 @@ def workload(name):
     raise SystemExit("unknown workload %s" % name)
 
 
-def isa_counts(kernel_name, wl, JT_R):
+def isa_counts(kernel_name, wl, JT_R, variant=0):
     p = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
     if not os.path.exists(p):
         return None
@@ -60,6 +60,8 @@ def isa_counts(kernel_name, wl, JT_R):
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
     if kernel_name == "cf_main_feqmod":
         key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1])
+    elif kernel_name == "cf_main_tile3e":
+        key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,ROWMASK=%d" % (ce, JT_R[0], JT_R[1], int(variant == 6))
     elif kernel_name == "cf_main_tile":
         key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,BARYON=0,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
     else:
@@ -120,6 +122,7 @@ def main():
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
     ap.add_argument("--cells", type=int, default=0, help="override cells per GPU (parity/dev runs)")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--zero-skip", type=int, default=0, choices=[0, 1, 2], help="dev: culling mode of the main kernel (2 = off)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true")
@@ -173,7 +176,7 @@ def main():
     n_loc = hi - lo
     cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
     tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}   # resident in HBM before timing
-    opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local)
+    opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local, zero_skip=a.zero_skip)
     fq = None
     if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, the surface-average temperature (all ranks' cells)
         fq = inputs.feqmod_tables(idist.surface_average_T_global(cells))
@@ -305,7 +308,7 @@ def main():
                         note="not the binding roofline: 1e6 flop/byte; see roofline_valu and DESIGN.md section 5")
         # ---- the binding roofline: fp64 VALU
         jt_r = plan.tile_shape
-        ic = isa_counts(plan.main_kernel_name, wl, jt_r)
+        ic = isa_counts(plan.main_kernel_name, wl, jt_r, st["kernel_variant"])
         unique_evals = float(n_loc) * nbins * st["n_classes"] * (len(grid["eta"]) if wl["dimension"] == 2 else 1)
         rv = None
         # rows the kernel proved to be exactly zero for a whole wave are not executed (status counters)

@@ -132,7 +132,9 @@ typedef struct {
     /* tuning; 0 = library default */
     int32_t kernel_variant;             /* 0 default (3 in 3+1D without baryon terms, else 2) | 1 direct kernel
                                            (flat streams, one exp per evaluation) | 2,3,4 LDS-staged tile kernel, (phi x rows)
-                                           tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61 in 2+1D */
+                                           tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61 in 2+1D | 5: variant 3 with the phi-side
+                                           exponentials read from a table stream written by the prep kernel (3+1D delta-f kernel without
+                                           baryon terms; elsewhere the default) */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
     int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per

@@ -63,6 +63,10 @@ struct PrepParams {
     const unsigned long long *pds_bound;   // tiled stream: bits of a bound on |p.dsigma| over all lanes and cells (cf_pds_bound)
     double mTmax, kmin, kmax;       // largest lane mT; range of the k grid (y in 3+1D, eta nodes in 2+1D): bound of p.u/T
     unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count, [7] min cell whose p.u/T can exceed 1e9
+    // E2 table stream (kernel variant 5, see "TE" below); TE == nullptr: not written
+    double *TE;
+    const double *pTgrid;           // [npT] the pT grid (the lanes' pT values are exactly these)
+    int32_t npT;
 };
 
 // ---- tiled stream TS (variants >= 2): what one workgroup of the main kernel streams through LDS ----
@@ -79,6 +83,14 @@ struct PrepParams {
 // include_baryon = 1 ("B" records): the header slot 3 holds L2_j, two doubles {alpha_B, 0} follow the header, and
 // every row carries two more scalars {L_k, 0} after W, where  b (mT L_k + pT L2_j)  is the part of df/feqbar
 // that is linear in the momentum and proportional to the baryon number b of the lane (cf_kernels.hip::cf_prep).
+// E2 table stream TE (kernel variant 5: 3+1D, no baryon slots): the phi-side factor of the factorised exponential,
+//   E2[ipT][jj] = exp(pT_ipT Dp_j - pT_ipT Dmax),   Dmax = max_j Dp_j over the tile (header slot 3 of the unit record),
+// depends on the lane only through its pT, and the grid has only npT (32) of them for thousands of lanes: cf_prep evaluates the
+// npT x JT exponentials of a (cell, phi tile) ONCE and the main kernel's lanes read theirs from the LDS-staged table instead of
+// each computing JT exponentials per live unit (the same for all row blocks and all lane-waves: 76x redundant on config 3).
+//   TE[((jt*n_cells + cell)*JT + jj)*kE2Stride + ipT]   (pT fastest: the lanes' LDS reads of one jj hit consecutive words;
+//                                                        grids of up to kE2Stride pT values, else the plan falls back to variant 3)
+constexpr int kE2Stride = 32;
 inline int unit_rec_doubles(int JT, int R, int baryon = 0) { return baryon ? 4 * JT + 2 + R * (6 + JT) : 4 * JT + R * (4 + JT); }
 
 // ---- main kernel geometry ----
@@ -96,6 +108,9 @@ struct MainGeom {
                        // of any accumulator (tile delta-f kernel with outflow && regulate_deltaf; cf_kernels.hip)
     int32_t wpb;       // lane-waves (= waves) per workgroup of the tile kernel: 2, 4 or 8
     int32_t baryon;    // 1: "B" unit records, lanes carry a baryon number
+    int32_t npT;       // variant 5: rows of the E2 table
+    int32_t ub;        // variant 5: units per LDS batch (from the LDS budget of the workgroup)
+    int32_t split;     // 2+1D: lane slots per momentum bin (unit-strided lanes, cf_main_tile); 1 = off
 };
 
 struct MainArgs {
@@ -104,6 +119,9 @@ struct MainArgs {
     unsigned long long *stats;   // [2] += wave-rows visited, [3] += wave-rows culled as exactly zero
     MainGeom g;
     const int32_t *lane_pe = nullptr;   // per lane: exponent pe with max(mT/mTmax, pT/pTmax) < 2^pe (accumulator-relative cull)
+    const double *TE = nullptr;         // variant 5: E2 table stream
+    const int32_t *lane_ipT = nullptr;  // variant 5: per lane, the index of its pT in the grid
+    const int32_t *lane_sub = nullptr;  // unit-strided lanes: per lane slot, which units (u = sub mod split) it takes
 };
 
 }  // namespace is3d

@@ -406,6 +406,20 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                     }
                 }
             }
+            if (p.TE && unit_bounds) {
+                // E2 table stream (cf_device.h): exp(pT Dp_j - pT Dmax) for every pT of the grid, with the roundings the main
+                // kernel's own header used (explicit mul / sub, no contraction): pT Dmax == max_j (pT Dp_j) for pT >= 0
+                const int NPJ = kE2Stride * JT;
+                for (int idx = tid; idx < ncb * p.jtiles * NPJ; idx += kPrepThreads) {
+                    const int ct = idx / NPJ, e = idx - ct * NPJ;
+                    const int c = ct / p.jtiles, jt = ct - c * p.jtiles;
+                    const int jj = e / kE2Stride, ipT = min(e - jj * kE2Stride, p.npT - 1);   // [jj][ipT], columns past the grid repeat the last
+                    const double pT = p.pTgrid[ipT];
+                    const double pTD = __dmul_rn(pT, l_Dp[c * J + min(jt * JT + jj, J - 1)]);
+                    const double bmax = __dmul_rn(pT, l_V2[c * p.jtiles + jt]);
+                    p.TE[((int64_t)jt * p.n_cells + (cbase + c)) * NPJ + e] = exp_full(__dsub_rn(pTD, bmax));
+                }
+            }
         }
         __syncthreads();
     }
@@ -576,13 +590,15 @@ template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R
 __global__ void __launch_bounds__(512)
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, const double *__restrict__ lane_b, double *__restrict__ partial,
-             unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe)
+             unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
+             const int32_t *__restrict__ lane_sub)
 {
     // unit record layout (cf_device.h); BARYON records carry alpha_B after the header and L_k in every row
     constexpr int HDR = 4 * JT + (BARYON ? 2 : 0);
     constexpr int RS = BARYON ? 6 : 4;          // row scalars before the beta entries
     constexpr int REC = HDR + R * (RS + JT);
-    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;  // units per batch (about 12 KB)
+    constexpr int UB0 = (1536 / REC) > 0 ? (1536 / REC) : 1;  // units per batch (about 12 KB)
+    constexpr int UB = (!DIM3 && R <= 32) ? ((UB0 + 3) / 4) * 4 : UB0;   // short 2+1D units: whole groups of 4 (unit-strided lanes, below)
     constexpr int BUF2 = UB * REC / 2;                       // double2 per buffer
     constexpr int NLD = (BUF2 + 127) / 128;                 // staging loads per thread for the smallest workgroup (2 waves)
     constexpr bool EARLY = LAZY;   // staging order, see the batch loop (eager tiles: 664 -> 666 ms, 2+1D 40.2 -> 42.0 ms with it)
@@ -610,6 +626,14 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 
     const int J = g.J, K = g.K;
     const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    // Unit-strided lanes (2+1D, g.split = S > 1): a surface with few momentum bins (3 species x 32 pT = 96 lanes) would leave a
+    // quarter of its two waves idle.  Instead every bin gets S lane slots (bin, s), slot s takes the units u = s (mod S) of the
+    // stream -- all units of a stream add into the same JT accumulators of a bin, so any partition of them is a partition of
+    // the sum -- and 96 x 4 = 384 lanes are six full waves.  The operands of a lane then come from ITS unit: the LDS addresses
+    // carry a per-lane offset (they are vector addresses anyway), the instruction stream is unchanged.  cf_finalize adds the S
+    // slots of a bin in slot order.
+    const int S = (!DIM3 && g.split > 1) ? g.split : 1;
+    const int sub_off = (!DIM3 && lane_sub) ? lane_sub[l] * REC : 0;
     const double hs = REG ? 0.5 : 1.0;  // u = (1 + df) * hs
     const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
     const double bq = BARYON ? lane_b[l] : 0.0;              // baryon number of the lane's species class
@@ -626,7 +650,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
-    int n_rows = 0, n_dead = 0;   // wave-uniform bookkeeping for the executed-work accounting of bench.py
+    int n_rows = 0, n_dead = 0, n_calls = 0;   // wave-uniform bookkeeping for the executed-work accounting of bench.py
     // Row culling threshold on earg = log E1.  Always: exp(earg) == +0 below -745.2.  With OUTFLOW && REG (g.zskip == 2) also
     // relative to the accumulators: every term of a row is pds w with 0 <= pds <= 1 (clamped, scaled stream), 0 <= u <= 1 and
     // z r <= 2 z <= 2 E1 (E2 <= 1; 1/(1 + sign z) <= 2 for z <= 1/2), the accumulators only grow, and fma(pds, w, acc) == acc
@@ -784,8 +808,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             }
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
-                const double *base = (const double *)lbuf[ib & 1];
-                for (int u = 0; u < nu; u++) process_unit(base + u * REC);
+                const double *base = (const double *)lbuf[ib & 1] + sub_off;
+                for (int u = 0; u < nu; u += S) { process_unit(base + u * REC); n_calls++; }   // nu is a multiple of S (plan)
                 // the threshold follows log2 of the accumulators, which grow about linearly with the cells seen: refresh after batches
                 // 0, 1, 3, 7, 15, ... and every 32nd
                 if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 31) == 31)) {
@@ -809,7 +833,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     if (!wave_active) return;
     if ((tid & 63) == 0) {
         // the 2+1D loop fetches one row past each unit; those are not rows of the surface
-        const int fetched = (DIM3 || (R & 1)) ? n_rows : n_rows - n_units;
+        const int fetched = (DIM3 || (R & 1)) ? n_rows : n_rows - n_calls;
         atomicAdd(&stats[2], (unsigned long long)fetched);
         atomicAdd(&stats[3], (unsigned long long)min(n_dead, fetched));
     }
@@ -841,13 +865,247 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// cf_main_tile3e (variant 5): cf_main_tile for 3+1D without baryon slots, with the phi-side exponentials read from the E2
+// table stream (cf_device.h "TE") instead of being computed by every lane: the JT header exponentials per live unit
+// (16 % of all issued VALU instructions of the variant-3 kernel on config 3) become JT/2 ds_read_b128.  Everything else --
+// unit records, unit- and row-level culling, the shared reciprocals, the partial layout -- is cf_main_tile<.., LAZY = true>.
+// LDS: two buffers of g.ub units, each unit REC doubles of record + npT*JT doubles of table (dynamic, sized by the launcher).
+// ------------------------------------------------------------------------------------------------
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R, bool ROWMASK = false>
+__global__ void __launch_bounds__(512)
+cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
+               const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
+               double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe)
+{
+    constexpr int HDR = 4 * JT, RS = 4, RW = RS + JT;
+    constexpr int REC = HDR + R * RW;
+    constexpr int RB = JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2);
+    static_assert(JT % RB == 0 && JT % 2 == 0, "phi tile: whole reciprocal batches, 16-byte records");
+    extern __shared__ double2 lds2[];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int stream = (q / g.G) * 8 + xcd;
+    if (stream >= g.NT) return;  // uniform for the whole workgroup
+    int sidx = stream;
+    const int jt = sidx % g.jtiles; sidx /= g.jtiles;
+    const int kt = sidx % g.ktiles; sidx /= g.ktiles;
+    const int chunk = sidx;
+    const int nthr = blockDim.x;
+    const int lw = grp * g.wpb + (tid >> 6);
+    const bool wave_active = lw * 64 < g.Lpad;
+    const int l = wave_active ? lw * 64 + (tid & 63) : 0;
+
+    const int J = g.J, K = g.K;
+    constexpr int TEREC = kE2Stride * JT;         // doubles of table per unit ([jj][kE2Stride], the first npT columns used)
+    const int UB = g.ub;
+    constexpr int URECT = REC + TEREC;            // LDS doubles per unit: its record and its table
+    const int BUFD = UB * URECT;                  // doubles per buffer
+    const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    const int tabrow = lane_ipT[l];               // the lane's column within a unit's table, stored [jj][ipT]: lanes of a wave read
+                                                  // consecutive 8-byte words for consecutive pT indices (no LDS bank conflicts)
+    const double hs = REG ? 0.5 : 1.0;
+    const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
+    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    const int n_units = c1 - c0;                  // one unit per cell in 3+1D
+    const int s_tile = jt * g.ktiles + kt;
+    const double2 *src_ts = (const double2 *)(TS + ((int64_t)s_tile * g.n_cells + c0) * REC);
+    const double2 *src_te = (const double2 *)(TE + ((int64_t)jt * g.n_cells + c0) * TEREC);
+    const int nb = (n_units + UB - 1) / UB;
+
+    constexpr int NACC = JT * R;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+
+    int n_rows = 0, n_dead = 0;
+    constexpr bool RELCULL = OUTFLOW && REG;      // accumulator-relative culling, see cf_main_tile
+    double cull_thr = -745.2;
+    const int pe = (RELCULL && lane_pe) ? lane_pe[l] : 0;
+
+    auto process_unit = [&](const double *U, const double *tab) {
+        const double bmax = __dmul_rn(pT, U[3]);                                         // pT Dmax == max_j pT Dp_j (pT >= 0)
+        {
+            const double eu = __dsub_rn(bmax, __dmul_rn(mT, U[7]));                      // unit-level cull, as in cf_main_tile
+            if (g.zskip && __all(eu < cull_thr)) { n_rows += R; n_dead += R; return; }
+        }
+        double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) {
+            pTB[jj] = pT * U[4 * jj + 0];
+            pTD[jj] = pT * U[4 * jj + 1];
+            pT2g[jj] = pT2s * U[4 * jj + 2];
+            E2[jj] = tab[jj * kE2Stride];
+        }
+        struct Row { const double *v; double mTC, E1; bool live; };
+        auto fetch = [&](Row &rw, const double *row) {
+            rw.v = row;
+            rw.mTC = mT * row[1];
+            const double earg = bmax - rw.mTC;
+            rw.live = !(g.zskip && __all(earg < cull_thr));
+            n_rows += 1;
+            n_dead += rw.live ? 0 : 1;
+            rw.E1 = exp_full(earg);
+        };
+        auto evals = [&](const Row &rw, int r) {
+            const double mTA = mT * rw.v[0];
+            const double mT2a = mT2s * rw.v[2];
+            const double mTC = rw.mTC, E1 = rw.E1;
+#pragma unroll
+            for (int j0 = 0; j0 < JT; j0 += RB) {
+                // Chapman-Enskog: with v = z x the shared reciprocal is of q = (1 + sign z) x = x + sign v, and f_eq = z / (1 + sign z)
+                // = v / q: v serves both (one multiplication fewer per evaluation than forming 1 + sign z, q and R x separately)
+                double zv[RB], qq[RB], inv[RB];
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const double z = E1 * E2[j0 + i];
+                    if (CE) {
+                        const double x = mTC - pTD[j0 + i];
+                        zv[i] = z * x;
+                        qq[i] = __builtin_fma(sign, zv[i], x);
+                    } else {
+                        zv[i] = z;
+                        qq[i] = __builtin_fma(sign, z, 1.0);
+                    }
+                }
+                rcp_batch<RB>(qq, inv);
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int jj = j0 + i;
+                    const double beta = rw.v[RS + jj];
+                    const double pds = OUTFLOW ? add_clamp01(mTA, pTB[jj]) : (mTA + pTB[jj]);
+                    const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
+                    const double dfr = inv[i];
+                    const double u = REG ? fma_clamp01_half(dfr, br) : __builtin_fma(dfr, br, 1.0);
+                    const double w = (zv[i] * dfr) * u;
+                    acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                }
+            }
+        };
+        const double *rows = U + HDR;
+        if constexpr (ROWMASK) {
+            // Liveness of the R rows first (3 instructions a row), then only the live rows pay their exponential: a dead row inside
+            // a live unit costs its test, not the 15-instruction exponential the row pipeline below computes for every row.
+            // Within a live row the exponential's dependent chain overlaps the row's E1-independent work (x, p.dsigma, br).
+            unsigned live = (1u << R) - 1u;
+            if (g.zskip) {
+                live = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double earg = bmax - mT * rows[r * RW + 1];
+                    live |= __all(earg < cull_thr) ? 0u : (1u << r);
+                }
+            }
+            n_rows += R;
+            n_dead += R - __builtin_popcount(live);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (live & (1u << r)) {
+                    Row rw;
+                    rw.v = rows + r * RW;
+                    rw.mTC = mT * rw.v[1];
+                    rw.E1 = exp_full(bmax - rw.mTC);
+                    rw.live = true;
+                    evals(rw, r);
+                }
+            }
+        } else {
+            Row cur, nxt;
+            fetch(cur, rows);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
+                if (cur.live) evals(cur, r);
+                if (r + 1 < R) cur = nxt;
+            }
+        }
+    };
+
+    // staging: records and tables of batch ib+1 go global -> LDS by direct-to-LDS loads (global_load_lds_dwordx4: 1 KiB per wave-
+    // instruction, no staging registers, nothing waits until the barrier that ends batch ib), issued BEFORE batch ib is consumed.
+    // LDS image of a buffer = the two contiguous global runs: [UB records][UB tables].
+    auto stage = [&](int ib, int buf) {
+        const int nu = min(UB, n_units - ib * UB);
+        char *dst = (char *)lds2 + (size_t)buf * BUFD * sizeof(double);
+        const char *s1 = (const char *)src_ts + (int64_t)ib * UB * REC * (int64_t)sizeof(double);
+        const char *s2 = (const char *)src_te + (int64_t)ib * UB * TEREC * (int64_t)sizeof(double);
+        const int b1 = nu * REC * (int)sizeof(double), b2 = nu * TEREC * (int)sizeof(double);
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane16 = (tid & 63) * 16, nw = nthr >> 6;   // wave-uniform piece index
+        for (int p = wave; p * 1024 < b1; p += nw)
+            if (p * 1024 + lane16 < b1) glds16(s1 + p * 1024 + lane16, dst + p * 1024);
+        char *dst2 = dst + (size_t)UB * REC * sizeof(double);
+        for (int p = wave; p * 1024 < b2; p += nw)
+            if (p * 1024 + lane16 < b2) glds16(s2 + p * 1024 + lane16, dst2 + p * 1024);
+    };
+    if (nb > 0) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ib = 0; ib < nb; ib++) {
+            if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
+            if (wave_active) {
+                const int nu = min(UB, n_units - ib * UB);
+                const double *base = (const double *)(lds2 + (size_t)(ib & 1) * (BUFD / 2));
+                for (int u = 0; u < nu; u++) process_unit(base + u * REC, base + UB * REC + u * TEREC + tabrow);
+                if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 63) == 63)) {
+                    double m = acc[0];
+#pragma unroll
+                    for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
+                    const int e = __builtin_amdgcn_frexp_exp(m);
+                    cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads of batch ib+1 have landed
+            __syncthreads();
+        }
+    }
+    if (!wave_active) return;
+    if ((tid & 63) == 0) {
+        atomicAdd(&stats[2], (unsigned long long)n_rows);
+        atomicAdd(&stats[3], (unsigned long long)min(n_dead, n_rows));
+    }
+    const double unscale = REG ? 2.0 : 1.0;
+    const int64_t JKacc = (int64_t)J * g.Kacc;
+    double *pp = partial + (int64_t)chunk * JKacc * g.Lpad;
+#pragma unroll
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = jt * JT + jj;
+        if (j < J) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int k = kt * R + r;
+                if (k < K) {
+                    double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + l;
+                    const double v = unscale * acc[jj * R + r];
+                    *o = g.first_pass ? v : (*o + v);
+                }
+            }
+        }
+    }
+}
+
+// LDS bytes per workgroup of cf_main_tile3e: four 2-wave workgroups share a CU's 160 KB
+constexpr int kTile3eLdsBudget = 40 * 1024;
+int tile3e_units_per_batch(int JT, int R, int npT, int wpb)
+{
+    if (npT > kE2Stride) return 0;
+    const int rect = 4 * JT + R * (4 + JT) + kE2Stride * JT;
+    const int budget = kTile3eLdsBudget * (wpb / 2 > 0 ? wpb / 2 : 1);    // larger workgroups: proportionally fewer per CU
+    const int ub = budget / (2 * 8 * rect);
+    return ub > 16 ? 16 : ub;
+}
+
+// ------------------------------------------------------------------------------------------------
 // cf_finalize: out[sp + npart*(ipT + npT*(j + J*k))] (smooth_kernels.cpp:363)
 //              (+)= prefactor * degeneracy[sp] * sum_chunks partial[chunk][j*Kacc + k][class(sp)*npT + ipT]
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, const double *__restrict__ degeneracy,
             double *__restrict__ out, int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch,
-            double prefactor, int accumulate, const unsigned long long *__restrict__ pds_bound)
+            double prefactor, int accumulate, const unsigned long long *__restrict__ pds_bound, int split, int Lbins)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nout) return;
@@ -861,7 +1119,8 @@ cf_finalize(const double *__restrict__ partial, const int *__restrict__ cls, con
     const int64_t stride = (int64_t)J * Kacc * Lpad;
     const double *p = partial + ((int64_t)j * Kacc + k) * Lpad + l;
     double s = 0.0;
-    for (int ch = 0; ch < nch; ch++) s += p[ch * stride];
+    for (int ch = 0; ch < nch; ch++)
+        for (int sl = 0; sl < split; sl++) s += p[ch * stride + (int64_t)sl * Lbins];   // unit-strided lanes: the bin's slots, in slot order
     double unscale;                            // the stream carried p.dsigma 2^-e: exact to put back
     (void)pds_scale(pds_bound, &unscale);
     const double v = (prefactor * degeneracy[sp]) * (s * unscale);
@@ -883,7 +1142,7 @@ cf_reduce_chunks(double *__restrict__ partial, int64_t n_per_chunk, int nch)
 
 hipError_t launch_finalize(double *partial, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
-                           int accumulate, const unsigned long long *pds_bound, hipStream_t stream)
+                           int accumulate, const unsigned long long *pds_bound, hipStream_t stream, int split, int Lbins)
 {
     if (nout <= 0) return hipSuccess;
     if (nch > 1) {
@@ -892,7 +1151,7 @@ hipError_t launch_finalize(double *partial, const int *cls, const double *degene
     }
     int grid = (int)((nout + 255) / 256);
     hipLaunchKernelGGL(cf_finalize, dim3(grid), dim3(256), 0, stream, (const double *)partial, cls, degeneracy, out, nout, npart,
-                       npT, J, Kacc, Lpad, 1, prefactor, accumulate, pds_bound);
+                       npT, J, Kacc, Lpad, 1, prefactor, accumulate, pds_bound, split < 1 ? 1 : split, Lbins);
     return hipGetLastError();
 }
 
@@ -912,10 +1171,10 @@ static void launch_tile_t(const MainArgs &a, hipStream_t st)
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
     if (a.g.baryon)
         hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, true, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
-                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe);
+                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe, a.lane_sub);
     else
         hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, false, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
-                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe);
+                           a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe, a.lane_sub);
 }
 
 // Kernel variants.  1: direct (flat streams).  2 (default), 3, 4: LDS-staged tile kernel, tile shapes for tuning.
@@ -923,18 +1182,44 @@ static void launch_tile_t(const MainArgs &a, hipStream_t st)
 constexpr int kV1KT3 = 7, kV1KT2 = 4;
 constexpr int kTileJT3[3] = {6, 8, 4}, kTileR3[3] = {7, 7, 7};
 constexpr int kTileJT2[3] = {8, 12, 4}, kTileR2[3] = {61, 61, 61};
+constexpr int kTile7JT = 8, kTile7R = 31;   // variant 7 (2+1D)
 
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
     if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
+    if (variant == 5 || variant == 6) variant = 3;   // same tile, E2 table stream
+    if (variant == 7) {
+        if (!dim3) { *JT = kTile7JT; *KT = kTile7R; return; }
+        variant = 3;
+    }
     int i = (variant >= 2 && variant <= 4) ? variant - 2 : 0;
     *JT = dim3 ? kTileJT3[i] : kTileJT2[i];
     *KT = dim3 ? kTileR3[i] : kTileR2[i];
 }
 
+template <bool CE, bool OF, bool RG, int JT, int R, bool ROWMASK = false>
+static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
+{
+    const int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    const size_t lds = (size_t)2 * a.g.ub * (4 * JT + R * (4 + JT) + kE2Stride * JT) * sizeof(double);
+    hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, ROWMASK>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT, a.lane_pT,
+                       a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe);
+}
+
 template <bool CE, bool DIM3, bool OF, bool RG>
 static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
 {
+    if constexpr (DIM3) {
+        // variant 5: the 8 x 7 tile with the E2 table stream (the plan only sets TE up for 3+1D without baryon slots)
+        if (variant == 5 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1]>(a, st); return; }
+        if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], true>(a, st); return; }
+    }
+    if (variant == 5 || variant == 6) variant = 3;
+    if constexpr (!DIM3) {
+        // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
+        if (variant == 7) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
+    }
+    if (variant == 7) variant = 3;
     switch (variant) {
     case 1: launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st); break;
     // 8 x 7 in 3+1D: its 56 accumulators leave no room to prefetch whole rows (54 VGPRs spill, 180 GB of scratch traffic per
@@ -1005,7 +1290,7 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
     return hipGetLastError();
 }
 
-const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : "cf_main_tile"; }
+const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : ((variant == 5 || variant == 6) ? "cf_main_tile3e" : "cf_main_tile"); }
 
 // ------------------------------------------------------------------------------------------------
 // Derived observables from the device-resident spectrum: what the reference's writers

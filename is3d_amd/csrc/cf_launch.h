@@ -10,11 +10,12 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT);
 hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st);  // a.g.baryon selects the B kernels
 hipError_t launch_finalize(double *partial /* chunk 0 receives the sum over chunks */, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
-                           int accumulate, const unsigned long long *pds_bound, hipStream_t stream);
+                           int accumulate, const unsigned long long *pds_bound, hipStream_t stream, int split = 1, int Lbins = 0);
 // *out (zeroed by the caller) = bits of a bound on |p.dsigma| over all lanes, bins and the given cells
 hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3, double kmin, double kmax, double gw2d, double mTmax,
                             double pTmax, unsigned long long *out, hipStream_t st);
 const char *main_kernel_name(int variant);
+int tile3e_units_per_batch(int JT, int R, int npT, int wpb);   // variant 5: units per LDS batch
 hipError_t launch_observables(const double *dN, const double *phi_w, const double *pT_w, const double *coskphi,
                               const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
                               int ny, hipStream_t st);

@@ -11,6 +11,14 @@ namespace is3d {
 #define IS3D_LN2_HI 6.93147180369123816490e-01 /* 0x3fe62e42fee00000: n*LN2_HI exact for |n| < 2^21 */
 #define IS3D_LN2_LO 1.90821492927058770002e-10 /* 0x3dea39ef35793c76 */
 
+// 16 bytes per lane global -> LDS without a register round trip (global_load_lds_dwordx4): the wave writes 1 KiB contiguously at
+// the wave-uniform LDS address `l` (lane i lands at l + 16 i), each lane reads its own global address g.  Asynchronous: it is
+// retired by s_waitcnt vmcnt.
+__device__ __forceinline__ void glds16(const void *g, void *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
 // e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-10 near-minimax polynomial of e^r, |r| <= ln2/2.  Splitting mantissa and exponent lets two exponentials be
 // multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
 // e^r on |r| <= ln2/2 as a degree-10 polynomial (Chebyshev-node interpolant computed in long double, rounded to

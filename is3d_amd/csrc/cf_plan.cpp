@@ -65,7 +65,9 @@ struct is3d_plan {
     is3d_options opts{};
     int device = 0;
     int npart = 0, ncls = 0, npT = 0, J = 0, K = 0, Kacc = 0, ny_eff = 0;
-    int L = 0, Lpad = 0;
+    int L = 0, Lpad = 0;      // L: lane slots in use (bins x split), Lpad: padded to whole waves
+    int Lbins = 0, split = 1; // momentum bins (classes x pT); lane slots per bin (unit-strided lanes, 2+1D variant 7)
+    DevBuf<int32_t> d_lane_sub;
     int variant = 2, JT = 1, KT = 1, jtiles = 1, ktiles = 1;
     bool dim3 = true, ce = false;
     int64_t max_cells = 0, pass_cells = 0, nout = 0;
@@ -84,6 +86,10 @@ struct is3d_plan {
     DevBuf<int32_t> d_lane_pe;      // per lane: max(mT/mTmax, pT/pTmax) < 2^pe
     DevBuf<double> d_splx, d_sply[3], d_splc[3];
     DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
+    DevBuf<double> d_TE, d_pTgrid;   // variant 5: E2 table stream (cf_device.h), the pT grid for cf_prep
+    DevBuf<int32_t> d_lane_ipT;      // variant 5: lane -> index of its pT
+    bool e2tab = false;
+    int ub3e = 0;
     int rblocks = 1, upc = 1;   // row blocks of the tiled stream; units per cell within a stream
     int wpb = 4;                // waves per workgroup of the main kernel
     DevBuf<unsigned long long> d_status, d_sticky;   // d_sticky: {min bad cell, min fast cell} over the executes since the last is3d_plan_check
@@ -181,10 +187,32 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     P->ny_eff = P->Kacc;
     P->nout = (int64_t)P->npart * P->npT * P->J * P->ny_eff;
     P->prefactor = std::pow(2.0 * M_PI * is3d::kHbarC, -3);  // smooth_kernels.cpp:36
-    // default tile: 8 x 7 in 3+1D (delta-f kernel, config 3: 638 vs 659 ms for 6 x 7 -- fewer exponentials per evaluation;
-    // modified-equilibrium kernel: 1005 vs 1028 ms), 6 x 7 with the baryon slots, 8 x 61 in 2+1D
-    const int default_variant = (o->dimension == 3 && !o->include_baryon) ? 3 : 2;
-    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 4) ? o->kernel_variant : default_variant;
+    // Default kernel per mode (A/B on MI355X):
+    //   3+1D delta-f without baryon slots, pT grid <= 32: variant 6 -- 8 x 7 tile, phi-side exponentials from the E2 table stream,
+    //     rows tested for liveness before their exponential (config 3: 354 ms against 404 ms for variant 3);
+    //   3+1D otherwise: 8 x 7 (modified equilibrium: 1005 vs 1028 ms for 6 x 7), 6 x 7 with the baryon slots;
+    //   2+1D delta-f: 8 x 61; with few momentum bins variant 7 -- 8 x 31 tile with unit-strided lanes, when that fills the waves
+    //     (config 2, 96 bins: 31.4 ms against 38.7 ms).
+    auto split_for = [&](int n_bins) {   // lane slots per bin for variant 7: S in {1, 2, 4} dividing the units per cell
+        int JT7 = 0, R7 = 0, S_best = 1;
+        is3d::main_tile_shape(7, 0, &JT7, &R7);
+        const int rblocks7 = (g->n_eta + R7 - 1) / R7;
+        double best = 1.0 - (double)n_bins / (double)(((n_bins + 63) / 64) * 64);
+        for (int S : {2, 4}) {
+            if (rblocks7 % S) continue;
+            const int tot = n_bins * S, pad = ((tot + 127) / 128) * 128;   // whole 2-wave workgroups
+            const double waste = 1.0 - (double)tot / (double)pad;
+            if (waste < best - 0.05) { best = waste; S_best = S; }
+        }
+        return S_best;
+    };
+    const bool plain3 = o->dimension == 3 && !o->include_baryon;
+    int default_variant = plain3 ? 3 : 2;
+    if (!fq && plain3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;
+    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 7) ? o->kernel_variant : default_variant;
+    if (P->variant == 7 && (o->dimension == 3 || fq)) P->variant = default_variant;   // unit-strided lanes: the 2+1D delta-f tile kernel
+    if ((P->variant == 5 || P->variant == 6) && !(plain3 && !fq && g->n_pT <= is3d::kE2Stride)) P->variant = (fq || !plain3) ? default_variant : 3;
+    P->e2tab = P->variant == 5 || P->variant == 6;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
@@ -203,13 +231,20 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         cls[s] = found;
     }
     P->ncls = (int)cmass.size();
-    P->L = P->ncls * P->npT;
+    P->Lbins = P->ncls * P->npT;
+    // unit-strided lanes (variant 7, 2+1D): S lane slots per bin so that the slots fill whole waves (96 bins: 128 slots = 25 %
+    // idle lanes with S = 1, 384 = 6 full waves with S = 4); S must divide the units per cell and the units per LDS batch (4)
+    P->split = 1;
+    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 7) && split_for(P->Lbins) > 1) P->variant = 7;   // default
+    if (P->variant == 7) P->split = split_for(P->Lbins);
+    P->L = P->Lbins * P->split;
     P->Lpad = ((P->L + 63) / 64) * 64;
     // lane slots sorted by mT: a wave then holds momenta of similar energy, which is what makes the exact-zero
     // row culling of the main kernel wave-uniform more often (and keeps exp arguments of a wave close together)
     std::vector<double> mT(P->Lpad, 1.0), pT(P->Lpad, 0.0), sg(P->Lpad, 1.0), lb(P->Lpad, 0.0);
-    std::vector<int> order(P->L), slot_of(P->L);
-    std::vector<double> mT_nat(P->L);
+    std::vector<int32_t> lsub(P->Lpad, 0);
+    std::vector<int> order(P->Lbins), slot_of(P->Lbins);
+    std::vector<double> mT_nat(P->Lbins);
     for (int c = 0; c < P->ncls; c++)
         for (int i = 0; i < P->npT; i++) {
             double m = cmass[c], p = g->pT[i];
@@ -217,13 +252,17 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             order[c * P->npT + i] = c * P->npT + i;
         }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mT_nat[a] < mT_nat[b]; });
-    for (int s = 0; s < P->L; s++) {
+    for (int s = 0; s < P->Lbins; s++) {
         const int nat = order[s], c = nat / P->npT, i = nat % P->npT;
         slot_of[nat] = s;
-        mT[s] = mT_nat[nat];
-        pT[s] = g->pT[i];
-        sg[s] = csign[c];
-        lb[s] = cbar[c];
+        for (int sl = 0; sl < P->split; sl++) {   // slot (bin s, sub sl) = sl * Lbins + s
+            const int t = sl * P->Lbins + s;
+            mT[t] = mT_nat[nat];
+            pT[t] = g->pT[i];
+            sg[t] = csign[c];
+            lb[t] = cbar[c];
+            lsub[t] = sl;
+        }
     }
     for (int s = 0; s < P->L; s++) { P->mTmax = std::max(P->mTmax, mT[s]); P->pTmax = std::max(P->pTmax, std::fabs(pT[s])); }
     std::vector<int> lane_sp((size_t)P->npart * P->npT);
@@ -247,6 +286,15 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     HIP_TRY(P->d_pT.upload(pT));
     HIP_TRY(P->d_sign.upload(sg));
     HIP_TRY(P->d_lane_b.upload(lb));
+    HIP_TRY(P->d_lane_sub.upload(lsub));
+    if (P->e2tab) {
+        std::vector<int32_t> ipT(P->Lpad, 0);
+        for (int s = 0; s < P->Lbins; s++) ipT[s] = order[s] % P->npT;
+        HIP_TRY(P->d_lane_ipT.upload(ipT));
+        HIP_TRY(P->d_pTgrid.upload(std::vector<double>(g->pT, g->pT + P->npT)));
+        for (int i = 0; i < P->npT; i++)
+            if (!(g->pT[i] >= 0.0)) return fail(IS3D_EINVAL, "kernel_variant 5 needs pT >= 0 (pT Dmax must be the maximum of pT D_j)");
+    }
     HIP_TRY(P->d_degeneracy.upload(deg));
     HIP_TRY(P->d_cls.upload(lane_sp));
     {
@@ -345,7 +393,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_jonah.upload(jon));
         std::vector<double> lane_mass(P->Lpad, 1.0);
         std::vector<int32_t> lane_cls(P->Lpad, 0);
-        for (int s = 0; s < P->L; s++) { lane_mass[s] = cmass[order[s] / P->npT]; lane_cls[s] = order[s] / P->npT; }
+        for (int s = 0; s < P->Lbins; s++) { lane_mass[s] = cmass[order[s] / P->npT]; lane_cls[s] = order[s] / P->npT; }
         HIP_TRY(P->d_lane_mass.upload(lane_mass));
         HIP_TRY(P->d_lane_cls.upload(lane_cls));
         HIP_TRY(P->d_cls_mass.upload(cmass));
@@ -367,6 +415,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0);
     else
         P->bytes_per_cell = sizeof(double) * ((size_t)P->K * is3d::kS1Rec + (size_t)P->J * is3d::kS2Rec + (size_t)P->J * P->K);
+    if (P->e2tab) P->bytes_per_cell += sizeof(double) * (size_t)P->jtiles * is3d::kE2Stride * P->JT;
     if (P->feqmod)   // fallback record, flag, list entry; df_mode 3: cell record + |renorm| per class
         P->bytes_per_cell += sizeof(double) * is3d::kFbRec + 2 * sizeof(int32_t) +
                              (o->df_mode == 3 ? sizeof(double) * ((size_t)is3d::kCrRec + P->ncls) : 0);
@@ -405,6 +454,11 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     }
     if (tiled) {
         HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0)));
+        if (P->e2tab) {
+            HIP_TRY(P->d_TE.alloc((size_t)pc * P->jtiles * is3d::kE2Stride * P->JT));
+            P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb);
+            if (P->ub3e < 1) return fail(IS3D_EINVAL, "kernel_variant 5: a unit record plus its %d x %d E2 table does not fit the LDS budget", P->npT, P->JT);
+        }
     } else {
         HIP_TRY(P->d_S1.alloc((size_t)pc * P->K * is3d::kS1Rec));
         HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
@@ -423,7 +477,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             HIP_TRY(P->d_RN.alloc((size_t)pc * P->ncls));
         }
     }
-    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_TS.n + P->d_partial.n + P->d_FB.n + P->d_CR.n + P->d_RN.n) * (int64_t)sizeof(double) +
+    P->workspace = (int64_t)(P->d_S1.n + P->d_S2.n + P->d_S3.n + P->d_TS.n + P->d_TE.n + P->d_partial.n + P->d_FB.n + P->d_CR.n + P->d_RN.n) * (int64_t)sizeof(double) +
                    (int64_t)(P->d_flag.n + P->d_list.n) * (int64_t)sizeof(int32_t);
     *out = P.release();
     return IS3D_OK;
@@ -627,6 +681,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             pp.pds_bound = use_scale ? P->d_status.p + 6 : nullptr;
             pp.mTmax = P->mTmax; pp.kmin = P->kmin; pp.kmax = P->kmax;
             pp.status = P->d_status.p;
+            pp.TE = P->e2tab ? P->d_TE.p : nullptr; pp.pTgrid = P->d_pTgrid.p; pp.npT = P->npT;
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 0], st));
             HIP_TRY(is3d::launch_prep(pp, st));
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 1], st));
@@ -650,12 +705,14 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.g.NT = P->jtiles * P->ktiles * nch_used;
             a.g.Kacc = P->Kacc;
             a.g.first_pass = (pass == 0);
+            a.TE = P->e2tab ? P->d_TE.p : nullptr; a.lane_ipT = P->d_lane_ipT.p; a.g.npT = P->npT; a.g.ub = P->ub3e;
+            a.g.split = P->split; a.lane_sub = P->d_lane_sub.p;
             HIP_TRY(is3d::launch_main(P->variant, P->ce, P->dim3, o.outflow != 0, o.regulate_deltaf != 0, a, st));
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 2], st));
         }
         HIP_TRY(is3d::launch_finalize(P->d_partial.p, P->d_cls.p, P->d_degeneracy.p, dN_out, P->nout, P->npart, P->npT, P->J,
                                       P->Kacc, P->Lpad, nch_used, P->prefactor, o.accumulate != 0,
-                                      use_scale ? P->d_status.p + 6 : nullptr, st));
+                                      use_scale ? P->d_status.p + 6 : nullptr, st, P->split, P->Lbins));
         if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[npasses * 3], st));
     }
 

@@ -108,8 +108,8 @@ def make_run_dir(root, cells, species_ids, params):
     # tables/gla_roots_weights_32_points.txt layout: "n_alpha\tn_points", rows "alpha\troot\tweight"; alpha = 0 is never read
     gla = fx["gla_32"]
     with open(os.path.join(root, "tables", "gla_roots_weights_32_points.txt"), "w") as f:
-        f.write("3\t%d\n" % len(gla["root1"]))
-        for al, (rk, wk) in enumerate([("root1", "weight1"), ("root1", "weight1"), ("root2", "weight2")]):
+        f.write("4\t%d\n" % len(gla["root1"]))
+        for al, (rk, wk) in enumerate([("root1", "weight1"), ("root1", "weight1"), ("root2", "weight2"), ("root3", "weight3")]):
             for r, w in zip(gla[rk], gla[wk]):
                 f.write("%d\t%s\t%s\n" % (al, repr(float(r) * (7.0 if al == 0 else 1.0)), repr(float(w))))
     particles = [r for r in fx["pdg_urqmd"] if r[3] >= 0]

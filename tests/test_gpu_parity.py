@@ -43,6 +43,7 @@ def run_plan(torch, cells, sp, grid, df, opts, n=None, out=None, first=0):
 
 
 SP7 = [211, 321, 2212, -2212, 3122, 333, 22]
+DEFAULT3 = 6   # the library's default kernel variant for 3+1D without baryon terms
 
 
 @pytest.mark.parametrize("dim", [3, 2])
@@ -54,9 +55,12 @@ def test_parity_matrix(fx, dim, df_mode, flags):
     sp = inputs.species(SP7) if dim == 3 else fx["pikp"]
     o = dict(dimension=dim, df_mode=df_mode, **flags)
     ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], o)
-    for variant in (1, 2, 3, 4):
+    for variant in (1, 2, 3, 4, 5, 6, 7):
         got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=variant))
-        assert st["kernel_variant"] == variant and st["code"] == 0
+        # variants 5, 6 (E2 table stream) exist for the 3+1D kernel, 7 (unit-strided lanes) for 2+1D; elsewhere the request falls
+        # back to that mode's default
+        want_variant = variant if variant < 5 else ((variant if variant < 7 else DEFAULT3) if dim == 3 else (7 if variant == 7 else 2))
+        assert st["kernel_variant"] == want_variant and st["code"] == 0
         assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
 
 
@@ -178,7 +182,7 @@ def test_odd_grids(fx):
         gg = dict(g, y=ygrid)
         for dfm in (1, 2):
             ref = oracle.dN_pTdpTdphidy(cells, fx["pikp"], gg, fx["df"], dict(dimension=3, df_mode=dfm))
-            for variant in (1, 2, 3, 4):
+            for variant in (1, 2, 3, 4, 5, 6):
                 got, _ = api.smooth_spectra(cells, fx["pikp"], gg, fx["df"], dict(dimension=3, df_mode=dfm, kernel_variant=variant))
                 assert relerr(got, ref) < TOL
     c2 = synth.synth_surface(5, 2, seed=9)
@@ -188,7 +192,7 @@ def test_odd_grids(fx):
         w[[0, -1]] *= 0.5
         gg = dict(g, eta=eta, eta_w=w)
         ref = oracle.dN_pTdpTdphidy(c2, fx["pikp"], gg, fx["df"], dict(dimension=2, df_mode=2))
-        for variant in (1, 2, 3, 4):
+        for variant in (1, 2, 3, 4, 7):
             got, _ = api.smooth_spectra(c2, fx["pikp"], gg, fx["df"], dict(dimension=2, df_mode=2, kernel_variant=variant))
             assert relerr(got, ref) < TOL
 
@@ -268,6 +272,25 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
     assert np.array_equal(a, b) and sa["n_wave_rows_culled"] == st1["n_wave_rows_culled"]
     if species == "pikp":
         assert relerr(rel, oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], dict(dimension=dim, df_mode=df_mode))) < TOL
+    if dim == 2:
+        # 96 momentum bins: the default is variant 7 (unit-strided lanes, four lane slots per bin); the plain 8 x 61 tile agrees to rounding
+        assert st0["kernel_variant"] == (7 if species == "pikp" else 2)
+        v2, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=2))
+        assert relerr(rel, v2) < 1e-12
+    if dim == 3:
+        # variant 5 reads the phi-side exponentials from the table stream cf_prep writes: culling changes no bit of it either, it
+        # agrees with variant 3 to rounding (the compiler may contract variant 3's pT D - bmax into one fma) and culls the same rows
+        v5, s5 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5))
+        v5e, s5e = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5, zero_skip=1))
+        v5f, s5f = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5, zero_skip=2))
+        v3, s3 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=3))
+        assert s5["kernel_variant"] == 5 and np.array_equal(v5, v5f) and np.array_equal(v5e, v5f)
+        assert relerr(v5, v3) < 1e-12
+        # variant 6 (the default here): the same with the rows' liveness tested before their exponentials
+        assert st0["kernel_variant"] == 6
+        assert relerr(rel, v5) < 1e-12 and abs(st0["n_wave_rows_culled"] - s5["n_wave_rows_culled"]) <= 2e-2 * s5["n_wave_rows_culled"]
+        # (the thresholds are refreshed per LDS batch, and the batches differ: the counts agree to a per cent, not to the row)
+        assert abs(s5["n_wave_rows_culled"] - s3["n_wave_rows_culled"]) <= 2e-2 * s3["n_wave_rows_culled"] and s5f["n_wave_rows_culled"] == 0
 
 
 @pytest.mark.parametrize("dim", [3, 2])
@@ -395,6 +418,42 @@ def test_full_size_config3_properties_and_spot_checks(fx, torch_mod):
     ref = _subset_oracle(fx, cells, ids, ipT, iphi, o).reshape(21, 2, 2, 3)
     got = w5[:, iphi][:, :, ipT][:, :, :, [0, 120, 304]]
     assert relerr(got, ref) < TOL
+
+
+def test_full_size_config3_stratified_oracle_sample(fx, torch_mod):
+    """BASELINE config 3, a stratified sample of > 1 % of the 4 919 040 bins against the oracle: one species of EVERY one of the
+    75 (mass, sign) classes x 6 pT (low / mid / high) x 6 phi (two per phi tile of the kernel) x all 21 rapidities = 56 700 bins,
+    over a 1e5-cell slice of the 1e6-cell surface; the shard-additivity test above ties slices to the whole surface bitwise-
+    reproducibly.  The slice runs through the default kernel (variant 6) and through variant 3."""
+    torch = torch_mod
+    n = 100000
+    cells = synth.synth_surface(1000000, 3)
+    sl = {k: v[300000:300000 + n] for k, v in cells.items()}
+    sp = fx["urqmd"]
+    o = dict(dimension=3, df_mode=2)
+    got, st = run_plan(torch, sl, sp, fx["grid"], fx["df"], o)
+    assert st["n_classes"] == 75 and st["kernel_variant"] == DEFAULT3
+    seen, reps = set(), []
+    for s, (m, sg) in enumerate(zip(sp["mass"], sp["sign"])):
+        if (m, sg) not in seen:
+            seen.add((m, sg))
+            reps.append(s)
+    assert len(reps) == 75
+    ipT, iphi = [0, 5, 12, 18, 25, 31], [1, 6, 9, 14, 17, 22]
+    ref = _subset_oracle(fx, sl, [int(sp["mc_id"][s]) for s in reps], ipT, iphi, o).reshape(21, 6, 6, 75)
+    g5 = got.reshape(21, 24, 32, 305)
+    sub = g5[:, iphi][:, :, ipT][:, :, :, reps]
+    assert sub.size == 56700 and sub.size > 0.01 * got.size
+    assert relerr(sub, ref) < TOL
+    # species of one class differ by the degeneracy only: every other species follows from its representative exactly
+    cls_of = {}
+    for s, (m, sg) in enumerate(zip(sp["mass"], sp["sign"])):
+        cls_of.setdefault((m, sg), s)
+    for s in (7, 150, 299):
+        r = cls_of[(sp["mass"][s], sp["sign"][s])]
+        assert relerr(g5[..., s] * sp["degeneracy"][r], g5[..., r] * sp["degeneracy"][s]) < 1e-15
+    old, _ = run_plan(torch, sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=3))
+    assert relerr(got, old) < 1e-12
 
 
 def test_full_size_config2_properties_and_spot_checks(fx, torch_mod):

@@ -210,3 +210,39 @@ def test_total_yield_matches_the_oracle(fx, dim, df_mode, baryon):
     with pytest.raises(api.Is3dError) as e:
         api.total_yield(cells, sp, df, gla, avg, o, y_cut=0.8)
     assert e.value.code == api.IS3D_EDOMAIN and "cell 123" in str(e.value)
+
+
+def test_sampler_config5_size(fx):
+    """BASELINE config 5's stated size for the sampler: the 1e6-cell config-3 surface, 305 species, 20 events (6e5 hadrons).
+    (i) the list restricted to the first 5e4 cells IS the oracle's list for that slice (same hadrons, same order) -- what
+    tests/bench_sampler.py prints; (ii) sharding by first_cell: four shards concatenated per event give the same list;
+    (iii) event batching does not change it; (iv) the mean multiplicity per event is the analytic yield (is3d_total_yield)
+    within the average-temperature approximation of that estimate."""
+    n, nev, nc = 1000000, 20, 50000
+    cells = synth.synth_surface(n, 3)
+    sp = fx["urqmd"]
+    gla = inputs.feqmod_tables(0.15)
+    o = dict(dimension=3, df_mode=2)
+    p, st = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=nev, seed=20260002)
+    assert st["n_particles"] == len(p) > 3e5 and np.all(np.diff(p["event"]) >= 0)
+    # (i)
+    ref, rst = oracle.sample_particles({k: v[:nc] for k, v in cells.items()}, sp, fx["df"], gla, o, n_events=nev, seed=20260002)
+    sel = p["cell"] < nc
+    assert int(sel.sum()) == len(ref["E"]) and np.array_equal(p["species"][sel], ref["species"]) and np.array_equal(p["cell"][sel], ref["cell"])
+    assert np.allclose(p["E"][sel], ref["E"], rtol=1e-11, atol=0) and np.allclose(p["pz"][sel], ref["pz"], rtol=1e-9, atol=1e-13)
+    # (ii)
+    shards = []
+    for r in range(4):
+        lo, hi = api.shard_bounds(n, r, 4)
+        q, _ = api.sample_particles({k: v[lo:hi] for k, v in cells.items()}, sp, fx["df"], gla, o, n_events=nev, seed=20260002, first_cell=lo)
+        shards.append(q)
+    merged = np.concatenate(shards)
+    merged = merged[np.lexsort((merged["cell"], merged["event"]))]
+    assert len(merged) == len(p) and all(np.array_equal(merged[f], p[f]) for f in ("event", "cell", "species", "E", "px", "py", "pz", "tau", "eta"))
+    # (iii)
+    q, _ = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=nev, seed=20260002, batch_events=3)
+    assert len(q) == len(p) and np.array_equal(q["E"], p["E"]) and np.array_equal(q["cell"], p["cell"])
+    # (iv)
+    avg = inputs.surface_averages(cells)
+    N, _ = api.total_yield(cells, sp, fx["df"], inputs.feqmod_tables(avg[0]), avg, o)
+    assert abs(len(p) / nev / N - 1) < 0.08

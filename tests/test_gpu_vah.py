@@ -46,6 +46,30 @@ def test_vah_species_collapse_passes_and_accumulate(fx):
         api.smooth_spectra_vah({k: v for k, v in cells.items() if k != "aL"}, sp, g, o)
 
 
+def test_vah_config5_size_properties(fx):
+    """BASELINE config 5's stated size for the VAH kernel: 1e6 cells x 305 species x 16 128 bins.  No reference behaviour exists
+    (the reference never calls this kernel), so properties: finite, shard additivity over three uneven shards, dsigma-linearity on
+    a slice, reproducibility."""
+    n = 1000000
+    cells = synth.synth_vah_surface(n, 3)
+    sp = fx["urqmd"]
+    o = dict(dimension=3)
+    whole, st = api.smooth_spectra_vah(cells, sp, fx["grid"], o)
+    assert np.isfinite(whole).all() and st["n_classes"] == 75
+    parts = np.zeros_like(whole)
+    for lo, hi in ((0, 333333), (333333, 700001), (700001, n)):
+        p, _ = api.smooth_spectra_vah({k: v[lo:hi] for k, v in cells.items()}, sp, fx["grid"], o)
+        parts += p
+    assert relerr(parts, whole, floor=1e-250) < 1e-10
+    again, _ = api.smooth_spectra_vah(cells, sp, fx["grid"], o)
+    assert np.array_equal(again, whole)
+    sl = {k: v[:50000] for k, v in cells.items()}
+    a, _ = api.smooth_spectra_vah(sl, sp, fx["grid"], o)
+    b, _ = api.smooth_spectra_vah({k: (3.0 * v if k in ("dat", "dax", "day", "dan") else v) for k, v in sl.items()}, sp, fx["grid"], o)
+    assert relerr(b, 3.0 * a, floor=1e-250) < 1e-14
+    print("vah 1e6 cells: main kernel ms", st["ms_main"], "prep", st["ms_prep"])
+
+
 def test_vah_full_size_properties(fx):
     """2e5 cells x 305 species: shard additivity and the equilibrium limit against the delta-f kernel with all corrections off."""
     n = 200000

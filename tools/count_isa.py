@@ -29,7 +29,7 @@ F64_OPS = ["v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_
 
 
 def demangle_params(sym):
-    m = re.match(r"_ZN4is3d(\d+)(cf_main_[a-z]+)I(.*?)EEvPKd", sym)
+    m = re.match(r"_ZN4is3d(\d+)(cf_main_[a-z0-9]+)I(.*?)EEvPKd", sym)
     if not m:
         return None
     name, args = m.group(2), m.group(3)
@@ -37,6 +37,8 @@ def demangle_params(sym):
     vals = [int(v) for _, v in vals]
     if name == "cf_main_tile":
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R"]
+    elif name == "cf_main_tile3e":
+        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "ROWMASK"]
     elif name == "cf_main_feqmod":
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON"]
     elif name == "cf_main_vah":
@@ -65,7 +67,7 @@ def main():
             continue
         if cur is None:
             continue
-        if "s_endpgm" in ln:
+        if ln.startswith(".Lfunc_end"):   # (an early-exit s_endpgm can sit in the middle of the body)
             cur = None
             continue
         m = re.match(r"^\.LBB\d+_\d+:(.*)", ln)
@@ -96,7 +98,7 @@ def main():
             rbatch = 1
         else:
             jt = params["JT"]
-            rbatch = (4 if jt % 4 == 0 else (3 if jt % 3 == 0 else 2)) if params["DIM3"] else (8 if jt % 8 == 0 else 4)
+            rbatch = (4 if jt % 4 == 0 else (3 if jt % 3 == 0 else 2)) if params.get("DIM3", 1) else (8 if jt % 8 == 0 else 4)
         n_eval = hot["v_rcp_f64"] * rbatch
         f64 = {k: v for k, v in hot.items() if k.endswith("_f64") or k == "v_mov_b64"}
         fma = hot["v_fma_f64"] + hot["v_fmac_f64"]

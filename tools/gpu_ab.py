@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--df", type=int, default=2)
     ap.add_argument("--species", default="urqmd")
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--sets", default="variant=2;variant=2,zero_skip=2;variant=3;variant=4")
+    ap.add_argument("--sets", default="variant=3;variant=5;variant=3,zero_skip=2;variant=5,zero_skip=2")
     a = ap.parse_args()
     import torch
     g = inputs.grid()
@@ -38,7 +38,7 @@ def main():
             k, v = kv.split("=")
             o["kernel_variant" if k == "variant" else k] = int(v)
         sets.append((s, o))
-    plans, outs, times = [], [], [[] for _ in sets]
+    plans, outs, times, preps = [], [], [[] for _ in sets], [[] for _ in sets]
     for s, o in sets:
         p = api.Plan(sp, grid, df, o, max_cells=a.cells)
         p.set_timing(True)
@@ -50,14 +50,16 @@ def main():
             t = p.timings()
             if r > 0:
                 times[i].append(t["ms_main"])
+                preps[i].append(t["ms_prep"])
     ref = outs[0].cpu().numpy()
     nb = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if a.dim == 3 else 1) * len(sp["mass"])
     for i, (s, o) in enumerate(sets):
         got = outs[i].cpu().numpy()
         err = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-280)))
         ms = np.array(times[i])
-        print("%-40s tile=%s main ms: median %.2f min %.2f  -> %.3e evals/s   max rel diff vs first %.2e  bitwise %s" % (
-            s, plans[i].tile_shape, np.median(ms), ms.min(), a.cells * nb / (np.median(ms) * 1e-3), err, bool(np.array_equal(got, ref))), flush=True)
+        print("%-40s %s tile=%s main ms: median %.2f min %.2f  prep ms %.2f  workspace %.1f GB -> %.3e evals/s   max rel diff vs first %.2e  bitwise %s" % (
+            s, plans[i].main_kernel_name, plans[i].tile_shape, np.median(ms), ms.min(), np.median(preps[i]), plans[i].workspace_bytes / 1e9,
+            a.cells * nb / (np.median(ms) * 1e-3), err, bool(np.array_equal(got, ref))), flush=True)
 
 
 if __name__ == "__main__":
