@@ -53,6 +53,7 @@ struct PrepParams {
     const double *cosphi, *sinphi;  // [J]
     const double *kgrid;            // [K] y values (3+1D) or eta nodes (2+1D)
     const double *kweight;          // [K] eta weights (2+1D), unused in 3+1D
+    const double *kch, *ksh;        // [K] 2+1D: cosh(0 - eta_k), sinh(0 - eta_k)
     SplineDev spl;
     double *S1, *S2, *S3;           // flat streams (variant 1); unused when tiled
     // tiled stream (variants >= 2), see "unit record" below

@@ -267,9 +267,14 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             const int c = idx / K, k = idx - c * K;
             const CellScal &s = cs[c];
             double dlt, w;
-            if (p.dim3) { dlt = p.kgrid[k] - s.eta; w = s.wvalid; }      // y - eta_cell, :279
-            else { dlt = 0.0 - p.kgrid[k]; w = p.kweight[k] * s.wvalid; }   // y = 0, eta = table node, :75-80
-            double ch = cosh(dlt), sh = sinh(dlt);
+            (void)dlt;
+            double ch, sh;
+            if (p.dim3) { dlt = p.kgrid[k] - s.eta; w = s.wvalid; ch = cosh(dlt); sh = sinh(dlt); }      // y - eta_cell, :279
+            else {
+                // y = 0, eta = table node (:75-80): cosh / sinh(0 - eta_k) do not depend on the cell -- tabulated once per plan
+                // (host libm, like the reference) instead of 2 x 241 device libm calls per cell
+                w = p.kweight[k] * s.wvalid; ch = p.kch[k]; sh = p.ksh[k];
+            }
             double C = ch * s.ut - sh * s.tau_un;
             double Q0 = s.pitt * ch * ch + s.t2pinn * sh * sh - 2.0 * s.tpitn * ch * sh;
             l_A[c * K + k] = w * (ch * s.dat + sh * s.dan_tau);
@@ -748,13 +753,34 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         };
         const double *rows = U + HDR;
         Row cur, nxt;
-        fetch(cur, rows);
+        if constexpr (DIM3 || R > 32) fetch(cur, rows);
         if (DIM3) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
                 if (cur.live) evals(cur, r);
                 if (r + 1 < R) cur = nxt;
+            }
+        } else if constexpr (R <= 32) {
+            // variant 7 (short units): no hand pipeline -- a row tests its liveness, then computes its exponential inside its own
+            // block, where the dependent chain overlaps the E1-independent part of the row's evaluations (what made variant 6
+            // faster than variant 5 in 3+1D)
+#pragma clang loop unroll_count(2)
+            for (int r = 0; r < R; r++) {
+                Row rw;
+                const double *row = rows + r * RW;
+                if constexpr (LAZY) rw.v = row;
+                else {
+#pragma unroll
+                    for (int i = 0; i < RW; i++) rw.v[i] = row[i];
+                }
+                rw.mTC = mT * row[1];
+                const double earg = BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC;
+                n_rows += 1;
+                if (g.zskip && __all(earg < cull_thr)) { n_dead += 1; continue; }
+                rw.live = true;
+                rw.E1 = exp_full(earg);
+                evals(rw, 0);
             }
         } else {
             // eta quadrature rows all feed the same JT accumulators: the loop stays ROLLED, two rows per trip with the
@@ -833,7 +859,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     if (!wave_active) return;
     if ((tid & 63) == 0) {
         // the 2+1D loop fetches one row past each unit; those are not rows of the surface
-        const int fetched = (DIM3 || (R & 1)) ? n_rows : n_rows - n_calls;
+        const int fetched = (DIM3 || (R & 1) || R <= 32) ? n_rows : n_rows - n_calls;
         atomicAdd(&stats[2], (unsigned long long)fetched);
         atomicAdd(&stats[3], (unsigned long long)min(n_dead, fetched));
     }

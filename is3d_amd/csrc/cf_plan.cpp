@@ -77,7 +77,7 @@ struct is3d_plan {
     double mTmax = 0, pTmax = 0;   // over the lane table: bound of |p.dsigma| for the stream's power-of-two scale
     double kmin = 0, kmax = 0, gw2d = 1;   // y range (3+1D) / max_k w_k cosh(eta_k) (2+1D) for the same bound
 
-    DevBuf<double> d_mT, d_pT, d_sign, d_lane_b, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight;
+    DevBuf<double> d_mT, d_pT, d_sign, d_lane_b, d_degeneracy, d_cosphi, d_sinphi, d_kgrid, d_kweight, d_kch, d_ksh;
     DevBuf<double> d_bilT, d_bilB, d_biltab[5];
     DevBuf<double> d_coskphi, d_sinkphi, d_phiw, d_pTw;   // derived observables
     is3d::BilinearDev bil{};
@@ -312,6 +312,12 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     HIP_TRY(P->d_sinphi.upload(sinphi));
     HIP_TRY(P->d_kgrid.upload(kgrid));
     HIP_TRY(P->d_kweight.upload(kweight));
+    {
+        std::vector<double> kch(P->K), ksh(P->K);
+        for (int k = 0; k < P->K; k++) { kch[k] = std::cosh(0.0 - kgrid[k]); ksh[k] = std::sinh(0.0 - kgrid[k]); }   // smooth_kernels.cpp:279-280 with y = 0
+        HIP_TRY(P->d_kch.upload(kch));
+        HIP_TRY(P->d_ksh.upload(ksh));
+    }
     {
         std::vector<double> ck((size_t)7 * P->J), sk((size_t)7 * P->J);
         for (int k = 0; k < 7; k++)
@@ -672,7 +678,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             pp.bil = P->bil;
             pp.cells.muB = cells->muB; pp.cells.nB = cells->nB; pp.cells.Vx = cells->Vx; pp.cells.Vy = cells->Vy; pp.cells.Vn = cells->Vn;
             pp.cosphi = P->d_cosphi.p; pp.sinphi = P->d_sinphi.p;
-            pp.kgrid = P->d_kgrid.p; pp.kweight = P->d_kweight.p;
+            pp.kgrid = P->d_kgrid.p; pp.kweight = P->d_kweight.p; pp.kch = P->d_kch.p; pp.ksh = P->d_ksh.p;
             pp.spl = P->spl;
             pp.S1 = P->d_S1.p; pp.S2 = P->d_S2.p; pp.S3 = P->d_S3.p;
             pp.tiled = (P->variant != 1);

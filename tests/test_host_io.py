@@ -198,7 +198,7 @@ def test_gla_reader(tmp_path):
     root = refformat.make_run_dir(str(tmp_path), synth.synth_surface(2, 3, seed=1), [211], dict())
     r, w = api.gla_read(os.path.join(root, "tables", "gla_roots_weights_32_points.txt"))
     g = inputs.load_fixture()["gla_32"]
-    assert r.shape == (3, 32) and np.array_equal(r[1], g["root1"]) and np.array_equal(w[1], g["weight1"])
+    assert r.shape == (4, 32) and np.array_equal(r[1], g["root1"]) and np.array_equal(w[1], g["weight1"]) and np.array_equal(r[3], g["root3"])
     assert np.array_equal(r[2], g["root2"]) and np.array_equal(w[2], g["weight2"])
     # generalized Gauss-Laguerre: sum_k w_k = Gamma(alpha + 1), sum_k w_k x_k = Gamma(alpha + 2)
     assert abs(w[1].sum() - 1.0) < 1e-13 and abs(w[2].sum() - 2.0) < 1e-13 and abs((w[1] * r[1]).sum() - 2.0) < 1e-12

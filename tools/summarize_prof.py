@@ -80,3 +80,26 @@ old.update(out)
 json.dump(old, open(tp, "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+# optional second workload of the same script (tools/profile_r02.sh: BASELINE config 2)
+c2 = glob.glob(os.path.join(src, "trace_c2", "*", "*_kernel_stats.csv"))
+if c2:
+    rows = list(csv.reader(open(max(c2, key=os.path.getmtime))))
+    with open(os.path.join(dst, tag + "_kernel_stats_config2.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        for r in rows:
+            r[0] = r[0][:120]
+            w.writerow(r)
+    b2 = json.load(open(os.path.join(src, "trace_c2_bench.json")))
+    json.dump(b2, open(os.path.join(dst, tag + "_bench_config2_under_rocprof.json"), "w"), indent=1)
+    agg2, cnt2 = collections.defaultdict(float), collections.Counter()
+    for f in glob.glob(os.path.join(src, "c2pmc_sq", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "cf_main" in r["Kernel_Name"]:
+                agg2[r["Counter_Name"]] += float(r["Counter_Value"])
+                cnt2[r["Counter_Name"]] += 1
+    old = json.load(open(tp))
+    old["config2"] = dict(cells=b2["config"]["cells_per_gpu"], kernel=b2["config"]["kernel"], kernel_variant=b2["config"]["kernel_variant"],
+                          bench_hip_event_kernel_ms=b2["kernel_ms"]["main"],
+                          rocprof_avg_kernel_ms=[float(r[3]) / 1e6 for r in rows[1:] if "cf_main" in r[0]][:1],
+                          sq_counters_per_launch={k: agg2[k] / cnt2[k] for k in sorted(agg2)})
+    json.dump(old, open(tp, "w"), indent=1)
