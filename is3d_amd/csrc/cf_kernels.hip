@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "cf_launch.h"
@@ -430,7 +431,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     }
 }
 
-// cells per batch: 16 while (9 K + 8 J) doubles per cell stay small (3+1D grids), else 4
+// cells per batch: 16 while (9 K + 8 J) doubles per cell stay small (3+1D grids), else 4 (2+1D, 241 eta rows: 1 / 2 / 4 cells per
+// batch measure 6.5 / 5.7 / 5.5 ms per 1e5 cells -- occupancy is not what limits it)
 static int prep_batch_cells(int K) { return K <= 32 ? kPrepCB3 : kPrepCB; }
 
 size_t prep_lds_bytes(int nT, int nspl, int J, int K)
@@ -910,15 +912,18 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     extern __shared__ double2 lds2[];
 
     const int tid = threadIdx.x;
+    // block -> task, XCD-aware (blocks b and b + 8 share an XCD under round-robin dispatch; speed only): all workgroups that
+    // read the E2 table of one (phi tile, cell chunk) pair -- its ktiles row-block streams x G lane-wave groups -- sit on ONE XCD,
+    // next to each other in that XCD's block order, so the table (and each record stream) is fetched into one L2
     const int b = blockIdx.x;
     const int xcd = b & 7, q = b >> 3;
     const int grp = q % g.G;
-    const int stream = (q / g.G) * 8 + xcd;
-    if (stream >= g.NT) return;  // uniform for the whole workgroup
-    int sidx = stream;
-    const int jt = sidx % g.jtiles; sidx /= g.jtiles;
-    const int kt = sidx % g.ktiles; sidx /= g.ktiles;
-    const int chunk = sidx;
+    const int m = q / g.G;
+    const int kt = m % g.ktiles;
+    const int pair = (m / g.ktiles) * 8 + xcd;
+    if (pair >= g.jtiles * g.nch) return;  // uniform for the whole workgroup
+    const int jt = pair % g.jtiles;
+    const int chunk = pair / g.jtiles;
     const int nthr = blockDim.x;
     const int lw = grp * g.wpb + (tid >> 6);
     const bool wave_active = lw * 64 < g.Lpad;
@@ -1226,7 +1231,8 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 template <bool CE, bool OF, bool RG, int JT, int R, bool ROWMASK = false>
 static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
 {
-    const int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    const int pairs = a.g.jtiles * a.g.nch;                                   // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
+    const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
     const size_t lds = (size_t)2 * a.g.ub * (4 * JT + R * (4 + JT) + kE2Stride * JT) * sizeof(double);
     hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, ROWMASK>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT, a.lane_pT,
                        a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe);

@@ -380,6 +380,29 @@ def test_status_less_executes_keep_their_domain_errors(fx, torch_mod):
     plan.close()
 
 
+@pytest.mark.parametrize("df_mode", [1, 2, 3, 4])
+def test_device_spectra_integrate_to_the_ideal_gas_density(fx, df_mode):
+    """A check that does NOT go through the oracle: static cells (u = (1, 0, 0, 0)), pi^{mu nu} = Pi = 0, so every df_mode reduces
+    to f_eq and the spectrum, integrated with the reference's own pT / phi / y quadratures (the weights of
+    write_dN_dy_toFile, emissionfunction.cpp:729-772; trapezoid in y), must give volume x n_eq with the closed form
+    n_eq = g m^2 T / (2 pi^2 hbarc^3) sum_k (-sign)^(k+1) K_2(k m / T) / k.  Agreement is limited by those quadratures (3e-6)."""
+    from scipy import special
+    g = fx["grid_w"]
+    sp = inputs.species([211, 321, 2212, 3122])
+    T, n = 0.15, 3
+    z = np.zeros(n)
+    cells = dict(tau=np.ones(n), eta=np.array([0.0, 0.3, -0.2]), dat=np.array([1.0, 2.0, 0.5]), dax=z.copy(), day=z.copy(), dan=z.copy(), ux=z.copy(),
+                 uy=z.copy(), un=z.copy(), T=T * np.ones(n), P=0.08 * np.ones(n), E=0.3 * np.ones(n), pixx=z.copy(), pixy=z.copy(), pixn=z.copy(),
+                 piyy=z.copy(), piyn=z.copy(), bulkPi=z.copy())
+    fq = inputs.feqmod_tables(T) if df_mode >= 3 else None
+    got, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=df_mode), fq=fq)
+    N = np.einsum("k,j,i,kjis->s", np.full(21, 0.5), g["phi_w"], g["pT_w"], got.reshape(21, 24, 32, 4))   # pT_w carries the pT Jacobian
+    k = np.arange(1, 60)
+    want = np.array([gd * m * m * T / (2 * np.pi ** 2 * 0.197327053 ** 3) * np.sum((-s) ** (k + 1) * special.kn(2, k * m / T) / k)
+                     for m, gd, s in zip(sp["mass"], sp["degeneracy"], sp["sign"])]) * cells["dat"].sum()
+    assert np.max(np.abs(N / want - 1)) < 1e-5, N / want - 1
+
+
 def _subset_oracle(fx, cells, sp_ids, ipT, iphi, opts):
     g = fx["grid"]
     sub = dict(g, pT=g["pT"][ipT], phi=g["phi"][iphi])
