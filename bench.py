@@ -298,7 +298,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tp):
                 tj = json.load(open(tp)).get(wl["name"])
-                if tj and tj.get("cells") == n_loc and not a.df_mode and not a.variant:
+                if tj and tj.get("cells") == n_loc and tj.get("hbm_bytes_per_launch") and not a.df_mode and not a.variant:
                     traffic = tj["hbm_bytes_per_launch"]
                     traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, not measured in this run)" % tname
                     break

@@ -369,6 +369,13 @@ typedef struct {
 int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
                           const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
                           int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats);
+/* is3d_sample_particles over several devices: the same contiguous cell shards, shard s on devices[s] with first_cell advanced to
+ * the shard's first cell -- the counter-based streams are keyed by the GLOBAL cell index, so the hadrons are exactly those one device
+ * samples; the shard lists are merged into the single-device order (event, cell, draw).  No collective at all.  Same calling
+ * pattern and return codes as is3d_sample_particles; stats are summed (times: the slowest shard's).  opts->device is ignored. */
+int is3d_sample_particles_multi(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
+                                const is3d_sampler_inputs *in, const is3d_options *opts, const int32_t *devices, int32_t n_devices,
+                                is3d_particle *particles, int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats);
 
 /* EmissionFunctionArray::calculate_total_yield (src/cpp/emissionfunction_sampling_kernels.cpp:653-830; call sites
  * emissionfunction.cpp:1527, :1591): the mean particle yield of the surface, from which an oversampled run takes its number of
@@ -423,7 +430,7 @@ typedef struct {
 int is3d_run_particlization(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,
                             is3d_run_result *result);
 /* The same on an explicit device list (operation 1: the cells are sharded over the devices as is3d_smooth_spectra_multi does;
- * operation 2 samples on devices[0]).  devices == NULL && n_devices > 0: ordinals 0 .. n_devices-1.  n_devices <= 0 is what
+ * operation 2 samples the shards on their devices and merges the lists, is3d_sample_particles_multi).  devices == NULL && n_devices > 0: ordinals 0 .. n_devices-1.  n_devices <= 0 is what
  * is3d_run_particlization and the command line tool do: the environment decides -- IS3D_DEVICES = "0,2,3" | "all" (default:
  * every visible device), IS3D_REDUCE = "ordered" (default) | "rccl". */
 int is3d_run_particlization_on(const is3d_cells *surface, const double *x, const double *y, int32_t kernel_variant,

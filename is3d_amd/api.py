@@ -100,7 +100,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
            "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
-           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check"]
+           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
 COMM_ID_BYTES = 128
@@ -548,7 +548,7 @@ def df_table_read_full(path):
 
 
 def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_cut=0.5, first_cell=0, capacity=None, fq=None, fast=0,
-                     T_avg=0.0, T_avg_switch=0.0, batch_events=0, muB_avg=0.0):
+                     T_avg=0.0, T_avg_switch=0.0, batch_events=0, muB_avg=0.0, devices=None):
     """is3d_sample_particles (the drop-in for sample_dN_pTdpTdphidy, df_mode 1-4).  cells: dict of host arrays (x, y optional);
     gla: dict with root1, weight1; fq: the feqmod tables (df_mode 3, 4; fast mode with df_mode 2).  Returns (numpy structured array of PARTICLE_DTYPE, stats dict); capacity = None sizes the
     buffer from a count-only first call."""
@@ -575,13 +575,24 @@ def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_c
                        float(T_avg), float(T_avg_switch), float(muB_avg))
     st = SamplerStats()
     cnt = C.c_int64(0)
+    if devices is not None:   # is3d_sample_particles_multi: one cell shard per listed device (an ordinal may repeat)
+        dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        L.is3d_sample_particles_multi.argtypes = [C.POINTER(Cells), C.POINTER(Species), C.POINTER(DfTables), C.POINTER(SamplerInputs),
+                                                  C.POINTER(Options), C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int64,
+                                                  C.POINTER(C.c_int64), C.POINTER(SamplerStats)]
+
+        def call(buf, cap):
+            return L.is3d_sample_particles_multi(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), dv, len(devices), buf, cap,
+                                                 C.byref(cnt), C.byref(st))
+    else:
+        def call(buf, cap):
+            return L.is3d_sample_particles(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), buf, cap, C.byref(cnt), C.byref(st))
     if capacity is None:
-        _check(L.is3d_sample_particles(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), None, 0, C.byref(cnt), C.byref(st)))
+        _check(call(None, 0))
         capacity = int(cnt.value)
     out = np.zeros(max(int(capacity), 1), dtype=PARTICLE_DTYPE)
     assert out.dtype.itemsize == C.sizeof(Particle)
-    rc = L.is3d_sample_particles(C.byref(cs), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), out.ctypes.data, int(capacity),
-                                 C.byref(cnt), C.byref(st))
+    rc = call(out.ctypes.data, int(capacity))
     _check(rc)
     d = st.as_dict()
     d["n_particles"] = int(cnt.value)

@@ -458,3 +458,103 @@ extern "C" int is3d_smooth_spectra_multi(const is3d_cells *cells, const is3d_spe
     if (status) *status = agg;
     return IS3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// particle sampler over several devices
+// ------------------------------------------------------------------------------------------------
+extern "C" int is3d_sample_particles_multi(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
+                                           const is3d_sampler_inputs *in, const is3d_options *opts, const int32_t *devices,
+                                           int32_t n_devices, is3d_particle *particles, int64_t capacity, int64_t *n_particles,
+                                           is3d_sampler_stats *stats)
+{
+    if (!cells || !in || !opts || !n_particles) return fail(IS3D_EINVAL, "null argument");
+    *n_particles = 0;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (cells->n_cells < 0) return fail(IS3D_EINVAL, "n_cells < 0");
+    const int visible = is3d_device_count();
+    if (visible < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (n_devices <= 0) { n_devices = visible; devices = nullptr; }
+    if (n_devices > 1024) return fail(IS3D_EINVAL, "n_devices = %d", n_devices);
+    std::vector<int> dev(n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        dev[i] = devices ? devices[i] : i;
+        if (dev[i] < 0 || dev[i] >= visible) return fail(IS3D_EINVAL, "device %d is not one of the %d visible HIP devices", dev[i], visible);
+    }
+    if (particles == nullptr) capacity = 0;
+    if (n_devices == 1) {
+        is3d_options o = *opts;
+        o.device = dev[0];
+        return is3d_sample_particles(cells, species, df, in, &o, particles, capacity, n_particles, stats);
+    }
+    struct SShard {
+        int device = 0;
+        int64_t lo = 0, hi = 0, count = 0;
+        std::vector<is3d_particle> list;
+        is3d_sampler_stats st{};
+        int rc = IS3D_OK;
+        std::string err;
+    };
+    std::vector<SShard> sh(n_devices);
+    const bool fill = capacity > 0;
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_devices; i++) {
+            sh[i].device = dev[i];
+            (void)is3d_shard_bounds(cells->n_cells, i, n_devices, &sh[i].lo, &sh[i].hi);
+            th.emplace_back([&, i] {
+                SShard &s = sh[i];
+                is3d_cells c = *cells;
+                c.n_cells = s.hi - s.lo;
+                const double **fields[] = {&c.tau, &c.eta, &c.dat, &c.dax, &c.day, &c.dan, &c.ux, &c.uy, &c.un, &c.T, &c.P, &c.E, &c.pixx, &c.pixy,
+                                           &c.pixn, &c.piyy, &c.piyn, &c.bulkPi, &c.muB, &c.nB, &c.Vx, &c.Vy, &c.Vn};
+                for (auto f : fields)
+                    if (*f) *f += s.lo;
+                is3d_sampler_inputs si = *in;
+                si.first_cell = in->first_cell + s.lo;
+                if (si.x) si.x += s.lo;
+                if (si.y) si.y += s.lo;
+                is3d_options o = *opts;
+                o.device = s.device;
+                s.rc = is3d_sample_particles(&c, species, df, &si, &o, nullptr, 0, &s.count, &s.st);
+                if (!s.rc && fill && s.count > 0) {
+                    s.list.resize((size_t)s.count);
+                    s.rc = is3d_sample_particles(&c, species, df, &si, &o, s.list.data(), s.count, &s.count, &s.st);
+                }
+                if (s.rc) s.err = is3d_last_error();
+            });
+        }
+        for (auto &t : th) t.join();
+    }
+    int64_t total = 0;
+    is3d_sampler_stats agg{};
+    for (int i = 0; i < n_devices; i++) {
+        if (sh[i].rc) return fail(sh[i].rc, "shard %d (device %d): %s", i, sh[i].device, sh[i].err.c_str());
+        total += sh[i].count;
+        const is3d_sampler_stats &t = sh[i].st;
+        agg.n_cells_skipped += t.n_cells_skipped; agg.n_hadrons_drawn += t.n_hadrons_drawn;
+        agg.n_momentum_samples += t.n_momentum_samples; agg.n_acceptances += t.n_acceptances;
+        agg.n_classes = std::max(agg.n_classes, t.n_classes); agg.n_cells_breakdown += t.n_cells_breakdown;
+        agg.ms_h2d = std::max(agg.ms_h2d, t.ms_h2d); agg.ms_prep = std::max(agg.ms_prep, t.ms_prep);
+        agg.ms_count = std::max(agg.ms_count, t.ms_count); agg.ms_fill = std::max(agg.ms_fill, t.ms_fill);
+    }
+    *n_particles = total;
+    if (stats) *stats = agg;
+    if (!fill) return IS3D_OK;
+    // merge: every shard list is ordered by (event, cell, draw) and the shards are ascending cell ranges, so the single-device order is,
+    // event by event, shard 0's hadrons of that event, then shard 1's, ...
+    std::vector<size_t> pos(n_devices, 0);
+    int64_t out = 0;
+    for (int32_t ev = 0; ev < in->n_events; ev++)
+        for (int i = 0; i < n_devices; i++) {
+            const std::vector<is3d_particle> &l = sh[i].list;
+            size_t p = pos[i];
+            while (p < l.size() && l[p].event == ev) {
+                if (out < capacity) particles[out] = l[p];
+                out++;
+                p++;
+            }
+            pos[i] = p;
+        }
+    if (total > capacity) return fail(IS3D_ENOMEM, "particle buffer too small: %lld particles, capacity %lld", (long long)total, (long long)capacity);
+    return IS3D_OK;
+}

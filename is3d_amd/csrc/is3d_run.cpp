@@ -377,10 +377,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (df_mode == 2) printf("Sampling particles with Chapman Enskog df...\n");
         if (df_mode == 3) printf("Sampling particles with Mike's modified distribution...\n");
         if (df_mode == 4) printf("Sampling particles with Jonah's modified distribution...\n");
-        int rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, nullptr, 0, &count, &ss);
+        int rc2 = is3d_sample_particles_multi(&cells, &sp, &df, &si, &opts, rd.list.empty() ? nullptr : rd.list.data(), (int32_t)rd.list.size(), nullptr, 0, &count, &ss);
         if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
         std::vector<is3d_particle> plist((size_t)std::max<int64_t>(count, 1));
-        rc2 = is3d_sample_particles(&cells, &sp, &df, &si, &opts, plist.data(), count, &count, &ss);
+        rc2 = is3d_sample_particles_multi(&cells, &sp, &df, &si, &opts, rd.list.empty() ? nullptr : rd.list.data(), (int32_t)rd.list.size(), plist.data(), count, &count, &ss);
         if (rc2) DIE("is3d_sample_particles failed (%d): %s", rc2, is3d_last_error());
         double t2s = now_s();
         printf("\nMomentum sampling efficiency = %f %%\n", 100.0 * (double)ss.n_acceptances / (double)std::max<int64_t>(ss.n_momentum_samples, 1));

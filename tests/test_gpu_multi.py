@@ -117,3 +117,21 @@ def test_rccl_calls_execute_with_one_rank(fx, tmp_path):
     with pytest.raises(api.Is3dError) as e:
         api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], o, devices=[0, 0], reduce=api.REDUCE_RCCL)
     assert e.value.code == api.IS3D_EINVAL and "distinct" in str(e.value)
+
+
+def test_sampler_over_several_shards_gives_the_single_device_list(fx):
+    """is3d_sample_particles_multi: three cell shards on one GPU (own threads, count + fill each), merged per event: the same
+    hadrons in the same order as one device gives (the streams are keyed by the global cell index)."""
+    cells = synth.synth_surface(30000, 3, seed=61)
+    sp = inputs.species([211, 321, 2212, -2212])
+    gla = inputs.feqmod_tables(0.15)
+    o = dict(dimension=3, df_mode=2)
+    one, st1 = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=7, seed=99)
+    three, st3 = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=7, seed=99, devices=[0, 0, 0])
+    assert len(one) == len(three) > 1000 and st3["n_particles"] == st1["n_particles"]
+    for f in one.dtype.names:
+        assert np.array_equal(one[f], three[f]), f
+    assert st3["n_hadrons_drawn"] == st1["n_hadrons_drawn"] and st3["n_momentum_samples"] == st1["n_momentum_samples"]
+    with pytest.raises(api.Is3dError) as e:                                   # buffer too small: full count reported, IS3D_ENOMEM
+        api.sample_particles(cells, sp, fx["df"], gla, o, n_events=7, seed=99, devices=[0, 0], capacity=10)
+    assert e.value.code == api.IS3D_ENOMEM
