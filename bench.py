@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true")
     ap.add_argument("--no-cull-check", action="store_true", help="skip the untimed bitwise comparison with culling off")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="dev, --gpus 1 only: run the N > 1 code path (process group, library RCCL communicator, is3d_plan_execute_allreduce, "
+                         "barriers, MAX over ranks) with a single rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)")
     a = ap.parse_args()
@@ -144,9 +147,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm, allreduce_by = None, None
-    if world > 1:
-        idist.init_process_group(a.backend)
-        import torch.distributed as dist
+    multi = world > 1 or a.rehearse_comm      # the distributed code path (a one-rank rehearsal takes it too)
+    if multi:
+        if world == 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group(a.backend, rank=0, world_size=1)
+        else:
+            idist.init_process_group(a.backend)
+            import torch.distributed as dist
         if a.backend == "nccl":
             # the data-path collective is the library's: an is3d_comm (RCCL) built from an id made through the C ABI
             try:
@@ -193,7 +203,7 @@ def main():
             plan.execute_allreduce(n_loc, ptrs, out.data_ptr(), comm, stream, want_status=False)
         else:
             plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
-            if world > 1:
+            if multi:
                 idist.allreduce_spectrum(out)
         if record:
             t = plan.timings()   # HIP events recorded on `stream` around each kernel of this step
@@ -203,7 +213,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -215,7 +225,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -353,7 +363,7 @@ def main():
     plan.close()
     if comm is not None:
         comm.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

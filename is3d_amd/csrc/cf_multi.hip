@@ -53,10 +53,16 @@ Rccl &rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // a copy the host process has already mapped (e.g. the one PyTorch bundles) is reused, so that the process holds ONE RCCL
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.handle) break;
         }
+        if (!r.handle)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.handle) break;
+            }
         if (!r.handle) {
             const char *e = dlerror();
             r.error = std::string("librccl.so.1 cannot be loaded: ") + (e ? e : "?");

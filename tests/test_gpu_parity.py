@@ -247,6 +247,16 @@ def test_passes_chunks_and_accumulate(fx, torch_mod):
     assert np.array_equal(again, base)                       # fixed-order reduction: bitwise reproducible
     acc, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, accumulate=1), out=base.copy())
     assert relerr(acc, 2.0 * base) < 1e-15
+    # 2+1D with unit-strided lanes (96 bins, four lane slots per bin): passes and chunk counts keep whole groups of four units
+    c2 = synth.synth_surface(37, 2, seed=22)
+    o2 = dict(dimension=2, df_mode=2)
+    b2, s2 = api.smooth_spectra(c2, fx["pikp"], fx["grid"], fx["df"], o2)
+    assert s2["kernel_variant"] == 7 and s2["n_passes"] == 1
+    small2, s2p = api.smooth_spectra(c2, fx["pikp"], fx["grid"], fx["df"], dict(o2, workspace_bytes=1 << 20))
+    assert s2p["n_passes"] > 2 and relerr(small2, b2) < 1e-13
+    for ch in (1, 2, 7):
+        got, _ = api.smooth_spectra(c2, fx["pikp"], fx["grid"], fx["df"], dict(o2, cell_chunks=ch))
+        assert relerr(got, b2) < 1e-13
 
 
 @pytest.mark.parametrize("dim,df_mode,species", [(3, 2, "urqmd"), (3, 1, "pikp"), (2, 1, "pikp"), (2, 2, "urqmd")])
