@@ -134,6 +134,12 @@ def main():
                     help="collective backend; gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)")
     a = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: native libraries print there too (RCCL's version banner when a communicator
+    # is created, gloo's connection notice), so file descriptor 1 is pointed at stderr for the run and the line goes to the saved one
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from is3d_amd import api, inputs, synth
     from is3d_amd import dist as idist
@@ -359,7 +365,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, fq=fq)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
             res["gpu_over_cpu_executed"] = executed_per_s / res["cpu_baseline"]["value"]   # the CPU port executes every eval
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     plan.close()
     if comm is not None:
         comm.close()

@@ -9,12 +9,17 @@
 //                everything in the integrand that does not depend on the species/pT of a lane is
 //                folded into ~4 numbers per (cell, phi, y) so the hot loop is ~20 fp64 VALU ops/eval.
 //   cf_main_*    lanes <-> (species class, pT) bins, loop over cells.  Cell coefficients are
-//                wave-uniform: cf_main_direct takes them through scalar loads, cf_main_tile (the default)
-//                through an LDS-staged stream of (phi tile x y tile) unit records; no cross-lane
-//                reduction exists in the hot loop and the accumulators stay in VGPRs for a whole cell
-//                chunk.  fp64 VALU bound (no MFMA: nothing to contract).  Rows and units that provably
-//                cannot change a bit of any accumulator are skipped (exact zeros; terms below half an
-//                ulp of every accumulator they would be added to): 58 % of the rows of BASELINE config 3.
+//                wave-uniform: cf_main_direct takes them through scalar loads, the tile kernels through an LDS-staged stream
+//                of (phi tile x y tile) unit records; no cross-lane reduction exists in the hot loop and the accumulators
+//                stay in VGPRs for a whole cell chunk.  fp64 VALU bound (fp64 MFMA measured: it blocks the VALU for its whole
+//                duration, tools/ubench_mfma64.hip).  Rows and units that provably cannot change a bit of any accumulator are
+//                skipped (exact zeros; terms below half an ulp of every accumulator they would be added to): 58 % of the rows
+//                of BASELINE config 3.
+//                  cf_main_tile3e (3+1D, the default there): the phi-side exponentials come from the E2 table stream cf_prep
+//                  writes once per (cell, phi tile) instead of being recomputed by every lane; direct-to-LDS staging
+//                  (global_load_lds_dwordx4); the rows of a unit are tested for liveness before their exponentials.
+//                  cf_main_tile (2+1D, include_baryon): with few momentum bins every bin gets S lane slots that take the units
+//                  u = s (mod S) of the stream (unit-strided lanes), so that the waves are full.
 //   cf_finalize  fixed-order sum over cell chunks (bitwise reproducible), x prefactor x degeneracy,
 //                scatter from class layout to the reference's species-fastest layout.
 #include <hip/hip_runtime.h>
