@@ -61,7 +61,7 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     if kernel_name == "cf_main_feqmod":
         key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_tile3e":
-        key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,ROWMASK=%d" % (ce, JT_R[0], JT_R[1], int(variant == 6))
+        key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,MODE=%d" % (ce, JT_R[0], JT_R[1], 0 if variant == 5 else 1)
     elif kernel_name == "cf_main_tile":
         key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,BARYON=0,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
     else:

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -904,7 +905,12 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 // unit records, unit- and row-level culling, the shared reciprocals, the partial layout -- is cf_main_tile<.., LAZY = true>.
 // LDS: two buffers of g.ub units, each unit REC doubles of record + npT*JT doubles of table (dynamic, sized by the launcher).
 // ------------------------------------------------------------------------------------------------
-template <bool CE, bool OUTFLOW, bool REG, int JT, int R, bool ROWMASK = false>
+// dev: cycle accounting of the PROF instantiation (IS3D_DEV_PROF=1, tools/gpu_ab.py): sums over waves of s_memtime intervals
+//   [0] waves  [1] wave lifetime  [2] staging issue  [3] vmcnt + barrier waits  [4] dead units  [5] live units  [6] their headers + row tests
+//   [7] dead units (count)  [8] live units (count)  [9] first-wave share of [3]  [10] threshold refresh  [11] vmcnt part of [3]  [12] prologue
+__device__ unsigned long long g_prof3e[16];
+
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false>
 __global__ void __launch_bounds__(512)
 cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
                const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
@@ -914,6 +920,10 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     constexpr int REC = HDR + R * RW;
     constexpr int RB = JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2);
     static_assert(JT % RB == 0 && JT % 2 == 0, "phi tile: whole reciprocal batches, 16-byte records");
+    // MODE 0 (variant 5): hand-pipelined rows; 1 (variant 6): the rows of a unit tested for liveness before their exponentials.
+    // (Tried and dropped, round 2: the liveness of all rows of a BATCH of units in one pipelined pass before the batch, masks in
+    // SGPRs -- 356.6 against 355.9 ms: the pass costs what it saves.)
+    constexpr bool ROWMASK = MODE >= 1;
     extern __shared__ double2 lds2[];
 
     const int tid = threadIdx.x;
@@ -937,8 +947,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     const int J = g.J, K = g.K;
     constexpr int TEREC = kE2Stride * JT;         // doubles of table per unit ([jj][kE2Stride], the first npT columns used)
     const int UB = g.ub;
-    constexpr int URECT = REC + TEREC;            // LDS doubles per unit: its record and its table
-    const int BUFD = UB * URECT;                  // doubles per buffer
+    static_assert((TEREC * sizeof(double)) % 1024 == 0, "a unit's table is a whole number of 1-KiB staging pieces");
     const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
     const int tabrow = lane_ipT[l];               // the lane's column within a unit's table, stored [jj][ipT]: lanes of a wave read
                                                   // consecutive 8-byte words for consecutive pT indices (no LDS bank conflicts)
@@ -962,11 +971,13 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     double cull_thr = -745.2;
     const int pe = (RELCULL && lane_pe) ? lane_pe[l] : 0;
 
-    auto process_unit = [&](const double *U, const double *tab) {
+    unsigned long long pf_stage = 0, pf_wait = 0, pf_dead = 0, pf_live = 0, pf_hdr = 0, pf_nd = 0, pf_nl = 0, pf_thr = 0, pf_t0 = 0, pf_u0 = 0, pf_vm = 0, pf_pro = 0, pf_mid = 0, pf_ts = 0;
+    if constexpr (PROF) pf_t0 = clock64();
+    auto process_unit = [&](const double *U, const double *tab) -> bool {
         const double bmax = __dmul_rn(pT, U[3]);                                         // pT Dmax == max_j pT Dp_j (pT >= 0)
         {
             const double eu = __dsub_rn(bmax, __dmul_rn(mT, U[7]));                      // unit-level cull, as in cf_main_tile
-            if (g.zskip && __all(eu < cull_thr)) { n_rows += R; n_dead += R; return; }
+            if (g.zskip && __all(eu < cull_thr)) { n_rows += R; n_dead += R; return false; }
         }
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
 #pragma unroll
@@ -1037,6 +1048,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
             }
             n_rows += R;
             n_dead += R - __builtin_popcount(live);
+            if constexpr (PROF) pf_hdr += clock64() - pf_u0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (live & (1u << r)) {
@@ -1058,34 +1070,66 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 if (r + 1 < R) cur = nxt;
             }
         }
+        return true;
     };
 
     // staging: records and tables of batch ib+1 go global -> LDS by direct-to-LDS loads (global_load_lds_dwordx4: 1 KiB per wave-
     // instruction, no staging registers, nothing waits until the barrier that ends batch ib), issued BEFORE batch ib is consumed.
-    // LDS image of a buffer = the two contiguous global runs: [UB records][UB tables].
+    // LDS image of a buffer = the two contiguous global runs, the first padded to whole KiB: [UB records | pad][UB tables].
+    // Whole 1-KiB pieces only, never predicated (a predicated piece is a v_cmp / saveexec / branch chain per load; the loop below is
+    // scalar): the last record piece and the pieces of a short last batch over-read the run -- the next units of the stream, or
+    // the slack the plan allocates behind TS and TE -- into the pad / the unused units of the buffer.
+    const int TSP = (UB * REC * (int)sizeof(double) + 1023) & ~1023;          // bytes of the padded record part
+    const int BUFB = TSP + UB * TEREC * (int)sizeof(double);                  // bytes per buffer
+    const unsigned lane16 = (unsigned)(tid & 63) * 16u;
+    // every wave of the workgroup takes a contiguous range of the pieces, four per address: the instruction's immediate offset
+    // advances the global and the LDS address together, so a group of four costs one address and one M0 setup
+    const int nw_ = nthr >> 6, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np1 = TSP >> 10, np2 = UB * (TEREC * (int)sizeof(double) / 1024);
+    const int p1lo = (np1 * wave_) / nw_, p1hi = (np1 * (wave_ + 1)) / nw_;
+    const int p2lo = (np2 * wave_) / nw_, p2hi = (np2 * (wave_ + 1)) / nw_;
+    auto pieces = [&](const char *g, char *l, int lo, int hi) {
+        for (int p = lo; p < hi; p += 4) {
+            const char *gp = g + p * 1024 + lane16;
+            char *lp = l + p * 1024;
+            const int n = hi - p;
+            glds16o<0>(gp, lp);
+            if (n > 1) glds16o<1024>(gp, lp);
+            if (n > 2) glds16o<2048>(gp, lp);
+            if (n > 3) glds16o<3072>(gp, lp);
+        }
+    };
     auto stage = [&](int ib, int buf) {
-        const int nu = min(UB, n_units - ib * UB);
-        char *dst = (char *)lds2 + (size_t)buf * BUFD * sizeof(double);
+        char *dst = (char *)lds2 + (size_t)buf * BUFB;
         const char *s1 = (const char *)src_ts + (int64_t)ib * UB * REC * (int64_t)sizeof(double);
         const char *s2 = (const char *)src_te + (int64_t)ib * UB * TEREC * (int64_t)sizeof(double);
-        const int b1 = nu * REC * (int)sizeof(double), b2 = nu * TEREC * (int)sizeof(double);
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane16 = (tid & 63) * 16, nw = nthr >> 6;   // wave-uniform piece index
-        for (int p = wave; p * 1024 < b1; p += nw)
-            if (p * 1024 + lane16 < b1) glds16(s1 + p * 1024 + lane16, dst + p * 1024);
-        char *dst2 = dst + (size_t)UB * REC * sizeof(double);
-        for (int p = wave; p * 1024 < b2; p += nw)
-            if (p * 1024 + lane16 < b2) glds16(s2 + p * 1024 + lane16, dst2 + p * 1024);
+        pieces(s1, dst, p1lo, p1hi);
+        if constexpr (PROF) pf_mid = clock64();
+        pieces(s2, dst + TSP, p2lo, p2hi);
     };
     if (nb > 0) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (PROF) pf_pro = clock64() - pf_t0;
         for (int ib = 0; ib < nb; ib++) {
+            unsigned long long pa = 0;
+            if constexpr (PROF) pa = clock64();
             if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
+            if constexpr (PROF) { pf_stage += clock64() - pa; if (ib + 1 < nb) pf_ts += pf_mid - pa; }
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
-                const double *base = (const double *)(lds2 + (size_t)(ib & 1) * (BUFD / 2));
-                for (int u = 0; u < nu; u++) process_unit(base + u * REC, base + UB * REC + u * TEREC + tabrow);
+                const double *base = (const double *)((const char *)lds2 + (size_t)(ib & 1) * BUFB);
+                const double *tabs = (const double *)((const char *)base + TSP) + tabrow;
+                for (int u = 0; u < nu; u++) {
+                    if constexpr (PROF) pf_u0 = clock64();
+                    const bool lv = process_unit(base + u * REC, tabs + u * TEREC);
+                    if constexpr (PROF) {
+                        const unsigned long long d = clock64() - pf_u0;
+                        if (lv) { pf_live += d; pf_nl++; } else { pf_dead += d; pf_nd++; }
+                    }
+                }
+                if constexpr (PROF) pa = clock64();
                 if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 63) == 63)) {
                     double m = acc[0];
 #pragma unroll
@@ -1093,15 +1137,35 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                     const int e = __builtin_amdgcn_frexp_exp(m);
                     cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
                 }
+                if constexpr (PROF) pf_thr += clock64() - pa;
             }
+            if constexpr (PROF) pa = clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads of batch ib+1 have landed
+            if constexpr (PROF) { const unsigned long long pb = clock64(); pf_vm += pb - pa; }
             __syncthreads();
+            if constexpr (PROF) pf_wait += clock64() - pa;
         }
     }
     if (!wave_active) return;
     if ((tid & 63) == 0) {
         atomicAdd(&stats[2], (unsigned long long)n_rows);
         atomicAdd(&stats[3], (unsigned long long)min(n_dead, n_rows));
+        if constexpr (PROF) {
+            atomicAdd(&g_prof3e[0], 1ull);
+            atomicAdd(&g_prof3e[1], clock64() - pf_t0);
+            atomicAdd(&g_prof3e[2], pf_stage);
+            atomicAdd(&g_prof3e[3], pf_wait);
+            atomicAdd(&g_prof3e[4], pf_dead);
+            atomicAdd(&g_prof3e[5], pf_live);
+            atomicAdd(&g_prof3e[6], pf_hdr);
+            atomicAdd(&g_prof3e[7], pf_nd);
+            atomicAdd(&g_prof3e[8], pf_nl);
+            if ((tid >> 6) == 0) atomicAdd(&g_prof3e[9], pf_wait);
+            atomicAdd(&g_prof3e[10], pf_thr);
+            atomicAdd(&g_prof3e[11], pf_vm);
+            atomicAdd(&g_prof3e[12], pf_pro);
+            atomicAdd(&g_prof3e[13], pf_ts);
+        }
     }
     const double unscale = REG ? 2.0 : 1.0;
     const int64_t JKacc = (int64_t)J * g.Kacc;
@@ -1123,16 +1187,24 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     }
 }
 
-// LDS bytes per workgroup of cf_main_tile3e: four 2-wave workgroups share a CU's 160 KB
-constexpr int kTile3eLdsBudget = 40 * 1024;
+// LDS bytes per workgroup of cf_main_tile3e: the CU's 160 KB shared by its 8 waves (two per SIMD), 20 KB per wave of the workgroup
+constexpr int kTile3eLdsPerWave = 20 * 1024;
+static size_t tile3e_lds_bytes(int JT, int R, int ub)   // two buffers of [ub records, padded to whole KiB][ub tables]
+{
+    const size_t tsp = ((size_t)ub * (4 * JT + R * (4 + JT)) * sizeof(double) + 1023) & ~(size_t)1023;
+    return 2 * (tsp + (size_t)ub * kE2Stride * JT * sizeof(double));
+}
 int tile3e_units_per_batch(int JT, int R, int npT, int wpb)
 {
     if (npT > kE2Stride) return 0;
-    const int rect = 4 * JT + R * (4 + JT) + kE2Stride * JT;
-    const int budget = kTile3eLdsBudget * (wpb / 2 > 0 ? wpb / 2 : 1);    // larger workgroups: proportionally fewer per CU
-    const int ub = budget / (2 * 8 * rect);
-    return ub > 16 ? 16 : ub;
+    const size_t budget = (size_t)kTile3eLdsPerWave * (wpb > 0 ? wpb : 1);
+    int ub = 16;
+    while (ub > 0 && tile3e_lds_bytes(JT, R, ub) > budget) ub--;
+    return ub;
 }
+// doubles of slack the plan allocates behind TS and TE: the unpredicated staging pieces of the last batch over-read up to one
+// batch of units plus one piece
+int tile3e_stream_slack_doubles(int JT, int R) { return 16 * (4 * JT + R * (4 + JT) + kE2Stride * JT) + 128; }
 
 // ------------------------------------------------------------------------------------------------
 // cf_finalize: out[sp + npart*(ipT + npT*(j + J*k))] (smooth_kernels.cpp:363)
@@ -1233,13 +1305,31 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
     *KT = dim3 ? kTileR3[i] : kTileR2[i];
 }
 
-template <bool CE, bool OF, bool RG, int JT, int R, bool ROWMASK = false>
+template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0>
 static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
 {
     const int pairs = a.g.jtiles * a.g.nch;                                   // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
     const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
-    const size_t lds = (size_t)2 * a.g.ub * (4 * JT + R * (4 + JT) + kE2Stride * JT) * sizeof(double);
-    hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, ROWMASK>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT, a.lane_pT,
+    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub);
+    if constexpr (CE && OF && RG && MODE >= 1) {
+        // dev: the cycle-accounting instantiation, synchronous, counters to stderr
+        static const bool prof = std::getenv("IS3D_DEV_PROF") != nullptr;
+        if (prof) {
+            unsigned long long h[16] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof3e), h, sizeof h);
+            hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, true>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
+                               a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof3e), sizeof h);
+            const double T = (double)h[1];
+            fprintf(stderr, "[prof3e] waves %llu  cycles/wave %.3e  stage %.4f  wait %.4f (first wave of the workgroup %.4f)  dead units %.4f  live units %.4f "
+                            "(headers + row tests %.4f)  thr %.4f  vmcnt part of wait %.4f  prologue %.4f  record part of stage %.4f | dead units %llu (%.0f cycles each)  live units %llu (%.0f cycles each)\n",
+                    h[0], T / (double)h[0], h[2] / T, h[3] / T, h[9] / T, h[4] / T, h[5] / T, h[6] / T, h[10] / T, h[11] / T, h[12] / T, h[13] / T, h[7], h[7] ? (double)h[4] / h[7] : 0.0,
+                    h[8], h[8] ? (double)h[5] / h[8] : 0.0);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT, a.lane_pT,
                        a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe);
 }
 
@@ -1249,7 +1339,7 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
     if constexpr (DIM3) {
         // variant 5: the 8 x 7 tile with the E2 table stream (the plan only sets TE up for 3+1D without baryon slots)
         if (variant == 5 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1]>(a, st); return; }
-        if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], true>(a, st); return; }
+        if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1>(a, st); return; }
     }
     if (variant == 5 || variant == 6) variant = 3;
     if constexpr (!DIM3) {

@@ -19,6 +19,13 @@ __device__ __forceinline__ void glds16(const void *g, void *l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
+// the same with an immediate offset OFF (< 4096) that advances both the global and the LDS address
+template <int OFF>
+__device__ __forceinline__ void glds16o(const void *g, void *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, OFF, 0);
+}
+
 // e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-10 near-minimax polynomial of e^r, |r| <= ln2/2.  Splitting mantissa and exponent lets two exponentials be
 // multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
 // e^r on |r| <= ln2/2 as a degree-10 polynomial (Chebyshev-node interpolant computed in long double, rounded to

@@ -447,6 +447,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
                 if (waste * 64 < best_waste * 64 && waste < best_waste) { best_waste = waste; P->wpb = w; }
             }
             if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
+            if (o->waves_per_group == 1 && P->e2tab) P->wpb = 1;   // cf_main_tile3e: one-wave workgroups (no barrier partner)
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves
@@ -459,9 +460,10 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         P->nch_max = (int)nch;
     }
     if (tiled) {
-        HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0)));
+        const size_t slack = P->e2tab ? (size_t)is3d::tile3e_stream_slack_doubles(P->JT, P->KT) : 0;
+        HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0) + slack));
         if (P->e2tab) {
-            HIP_TRY(P->d_TE.alloc((size_t)pc * P->jtiles * is3d::kE2Stride * P->JT));
+            HIP_TRY(P->d_TE.alloc((size_t)pc * P->jtiles * is3d::kE2Stride * P->JT + slack));
             P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb);
             if (P->ub3e < 1) return fail(IS3D_EINVAL, "kernel_variant 5: a unit record plus its %d x %d E2 table does not fit the LDS budget", P->npT, P->JT);
         }

@@ -259,6 +259,26 @@ def test_passes_chunks_and_accumulate(fx, torch_mod):
         assert relerr(got, b2) < 1e-13
 
 
+def test_workgroup_sizes_and_batch_tails_change_no_bit(fx):
+    """waves_per_group (1, 2, 4, 8 lane-waves sharing one LDS-staged stream; 1 = no barrier partner, cf_main_tile3e only) and the
+    cell count modulo the units per LDS batch are scheduling only: a lane sees the same units in the same order, so the spectrum
+    is bitwise the same.  Cell counts around the batch sizes exercise the unpredicated staging pieces that over-read a short
+    last batch (into the slack behind the streams / unused units of the LDS buffer)."""
+    sp = inputs.species("urqmd")
+    o = dict(dimension=3, df_mode=2, cell_chunks=2)
+    for n in (1, 5, 6, 7, 13, 97):
+        cells = synth.synth_surface(n, 3, seed=31)
+        base, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+        assert st["kernel_variant"] == DEFAULT3 and np.isfinite(base).all()
+        for w in (1, 2, 4, 8):
+            got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, waves_per_group=w))
+            assert st["kernel_variant"] == DEFAULT3 and np.array_equal(got, base), (n, w)
+    cells = synth.synth_surface(97, 3, seed=31)
+    ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], o)
+    got, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, waves_per_group=1))
+    assert relerr(got, ref) < TOL
+
+
 @pytest.mark.parametrize("dim,df_mode,species", [(3, 2, "urqmd"), (3, 1, "pikp"), (2, 1, "pikp"), (2, 2, "urqmd")])
 def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
     """zero_skip: 2 evaluates every row; 1 skips wave-rows whose exp(-p.u/T) is exactly +0; 0 (default) also skips rows whose

@@ -38,7 +38,7 @@ def demangle_params(sym):
     if name == "cf_main_tile":
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R"]
     elif name == "cf_main_tile3e":
-        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "ROWMASK"]
+        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF"]
     elif name == "cf_main_feqmod":
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON"]
     elif name == "cf_main_vah":
@@ -84,6 +84,8 @@ def main():
         if not p:
             continue
         name, params = p
+        if params.pop("PROF", 0):   # the cycle-accounting instantiation (dev) is not a product kernel
+            continue
         rb = [b for b in blocks if b["ops"].get("v_rcp_f64", 0) > 0]
         if not rb:
             continue
