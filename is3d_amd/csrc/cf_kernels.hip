@@ -923,6 +923,9 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // MODE 0 (variant 5): hand-pipelined rows; 1 (variant 6): the rows of a unit tested for liveness before their exponentials.
     // (Tried and dropped, round 2: the liveness of all rows of a BATCH of units in one pipelined pass before the batch, masks in
     // SGPRs -- 356.6 against 355.9 ms: the pass costs what it saves.)
+    // (Tried and dropped, round 2: a ring of three LDS buffers with one progress word per wave in place of the per-batch
+    // barrier -- bitwise the same spectrum, 360 against 352 ms: with LDS for 12 units in all, a wave can run at most one
+    // 4-unit batch ahead of its partner, and the polling costs more than that slack returns.)
     constexpr bool ROWMASK = MODE >= 1;
     extern __shared__ double2 lds2[];
 
@@ -1107,43 +1110,49 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
         if constexpr (PROF) pf_mid = clock64();
         pieces(s2, dst + TSP, p2lo, p2hi);
     };
-    if (nb > 0) {
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if constexpr (PROF) pf_pro = clock64() - pf_t0;
-        for (int ib = 0; ib < nb; ib++) {
-            unsigned long long pa = 0;
-            if constexpr (PROF) pa = clock64();
-            if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
-            if constexpr (PROF) { pf_stage += clock64() - pa; if (ib + 1 < nb) pf_ts += pf_mid - pa; }
-            if (wave_active) {
-                const int nu = min(UB, n_units - ib * UB);
-                const double *base = (const double *)((const char *)lds2 + (size_t)(ib & 1) * BUFB);
-                const double *tabs = (const double *)((const char *)base + TSP) + tabrow;
-                for (int u = 0; u < nu; u++) {
-                    if constexpr (PROF) pf_u0 = clock64();
-                    const bool lv = process_unit(base + u * REC, tabs + u * TEREC);
-                    if constexpr (PROF) {
-                        const unsigned long long d = clock64() - pf_u0;
-                        if (lv) { pf_live += d; pf_nl++; } else { pf_dead += d; pf_nd++; }
-                    }
-                }
-                if constexpr (PROF) pa = clock64();
-                if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 63) == 63)) {
-                    double m = acc[0];
-#pragma unroll
-                    for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
-                    const int e = __builtin_amdgcn_frexp_exp(m);
-                    cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
-                }
-                if constexpr (PROF) pf_thr += clock64() - pa;
+    auto consume = [&](int ib, int buf) {
+        const int nu = min(UB, n_units - ib * UB);
+        const double *base = (const double *)((const char *)lds2 + (size_t)buf * BUFB);
+        const double *tabs = (const double *)((const char *)base + TSP) + tabrow;
+        for (int u = 0; u < nu; u++) {
+            if constexpr (PROF) pf_u0 = clock64();
+            const bool lv = process_unit(base + u * REC, tabs + u * TEREC);
+            if constexpr (PROF) {
+                const unsigned long long d = clock64() - pf_u0;
+                if (lv) { pf_live += d; pf_nl++; } else { pf_dead += d; pf_nd++; }
             }
-            if constexpr (PROF) pa = clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads of batch ib+1 have landed
-            if constexpr (PROF) { const unsigned long long pb = clock64(); pf_vm += pb - pa; }
+        }
+        unsigned long long pa = 0;
+        if constexpr (PROF) pa = clock64();
+        // the threshold follows log2 of the accumulators, which grow about linearly with the cells seen: refresh after batches
+        // 0, 1, 3, 7, 15, ... and every 64th
+        if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 63) == 63)) {
+            double m = acc[0];
+#pragma unroll
+            for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
+            const int e = __builtin_amdgcn_frexp_exp(m);
+            cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
+        }
+        if constexpr (PROF) pf_thr += clock64() - pa;
+    };
+    {
+        if (nb > 0) {
+            stage(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if constexpr (PROF) pf_wait += clock64() - pa;
+            if constexpr (PROF) pf_pro = clock64() - pf_t0;
+            for (int ib = 0; ib < nb; ib++) {
+                unsigned long long pa = 0;
+                if constexpr (PROF) pa = clock64();
+                if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
+                if constexpr (PROF) { pf_stage += clock64() - pa; if (ib + 1 < nb) pf_ts += pf_mid - pa; }
+                if (wave_active) consume(ib, ib & 1);
+                if constexpr (PROF) pa = clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads of batch ib+1 have landed
+                if constexpr (PROF) { const unsigned long long pb = clock64(); pf_vm += pb - pa; }
+                __syncthreads();
+                if constexpr (PROF) pf_wait += clock64() - pa;
+            }
         }
     }
     if (!wave_active) return;
@@ -1189,10 +1198,10 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
 
 // LDS bytes per workgroup of cf_main_tile3e: the CU's 160 KB shared by its 8 waves (two per SIMD), 20 KB per wave of the workgroup
 constexpr int kTile3eLdsPerWave = 20 * 1024;
-static size_t tile3e_lds_bytes(int JT, int R, int ub)   // two buffers of [ub records, padded to whole KiB][ub tables]
+static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
 {
     const size_t tsp = ((size_t)ub * (4 * JT + R * (4 + JT)) * sizeof(double) + 1023) & ~(size_t)1023;
-    return 2 * (tsp + (size_t)ub * kE2Stride * JT * sizeof(double));
+    return nbuf * (tsp + (size_t)ub * kE2Stride * JT * sizeof(double));
 }
 int tile3e_units_per_batch(int JT, int R, int npT, int wpb)
 {
