@@ -923,6 +923,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // MODE 0 (variant 5): hand-pipelined rows; 1 (variant 6): the rows of a unit tested for liveness before their exponentials.
     // (Tried and dropped, round 2: the liveness of all rows of a BATCH of units in one pipelined pass before the batch, masks in
     // SGPRs -- 356.6 against 355.9 ms: the pass costs what it saves.)
+    // (Tried and dropped, round 2: a 6 x 4 tile in 166 VGPRs, three waves per SIMD -- 408 against 353 ms, with culling off 835
+    // against 691: the third wave does not pay for the exponentials and headers amortised over fewer evaluations.)
     // (Tried and dropped, round 2: a ring of three LDS buffers with one progress word per wave in place of the per-batch
     // barrier -- bitwise the same spectrum, 360 against 352 ms: with LDS for 12 units in all, a wave can run at most one
     // 4-unit batch ahead of its partner, and the polling costs more than that slack returns.)
@@ -950,7 +952,6 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     const int J = g.J, K = g.K;
     constexpr int TEREC = kE2Stride * JT;         // doubles of table per unit ([jj][kE2Stride], the first npT columns used)
     const int UB = g.ub;
-    static_assert((TEREC * sizeof(double)) % 1024 == 0, "a unit's table is a whole number of 1-KiB staging pieces");
     const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
     const int tabrow = lane_ipT[l];               // the lane's column within a unit's table, stored [jj][ipT]: lanes of a wave read
                                                   // consecutive 8-byte words for consecutive pT indices (no LDS bank conflicts)
@@ -1083,12 +1084,13 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // scalar): the last record piece and the pieces of a short last batch over-read the run -- the next units of the stream, or
     // the slack the plan allocates behind TS and TE -- into the pad / the unused units of the buffer.
     const int TSP = (UB * REC * (int)sizeof(double) + 1023) & ~1023;          // bytes of the padded record part
-    const int BUFB = TSP + UB * TEREC * (int)sizeof(double);                  // bytes per buffer
+    const int TEP = (UB * TEREC * (int)sizeof(double) + 1023) & ~1023;        // bytes of the padded table part
+    const int BUFB = TSP + TEP;                                               // bytes per buffer
     const unsigned lane16 = (unsigned)(tid & 63) * 16u;
     // every wave of the workgroup takes a contiguous range of the pieces, four per address: the instruction's immediate offset
     // advances the global and the LDS address together, so a group of four costs one address and one M0 setup
     const int nw_ = nthr >> 6, wave_ = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int np1 = TSP >> 10, np2 = UB * (TEREC * (int)sizeof(double) / 1024);
+    const int np1 = TSP >> 10, np2 = TEP >> 10;
     const int p1lo = (np1 * wave_) / nw_, p1hi = (np1 * (wave_ + 1)) / nw_;
     const int p2lo = (np2 * wave_) / nw_, p2hi = (np2 * (wave_ + 1)) / nw_;
     auto pieces = [&](const char *g, char *l, int lo, int hi) {
@@ -1201,7 +1203,8 @@ constexpr int kTile3eLdsPerWave = 20 * 1024;
 static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
 {
     const size_t tsp = ((size_t)ub * (4 * JT + R * (4 + JT)) * sizeof(double) + 1023) & ~(size_t)1023;
-    return nbuf * (tsp + (size_t)ub * kE2Stride * JT * sizeof(double));
+    const size_t tep = ((size_t)ub * kE2Stride * JT * sizeof(double) + 1023) & ~(size_t)1023;
+    return nbuf * (tsp + tep);
 }
 int tile3e_units_per_batch(int JT, int R, int npT, int wpb)
 {
