@@ -928,6 +928,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // (Tried and dropped, round 2: a ring of three LDS buffers with one progress word per wave in place of the per-batch
     // barrier -- bitwise the same spectrum, 360 against 352 ms: with LDS for 12 units in all, a wave can run at most one
     // 4-unit batch ahead of its partner, and the polling costs more than that slack returns.)
+    // (Tried and dropped, round 2: one LDS round trip at the head of a unit -- test operands first, the header speculatively behind
+    // them, votes while it arrives, dead units drop the reads: 352.1 against 347.9 ms.)
     constexpr bool ROWMASK = MODE >= 1;
     extern __shared__ double2 lds2[];
 
@@ -1096,12 +1098,14 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     auto pieces = [&](const char *g, char *l, int lo, int hi) {
         for (int p = lo; p < hi; p += 4) {
             const char *gp = g + p * 1024 + lane16;
-            char *lp = l + p * 1024;
             const int n = hi - p;
-            glds16o<0>(gp, lp);
-            if (n > 1) glds16o<1024>(gp, lp);
-            if (n > 2) glds16o<2048>(gp, lp);
-            if (n > 3) glds16o<3072>(gp, lp);
+            // written-out instruction (glds16a, cf_math.h): with the builtin in flight the compiler's waitcnt pass drains the LDS
+            // queue (lgkmcnt(0)) before every use of an LDS read in the whole kernel; this way it counts (692 -> 678 ms with culling off)
+            const unsigned lp = __builtin_amdgcn_readfirstlane(lds_addr32(l + p * 1024));
+            glds16a<0>(gp, lp);
+            if (n > 1) glds16a<1024>(gp, lp);
+            if (n > 2) glds16a<2048>(gp, lp);
+            if (n > 3) glds16a<3072>(gp, lp);
         }
     };
     auto stage = [&](int ib, int buf) {

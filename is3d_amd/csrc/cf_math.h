@@ -12,18 +12,20 @@ namespace is3d {
 #define IS3D_LN2_LO 1.90821492927058770002e-10 /* 0x3dea39ef35793c76 */
 
 // 16 bytes per lane global -> LDS without a register round trip (global_load_lds_dwordx4): the wave writes 1 KiB contiguously at
-// the wave-uniform LDS address `l` (lane i lands at l + 16 i), each lane reads its own global address g.  Asynchronous: it is
-// retired by s_waitcnt vmcnt.
-__device__ __forceinline__ void glds16(const void *g, void *l)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-}
-
-// the same with an immediate offset OFF (< 4096) that advances both the global and the LDS address
+// the wave-uniform LDS byte address l32 (M0; lane i lands at l32 + 16 i), each lane reads its own global address g; OFF (< 4096)
+// advances both addresses.  Asynchronous: it is retired by s_waitcnt vmcnt.
+// The instruction is written out so that the compiler does not know LDS is being written behind its back: with a
+// __builtin_amdgcn_global_load_lds in flight its waitcnt pass answers every LDS read of the kernel with s_waitcnt lgkmcnt(0) (no
+// counted waits at all in cf_main_tile3e; 692 -> 678 ms with culling off); the caller orders reads against these loads itself
+// (s_waitcnt vmcnt + barrier), as it has to anyway.
 template <int OFF>
-__device__ __forceinline__ void glds16o(const void *g, void *l)
+__device__ __forceinline__ void glds16a(const void *g, unsigned l32)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, OFF, 0);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(l32), "n"(OFF) : "memory");   // M0 is not allocatable: the compiler keeps nothing in it across the statement
+}
+__device__ __forceinline__ unsigned lds_addr32(const void *p)
+{
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
 }
 
 // e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-10 near-minimax polynomial of e^r, |r| <= ln2/2.  Splitting mantissa and exponent lets two exponentials be
