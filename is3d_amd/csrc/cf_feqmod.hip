@@ -465,7 +465,9 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     constexpr int NLD = (BUF2 + 127) / 128;
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
     static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples (JT even)");
-    __shared__ double2 lbuf[2][BUF2 + RW / 2 + 1];
+    constexpr int BUFP = ((BUF2 * 16 + 1023) / 1024) * 64;   // the batch as whole 1-KiB staging pieces (64 double2 each)
+    __shared__ double2 lbuf[2][BUFP + RW / 2 + 1];
+    (void)NLD;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -602,26 +604,14 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
         }
     };
 
-    double2 pre[NLD];
+    // staging: the next batch by direct-to-LDS loads (stage_pieces, cf_math.h), issued before the current batch is consumed
+    auto stage = [&](int ib, int buf) { stage_pieces<BUFP / 64>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
     if (nb > 0) {
-        {
-            const int n2 = min(UB, n_units) * (REC / 2);
-#pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                if (i < n2) lbuf[0][i] = src[i];
-            }
-        }
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int ib = 0; ib < nb; ib++) {
-            const bool more = ib + 1 < nb;
-            const int n2next = more ? min(UB, n_units - (ib + 1) * UB) * (REC / 2) : 0;
-            const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
-#pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
-            }
+            if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1];
@@ -644,11 +634,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                     acc_e = (m > 1.0e-290) ? __builtin_amdgcn_frexp_exp(m) : -100000;
                 }
             }
-#pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }

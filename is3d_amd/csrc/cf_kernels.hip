@@ -599,8 +599,12 @@ cf_main_direct(const double *__restrict__ S1, const double *__restrict__ S2, con
 // compiler can hoist far ahead of their use, so no evaluation waits on memory.  (The first version
 // used scalar loads; each s_load sat 4 instructions in front of its s_waitcnt and the kernel ran at
 // ~60 % of its issue bound.)
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R, bool LAZY = false>
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R, bool LAZY = false, bool DMA = true>
+// The 14-moment 2+1D kernel on the 8 x 31 tile (8 accumulators, no staging registers since the direct-to-LDS copy) fits 168 VGPRs without
+// a spill: three waves per SIMD (config 2: 31.5 -> 29.9 ms).  Everything else is a two-wave kernel (the Chapman-Enskog form of the same
+// tile would spill 42 registers at 168), and the compiler is told not to trade the schedule for a third wave it cannot reach.
 __global__ void __launch_bounds__(512)
+__attribute__((amdgpu_waves_per_eu((!DIM3 && !CE && !BARYON && JT <= 8 && R <= 32 && DMA) ? 3 : 2, (!DIM3 && !CE && !BARYON && JT <= 8 && R <= 32 && DMA) ? 3 : 2)))
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, const double *__restrict__ lane_b, double *__restrict__ partial,
              unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
@@ -620,7 +624,12 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);
     static_assert(JT % RB == 0, "the phi tile is a whole number of reciprocal batches");
     static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
-    __shared__ double2 lbuf[2][BUF2 + (RS + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
+    // DMA (the default since round 2; DMA = false keeps the register-staged copy for A/B, variant 8): the next batch is staged by
+    // direct-to-LDS loads -- no staging registers (28 VGPRs in 2+1D), no ds_write, nothing waits before the batch's closing
+    // barrier: config 2 31.5 -> 29.9 ms, bitwise the same spectrum.  (With four evaluations per reciprocal the 2+1D kernel then
+    // fits 146 VGPRs, three waves per SIMD: 30.5 ms -- the third wave is worth less than the eight-wide reciprocal batch.)
+    constexpr int BUFP = DMA ? ((BUF2 * 16 + 1023) / 1024) * 64 : BUF2;   // DMA: whole 1-KiB pieces (64 double2 each), the last one over-reads
+    __shared__ double2 lbuf[2][BUFP + (RS + JT) / 2 + 1];   // + one row of pad: the 2+1D row prefetch reads one row ahead
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -811,7 +820,34 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     // double-buffered staging: batch ib+1 is copied global -> LDS by every wave BEFORE it consumes batch ib (the other buffer
     // was released by the barrier that ended batch ib-1).  The copy's latency is covered by the other waves of the SIMD;
     // holding the batch in registers across the evaluations instead costs 4 NLD VGPRs that the 8 x 7 tile does not have.
-    if (nb > 0) {
+    if constexpr (DMA) {
+        // whole 1-KiB pieces, contiguous ranges per wave, four per address (as in cf_main_tile3e); the last piece of a batch and
+        // the pieces of a short last batch over-read the stream (slack behind TS) into the pad / unused units of the buffer
+        constexpr int NP = BUFP / 64;
+        auto stage = [&](int ib, int buf) { stage_pieces<NP>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
+        if (nb > 0) {
+            stage(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int ib = 0; ib < nb; ib++) {
+                if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
+                if (wave_active) {
+                    const int nu = min(UB, n_units - ib * UB);
+                    const double *base = (const double *)lbuf[ib & 1] + sub_off;
+                    for (int u = 0; u < nu; u += S) { process_unit(base + u * REC); n_calls++; }
+                    if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 31) == 31)) {
+                        double m = acc[0];
+#pragma unroll
+                        for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
+                        const int e = __builtin_amdgcn_frexp_exp(m);
+                        cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    } else if (nb > 0) {
         {
             const int n2 = min(UB, n_units) * (REC / 2);
 #pragma unroll
@@ -1289,10 +1325,17 @@ static void launch_direct_t(const MainArgs &a, hipStream_t st)
     hipLaunchKernelGGL((cf_main_direct<CE, DIM3, OUTFLOW, REG, KT>), dim3(grid), dim3(kWPB * 64), 0, st, a.S1, a.S2,
                        a.S3, a.lane_mT, a.lane_pT, a.lane_sign, a.partial, a.g);
 }
-template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R, bool LAZY = false>
+template <bool CE, bool DIM3, bool OUTFLOW, bool REG, int JT, int R, bool LAZY = false, bool DMA = true>
 static void launch_tile_t(const MainArgs &a, hipStream_t st)
 {
     int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
+    if constexpr (!DMA) {   // variant 8: the register-staged copy of round 1, kept for A/B (without baryon slots)
+        if (!a.g.baryon) {
+            hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, false, JT, R, LAZY, false>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
+                               a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe, a.lane_sub);
+            return;
+        }
+    }
     if (a.g.baryon)
         hipLaunchKernelGGL((cf_main_tile<CE, DIM3, OUTFLOW, REG, true, JT, R, LAZY>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS,
                            a.lane_mT, a.lane_pT, a.lane_sign, a.lane_b, a.partial, a.stats, a.g, a.lane_pe, a.lane_sub);
@@ -1312,7 +1355,7 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
     if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
     if (variant == 5 || variant == 6) variant = 3;   // same tile, E2 table stream
-    if (variant == 7) {
+    if (variant == 7 || variant == 8) {
         if (!dim3) { *JT = kTile7JT; *KT = kTile7R; return; }
         variant = 3;
     }
@@ -1361,8 +1404,9 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
     if constexpr (!DIM3) {
         // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
         if (variant == 7) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
+        if (variant == 8) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R, false, false>(a, st); return; }
     }
-    if (variant == 7) variant = 3;
+    if (variant == 7 || variant == 8) variant = 3;
     switch (variant) {
     case 1: launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st); break;
     // 8 x 7 in 3+1D: its 56 accumulators leave no room to prefetch whole rows (54 VGPRs spill, 180 GB of scratch traffic per

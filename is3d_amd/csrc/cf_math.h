@@ -28,6 +28,26 @@ __device__ __forceinline__ unsigned lds_addr32(const void *p)
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
 }
 
+// The waves of a workgroup copy NP whole 1-KiB pieces global -> LDS (contiguous on both sides): a contiguous range of pieces per
+// wave, four pieces per address through the immediate offset, nothing predicated -- the caller pads the LDS buffer to NP KiB and
+// leaves slack behind the global stream for the over-read of the last piece.  Retired by s_waitcnt vmcnt(0) + barrier.
+template <int NP>
+__device__ __forceinline__ void stage_pieces(const char *gsrc, const void *lds_dst, int tid, int nthr)
+{
+    const int nw = nthr >> 6, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = (NP * wave) / nw, hi = (NP * (wave + 1)) / nw;
+    const unsigned lane16 = (unsigned)(tid & 63) * 16u;
+    for (int p = lo; p < hi; p += 4) {
+        const char *gp = gsrc + p * 1024 + lane16;
+        const unsigned lp = __builtin_amdgcn_readfirstlane(lds_addr32((const char *)lds_dst + p * 1024));
+        const int n = hi - p;
+        glds16a<0>(gp, lp);
+        if (n > 1) glds16a<1024>(gp, lp);
+        if (n > 2) glds16a<2048>(gp, lp);
+        if (n > 3) glds16a<3072>(gp, lp);
+    }
+}
+
 // e^v = f * 2^n with f in [0.70, 1.42].  Cody-Waite reduction + degree-10 near-minimax polynomial of e^r, |r| <= ln2/2.  Splitting mantissa and exponent lets two exponentials be
 // multiplied without overflow: e^(a-b) = (f_a f_b) 2^(n_a+n_b)  (used by the factorised kernel).
 // e^r on |r| <= ln2/2 as a degree-10 polynomial (Chebyshev-node interpolant computed in long double, rounded to

@@ -209,8 +209,9 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     const bool plain3 = o->dimension == 3 && !o->include_baryon;
     int default_variant = plain3 ? 3 : 2;
     if (!fq && plain3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;
-    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 7) ? o->kernel_variant : default_variant;
-    if (P->variant == 7 && (o->dimension == 3 || fq)) P->variant = default_variant;   // unit-strided lanes: the 2+1D delta-f tile kernel
+    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 8) ? o->kernel_variant : default_variant;
+    if ((P->variant == 7 || P->variant == 8) && (o->dimension == 3 || fq)) P->variant = default_variant;
+    if (P->variant == 8 && o->include_baryon) P->variant = 7;   // variant 8 = variant 7 with the register-staged copy (A/B), without baryon slots only   // unit-strided lanes: the 2+1D delta-f tile kernel
     if ((P->variant == 5 || P->variant == 6) && !(plain3 && !fq && g->n_pT <= is3d::kE2Stride)) P->variant = (fq || !plain3) ? default_variant : 3;
     P->e2tab = P->variant == 5 || P->variant == 6;
 
@@ -235,8 +236,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // unit-strided lanes (variant 7, 2+1D): S lane slots per bin so that the slots fill whole waves (96 bins: 128 slots = 25 %
     // idle lanes with S = 1, 384 = 6 full waves with S = 4); S must divide the units per cell and the units per LDS batch (4)
     P->split = 1;
-    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 7) && split_for(P->Lbins) > 1) P->variant = 7;   // default
-    if (P->variant == 7) P->split = split_for(P->Lbins);
+    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8) && split_for(P->Lbins) > 1) P->variant = 7;   // default
+    if (P->variant == 7 || P->variant == 8) P->split = split_for(P->Lbins);
     P->L = P->Lbins * P->split;
     P->Lpad = ((P->L + 63) / 64) * 64;
     // lane slots sorted by mT: a wave then holds momenta of similar energy, which is what makes the exact-zero
@@ -460,7 +461,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         P->nch_max = (int)nch;
     }
     if (tiled) {
-        const size_t slack = P->e2tab ? (size_t)is3d::tile3e_stream_slack_doubles(P->JT, P->KT) : 0;
+        // unpredicated direct-to-LDS staging over-reads a short last batch (cf_main_tile3e, cf_main_tile variant 8)
+        const size_t slack = (size_t)is3d::tile3e_stream_slack_doubles(P->JT, P->KT) + 16 * (size_t)is3d::unit_rec_doubles(P->JT, P->KT, 1);
         HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0) + slack));
         if (P->e2tab) {
             HIP_TRY(P->d_TE.alloc((size_t)pc * P->jtiles * is3d::kE2Stride * P->JT + slack));

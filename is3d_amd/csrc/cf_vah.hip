@@ -186,7 +186,9 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
     constexpr int NLD = (BUF2 + 127) / 128;
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
     static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples");
-    __shared__ double2 lbuf[2][BUF2 + RW / 2 + 1];
+    constexpr int BUFP = ((BUF2 * 16 + 1023) / 1024) * 64;   // the batch as whole 1-KiB staging pieces (64 double2 each)
+    __shared__ double2 lbuf[2][BUFP + RW / 2 + 1];
+    (void)NLD;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -289,36 +291,20 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
         }
     };
 
-    double2 pre[NLD];
+    // staging: the next batch by direct-to-LDS loads (stage_pieces, cf_math.h), issued before the current batch is consumed
+    auto stage = [&](int ib, int buf) { stage_pieces<BUFP / 64>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
     if (nb > 0) {
-        {
-            const int n2 = min(UB, n_units) * (REC / 2);
-#pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                if (i < n2) lbuf[0][i] = src[i];
-            }
-        }
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int ib = 0; ib < nb; ib++) {
-            const bool more = ib + 1 < nb;
-            const int n2next = more ? min(UB, n_units - (ib + 1) * UB) * (REC / 2) : 0;
-            const double2 *s2 = src + (int64_t)(ib + 1) * BUF2;
-#pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                pre[t] = (i < n2next) ? s2[i] : double2{0.0, 0.0};
-            }
+            if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1];
                 for (int u = 0; u < nu; u++) process_unit(base + u * REC);
             }
-#pragma unroll
-            for (int t = 0; t < NLD; t++) {
-                const int i = tid + t * nthr;
-                if (i < n2next) lbuf[(ib + 1) & 1][i] = pre[t];
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
@@ -466,7 +452,7 @@ extern "C" int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_s
     int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24LL * 4096 + (int64_t)lane_waves * jtiles * ktiles - 1) / ((int64_t)lane_waves * jtiles * ktiles);
     nch = std::min<int64_t>(nch, std::max<int64_t>(1, pass_cells / 64));
     nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)2 << 30) / ((int64_t)J * Kacc * Lpad * 8)));
-    VAH_TRY(d_TS.alloc((size_t)pass_cells * bytes_per_cell));
+    VAH_TRY(d_TS.alloc((size_t)pass_cells * bytes_per_cell + 64 * 1024));   // + slack: the staging pieces of the last batch over-read the stream
     VAH_TRY(d_partial.alloc((size_t)nch * J * Kacc * Lpad * sizeof(double)));
     VAH_TRY(d_out.alloc((size_t)nout * sizeof(double)));
     if (o->accumulate) VAH_TRY(hipMemcpyAsync(d_out.p, dN_out, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, nullptr));

@@ -36,7 +36,7 @@ def demangle_params(sym):
     vals = re.findall(r"L([bi])(\d+)E", args)
     vals = [int(v) for _, v in vals]
     if name == "cf_main_tile":
-        keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R"]
+        keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R", "LAZY", "DMA"]
     elif name == "cf_main_tile3e":
         keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF"]
     elif name == "cf_main_feqmod":
@@ -86,6 +86,10 @@ def main():
         name, params = p
         if params.pop("PROF", 0):   # the cycle-accounting instantiation (dev) is not a product kernel
             continue
+        if name == "cf_main_tile":
+            params.pop("LAZY", None)
+            if not params.pop("DMA", 1):   # the register-staged copy kept for A/B (variant 8)
+                continue
         rb = [b for b in blocks if b["ops"].get("v_rcp_f64", 0) > 0]
         if not rb:
             continue
