@@ -130,11 +130,14 @@ typedef struct {
     int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
     int32_t device;                     /* HIP device ordinal; -1 = current device */
     /* tuning; 0 = library default */
-    int32_t kernel_variant;             /* 0 default (3 in 3+1D without baryon terms, else 2) | 1 direct kernel
-                                           (flat streams, one exp per evaluation) | 2,3,4 LDS-staged tile kernel, (phi x rows)
-                                           tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61 in 2+1D | 5: variant 3 with the phi-side
-                                           exponentials read from a table stream written by the prep kernel (3+1D delta-f kernel without
-                                           baryon terms; elsewhere the default) */
+    int32_t kernel_variant;             /* 0 default: 6 in 3+1D without baryon terms (pT grids of up to 32 values, else 3), 7 in 2+1D when
+                                           its lane slots fill the waves, else 2.  1: direct kernel (flat streams, one exp per evaluation) |
+                                           2, 3, 4: LDS-staged tile kernel, (phi x rows) tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61
+                                           in 2+1D | 5: variant 3 with the phi-side exponentials read from a table stream written by the
+                                           prep kernel | 6: variant 5 with the rows of a unit tested for liveness before their exponentials |
+                                           7: 2+1D, 8x31 tile with unit-strided lanes | 8: variant 7 with the register-staged LDS copy of
+                                           round 1 (A/B only).  A variant that does not exist for the requested mode falls back to the
+                                           default; status.kernel_variant says which one ran */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
     int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per
@@ -144,7 +147,8 @@ typedef struct {
                                            rows whose every term is below half an ulp of every accumulator it would be added to
                                            (delta-f tile kernel with outflow && regulate_deltaf); 2: off */
     int32_t waves_per_group;            /* 0 default | 2, 4, 8: lane-waves per workgroup of the tile kernel (they share
-                                           one LDS-staged coefficient stream) */
+                                           one LDS-staged coefficient stream) | 1: one-wave workgroups, no barrier partner
+                                           (variants 5, 6 only) */
     int32_t reference_bilinear_indexing; /* include_baryon = 1 only.  0 (default): the (T, mu_B) coefficient tables are read [imuB][iT], as they
                                            are stored.  1: bug-compatible with the reference's calculate_bilinear, which reads f_data[iT][imuB]
                                            (deltafReader.cpp:404-407) from arrays allocated [points_muB][points_T] (:36-61): the value at

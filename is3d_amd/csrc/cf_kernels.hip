@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *l_A = lk, *l_Cp = lk + CK, *l_al = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK, *l_C = lk + 6 * CK;
     double *l_B = lj, *l_Dp = lj + CJ, *l_ga = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_E = lj + 4 * CJ, *l_F = lj + 5 * CJ;
     double *l_V1 = lk + 7 * CK, *l_Lk = lk + 8 * CK, *l_V2 = lj + 6 * CJ, *l_L2 = lj + 7 * CJ;   // include_baryon only
+    double *l_bD = lj + 8 * CJ;                // [CB][jtiles] max_j Dp_j of a phi tile   (unit-level cull bounds, 3+1D)
+    double *l_bC = l_bD + CB * ((J + 1) / 2);  // [CB][rblocks] min_k Cp_k of a row block
 
     const int tid = threadIdx.x;
     for (int i = tid; i < nT; i += kPrepThreads) {
@@ -360,21 +362,21 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             // (q < 2^15, RWD < 64: q * ceil(2^20 / RWD) >> 20 is exact); decoding a flat index with five runtime divisions per
             // element made this kernel VALU-bound (200 instructions per double written).
             const int JT = p.JT, R = p.R;
-            // 3+1D records without baryon slots carry the bounds of the main kernel's unit-level cull in two free header slots;
-            // they are formed here, in the LDS slots that only include_baryon uses
-            const bool unit_bounds = !p.baryon && p.dim3 && JT >= 2;
+            // 3+1D records carry the bounds of the main kernel's unit-level cull in free slots: without baryon slots the x of header
+            // entries jj = 0, 1; "B" records the free double behind alpha_B and the free scalar of row 0 (cf_device.h)
+            const bool unit_bounds = p.dim3 && JT >= 2;
             if (unit_bounds) {
                 for (int idx = tid; idx < ncb * p.jtiles; idx += kPrepThreads) {
                     const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
                     double v = -1.0e300;
                     for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_Dp[c * J + min(jt * JT + q2, J - 1)]);
-                    l_V2[idx] = v;
+                    l_bD[idx] = v;
                 }
                 for (int idx = tid; idx < ncb * p.rblocks; idx += kPrepThreads) {
                     const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
                     double v = 1.0e300;
                     for (int q2 = 0; q2 < R; q2++) v = fmin(v, l_Cp[c * K + min(rb * R + q2, K - 1)]);   // padding rows repeat row K-1
-                    l_V1[idx] = v;
+                    l_bC[idx] = v;
                 }
                 __syncthreads();
             }
@@ -398,16 +400,16 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                                 const int jj = e >> 2, f = e & 3;
                                 const int j = min(jt * JT + jj, J - 1);
                                 v = f == 0 ? l_B[c * J + j] * psc : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
-                                if (unit_bounds && e == 3) v = l_V2[c * p.jtiles + jt];         // max_j D'_j of the tile: bmax = pT Dmax
-                                else if (unit_bounds && e == 7) v = l_V1[c * p.rblocks + rb];   // min_k C'_k of the unit's rows
+                                if (unit_bounds && !p.baryon && e == 3) v = l_bD[c * p.jtiles + jt];         // max_j D'_j of the tile: bmax = pT Dmax
+                                else if (unit_bounds && !p.baryon && e == 7) v = l_bC[c * p.rblocks + rb];   // min_k C'_k of the unit's rows
                             } else if (e < HDR) {
-                                v = (e == 4 * JT) ? cs[c].alphaB : 0.0;
+                                v = (e == 4 * JT) ? cs[c].alphaB : ((unit_bounds && e == 4 * JT + 1) ? l_bD[c * p.jtiles + jt] : 0.0);
                             } else {
                                 const int q = e - HDR, r = (int)(((unsigned)q * rwd_magic) >> 20), f = q - r * RWD;
                                 const int k = rb * R + r;
                                 if (k < K) {
                                     if (f < 4) v = f == 0 ? l_A[c * K + k] * psc : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
-                                    else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : 0.0;
+                                    else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : ((unit_bounds && r == 0) ? l_bC[c * p.rblocks + rb] : 0.0);
                                     else v = beta_of(c, min(jt * JT + (f - RS), J - 1), k);
                                 } else {
                                     v = (f == 1) ? l_Cp[c * K + K - 1] : 0.0;   // neutral padding row
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                     const int jj = e / kE2Stride, ipT = min(e - jj * kE2Stride, p.npT - 1);   // [jj][ipT], columns past the grid repeat the last
                     const double pT = p.pTgrid[ipT];
                     const double pTD = __dmul_rn(pT, l_Dp[c * J + min(jt * JT + jj, J - 1)]);
-                    const double bmax = __dmul_rn(pT, l_V2[c * p.jtiles + jt]);
+                    const double bmax = __dmul_rn(pT, l_bD[c * p.jtiles + jt]);
                     p.TE[((int64_t)jt * p.n_cells + (cbase + c)) * NPJ + e] = exp_full(__dsub_rn(pTD, bmax));
                 }
             }
@@ -444,7 +446,7 @@ static int prep_batch_cells(int K) { return K <= 32 ? kPrepCB3 : kPrepCB; }
 size_t prep_lds_bytes(int nT, int nspl, int J, int K)
 {
     const int cb = prep_batch_cells(K);
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (9 * K + 8 * J)) + sizeof(CellScal) * cb;
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (9 * K + 8 * J + (J + 1) / 2 + K)) + sizeof(CellScal) * cb;
 }
 
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
@@ -946,13 +948,16 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 //   [7] dead units (count)  [8] live units (count)  [9] first-wave share of [3]  [10] threshold refresh  [11] vmcnt part of [3]  [12] prologue
 __device__ unsigned long long g_prof3e[16];
 
-template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false>
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false>
 __global__ void __launch_bounds__(512)
 cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
                const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
-               double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe)
+               double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
+               const double *__restrict__ lane_b)
 {
-    constexpr int HDR = 4 * JT, RS = 4, RW = RS + JT;
+    // "B" records (include_baryon, cf_device.h): alpha_B and Dmax behind the header, {L_k, Cmin (row 0)} behind W in every row, L2_j in
+    // the header's x; the lane's baryon number b enters the exponent (b alpha_B) and the b-linear part of df (cf_main_tile)
+    constexpr int HDR = 4 * JT + (BARYON ? 2 : 0), RS = BARYON ? 6 : 4, RW = RS + JT;
     constexpr int REC = HDR + R * RW;
     constexpr int RB = JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2);
     static_assert(JT % RB == 0 && JT % 2 == 0, "phi tile: whole reciprocal batches, 16-byte records");
@@ -995,6 +1000,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                                                   // consecutive 8-byte words for consecutive pT indices (no LDS bank conflicts)
     const double hs = REG ? 0.5 : 1.0;
     const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
+    const double bq = BARYON ? lane_b[l] : 0.0;
+    const double hbmT = hs * bq * mT, hbpT = hs * bq * pT;
     const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
     const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
     const int n_units = c1 - c0;                  // one unit per cell in 3+1D
@@ -1016,9 +1023,11 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     unsigned long long pf_stage = 0, pf_wait = 0, pf_dead = 0, pf_live = 0, pf_hdr = 0, pf_nd = 0, pf_nl = 0, pf_thr = 0, pf_t0 = 0, pf_u0 = 0, pf_vm = 0, pf_pro = 0, pf_mid = 0, pf_ts = 0;
     if constexpr (PROF) pf_t0 = clock64();
     auto process_unit = [&](const double *U, const double *tab) -> bool {
-        const double bmax = __dmul_rn(pT, U[3]);                                         // pT Dmax == max_j pT Dp_j (pT >= 0)
+        const double bmax = __dmul_rn(pT, BARYON ? U[4 * JT + 1] : U[3]);                // pT Dmax == max_j pT Dp_j (pT >= 0)
+        const double baB = BARYON ? bq * U[4 * JT] : 0.0;                                // b mu_B / T: f_eq = 1/(exp(x - b alpha_B) + sign)
         {
-            const double eu = __dsub_rn(bmax, __dmul_rn(mT, U[7]));                      // unit-level cull, as in cf_main_tile
+            double eu = __dsub_rn(bmax, __dmul_rn(mT, BARYON ? U[HDR + 5] : U[7]));      // unit-level cull, as in cf_main_tile
+            if (BARYON) eu += baB;
             if (g.zskip && __all(eu < cull_thr)) { n_rows += R; n_dead += R; return false; }
         }
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
@@ -1027,13 +1036,14 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
             pTB[jj] = pT * U[4 * jj + 0];
             pTD[jj] = pT * U[4 * jj + 1];
             pT2g[jj] = pT2s * U[4 * jj + 2];
+            if (BARYON) pT2g[jj] = __builtin_fma(hbpT, U[4 * jj + 3], pT2g[jj]);       // + hs b pT L2_j
             E2[jj] = tab[jj * kE2Stride];
         }
         struct Row { const double *v; double mTC, E1; bool live; };
         auto fetch = [&](Row &rw, const double *row) {
             rw.v = row;
             rw.mTC = mT * row[1];
-            const double earg = bmax - rw.mTC;
+            const double earg = BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC;
             rw.live = !(g.zskip && __all(earg < cull_thr));
             n_rows += 1;
             n_dead += rw.live ? 0 : 1;
@@ -1041,7 +1051,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
         };
         auto evals = [&](const Row &rw, int r) {
             const double mTA = mT * rw.v[0];
-            const double mT2a = mT2s * rw.v[2];
+            const double mT2a = BARYON ? __builtin_fma(hbmT, rw.v[4], mT2s * rw.v[2]) : mT2s * rw.v[2];   // + hs b mT L_k
             const double mTC = rw.mTC, E1 = rw.E1;
 #pragma unroll
             for (int j0 = 0; j0 < JT; j0 += RB) {
@@ -1084,7 +1094,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 live = 0;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const double earg = bmax - mT * rows[r * RW + 1];
+                    const double earg = BARYON ? (bmax - mT * rows[r * RW + 1]) + baB : bmax - mT * rows[r * RW + 1];
                     live |= __all(earg < cull_thr) ? 0u : (1u << r);
                 }
             }
@@ -1097,7 +1107,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                     Row rw;
                     rw.v = rows + r * RW;
                     rw.mTC = mT * rw.v[1];
-                    rw.E1 = exp_full(bmax - rw.mTC);
+                    rw.E1 = exp_full(BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC);
                     rw.live = true;
                     evals(rw, r);
                 }
@@ -1240,23 +1250,23 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
 
 // LDS bytes per workgroup of cf_main_tile3e: the CU's 160 KB shared by its 8 waves (two per SIMD), 20 KB per wave of the workgroup
 constexpr int kTile3eLdsPerWave = 20 * 1024;
-static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
+static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2, int baryon = 0)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
 {
-    const size_t tsp = ((size_t)ub * (4 * JT + R * (4 + JT)) * sizeof(double) + 1023) & ~(size_t)1023;
+    const size_t tsp = ((size_t)ub * unit_rec_doubles(JT, R, baryon) * sizeof(double) + 1023) & ~(size_t)1023;
     const size_t tep = ((size_t)ub * kE2Stride * JT * sizeof(double) + 1023) & ~(size_t)1023;
     return nbuf * (tsp + tep);
 }
-int tile3e_units_per_batch(int JT, int R, int npT, int wpb)
+int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon)
 {
     if (npT > kE2Stride) return 0;
     const size_t budget = (size_t)kTile3eLdsPerWave * (wpb > 0 ? wpb : 1);
     int ub = 16;
-    while (ub > 0 && tile3e_lds_bytes(JT, R, ub) > budget) ub--;
+    while (ub > 0 && tile3e_lds_bytes(JT, R, ub, 2, baryon) > budget) ub--;
     return ub;
 }
 // doubles of slack the plan allocates behind TS and TE: the unpredicated staging pieces of the last batch over-read up to one
 // batch of units plus one piece
-int tile3e_stream_slack_doubles(int JT, int R) { return 16 * (4 * JT + R * (4 + JT) + kE2Stride * JT) + 128; }
+int tile3e_stream_slack_doubles(int JT, int R) { return 16 * (unit_rec_doubles(JT, R, 1) + kE2Stride * JT) + 128; }
 
 // ------------------------------------------------------------------------------------------------
 // cf_finalize: out[sp + npart*(ipT + npT*(j + J*k))] (smooth_kernels.cpp:363)
@@ -1364,20 +1374,20 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
     *KT = dim3 ? kTileR3[i] : kTileR2[i];
 }
 
-template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0>
+template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false>
 static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
 {
     const int pairs = a.g.jtiles * a.g.nch;                                   // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
     const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
-    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub);
-    if constexpr (CE && OF && RG && MODE >= 1) {
+    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0);
+    if constexpr (CE && OF && RG && MODE >= 1 && !BARYON) {
         // dev: the cycle-accounting instantiation, synchronous, counters to stderr
         static const bool prof = std::getenv("IS3D_DEV_PROF") != nullptr;
         if (prof) {
             unsigned long long h[16] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof3e), h, sizeof h);
             hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, true>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
-                               a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe);
+                               a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof3e), sizeof h);
             const double T = (double)h[1];
@@ -1388,8 +1398,8 @@ static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
             return;
         }
     }
-    hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT, a.lane_pT,
-                       a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe);
+    hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
+                       a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b);
 }
 
 template <bool CE, bool DIM3, bool OF, bool RG>
@@ -1399,6 +1409,7 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
         // variant 5: the 8 x 7 tile with the E2 table stream (the plan only sets TE up for 3+1D without baryon slots)
         if (variant == 5 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1]>(a, st); return; }
         if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1>(a, st); return; }
+        if ((variant == 5 || variant == 6) && a.TE && a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, true>(a, st); return; }
     }
     if (variant == 5 || variant == 6) variant = 3;
     if constexpr (!DIM3) {

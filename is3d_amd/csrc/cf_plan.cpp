@@ -208,11 +208,12 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     };
     const bool plain3 = o->dimension == 3 && !o->include_baryon;
     int default_variant = plain3 ? 3 : 2;
-    if (!fq && plain3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;
+    if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
     P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 8) ? o->kernel_variant : default_variant;
     if ((P->variant == 7 || P->variant == 8) && (o->dimension == 3 || fq)) P->variant = default_variant;
     if (P->variant == 8 && o->include_baryon) P->variant = 7;   // variant 8 = variant 7 with the register-staged copy (A/B), without baryon slots only   // unit-strided lanes: the 2+1D delta-f tile kernel
-    if ((P->variant == 5 || P->variant == 6) && !(plain3 && !fq && g->n_pT <= is3d::kE2Stride)) P->variant = (fq || !plain3) ? default_variant : 3;
+    const bool e2ok = o->dimension == 3 && !fq && g->n_pT <= is3d::kE2Stride;   // the E2 table stream exists for the 3+1D delta-f kernels
+    if ((P->variant == 5 || P->variant == 6) && !e2ok) P->variant = (fq || !plain3) ? default_variant : 3;
     P->e2tab = P->variant == 5 || P->variant == 6;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
@@ -466,7 +467,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0) + slack));
         if (P->e2tab) {
             HIP_TRY(P->d_TE.alloc((size_t)pc * P->jtiles * is3d::kE2Stride * P->JT + slack));
-            P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb);
+            P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb, P->baryon ? 1 : 0);
             if (P->ub3e < 1) return fail(IS3D_EINVAL, "kernel_variant 5: a unit record plus its %d x %d E2 table does not fit the LDS budget", P->npT, P->JT);
         }
     } else {

@@ -76,9 +76,16 @@ def test_parity_include_baryon(fx, dim, df_mode, diff):
     for flags in (dict(), dict(outflow=0, regulate_deltaf=0), dict(include_bulk_deltaf=0), dict(include_shear_deltaf=0)):
         o = dict(dimension=dim, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=diff, **flags)
         ref = oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], dff, o)
-        for variant in (2, 3, 4):
+        for variant in (2, 3, 4, 5, 6):   # 5, 6: the E2-table kernel with baryon slots (3+1D; 2+1D falls back to the default)
             got, st = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, kernel_variant=variant))
             assert relerr(got, ref) < TOL, (variant, flags, relerr(got, ref))
+            if dim == 3:
+                assert st["kernel_variant"] == variant
+        # culling (exact zeros; accumulator-relative with the default flags) changes no bit with baryon slots either
+        if dim == 3:
+            a0, st0 = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, zero_skip=0))
+            a2, _ = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, zero_skip=2))
+            assert st0["kernel_variant"] == DEFAULT3 and np.array_equal(a0, a2)
     # classes now carry the baryon number: p and pbar are different classes, Lambda/Lambdabar too
     _, st = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(dimension=dim, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=diff))
     assert st["n_classes"] == 6

@@ -19,21 +19,25 @@ def main():
     ap.add_argument("--df", type=int, default=2)
     ap.add_argument("--species", default="urqmd")
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--baryon", action="store_true", help="include_baryon = 1 with baryon diffusion (full (T, mu_B) tables, muB/nB/V^mu cell arrays)")
     ap.add_argument("--sets", default="variant=3;variant=5;variant=3,zero_skip=2;variant=5,zero_skip=2")
     a = ap.parse_args()
     import torch
     g = inputs.grid()
     grid = dict(pT=g["pT"], phi=g["phi"], y=g["y"], eta=g["eta"], eta_w=g["eta_w"])
-    df = inputs.df_tables()
+    df = inputs.df_tables_full() if a.baryon else inputs.df_tables()
     sp = inputs.species(a.species)
-    cells = synth.synth_surface(a.cells, a.dim)
+    cells = synth.synth_surface(a.cells, a.dim, baryon=a.baryon)
     dev = torch.device("cuda:0")
-    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}
+    fields = synth.CELL_FIELDS + (synth.BARYON_FIELDS if a.baryon else [])
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in fields}
     ptrs = {k: v.data_ptr() for k, v in tens.items()}
     stream = torch.cuda.current_stream().cuda_stream
     sets = []
     for s in a.sets.split(";"):
         o = dict(dimension=a.dim, df_mode=a.df)
+        if a.baryon:
+            o.update(include_baryon=1, include_baryondiff_deltaf=1)
         for kv in s.split(","):
             k, v = kv.split("=")
             o["kernel_variant" if k == "variant" else k] = int(v)
