@@ -38,7 +38,7 @@ def demangle_params(sym):
     if name == "cf_main_tile":
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R", "LAZY", "DMA"]
     elif name == "cf_main_tile3e":
-        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF"]
+        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON"]
     elif name == "cf_main_feqmod":
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON"]
     elif name == "cf_main_vah":
@@ -116,6 +116,8 @@ def main():
         cycles = 4 * full_rate + 16 * trans + 2 * int_ops
         if name == "cf_main_feqmod" and params.pop("BARYON", 0):
             name = "cf_main_feqmod_baryon"
+        if name == "cf_main_tile3e" and params.pop("BARYON", 0):
+            name = "cf_main_tile3e_baryon"
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
         out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
