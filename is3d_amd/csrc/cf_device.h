@@ -81,10 +81,11 @@ struct PrepParams {
 // Scale: A_k and B_j are stored times 2^-e, one integer e per execute chosen (cf_pds_bound) so that |p.dsigma| 2^-e <= 1
 // for every lane and cell; cf_finalize multiplies 2^e back.  With |p.dsigma| <= 1 the outflow test max(p.dsigma, 0) is
 // the VOP3 clamp modifier of the add/fma that forms p.dsigma (no v_max_f64).  Exact: powers of two.
-// include_baryon = 1 ("B" records): the header slot 3 holds L2_j, two doubles {alpha_B, 0} follow the header, and
-// every row carries two more scalars {L_k, 0} after W, where  b (mT L_k + pT L2_j)  is the part of df/feqbar
-// that is linear in the momentum and proportional to the baryon number b of the lane (cf_kernels.hip::cf_prep).
-// E2 table stream TE (kernel variant 5: 3+1D, no baryon slots): the phi-side factor of the factorised exponential,
+// include_baryon = 1 ("B" records): the header slot 3 holds L2_j, two doubles {alpha_B, Dmax} follow the header, and
+// every row carries two more scalars {L_k, c} after W, where  b (mT L_k + pT L2_j)  is the part of df/feqbar
+// that is linear in the momentum and proportional to the baryon number b of the lane (cf_kernels.hip::cf_prep); in 3+1D Dmax =
+// max_j Dp_j of the tile and c of row 0 = min_k Cp_k of the unit's rows (the unit-level cull bounds; c = 0 in the other rows).
+// E2 table stream TE (kernel variants 5, 6: 3+1D, with or without baryon slots): the phi-side factor of the factorised exponential,
 //   E2[ipT][jj] = exp(pT_ipT Dp_j - pT_ipT Dmax),   Dmax = max_j Dp_j over the tile (header slot 3 of the unit record),
 // depends on the lane only through its pT, and the grid has only npT (32) of them for thousands of lanes: cf_prep evaluates the
 // npT x JT exponentials of a (cell, phi tile) ONCE and the main kernel's lanes read theirs from the LDS-staged table instead of
