@@ -136,14 +136,19 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *sc = sy + nspl * nT;              // [nspl][nT]
     CellScal *cs = (CellScal *)(sc + nspl * nT);  // [CB]
     // per (cell, k): A, Cp, alpha, W, ch, sh, C ; per (cell, j): B, Dp, gamma, D, E, F
-    double *lk = (double *)(cs + CB);    // [9][CB][K]
-    double *lj = lk + 9 * CB * K;        // [8][CB][J]
+    // (the two last arrays of each group exist with include_baryon only: a 241-row eta table would pay 15 KB for them, and two
+    // workgroups per CU need <= 80 KB each)
+    const int NKA = p.baryon ? 9 : 7, NJA = p.baryon ? 8 : 6;
+    double *lk = (double *)(cs + CB);    // [NKA][CB][K]
+    double *lj = lk + NKA * CB * K;      // [NJA][CB][J]
     const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_Cp = lk + CK, *l_al = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK, *l_C = lk + 6 * CK;
     double *l_B = lj, *l_Dp = lj + CJ, *l_ga = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_E = lj + 4 * CJ, *l_F = lj + 5 * CJ;
     double *l_V1 = lk + 7 * CK, *l_Lk = lk + 8 * CK, *l_V2 = lj + 6 * CJ, *l_L2 = lj + 7 * CJ;   // include_baryon only
-    double *l_bD = lj + 8 * CJ;                // [CB][jtiles] max_j Dp_j of a phi tile   (unit-level cull bounds, 3+1D)
+    double *l_bD = lj + NJA * CJ;              // [CB][jtiles] max_j Dp_j of a phi tile   (unit-level cull bounds, 3+1D)
     double *l_bC = l_bD + CB * ((J + 1) / 2);  // [CB][rblocks] min_k Cp_k of a row block
+    // element descriptors of a unit record (tiled stream), one int2 per record element, filled once per workgroup (below)
+    int2 *desc = (int2 *)(p.dim3 ? l_bC + CB * K : l_bD);
 
     const int tid = threadIdx.x;
     for (int i = tid; i < nT; i += kPrepThreads) {
@@ -154,6 +159,44 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
         }
     }
     __syncthreads();
+
+    // Record-element descriptors (tiled stream).  Every element of a unit record is a copy of one LDS double (possibly times the
+    // p.dsigma scale), an exact zero, or a beta_jk; WHICH is the same for every unit, so the decode is done once:
+    //   x: bits 0-15 offset of the source array in the LDS block | 16-18 how the index continues (0: c J + j, 1: c K + k, 2: c jtiles + jt,
+    //      3: c rblocks + rb, 4: c sizeof(CellScal)/8) | 19 scaled | 20 beta | 21 zero when the row is padding (k >= K) | 22 always zero
+    //   y: jj (header entry / beta column) | r << 16 (row)
+    // (As nested conditionals inside the writer loop the decode compiled to ~30 exec-masked branches with an LDS round trip in each arm:
+    // 1 400 cycles per 64 elements, 91 % of the 2+1D prep kernel.)
+    if (p.tiled) {
+        const int JT = p.JT, R = p.R;
+        const bool unit_bounds = p.dim3 && JT >= 2;
+        const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
+        const int o_A = (int)(l_A - lds), o_Cp = (int)(l_Cp - lds), o_al = (int)(l_al - lds), o_W = (int)(l_W - lds), o_Lk = (int)(l_Lk - lds);
+        const int o_B = (int)(l_B - lds), o_Dp = (int)(l_Dp - lds), o_ga = (int)(l_ga - lds), o_L2 = (int)(l_L2 - lds);
+        const int o_bD = (int)(l_bD - lds), o_bC = (int)(l_bC - lds);
+        const int o_alphaB = (int)(&cs[0].alphaB - lds);
+        constexpr int ZERO = 1 << 22, PADZ = 1 << 21, BETA = 1 << 20, SCALED = 1 << 19;
+        for (int e = tid; e < REC; e += kPrepThreads) {
+            int x = ZERO, y = 0;
+            if (e < 4 * JT) {
+                const int jj = e >> 2, f = e & 3;
+                y = jj;
+                x = f == 0 ? (o_B | SCALED) : f == 1 ? o_Dp : f == 2 ? o_ga : (p.baryon ? o_L2 : ZERO);
+                if (unit_bounds && !p.baryon && e == 3) x = o_bD | (2 << 16);         // max_j D'_j of the tile: bmax = pT Dmax
+                else if (unit_bounds && !p.baryon && e == 7) x = o_bC | (3 << 16);    // min_k C'_k of the unit's rows
+            } else if (e < HDR) {
+                x = (e == 4 * JT) ? (o_alphaB | (4 << 16)) : ((unit_bounds && e == 4 * JT + 1) ? (o_bD | (2 << 16)) : ZERO);
+            } else {
+                const int q = e - HDR, r = q / RWD, f = q - r * RWD;
+                y = r << 16;
+                if (f < 4) x = (f == 0 ? (o_A | SCALED | PADZ) : f == 1 ? o_Cp : f == 2 ? (o_al | PADZ) : (o_W | PADZ)) | (1 << 16);   // a padding row keeps Cp of row K-1
+                else if (f < RS) x = (f == 4) ? (o_Lk | (1 << 16) | PADZ) : ((unit_bounds && r == 0) ? (o_bC | (3 << 16) | PADZ) : ZERO);
+                else { x = BETA | PADZ; y |= f - RS; }
+            }
+            desc[e] = int2{x, y};
+        }
+        __syncthreads();
+    }
 
     const int nbatch = (p.n_cells + CB - 1) / CB;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
@@ -382,7 +425,6 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             }
             const double psc = pds_scale(p.pds_bound, nullptr);
             const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
-            const unsigned rwd_magic = ((1u << 20) + (unsigned)RWD - 1u) / (unsigned)RWD;
             const int wave = tid >> 6, lane = tid & 63;
             int n = 0;
             for (int c = 0; c < ncb; c++) {
@@ -394,28 +436,22 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                         if (p.dim3) unit = (int64_t)(jt * p.rblocks + rb) * p.n_cells + cell;       // s = jt*rblocks + rb
                         else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;              // s = jt
                         double *o = p.TS + unit * REC;
+                        // one LDS round trip per 64 elements: the descriptor, then the source double next to the six reads of a
+                        // (clamped) beta_of; no divergent branch
+                        const int cJ = c * J, cK = c * K, cT = c * p.jtiles + jt, cR = c * p.rblocks + rb, cS = c * (int)(sizeof(CellScal) / sizeof(double));
                         for (int e = lane; e < REC; e += 64) {
-                            double v;
-                            if (e < 4 * JT) {
-                                const int jj = e >> 2, f = e & 3;
-                                const int j = min(jt * JT + jj, J - 1);
-                                v = f == 0 ? l_B[c * J + j] * psc : f == 1 ? l_Dp[c * J + j] : f == 2 ? l_ga[c * J + j] : (p.baryon ? l_L2[c * J + j] : 0.0);
-                                if (unit_bounds && !p.baryon && e == 3) v = l_bD[c * p.jtiles + jt];         // max_j D'_j of the tile: bmax = pT Dmax
-                                else if (unit_bounds && !p.baryon && e == 7) v = l_bC[c * p.rblocks + rb];   // min_k C'_k of the unit's rows
-                            } else if (e < HDR) {
-                                v = (e == 4 * JT) ? cs[c].alphaB : ((unit_bounds && e == 4 * JT + 1) ? l_bD[c * p.jtiles + jt] : 0.0);
-                            } else {
-                                const int q = e - HDR, r = (int)(((unsigned)q * rwd_magic) >> 20), f = q - r * RWD;
-                                const int k = rb * R + r;
-                                if (k < K) {
-                                    if (f < 4) v = f == 0 ? l_A[c * K + k] * psc : f == 1 ? l_Cp[c * K + k] : f == 2 ? l_al[c * K + k] : l_W[c * K + k];
-                                    else if (f < RS) v = (f == 4) ? l_Lk[c * K + k] : ((unit_bounds && r == 0) ? l_bC[c * p.rblocks + rb] : 0.0);
-                                    else v = beta_of(c, min(jt * JT + (f - RS), J - 1), k);
-                                } else {
-                                    v = (f == 1) ? l_Cp[c * K + K - 1] : 0.0;   // neutral padding row
-                                }
-                            }
-                            o[e] = v;
+                            const int2 d = desc[e];
+                            const int jj = d.y & 0xffff, r = d.y >> 16;
+                            const int jcl = min(jt * JT + jj, J - 1);
+                            const int k = rb * R + r, kcl = min(k, K - 1);
+                            const int msel = (d.x >> 16) & 7;
+                            const int add = msel == 0 ? cJ + jcl : msel == 1 ? cK + kcl : msel == 2 ? cT : msel == 3 ? cR : cS;
+                            const bool zero = ((d.x >> 22) & 1) | (((d.x >> 21) & 1) & (k >= K));
+                            const double raw = lds[zero ? 0 : (d.x & 0xffff) + add];
+                            const double bet = beta_of(c, jcl, kcl);
+                            double v = ((d.x >> 19) & 1) ? raw * psc : raw;
+                            v = ((d.x >> 20) & 1) ? bet : v;
+                            o[e] = zero ? 0.0 : v;
                         }
                     }
                 }
@@ -443,10 +479,15 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 // batch measure 6.5 / 5.7 / 5.5 ms per 1e5 cells -- occupancy is not what limits it)
 static int prep_batch_cells(int K) { return K <= 32 ? kPrepCB3 : kPrepCB; }
 
-size_t prep_lds_bytes(int nT, int nspl, int J, int K)
+size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec)
 {
     const int cb = prep_batch_cells(K);
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (9 * K + 8 * J + (J + 1) / 2 + K)) + sizeof(CellScal) * cb;
+    const int nka = baryon ? 9 : 7, nja = baryon ? 8 : 6;
+    // the unit-level cull bounds ([cb][jtiles] + [cb][rblocks] <= cb ((J + 1) / 2 + K) doubles) exist for 3+1D grids only, where K is small;
+    // a 2+1D eta table of 241 rows must not pay 8 KB for them (two workgroups per CU need <= 80 KB each)
+    const size_t bounds = K <= 32 ? (size_t)cb * ((J + 1) / 2 + K) : 0;
+    // + one int2 per element of a unit record (rec doubles; 0 for the flat streams of variant 1)
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (nka * K + nja * J) + bounds + (size_t)rec) + sizeof(CellScal) * cb;
 }
 
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
@@ -455,7 +496,7 @@ hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
     const int cb = prep_batch_cells(p.K);
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
-    size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K);
+    size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0);
     if (cb == kPrepCB3) hipLaunchKernelGGL(cf_prep<kPrepCB3>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     else hipLaunchKernelGGL(cf_prep<kPrepCB>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     return hipGetLastError();

@@ -409,13 +409,14 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         if (P->baryon) HIP_TRY(P->d_cls_baryon.upload(cbar));
         if (is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K, P->dim3 ? (P->J + 3) / 4 : 0) > 160 * 1024)   // jtiles <= J/4 (4-wide tiles)
             return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
-    } else if (is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K) > 160 * 1024)
-        return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
+    }
 
     // ---- tiling / workspace ----
     is3d::main_tile_shape(P->variant, P->dim3 ? 1 : 0, &P->JT, &P->KT);
     P->jtiles = (P->J + P->JT - 1) / P->JT;
     const bool tiled = P->variant != 1;
+    if (!fq && is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K, P->baryon ? 1 : 0, tiled ? is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0) : 0) > 160 * 1024)
+        return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     P->rblocks = tiled ? (P->K + P->KT - 1) / P->KT : 1;
     P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;   // k tiles are separate tasks only in 3+1D
     P->upc = (tiled && !P->dim3) ? P->rblocks : 1;            // 2+1D: eta blocks are consecutive units of one stream
