@@ -459,15 +459,24 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             if (p.TE && unit_bounds) {
                 // E2 table stream (cf_device.h): exp(pT Dp_j - pT Dmax) for every pT of the grid, with the roundings the main
                 // kernel's own header used (explicit mul / sub, no contraction): pT Dmax == max_j (pT Dp_j) for pT >= 0
+                // One (cell, phi tile) table per wave at a time, lanes <-> (jj, ipT) with ipT fastest (kE2Stride = 32: shifts, no division;
+                // the lane's pT is loop-invariant: 64 lanes = two jj rows of the 32 pT columns).
                 const int NPJ = kE2Stride * JT;
-                for (int idx = tid; idx < ncb * p.jtiles * NPJ; idx += kPrepThreads) {
-                    const int ct = idx / NPJ, e = idx - ct * NPJ;
-                    const int c = ct / p.jtiles, jt = ct - c * p.jtiles;
-                    const int jj = e / kE2Stride, ipT = min(e - jj * kE2Stride, p.npT - 1);   // [jj][ipT], columns past the grid repeat the last
-                    const double pT = p.pTgrid[ipT];
-                    const double pTD = __dmul_rn(pT, l_Dp[c * J + min(jt * JT + jj, J - 1)]);
-                    const double bmax = __dmul_rn(pT, l_bD[c * p.jtiles + jt]);
-                    p.TE[((int64_t)jt * p.n_cells + (cbase + c)) * NPJ + e] = exp_full(__dsub_rn(pTD, bmax));
+                static_assert(kE2Stride == 32, "lane -> (jj, ipT) decode below");
+                const int wv = tid >> 6, ln = tid & 63;
+                const double pTl = p.pTgrid[min(ln & 31, p.npT - 1)];           // [jj][ipT], columns past the grid repeat the last
+                int m = 0;
+                for (int c = 0; c < ncb; c++) {
+                    for (int jt = 0; jt < p.jtiles; jt++, m++) {
+                        if ((m & (kPrepThreads / 64 - 1)) != wv) continue;
+                        const double bmax = __dmul_rn(pTl, l_bD[c * p.jtiles + jt]);
+                        double *t = p.TE + ((int64_t)jt * p.n_cells + (cbase + c)) * NPJ;
+                        for (int e = ln; e < NPJ; e += 64) {
+                            const int jj = e >> 5;
+                            const double pTD = __dmul_rn(pTl, l_Dp[c * J + min(jt * JT + jj, J - 1)]);
+                            t[e] = exp_full(__dsub_rn(pTD, bmax));
+                        }
+                    }
                 }
             }
         }
