@@ -656,7 +656,7 @@ template <bool CE, bool DIM3, bool OUTFLOW, bool REG, bool BARYON, int JT, int R
 // a spill: three waves per SIMD (config 2: 31.5 -> 29.9 ms).  Everything else is a two-wave kernel (the Chapman-Enskog form of the same
 // tile would spill 42 registers at 168), and the compiler is told not to trade the schedule for a third wave it cannot reach.
 __global__ void __launch_bounds__(512)
-__attribute__((amdgpu_waves_per_eu((!DIM3 && !CE && !BARYON && JT <= 8 && R <= 32 && DMA) ? 3 : 2, (!DIM3 && !CE && !BARYON && JT <= 8 && R <= 32 && DMA) ? 3 : 2)))
+__attribute__((amdgpu_waves_per_eu((!DIM3 && !BARYON && JT <= 8 && R <= 32 && DMA) ? 3 : 2, (!DIM3 && !BARYON && JT <= 8 && R <= 32 && DMA) ? 3 : 2)))
 cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, const double *__restrict__ lane_b, double *__restrict__ partial,
              unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
@@ -673,7 +673,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr bool EARLY = LAZY;   // staging order, see the batch loop (eager tiles: 664 -> 666 ms, 2+1D 40.2 -> 42.0 ms with it)
     // evaluations per shared reciprocal (A/B on config 3 / config 2): 3+1D 8 x 7: 1 -> 685, 2 -> 651, 4 -> 637,
     // 8 -> 716 ms (spills); 2+1D 8 x 61: 1 -> 44.1, 2 -> 41.5, 4 -> 40.7, 8 -> 40.2 ms
-    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);
+    // (the Chapman-Enskog 8 x 31 tile takes four evaluations per reciprocal so that it, too, fits three waves per SIMD)
+    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : ((JT % 8 == 0 && !(CE && !BARYON && R <= 32 && DMA)) ? 8 : 4);
     static_assert(JT % RB == 0, "the phi tile is a whole number of reciprocal batches");
     static_assert(REC % 2 == 0, "unit records must be 16-byte multiples (JT even)");
     // DMA (the default since round 2; DMA = false keeps the register-staged copy for A/B, variant 8): the next batch is staged by
