@@ -132,6 +132,22 @@ struct is3d_comm {
     int32_t n_ranks = 1, rank = 0, device = 0;
 };
 
+namespace is3d {
+void warm_devices(const int *devices, int n)
+{
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return;
+    const int cnt = (devices && n > 0) ? n : visible;
+    for (int i = 0; i < cnt; i++) {
+        const int d = (devices && n > 0) ? devices[i] : i;
+        if (d < 0 || d >= visible) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        (void)hipFree(nullptr);                 // creates the context
+    }
+    (void)hipGetLastError();
+}
+}  // namespace is3d
+
 extern "C" int is3d_shard_bounds(int64_t n_cells, int32_t rank, int32_t n_ranks, int64_t *lo, int64_t *hi)
 {
     if (!lo || !hi || n_cells < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(IS3D_EINVAL, "is3d_shard_bounds: bad argument");

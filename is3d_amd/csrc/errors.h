@@ -2,4 +2,7 @@
 #pragma once
 namespace is3d {
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// Create the HIP contexts of the listed devices (all visible ones for n == 0) ahead of their first use: the run driver calls it on
+// a thread of its own while it parses the surface file (a cold context costs a quarter of a second).  Errors are left to the real calls.
+void warm_devices(const int *devices, int n);
 }

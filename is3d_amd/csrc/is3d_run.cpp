@@ -25,6 +25,7 @@
 #include <fstream>
 #include <iomanip>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <cstdarg>
@@ -172,6 +173,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     else DIE("hrg_eos = %d: please choose hrg_eos = (1,2,3)", hrg_eos);
 
     double t0 = now_s();
+    // the device contexts are created while the surface is being parsed (joined before the first device call)
+    std::vector<int> warm_list(rd.list.begin(), rd.list.end());
+    std::thread warm([&warm_list] { is3d::warm_devices(warm_list.empty() ? nullptr : warm_list.data(), (int)warm_list.size()); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
     // ---- surface (iS3D.cpp:90-98) ----
     int64_t n_cells = 0;
     std::vector<std::vector<double>> arr(23);
@@ -248,6 +253,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
             if (is3d_df_table_read_full(p.c_str(), &nT, &nB, Tk.data(), Bk.data(), tab[t].data(), (int64_t)tab[t].size())) DIE("%s", is3d_last_error());
         }
     }
+    if (warm.joinable()) warm.join();
     double t1 = now_s();
     printf("Total number of freezeout cells: %lld\nNumber of chosen particles: %zu\n", (long long)n_cells, mcid.size());
 
