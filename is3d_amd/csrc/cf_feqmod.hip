@@ -606,6 +606,10 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
 
     // staging: the next batch by direct-to-LDS loads (stage_pieces, cf_math.h), issued before the current batch is consumed
     auto stage = [&](int ib, int buf) { stage_pieces<BUFP / 64>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
+    // The lane constants must have ARRIVED before the batch loop: the compiler sinks the loads of restrict-qualified data to their first
+    // use and waits for them there (s_waitcnt vmcnt(0) in every row of the unrolled loop) -- a wait that also covers the direct-to-LDS
+    // loads of the next batch, which it does not know about, i.e. it would expose the staging latency in every batch
+    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2), "v"(mTpT), "v"(pT2), "v"(bq) : "memory");
     if (nb > 0) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

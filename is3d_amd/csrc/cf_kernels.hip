@@ -878,6 +878,10 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         // the pieces of a short last batch over-read the stream (slack behind TS) into the pad / unused units of the buffer
         constexpr int NP = BUFP / 64;
         auto stage = [&](int ib, int buf) { stage_pieces<NP>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
+        // The lane constants must have ARRIVED before the batch loop: the compiler sinks the loads of restrict-qualified data to their first
+        // use and waits for them there (s_waitcnt vmcnt(0) in every row of the unrolled loop) -- a wait that also covers the direct-to-LDS
+        // loads of the next batch, which it does not know about, i.e. it would expose the staging latency in every batch
+        asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2s), "v"(mTpTs), "v"(pT2s), "v"(hbmT), "v"(hbpT), "v"(bq), "v"(sub_off), "v"(pe) : "memory");
         if (nb > 0) {
             stage(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1019,7 +1023,14 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // against 691: the third wave does not pay for the exponentials and headers amortised over fewer evaluations.)
     // (Tried and dropped, round 2: a ring of three LDS buffers with one progress word per wave in place of the per-batch
     // barrier -- bitwise the same spectrum, 360 against 352 ms: with LDS for 12 units in all, a wave can run at most one
-    // 4-unit batch ahead of its partner, and the polling costs more than that slack returns.)
+    // 4-unit batch ahead of its partner, and the polling costs more than that slack returns.  And the fine-grained form: 13
+    // single-unit slots, wave w stages the units u = w (mod 2) whole, landed / consumed counts in LDS words, no barrier in the
+    // loop -- 381 against 346 ms (stage 8.4 %, wait 9.5 % of the wave cycles): a wave can only know "all but my newest unit have
+    // landed", two units after their issue instead of a batch later, and that wait plus the publish lag eat the slack.  Two
+    // traps met on the way, both because the compiler does not know about the written-out direct-to-LDS loads: a release store
+    // or acquire fence at workgroup scope, and a compiler-placed s_waitcnt vmcnt(n) for a lane constant whose load it had sunk
+    // into the loop, each drain the staging pipeline every unit (405 ms) -- flags must be relaxed LDS accesses behind the
+    // kernel's own waits, and the lane constants must be forced to arrive before the loop.)
     // (Tried and dropped, round 2: one LDS round trip at the head of a unit -- test operands first, the header speculatively behind
     // them, votes while it arrives, dead units drop the reads: 352.1 against 347.9 ms.)
     constexpr bool ROWMASK = MODE >= 1;
