@@ -1085,12 +1085,15 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     unsigned long long pf_stage = 0, pf_wait = 0, pf_dead = 0, pf_live = 0, pf_hdr = 0, pf_nd = 0, pf_nl = 0, pf_thr = 0, pf_t0 = 0, pf_u0 = 0, pf_vm = 0, pf_pro = 0, pf_mid = 0, pf_ts = 0;
     if constexpr (PROF) pf_t0 = clock64();
     auto process_unit = [&](const double *U, const double *tab) -> bool {
-        const double bmax = __dmul_rn(pT, BARYON ? U[4 * JT + 1] : U[3]);                // pT Dmax == max_j pT Dp_j (pT >= 0)
+        // (both bounds in ONE LDS round trip: read before the test is formed, not under its g.zskip short-circuit)
+        const double dmaxv = BARYON ? U[4 * JT + 1] : U[3], cminv = BARYON ? U[HDR + 5] : U[7];
+        const double bmax = __dmul_rn(pT, dmaxv);                                        // pT Dmax == max_j pT Dp_j (pT >= 0)
         const double baB = BARYON ? bq * U[4 * JT] : 0.0;                                // b mu_B / T: f_eq = 1/(exp(x - b alpha_B) + sign)
         {
-            double eu = __dsub_rn(bmax, __dmul_rn(mT, BARYON ? U[HDR + 5] : U[7]));      // unit-level cull, as in cf_main_tile
+            double eu = __dsub_rn(bmax, __dmul_rn(mT, cminv));                           // unit-level cull, as in cf_main_tile
             if (BARYON) eu += baB;
-            if (g.zskip && __all(eu < cull_thr)) { n_rows += R; n_dead += R; return false; }
+            const bool dead = __all(eu < cull_thr);
+            if (g.zskip && dead) { n_rows += R; n_dead += R; return false; }
         }
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
 #pragma unroll
