@@ -1087,6 +1087,14 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     auto process_unit = [&](const double *U, const double *tab) -> bool {
         // (both bounds in ONE LDS round trip: read before the test is formed, not under its g.zskip short-circuit)
         const double dmaxv = BARYON ? U[4 * JT + 1] : U[3], cminv = BARYON ? U[HDR + 5] : U[7];
+        // ... and, in the same round trip, the operands of the row tests (MODE 1): a live unit then forms its row mask while its header
+        // is arriving instead of paying two more round trips for the C'_k; a dead unit drops four reads
+        double cn[R];
+        if constexpr (ROWMASK) {
+#pragma unroll
+            for (int r = 0; r < R; r++) cn[r] = U[HDR + r * RW + 1];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const double bmax = __dmul_rn(pT, dmaxv);                                        // pT Dmax == max_j pT Dp_j (pT >= 0)
         const double baB = BARYON ? bq * U[4 * JT] : 0.0;                                // b mu_B / T: f_eq = 1/(exp(x - b alpha_B) + sign)
         {
@@ -1159,7 +1167,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 live = 0;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const double earg = BARYON ? (bmax - mT * rows[r * RW + 1]) + baB : bmax - mT * rows[r * RW + 1];
+                    const double earg = BARYON ? (bmax - mT * cn[r]) + baB : bmax - mT * cn[r];
                     live |= __all(earg < cull_thr) ? 0u : (1u << r);
                 }
             }
