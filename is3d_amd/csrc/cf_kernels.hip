@@ -1103,6 +1103,15 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
             const bool dead = __all(eu < cull_thr);
             if (g.zskip && dead) { n_rows += R; n_dead += R; return false; }
         }
+        if constexpr (ROWMASK) {
+            // live unit: the C'_k are wave-uniform and stay live through the rows (each row's exponential starts from them before the
+            // row's own reads return): moved to SGPRs, no VGPR is free there
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(cn[r])), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(cn[r]));
+                cn[r] = __hiloint2double((int)hi, (int)lo);
+            }
+        }
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
@@ -1179,7 +1188,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 if (live & (1u << r)) {
                     Row rw;
                     rw.v = rows + r * RW;
-                    rw.mTC = mT * rw.v[1];
+                    rw.mTC = mT * cn[r];   // C'_k is already here (read with the unit bounds): the exponential starts before the row's own reads return
                     rw.E1 = exp_full(BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC);
                     rw.live = true;
                     evals(rw, r);
