@@ -1030,7 +1030,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // traps met on the way, both because the compiler does not know about the written-out direct-to-LDS loads: a release store
     // or acquire fence at workgroup scope, and a compiler-placed s_waitcnt vmcnt(n) for a lane constant whose load it had sunk
     // into the loop, each drain the staging pipeline every unit (405 ms) -- flags must be relaxed LDS accesses behind the
-    // kernel's own waits, and the lane constants must be forced to arrive before the loop.)
+    // kernel's own waits, and the lane constants must be forced to arrive before the loop.  The three-buffer batch ring again
+    // with relaxed flags: 342.8 against 335.8 ms, culling off 713.9 against 677.9.)
     // (Tried and dropped, round 2: one LDS round trip at the head of a unit -- test operands first, the header speculatively behind
     // them, votes while it arrives, dead units drop the reads: 352.1 against 347.9 ms.)
     constexpr bool ROWMASK = MODE >= 1;
