@@ -58,6 +58,7 @@ struct FqMainArgs {
     const double *lane_b;               // include_baryon: baryon number of each lane slot's class
     const double *RN;                   // df_mode 3: [n_cells][ncls] |renorm|
     const int32_t *lane_cls;            // df_mode 3: class of each lane slot
+    const int32_t *lane_sub;            // 2+1D unit-strided lanes (g.split > 1): the slot's sub-index s, it takes the units u = s (mod split)
     int32_t ncls;
     double *partial;
     unsigned long long *stats;
@@ -72,6 +73,7 @@ struct FqLinearArgs {
     const double *cosphi, *sinphi, *kgrid, *kweight;
     double *partial;                    // chunk 0 of the partial buffer: += after the main kernel
     int32_t J, K, Kacc, Lpad, dim3, mode, outflow, regulate;
+    int32_t Lbins;                      // momentum bins: with unit-strided lanes only a bin's first slot (lanes < Lbins) takes the fallback cells
 };
 
 size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles);

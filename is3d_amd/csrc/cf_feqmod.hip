@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(512)
 cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
                const double *__restrict__ lane_sign, const double *__restrict__ RN, const int32_t *__restrict__ lane_cls,
                int ncls, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g,
-               const double *__restrict__ lane_b)
+               const double *__restrict__ lane_b, const int32_t *__restrict__ lane_sub)
 {
     constexpr int HDR = 4 * JT;
     constexpr int RW = 4 + JT;
@@ -488,6 +488,13 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
     const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
     const double bq = BARYON ? lane_b[l] : 0.0;
+    // Unit-strided lanes (2+1D, g.split = S > 1; cf_main_tile has the same): a surface with few momentum bins gives every bin S lane
+    // slots, slot s takes the units u = s (mod S) of the stream -- all units of a stream add into the same JT accumulators of a
+    // bin -- and cf_finalize adds a bin's slots in slot order.  S divides the units per cell, so the S units of a step belong to
+    // one cell (one renormalisation factor); the row votes then span lanes on different units and skip a row only when it is
+    // dead for every one of them.
+    const int S = (!DIM3 && g.split > 1) ? g.split : 1;
+    const int sub_off = (!DIM3 && g.split > 1 && lane_sub) ? lane_sub[l] * REC : 0;
     const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
     const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
     const int n_units = (c1 - c0) * g.upc;
@@ -609,7 +616,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     // The lane constants must have ARRIVED before the batch loop: the compiler sinks the loads of restrict-qualified data to their first
     // use and waits for them there (s_waitcnt vmcnt(0) in every row of the unrolled loop) -- a wait that also covers the direct-to-LDS
     // loads of the next batch, which it does not know about, i.e. it would expose the staging latency in every batch
-    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2), "v"(mTpT), "v"(pT2), "v"(bq) : "memory");
+    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2), "v"(mTpT), "v"(pT2), "v"(bq), "v"(sub_off) : "memory");
     if (nb > 0) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -618,14 +625,14 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
-                const double *base = (const double *)lbuf[ib & 1];
+                const double *base = (const double *)lbuf[ib & 1] + sub_off;
                 const int u0 = ib * UB;
                 double rn = 1.0;
                 if (MODE3) rn = rn_col[(int64_t)(c0 + u0 / g.upc) * ncls];
-                for (int u = 0; u < nu; u++) {
+                for (int u = 0; u < nu; u += S) {      // nu is a multiple of S (plan)
                     double rn_next = 1.0;
                     if (MODE3) {
-                        const int un = min(u0 + u + 1, n_units - 1);
+                        const int un = min(u0 + u + S, n_units - 1);
                         rn_next = rn_col[(int64_t)(c0 + un / g.upc) * ncls];
                     }
                     process_unit(base + u * REC, rn);
@@ -678,12 +685,12 @@ static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
     if constexpr (M3) {
         if (a.lane_b) {   // include_baryon (df_mode 3 only)
             hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, true>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT,
-                               a.lane_pT, a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b);
+                               a.lane_pT, a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
             return;
         }
     }
     hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
-                       a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b);
+                       a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
 }
 
 template <bool DIM3, bool OF, bool M3>
@@ -772,6 +779,7 @@ __global__ void __launch_bounds__(256) cf_feqmod_linear(FqLinearArgs a)
     if (idx >= total) return;
     const int l = (int)(idx % a.Lpad);
     const int jk = (int)(idx / a.Lpad);
+    if (l >= a.Lbins) return;   // unit-strided lanes: the fallback cells go to a bin's first slot only (padding lanes add nothing either way)
     const int j = jk / a.Kacc, k = jk - j * a.Kacc;
     const double mT = a.lane_mT[l], pT = a.lane_pT[l], sign = a.lane_sign[l], mass = a.lane_mass[l];
     const double baryon = a.lane_b ? a.lane_b[l] : 0.0;

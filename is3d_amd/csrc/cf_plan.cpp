@@ -239,6 +239,17 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     P->split = 1;
     if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8) && split_for(P->Lbins) > 1) P->variant = 7;   // default
     if (P->variant == 7 || P->variant == 8) P->split = split_for(P->Lbins);
+    if (fq && o->dimension == 2) {
+        // modified equilibrium, 2+1D: the same lane slots on the kernel's own tile -- S = 2 when it divides the units per cell and
+        // the units per LDS batch (cf_main_feqmod stages 1536 / REC units) and fills the two-wave workgroups better
+        int JTf = 0, Rf = 0;
+        is3d::main_tile_shape(P->variant, 0, &JTf, &Rf);
+        const int recf = 4 * JTf + Rf * (4 + JTf), ubf = std::max(1, 1536 / recf), rblocksf = (g->n_eta + Rf - 1) / Rf;
+        const int nb = P->Lbins;
+        const double waste1 = 1.0 - (double)nb / (double)(((nb + 63) / 64) * 64);
+        const double waste2 = 1.0 - (double)(2 * nb) / (double)(((2 * nb + 63) / 64) * 64);
+        if (rblocksf % 2 == 0 && ubf % 2 == 0 && waste2 < waste1 - 0.05) P->split = 2;
+    }
     P->L = P->Lbins * P->split;
     P->Lpad = ((P->L + 63) / 64) * 64;
     // lane slots sorted by mT: a wave then holds momenta of similar energy, which is what makes the exact-zero
@@ -401,7 +412,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_jonah.upload(jon));
         std::vector<double> lane_mass(P->Lpad, 1.0);
         std::vector<int32_t> lane_cls(P->Lpad, 0);
-        for (int s = 0; s < P->Lbins; s++) { lane_mass[s] = cmass[order[s] / P->npT]; lane_cls[s] = order[s] / P->npT; }
+        for (int sl = 0; sl < P->split; sl++)   // every slot of a bin carries the bin's class
+            for (int s = 0; s < P->Lbins; s++) { lane_mass[sl * P->Lbins + s] = cmass[order[s] / P->npT]; lane_cls[sl * P->Lbins + s] = order[s] / P->npT; }
         HIP_TRY(P->d_lane_mass.upload(lane_mass));
         HIP_TRY(P->d_lane_cls.upload(lane_cls));
         HIP_TRY(P->d_cls_mass.upload(cmass));
@@ -649,6 +661,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 is3d::FqMainArgs a{};
                 a.TS = P->d_TS.p; a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p;
                 a.RN = P->d_RN.p; a.lane_cls = P->d_lane_cls.p; a.ncls = P->ncls;
+                a.lane_sub = P->d_lane_sub.p; a.g.split = P->split;
                 a.lane_b = P->baryon ? P->d_lane_b.p : nullptr;
                 a.partial = P->d_partial.p; a.stats = P->d_status.p;
                 a.g.upc = P->upc; a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2); a.g.baryon = 0;
@@ -665,7 +678,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 la.lane_b = P->baryon ? P->d_lane_b.p : nullptr;
                 la.cosphi = P->d_cosphi.p; la.sinphi = P->d_sinphi.p; la.kgrid = P->d_kgrid.p; la.kweight = P->d_kweight.p;
                 la.partial = P->d_partial.p;
-                la.J = P->J; la.K = P->K; la.Kacc = P->Kacc; la.Lpad = P->Lpad; la.dim3 = P->dim3; la.mode = o.df_mode;
+                la.J = P->J; la.K = P->K; la.Kacc = P->Kacc; la.Lpad = P->Lpad; la.dim3 = P->dim3; la.mode = o.df_mode; la.Lbins = P->Lbins;
                 la.outflow = o.outflow != 0; la.regulate = o.regulate_deltaf != 0;
                 HIP_TRY(is3d::launch_feqmod_linear(la, st));
                 if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 2], st));
