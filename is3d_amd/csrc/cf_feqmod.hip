@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     double *lk = (double *)(cs + kFqCB);       // [6][CB][K]: A, alphaf, W, a'x, a'y, a'z
     double *lj = lk + 6 * kFqCB * K;           // [5][CB][J]: B, gammaf, b'x, b'y, b'z
     double *l_bm = lj + 5 * kFqCB * J;         // [CB][K][jtiles]: min over a phi tile of betaf_jk
+    // 3+1D: bounds of the main kernel's unit-level cull, per (cell, row block): min alphaf, max |A|, max |W|; per (cell, row block, phi
+    // tile): min betaf; per (cell, phi tile): min gammaf, max |B|   (row blocks <= K, phi tiles <= J / 4)
+    double *l_ub = l_bm + (p.dim3 ? kFqCB * K * p.jtiles : 0);   // [CB][3 rblocks + rblocks jtiles + 2 jtiles]
     const int CK = kFqCB * K, CJ = kFqCB * J;
     double *l_A = lk, *l_al = lk + CK, *l_W = lk + 2 * CK, *l_ax = lk + 3 * CK, *l_ay = lk + 4 * CK, *l_az = lk + 5 * CK;
     double *l_B = lj, *l_ga = lj + CJ, *l_bx = lj + 2 * CJ, *l_by = lj + 3 * CJ, *l_bz = lj + 4 * CJ;
@@ -333,6 +336,40 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             l_bm[idx] = v;
         }
         __syncthreads();
+        // ---- phase 2d (3+1D): the unit-level cull bounds ----
+        const int ubs = 3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles;   // doubles per cell in l_ub
+        if (p.dim3) {
+            const int R = p.R, JT = p.JT;
+            for (int idx = tid; idx < ncb * p.rblocks; idx += kFqThreads) {
+                const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
+                double amin = 1.0e300, Amax = 0.0, Wmax = 0.0;
+                for (int r = 0; r < R; r++) {
+                    const int k = rb * R + r, kc = min(k, K - 1);
+                    amin = fmin(amin, l_al[c * K + kc]);
+                    if (k < K) { Amax = fmax(Amax, fabs(l_A[c * K + kc])); Wmax = fmax(Wmax, fabs(l_W[c * K + kc])); }
+                }
+                double *o = l_ub + c * ubs + 3 * rb;
+                o[0] = amin; o[1] = Amax; o[2] = Wmax;
+            }
+            for (int idx = tid; idx < ncb * p.rblocks * p.jtiles; idx += kFqThreads) {
+                const int c = idx / (p.rblocks * p.jtiles), rem = idx - c * (p.rblocks * p.jtiles), rb = rem / p.jtiles, jt = rem - rb * p.jtiles;
+                double bmm = 1.0e300;
+                for (int r = 0; r < R; r++) bmm = fmin(bmm, l_bm[(c * K + min(rb * R + r, K - 1)) * p.jtiles + jt]);
+                l_ub[c * ubs + 3 * p.rblocks + rb * p.jtiles + jt] = bmm;
+            }
+            for (int idx = tid; idx < ncb * p.jtiles; idx += kFqThreads) {
+                const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
+                double gmin = 1.0e300, Bmax = 0.0;
+                for (int q2 = 0; q2 < JT; q2++) {
+                    const int j2 = min(jt * JT + q2, J - 1);
+                    gmin = fmin(gmin, l_ga[c * J + j2]);
+                    Bmax = fmax(Bmax, fabs(l_B[c * J + j2]));
+                }
+                double *o = l_ub + c * ubs + 3 * p.rblocks + p.rblocks * p.jtiles + 2 * jt;
+                o[0] = gmin; o[1] = Bmax;
+            }
+            __syncthreads();
+        }
         // ---- phase 3: unit records (layout of cf_device.h, slots as in cf_feqmod.h) ----
         {
             const int JT = p.JT, R = p.R;
@@ -351,6 +388,17 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                     if (f == 0) v = l_B[c * J + j];
                     else if (f == 1) v = l_ga[c * J + j];
                     else if (e == 2) v = cs[c].alphaB_mod;
+                    else if (p.dim3 && JT >= 4 && jj < 4) {
+                        // bounds of the main kernel's unit-level cull, in free header slots (3+1D; phase 2d): over the rows of the unit
+                        // min alphaf_k (e = 3), min_k min_j betaf_jk (6), max |A_k| (10), max |W_k| (11); over its phi's min gammaf_j (7), max |B_j| (14)
+                        const double *ub = l_ub + c * ubs;
+                        if (e == 3) v = ub[3 * rb];
+                        else if (e == 10) v = ub[3 * rb + 1];
+                        else if (e == 11) v = ub[3 * rb + 2];
+                        else if (e == 6) v = ub[3 * p.rblocks + rb * p.jtiles + jt];
+                        else if (e == 7) v = ub[3 * p.rblocks + p.rblocks * p.jtiles + 2 * jt];
+                        else if (e == 14) v = ub[3 * p.rblocks + p.rblocks * p.jtiles + 2 * jt + 1];
+                    }
                 } else {
                     const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                     const int k = rb * R + r;
@@ -377,7 +425,8 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
 
 size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles /* 0 in 2+1D: no beta-min table */)
 {
-    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J + K * jtiles)) + sizeof(FqScal) * kFqCB;
+    const size_t bounds = jtiles ? (size_t)kFqCB * (3 * (size_t)K + (size_t)K * jtiles + 2 * (size_t)jtiles) : 0;   // row blocks <= K
+    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J + K * jtiles) + bounds) + sizeof(FqScal) * kFqCB;
 }
 
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
@@ -522,6 +571,24 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
         // exact-zero culling: exp(cm - X) == +0 needs X > 745.25 + cm
         const double xcut = BARYON ? 745.25 + __builtin_fmax(cm, 0.0) : 745.25;
         const double x2cut = BARYON ? xcut * xcut : 555400.0;
+        if constexpr (DIM3 && JT >= 4) {
+            // Unit-level cull (3+1D; bounds from cf_prep_feqmod in free header slots): X^2 >= mT^2 min_k alphaf + mT pT min_jk betaf + pT^2
+            // min_j gammaf for every evaluation of the unit, and the threshold of every row is at most the one formed with max_k |A_k|,
+            // max_k |W_k| and max_j |B_j| (all roundings monotone): a unit that fails here would have every row culled below, so its
+            // header work and its R row fetches are skipped -- bitwise the same spectrum
+            if (g.zskip) {
+                double x2c_u = x2cut;
+                if (RELCULL && g.zskip == 2) {
+                    const double pmax = __builtin_fma(__builtin_fabs(rpT * U[14]), U[11], __builtin_fabs(rmT * U[10]));
+                    const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
+                    const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
+                    const double xcp = __builtin_fmax(xc, 0.0);
+                    x2c_u = __builtin_fmin(x2cut, xcp * xcp);
+                }
+                const double x2lb_u = __builtin_fma(mTpT, U[6], mT2 * U[3] + pT2 * U[7]);
+                if (__all(x2lb_u > x2c_u)) { n_rows += R; n_dead += R; return; }
+            }
+        }
         double g_min = 1.0e300, pb_max = 0.0;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
