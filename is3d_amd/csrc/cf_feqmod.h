@@ -76,7 +76,7 @@ struct FqLinearArgs {
     int32_t Lbins;                      // momentum bins: with unit-strided lanes only a bin's first slot (lanes < Lbins) takes the fallback cells
 };
 
-size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles);
+size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles, int rec);
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st);
 // RN[cell][cls] = |n_linear / n_mod| (/ detA in 3+1D), 0 where the reference skips the species (nan / inf) or the cell
 hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, const double *cls_mass, const double *cls_sign,

@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     // 3+1D: bounds of the main kernel's unit-level cull, per (cell, row block): min alphaf, max |A|, max |W|; per (cell, row block, phi
     // tile): min betaf; per (cell, phi tile): min gammaf, max |B|   (row blocks <= K, phi tiles <= J / 4)
     double *l_ub = l_bm + (p.dim3 ? kFqCB * K * p.jtiles : 0);   // [CB][3 rblocks + rblocks jtiles + 2 jtiles]
+    // element descriptors of a unit record, one int2 per element, filled once per workgroup (as in cf_prep, cf_kernels.hip)
+    int2 *desc = (int2 *)(l_ub + (p.dim3 ? kFqCB * (3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles) : 0));
     const int CK = kFqCB * K, CJ = kFqCB * J;
     double *l_A = lk, *l_al = lk + CK, *l_W = lk + 2 * CK, *l_ax = lk + 3 * CK, *l_ay = lk + 4 * CK, *l_az = lk + 5 * CK;
     double *l_B = lj, *l_ga = lj + CJ, *l_bx = lj + 2 * CJ, *l_by = lj + 3 * CJ, *l_bz = lj + 4 * CJ;
@@ -103,6 +105,47 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
         jx[i] = p.jx[i]; jx[nj + i] = p.jl2[i]; jx[2 * nj + i] = p.jz[i]; jx[3 * nj + i] = p.jcl[i]; jx[4 * nj + i] = p.jcz[i];
     }
     for (int i = tid; i < 4 * ngl; i += kFqThreads) gl[i] = p.gl[i];
+    // Record-element descriptors: every element of a unit record is a copy of one LDS double, an exact zero, or a betaf_jk, and WHICH
+    // is the same for every unit -- decoded once here instead of per element with five divisions and a branch per field:
+    //   x: bits 0-15 offset of the source in the LDS block | 16-18 index rule (0: + c J + j, 1: + c K + k, 2: + c ubs + 3 rb, 3: + c ubs + rb
+    //      jtiles + jt, 4: + c ubs + 2 jt, 5: + c sizeof(FqScal)/8, 6: + (c K + k) jtiles + jt) | 20 betaf | 21 zero in a padding row | 22 zero
+    //   y: jj (header entry / beta column) | r << 16 (row)
+    const int ubs = p.dim3 ? 3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles : 0;   // doubles per cell in l_ub
+    {
+        const int JT = p.JT, R = p.R, HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
+        const int o_A = (int)(l_A - lds), o_al = (int)(l_al - lds), o_W = (int)(l_W - lds), o_B = (int)(l_B - lds), o_ga = (int)(l_ga - lds);
+        const int o_bm = (int)(l_bm - lds), o_ub = (int)(l_ub - lds), o_aB = (int)(&cs[0].alphaB_mod - lds);
+        constexpr int ZERO = 1 << 22, PADZ = 1 << 21, BETA = 1 << 20;
+        for (int e = tid; e < REC; e += kFqThreads) {
+            int x = ZERO, y = 0;
+            if (e < HDR) {
+                const int jj = e >> 2, f = e & 3;
+                y = jj;
+                if (f == 0) x = o_B;
+                else if (f == 1) x = o_ga;
+                else if (e == 2) x = o_aB | (5 << 16);
+                else if (p.dim3 && JT >= 4 && jj < 4) {
+                    // bounds of the main kernel's unit-level cull (phase 2d): min alphaf_k (e = 3), min_jk betaf_jk (6), max |A_k| (10),
+                    // max |W_k| (11) over the unit's rows; min gammaf_j (7), max |B_j| (14) over its phi's
+                    if (e == 3) x = o_ub | (2 << 16);
+                    else if (e == 10) x = (o_ub + 1) | (2 << 16);
+                    else if (e == 11) x = (o_ub + 2) | (2 << 16);
+                    else if (e == 6) x = (o_ub + 3 * p.rblocks) | (3 << 16);
+                    else if (e == 7) x = (o_ub + 3 * p.rblocks + p.rblocks * p.jtiles) | (4 << 16);
+                    else if (e == 14) x = (o_ub + 3 * p.rblocks + p.rblocks * p.jtiles + 1) | (4 << 16);
+                }
+            } else {
+                const int q = e - HDR, r = q / RWD, f = q - r * RWD;
+                y = r << 16;
+                if (f == 0) x = o_A | (1 << 16) | PADZ;        // padding rows: p.dsigma = 0, the quadratic form of row K-1
+                else if (f == 1) x = o_al | (1 << 16);
+                else if (f == 2) x = o_W | (1 << 16) | PADZ;
+                else if (f == 3) x = p.dim3 ? (o_bm | (6 << 16)) : ZERO;
+                else { x = BETA; y |= f - 4; }
+            }
+            desc[e] = int2{x, y};
+        }
+    }
     __syncthreads();
     const double two_pi2_hbarC3 = 2.0 * M_PI * M_PI * (kHbarC * kHbarC * kHbarC);   // iS3D.h:11
 
@@ -337,7 +380,6 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
         }
         __syncthreads();
         // ---- phase 2d (3+1D): the unit-level cull bounds ----
-        const int ubs = 3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles;   // doubles per cell in l_ub
         if (p.dim3) {
             const int R = p.R, JT = p.JT;
             for (int idx = tid; idx < ncb * p.rblocks; idx += kFqThreads) {
@@ -370,63 +412,54 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             }
             __syncthreads();
         }
-        // ---- phase 3: unit records (layout of cf_device.h, slots as in cf_feqmod.h) ----
+        // ---- phase 3: unit records (layout of cf_device.h, slots as in cf_feqmod.h): one unit per wave at a time, lanes <-> elements,
+        // one descriptor read and one batch of source reads per 64 elements ----
         {
             const int JT = p.JT, R = p.R;
             const int HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
-            const int units_per_cell = p.jtiles * p.rblocks;
-            const int per_cell = units_per_cell * REC;
-            for (int idx = tid; idx < ncb * per_cell; idx += kFqThreads) {
-                const int c = idx / per_cell;
-                const int rem = idx - c * per_cell;
-                const int ut = rem / REC, e = rem - ut * REC;
-                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
-                double v = 0.0;
-                if (e < HDR) {
-                    const int jj = e >> 2, f = e & 3;
-                    const int j = min(jt * JT + jj, J - 1);
-                    if (f == 0) v = l_B[c * J + j];
-                    else if (f == 1) v = l_ga[c * J + j];
-                    else if (e == 2) v = cs[c].alphaB_mod;
-                    else if (p.dim3 && JT >= 4 && jj < 4) {
-                        // bounds of the main kernel's unit-level cull, in free header slots (3+1D; phase 2d): over the rows of the unit
-                        // min alphaf_k (e = 3), min_k min_j betaf_jk (6), max |A_k| (10), max |W_k| (11); over its phi's min gammaf_j (7), max |B_j| (14)
-                        const double *ub = l_ub + c * ubs;
-                        if (e == 3) v = ub[3 * rb];
-                        else if (e == 10) v = ub[3 * rb + 1];
-                        else if (e == 11) v = ub[3 * rb + 2];
-                        else if (e == 6) v = ub[3 * p.rblocks + rb * p.jtiles + jt];
-                        else if (e == 7) v = ub[3 * p.rblocks + p.rblocks * p.jtiles + 2 * jt];
-                        else if (e == 14) v = ub[3 * p.rblocks + p.rblocks * p.jtiles + 2 * jt + 1];
-                    }
-                } else {
-                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
-                    const int k = rb * R + r;
-                    const int kc = min(k, K - 1);   // padding rows copy the quadratic form of row K-1 with p.dsigma = 0
-                    if (f == 0) v = (k < K) ? l_A[c * K + kc] : 0.0;
-                    else if (f == 1) v = l_al[c * K + kc];
-                    else if (f == 2) v = (k < K) ? l_W[c * K + kc] : 0.0;
-                    else if (f == 3) v = p.dim3 ? l_bm[(c * K + kc) * p.jtiles + jt] : 0.0;
-                    else if (f >= 4) {
-                        const int j = min(jt * JT + (f - 4), J - 1);
-                        v = 2.0 * (l_ax[c * K + kc] * l_bx[c * J + j] + l_ay[c * K + kc] * l_by[c * J + j] + l_az[c * K + kc] * l_bz[c * J + j]) * cs[c].invTm2;
+            const int wave = tid >> 6, lane = tid & 63;
+            const int cSd = (int)(sizeof(FqScal) / sizeof(double));
+            int n = 0;
+            for (int c = 0; c < ncb; c++) {
+                const int64_t cell = cbase + c;
+                const double i2 = 2.0 * cs[c].invTm2;
+                for (int jt = 0; jt < p.jtiles; jt++) {
+                    for (int rb = 0; rb < p.rblocks; rb++, n++) {
+                        if ((n & (kFqThreads / 64 - 1)) != wave) continue;
+                        int64_t unit;
+                        if (p.dim3) unit = (int64_t)(jt * p.rblocks + rb) * p.n_cells + cell;
+                        else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
+                        double *o = p.TS + unit * REC;
+                        const int cJ = c * J, cK = c * K;
+                        for (int e = lane; e < REC; e += 64) {
+                            const int2 d = desc[e];
+                            const int jj = d.y & 0xffff, r = d.y >> 16;
+                            const int jcl = min(jt * JT + jj, J - 1);
+                            const int k = rb * R + r, kcl = min(k, K - 1);
+                            const int msel = (d.x >> 16) & 7;
+                            const int add = msel == 0 ? cJ + jcl : msel == 1 ? cK + kcl : msel == 2 ? c * ubs + 3 * rb
+                                          : msel == 3 ? c * ubs + rb * p.jtiles + jt : msel == 4 ? c * ubs + 2 * jt : msel == 5 ? c * cSd
+                                          : (cK + kcl) * p.jtiles + jt;
+                            const bool zero = ((d.x >> 22) & 1) | (((d.x >> 21) & 1) & (k >= K));
+                            const double raw = lds[zero ? 0 : (d.x & 0xffff) + add];
+                            // betaf_jk, as the flat writer formed it: 2 (a'_k . b'_j) / T_mod^2
+                            const double bet = 2.0 * (l_ax[cK + kcl] * l_bx[cJ + jcl] + l_ay[cK + kcl] * l_by[cJ + jcl] + l_az[cK + kcl] * l_bz[cJ + jcl]) * cs[c].invTm2;
+                            const double v = ((d.x >> 20) & 1) ? bet : raw;
+                            o[e] = zero ? 0.0 : v;
+                        }
                     }
                 }
-                const int64_t cell = cbase + c;
-                int64_t unit;
-                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;
-                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
-                p.TS[unit * REC + e] = v;
+                (void)i2;
             }
         }
         __syncthreads();
     }
 }
 
-size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles /* 0 in 2+1D: no beta-min table */)
+size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles /* 0 in 2+1D: no beta-min table */, int rec)
 {
     const size_t bounds = jtiles ? (size_t)kFqCB * (3 * (size_t)K + (size_t)K * jtiles + 2 * (size_t)jtiles) : 0;   // row blocks <= K
-    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J + K * jtiles) + bounds) + sizeof(FqScal) * kFqCB;
+    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J + K * jtiles) + bounds + (size_t)rec) + sizeof(FqScal) * kFqCB;   // + one int2 per record element
 }
 
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
@@ -434,7 +467,7 @@ hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
     if (p.n_cells <= 0) return hipSuccess;
     const int nbatch = (p.n_cells + kFqCB - 1) / kFqCB;
     const int grid = nbatch < 4096 ? nbatch : 4096;
-    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K, p.dim3 ? p.jtiles : 0);
+    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K, p.dim3 ? p.jtiles : 0, 4 * p.JT + p.R * (4 + p.JT));
     hipLaunchKernelGGL(cf_prep_feqmod, dim3(grid), dim3(kFqThreads), lds, st, p);
     return hipGetLastError();
 }

@@ -419,7 +419,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_cls_mass.upload(cmass));
         HIP_TRY(P->d_cls_sign.upload(csign));
         if (P->baryon) HIP_TRY(P->d_cls_baryon.upload(cbar));
-        if (is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K, P->dim3 ? (P->J + 3) / 4 : 0) > 160 * 1024)   // jtiles <= J/4 (4-wide tiles)
+        if (is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K, P->dim3 ? (P->J + 3) / 4 : 0, 1152) > 160 * 1024)   // jtiles <= J/4 (4-wide tiles); records <= 1152 doubles
             return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     }
 
