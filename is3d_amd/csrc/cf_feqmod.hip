@@ -717,9 +717,17 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     // use and waits for them there (s_waitcnt vmcnt(0) in every row of the unrolled loop) -- a wait that also covers the direct-to-LDS
     // loads of the next batch, which it does not know about, i.e. it would expose the staging latency in every batch
     asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2), "v"(mTpT), "v"(pT2), "v"(bq), "v"(sub_off) : "memory");
+    // df_mode 3: the renormalisation factor of a (cell, class) is a per-lane global load.  The compiler waits for it with
+    // s_waitcnt vmcnt(0), which also drains the direct-to-LDS loads of the next batch it does not know about, so no such load may be
+    // consumed while a batch is young: the factors of a batch's first two steps are loaded at the end of the batch before (they arrive
+    // under its closing wait), step u > 0 loads the factor of step u + 1 while it runs.
+    auto rn_at = [&](int u) { return rn_col[(int64_t)(c0 + min(u, n_units - 1) / g.upc) * ncls]; };
+    double rn = 1.0, rn1 = 1.0;
+    if (MODE3 && nb > 0) { rn = rn_at(0); rn1 = rn_at(S); }
     if (nb > 0) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE3) asm volatile("" :: "v"(rn), "v"(rn1));   // a use: the compiler's own wait for the two loads goes here
         __syncthreads();
         for (int ib = 0; ib < nb; ib++) {
             if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
@@ -727,17 +735,13 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1] + sub_off;
                 const int u0 = ib * UB;
-                double rn = 1.0;
-                if (MODE3) rn = rn_col[(int64_t)(c0 + u0 / g.upc) * ncls];
                 for (int u = 0; u < nu; u += S) {      // nu is a multiple of S (plan)
-                    double rn_next = 1.0;
-                    if (MODE3) {
-                        const int un = min(u0 + u + S, n_units - 1);
-                        rn_next = rn_col[(int64_t)(c0 + un / g.upc) * ncls];
-                    }
+                    double rn_next = rn1;
+                    if (MODE3 && u > 0) rn_next = rn_at(u0 + u + S);
                     process_unit(base + u * REC, rn);
                     rn = rn_next;
                 }
+                if (MODE3) rn1 = rn_at(u0 + nu + S);
                 if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 31) == 31)) {   // as in cf_main_tile: log2(acc) moves slowly
                     double m = acc[0];
 #pragma unroll
@@ -746,6 +750,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (MODE3) asm volatile("" :: "v"(rn), "v"(rn1));
             __syncthreads();
         }
     }
