@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                             const double bet = beta_of(c, jcl, kcl);
                             double v = ((d.x >> 19) & 1) ? raw * psc : raw;
                             v = ((d.x >> 20) & 1) ? bet : v;
-                            o[e] = zero ? 0.0 : v;
+                            __builtin_nontemporal_store(zero ? 0.0 : v, &o[e]);
                         }
                     }
                 }
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                         for (int e = ln; e < NPJ; e += 64) {
                             const int jj = e >> 5;
                             const double pTD = __dmul_rn(pTl, l_Dp[c * J + min(jt * JT + jj, J - 1)]);
-                            t[e] = exp_full(__dsub_rn(pTD, bmax));
+                            __builtin_nontemporal_store(exp_full(__dsub_rn(pTD, bmax)), &t[e]);
                         }
                     }
                 }
