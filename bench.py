@@ -2,15 +2,19 @@
 """bench.py -- throughput of the smooth Cooper-Frye spectra path on N GPUs of one node.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N ...            (no launcher: starts N rank processes itself, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Metric (BASELINE.json): FO-cell x momentum-bin x species evals/sec.  A "step" is one pass of the hot path
 (prep -> main -> finalize, plus the spectrum all-reduce when N > 1) over one synthetic surface whose cell
 arrays are already resident in HBM.  Default workload = BASELINE config 3 (the configuration north_star
 quotes its target on): 1e6-cell seeded 3+1D surface, Chapman-Enskog delta-f, the 305-species urqmd list,
-32 x 24 x 21 momentum bins = 4.919e12 evals per GPU per step.  N > 1: the cell axis is sharded, every rank
-takes its own 1e6-cell slice of the (infinite, counter-based) seeded surface -- weak scaling -- and one RCCL
-all-reduce of the 39 MB spectrum ends the step.  `--workload config2` gives the 1e5-cell 2+1D case.
+32 x 24 x 21 momentum bins = 4.919e12 evals per step.  N > 1 is BASELINE config 4: the SAME 1e6-cell surface,
+its cell axis in N contiguous shards (8 x 125 000 cells at N = 8) -- strong scaling, `"scaling": "strong"` -- and one
+RCCL all-reduce of the 39 MB spectrum ends the step (the sum over chunks of cells of
+/root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:363-375 is what makes the split exact).  `--scaling weak` gives
+every rank its own 1e6-cell slice of the (infinite, counter-based) seeded surface instead.  `--workload config2` gives
+the 1e5-cell 2+1D case.
 
 One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   roofline        the contract's object for the dominant kernel, HBM view: algorithmic bytes / kernel time
@@ -22,12 +26,16 @@ One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   value_incl_transfers, ms_per_step_incl_transfers   the same steps with the H->D upload of the cell arrays and the D->H
                               download of the spectrum inside the timed region (SURVEY.md 8d's t_kernel), N = 1 only
   kernel_ms.main_no_cull      the dominant kernel with all culling off (zero_skip = 2): the data-independent floor
+  ranks           N > 1: one entry per rank -- device, cells, kernel_ms, allreduce_ms (device time of the collective on that rank,
+                  the wait for the slowest rank included), the rank / size its library communicator reports (is3d_comm_rank)
 N > 1: the all-reduce is the library's own RCCL call (is3d_plan_execute_allreduce over an is3d_comm); torch.distributed
 only launches the ranks, ships the ncclUniqueId and provides the barrier.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -112,6 +120,40 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     return res
 
 
+def launcher_command(argv, n_ranks, port):
+    """The child a launcher-less `python bench.py --gpus N` starts: torch.distributed.run with N fresh rank processes of this
+    script, same arguments, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_ranks)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process becomes the launcher.  It has not imported
+    torch and has made no HIP call -- the ranks are fresh child processes, nothing that initialised the GPU is ever re-exec'd --
+    it relays rank 0's one JSON line and returns the children's exit code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(argv, n_ranks, port)
+    print("bench.py: no launcher in the environment, starting %d ranks: %s" % (n_ranks, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out, _ = proc.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in lines[-1:]:
+        sys.stdout.write(ln + "\n")
+    sys.stdout.flush()
+    if proc.returncode != 0:
+        print("bench.py: the rank processes exited with code %d" % proc.returncode, file=sys.stderr, flush=True)
+        return proc.returncode if 0 < proc.returncode < 256 else 1
+    if not lines:
+        print("bench.py: the rank processes printed no result line", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,10 +162,12 @@ def main():
     ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
     ap.add_argument("--df-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
-    ap.add_argument("--cells", type=int, default=0, help="override cells per GPU (parity/dev runs)")
+    ap.add_argument("--cells", type=int, default=0, help="override the surface size: total cells (strong scaling) / cells per GPU (weak)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zero-skip", type=int, default=0, choices=[0, 1, 2], help="dev: culling mode of the main kernel (2 = off)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default) = BASELINE config 4, ONE surface in N shards; weak = every rank its own surface")
+    ap.add_argument("--cell-chunks", type=int, default=0, help="dev: override the number of cell chunks of the main kernel's grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true")
     ap.add_argument("--no-cull-check", action="store_true", help="skip the untimed bitwise comparison with culling off")
@@ -133,6 +177,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))   # before torch is imported or HIP touched in this process
 
     # stdout carries ONE JSON line and nothing else: native libraries print there too (RCCL's version banner when a communicator
     # is created, gloo's connection notice), so file descriptor 1 is pointed at stderr for the run and the line goes to the saved one
@@ -187,12 +235,12 @@ def main():
     grid = dict(pT=g["pT"], phi=g["phi"], y=g["y"], eta=g["eta"], eta_w=g["eta_w"])
     df = inputs.df_tables()
     sp = inputs.species(wl["species"])
-    n_total = a.cells * world if (a.cells and a.scaling == "weak") else (a.cells or wl["cells"] * (world if a.scaling == "weak" else 1))
+    n_total = (a.cells or wl["cells"]) * (world if a.scaling == "weak" else 1)
     lo, hi = idist.shard_bounds(n_total, rank, world)
     n_loc = hi - lo
     cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
     tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}   # resident in HBM before timing
-    opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local, zero_skip=a.zero_skip)
+    opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local, zero_skip=a.zero_skip, cell_chunks=a.cell_chunks)
     fq = None
     if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, the surface-average temperature (all ranks' cells)
         fq = inputs.feqmod_tables(idist.surface_average_T_global(cells))
@@ -202,7 +250,7 @@ def main():
     ptrs = {k: v.data_ptr() for k, v in tens.items()}
     stream = torch.cuda.current_stream().cuda_stream
 
-    ms = dict(prep=[], main=[], finalize=[])
+    ms = dict(prep=[], main=[], finalize=[], allreduce=[])
 
     def step(record):
         if comm is not None:
@@ -210,12 +258,20 @@ def main():
         else:
             plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
             if multi:
+                if record:
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
                 idist.allreduce_spectrum(out)
+                if record:
+                    torch.cuda.synchronize()
+                    ms["allreduce"].append((time.perf_counter() - ta) * 1e3)   # host clock: the torch / gloo fallback of a rehearsal
         if record:
             t = plan.timings()   # HIP events recorded on `stream` around each kernel of this step
             ms["prep"].append(t["ms_prep"])
             ms["main"].append(t["ms_main"])
             ms["finalize"].append(t["ms_finalize"])
+            if comm is not None:
+                ms["allreduce"].append(comm.allreduce_ms())   # HIP events on `stream` around the library's RCCL group
 
     def fence():
         torch.cuda.synchronize()
@@ -236,8 +292,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     plan.check(stream)   # the timed steps ran without status read-back: any cell outside the coefficient table surfaces here
+    if comm is not None:
+        comm.check(stream)   # ... and so does any rank whose execute failed before a collective (the error word summed beside the spectrum)
     st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
     torch.cuda.synchronize()
+    nbins = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if wl["dimension"] == 3 else 1)
+    culled = (st["n_wave_rows_culled"] / st["n_wave_rows"]) if st.get("n_wave_rows") else 0.0
+    unique_evals = float(n_loc) * nbins * st["n_classes"] * (len(grid["eta"]) if wl["dimension"] == 2 else 1)
+    executed_evals = unique_evals * (1.0 - culled)   # rows the kernel proved unable to change a bit for a whole wave are not executed
+    ranks = None
+    if multi:
+        mine = dict(rank=rank, device=local, cells=n_loc, first_cell=lo,
+                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=float(np.mean(ms["main"])), finalize=float(np.mean(ms["finalize"]))),
+                    allreduce_ms=float(np.mean(ms["allreduce"])) if ms["allreduce"] else None,
+                    comm_rank_seen=list(comm.rank_seen()) if comm is not None else None,
+                    wave_rows_culled_frac=culled, integrands_executed=executed_evals)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     # SURVEY.md 8d's t_kernel: the same steps with the upload of the cell arrays and the download of the spectrum inside the timed
     # region (pinned host buffers, as a host that cares would hold them); N = 1 only
     incl = None
@@ -301,7 +372,6 @@ def main():
     spectrum_ok = bool(torch.isfinite(out).all().item())
 
     if rank == 0:
-        nbins = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if wl["dimension"] == 3 else 1)
         nsp = len(sp["mass"])
         evals_step = float(n_total) * nbins * nsp
         value = evals_step * a.steps / elapsed
@@ -310,7 +380,7 @@ def main():
         ncell_arrays = 18 if wl["dimension"] == 3 else 17
         b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
         traffic, traffic_source = None, None
-        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC counters need their own rocprofv3 passes: not this run
+        for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC counters need their own rocprofv3 passes: not this run
             tp = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tp):
                 tj = json.load(open(tp)).get(wl["name"])
@@ -325,11 +395,7 @@ def main():
         # ---- the binding roofline: fp64 VALU
         jt_r = plan.tile_shape
         ic = isa_counts(plan.main_kernel_name, wl, jt_r, st["kernel_variant"])
-        unique_evals = float(n_loc) * nbins * st["n_classes"] * (len(grid["eta"]) if wl["dimension"] == 2 else 1)
         rv = None
-        # rows the kernel proved to be exactly zero for a whole wave are not executed (status counters)
-        culled = (st["n_wave_rows_culled"] / st["n_wave_rows"]) if st.get("n_wave_rows") else 0.0
-        executed_evals = unique_evals * (1.0 - culled)
         if ic:
             tf = executed_evals * ic["flop_per_eval"] / (ms_main * 1e-3) / 1e12
             rv = dict(bound="fp64_valu", achieved=tf, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_VALU_PEAK_TF,
@@ -341,8 +407,9 @@ def main():
                       integrands_per_launch=unique_evals, integrands_executed=executed_evals, wave_rows_culled_frac=culled,
                       note="flops and issue cycles count executed integrands only: rows whose exp(-p.u/T) is exactly +0 for a "
                            "whole wave are skipped (bitwise-identical result)")
-        # integrands the kernels actually executed per second (rank 0's executed fraction stands for every rank's: same surface statistics)
-        executed_per_s = executed_evals * world * a.steps / elapsed
+        # integrands the kernels actually executed per second, summed over the ranks' own counters
+        executed_all = sum(r["integrands_executed"] for r in ranks) if ranks else executed_evals
+        executed_per_s = executed_all * a.steps / elapsed
         res = dict(metric="FO-cell x momentum-bin x species evals/sec", value=value, unit="evals/s", n_gpus=world, steps=a.steps,
                    warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling, vs_baseline=None,
                    dtype="f64", data="synthetic",
@@ -354,9 +421,13 @@ def main():
                    ms_per_step_incl_transfers=(incl * 1e3) if incl else None,
                    host_entry=host_entry if incl else None,
                    allreduce=allreduce_by,
+                   allreduce_ms=(max(r["allreduce_ms"] for r in ranks) if ranks and all(r["allreduce_ms"] is not None for r in ranks) else None),
+                   ranks_seen=(sorted(r["comm_rank_seen"][0] for r in ranks) if ranks and all(r["comm_rank_seen"] for r in ranks) else None),
+                   ranks=ranks,
                    config=dict(workload=wl["text"], cells_total=n_total, cells_per_gpu=n_loc, species=nsp, species_classes_evaluated=st["n_classes"],
                                bins=nbins, evals_per_step=evals_step, kernel=plan.main_kernel_name, kernel_variant=st["kernel_variant"],
-                               parallelism="cell-axis shards x%d, one all-reduce of the spectrum" % world if world > 1 else "1 GPU",
+                               parallelism=("cell-axis shards x%d of %s, one all-reduce of the spectrum" % (
+                                   world, "one surface (BASELINE config 4 at 8)" if a.scaling == "strong" else "a surface that grows with N")) if world > 1 else "1 GPU",
                                workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok,
                                culled_rows_change_no_bit=cull_identical),
                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"])), main_no_cull=ms_no_cull),

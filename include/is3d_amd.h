@@ -50,6 +50,7 @@ extern "C" {
                              /* (reference: GSL domain error -> abort, deltafReader.cpp:339) */
 #define IS3D_ENOMEM (-4)
 #define IS3D_EIO (-5)        /* host reader/writer failure                               */
+#define IS3D_EPEER (-6)      /* multi-GPU: another rank's execute failed before the all-reduce; the sum is incomplete */
 
 /* Freezeout cells, structure of arrays, fp64, length n_cells each.  Replaces the *_fo pointer
  * arguments of calculate_dN_pTdpTdphidy (emissionfunction.h:179).  Units as after the reader's
@@ -261,9 +262,11 @@ void is3d_plan_destroy(is3d_plan *plan);
  *   (2) one process per GPU (MPI / torchrun style hosts): an is3d_comm (RCCL communicator) + is3d_plan_execute_allreduce.
  * RCCL (librccl.so.1) is loaded on first use; a host that never asks for it does not need it installed.
  * --------------------------------------------------------------------------------------------- */
-#define IS3D_REDUCE_ORDERED 0   /* shard spectra are copied to the first shard's device (hipMemcpyPeer) and added in shard order
-                                   by a device kernel: ((s0 + s1) + s2) + ... -- bitwise reproducible for a given shard count,
-                                   whatever the devices; a device may be listed more than once */
+#define IS3D_REDUCE_ORDERED 0   /* shard spectra are added pairwise in a fixed binary tree by a device kernel (the partner's spectrum
+                                   read over hipMemcpyPeer): round r adds shard i + 2^r into shard i for every i that is a multiple of
+                                   2^(r+1) -- ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)) for eight shards -- the pairs of a round
+                                   run concurrently on their own devices.  Bitwise reproducible for a given shard count, whatever
+                                   the devices; a device may be listed more than once */
 #define IS3D_REDUCE_RCCL 1      /* ncclAllReduce(ncclDouble, ncclSum) over a communicator of the listed devices (distinct) */
 
 /* Host entry over several devices: what is3d_smooth_spectra / is3d_smooth_spectra_feqmod (fq != NULL: df_mode 3, 4) compute,
@@ -292,11 +295,41 @@ int is3d_comm_rank(const is3d_comm *comm, int32_t *rank, int32_t *n_ranks);
  * the "+=" of smooth_kernels.cpp:375 across shards (ncclAllReduce, ncclDouble, ncclSum). */
 int is3d_comm_allreduce(is3d_comm *comm, double *dN_dev, int64_t n, void *hip_stream);
 void is3d_comm_destroy(is3d_comm *comm);
-/* is3d_plan_execute on this rank's shard of the cells, then is3d_comm_allreduce of dN_out on the same stream: every rank ends
- * with the spectrum of the whole surface.  comm == NULL: plain is3d_plan_execute.  opts.accumulate must be 0 with a
- * communicator (the old contents would be summed n_ranks times). */
+/* is3d_plan_execute on this rank's shard of the cells, then the sum of dN_out over the ranks on the same stream (ncclAllReduce):
+ * every rank ends with the spectrum of the whole surface.  comm == NULL: plain is3d_plan_execute.  The plan must have been created
+ * with opts.accumulate = 0 (the old contents would be summed n_ranks times): IS3D_EINVAL otherwise.
+ * No rank is ever left waiting in the collective.  A one-double error word is summed next to the spectrum (same RCCL group):
+ *   - a rank whose execute fails in a way that leaves its stream usable (IS3D_EDOMAIN; IS3D_EINVAL for a bad shard or plan option)
+ *     still joins -- after a domain error with the cells it could evaluate, after an argument error with zeros -- with its error word
+ *     set, and returns its own error code;
+ *   - the other ranks learn of it: with status != NULL (the call synchronises anyway) they return IS3D_EPEER; with status == NULL
+ *     (fully asynchronous) at the next is3d_comm_check;
+ *   - a rank that cannot join (dN_out or plan NULL, a HIP error) calls ncclCommAbort on its communicator before it returns, so that
+ *     the peers' collective fails instead of blocking; the communicator is unusable afterwards (every call returns IS3D_ENODEVICE). */
 int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *shard, double *dN_out, is3d_comm *comm, void *hip_stream,
                                 is3d_status *status);
+/* Error words of the collectives since the last check (synchronises hip_stream): IS3D_OK, or IS3D_EPEER with *n_failed (may be NULL)
+ * = how many rank-executes had failed before their all-reduce -- this rank's own failures included. */
+int is3d_comm_check(is3d_comm *comm, void *hip_stream, int32_t *n_failed);
+/* ncclCommAbort: for a host that has to leave a job whose other ranks may be inside a collective. */
+int is3d_comm_abort(is3d_comm *comm);
+/* Device time of the last collective on this rank (HIP events on its stream around the RCCL group; it includes the wait for the
+ * slowest rank).  Synchronises the closing event. */
+int is3d_comm_timings(is3d_comm *comm, double *ms_allreduce);
+
+/* Persistent form of is3d_smooth_spectra_multi: one plan, one workspace, one stream, pinned staging buffers and (IS3D_REDUCE_RCCL) the
+ * communicator set per shard are created ONCE; every execute then only uploads its cells, runs the shards concurrently and sums the
+ * spectra.  max_cells bounds cells->n_cells of any execute.  The result of an execute is bitwise the one is3d_smooth_spectra_multi
+ * returns for the same arguments. */
+typedef struct is3d_multi_plan is3d_multi_plan;
+int is3d_multi_plan_create(is3d_multi_plan **mplan, const is3d_species *species, const is3d_grid *grid, const is3d_df_tables *df,
+                           const is3d_feqmod_tables *fq, const is3d_options *opts, const int32_t *devices, int32_t n_devices,
+                           int32_t reduce, int64_t max_cells);
+int is3d_multi_plan_execute(is3d_multi_plan *mplan, const is3d_cells *cells, double *dN_out, is3d_status *status,
+                            is3d_status *shard_status);
+int32_t is3d_multi_plan_shards(const is3d_multi_plan *mplan);
+int64_t is3d_multi_plan_output_size(const is3d_multi_plan *mplan);
+void is3d_multi_plan_destroy(is3d_multi_plan *mplan);
 
 /* ---------------------------------------------------------------------------------------------
  * Anisotropic hydro (VAH, P_L matching): replaces EmissionFunctionArray::calculate_dN_pTdpTdphidy_VAH_PL

@@ -100,16 +100,20 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
            "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
-           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi"]
+           "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi",
+           "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_multi_plan_create", "is3d_multi_plan_execute",
+           "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
+IS3D_EPEER = -6
 COMM_ID_BYTES = 128
 
 
 class Is3dError(RuntimeError):
-    def __init__(self, code, msg):
+    def __init__(self, code, msg, bad_cell=None):
         super().__init__("is3d_amd error %d: %s" % (code, msg))
         self.code = code
+        self.bad_cell = bad_cell
 
 
 _LIB = None
@@ -187,6 +191,18 @@ def load():
     L.is3d_comm_destroy.argtypes = [C.c_void_p]
     L.is3d_comm_destroy.restype = None
     L.is3d_plan_execute_allreduce.argtypes = [C.c_void_p, C.POINTER(Cells), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Status)]
+    L.is3d_comm_check.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.is3d_comm_abort.argtypes = [C.c_void_p]
+    L.is3d_comm_timings.argtypes = [C.c_void_p, _dp]
+    L.is3d_plan_check.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.is3d_multi_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(Grid), C.POINTER(DfTables),
+                                         C.POINTER(FeqmodTables), C.POINTER(Options), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64]
+    L.is3d_multi_plan_execute.argtypes = [C.c_void_p, C.POINTER(Cells), _dp, C.POINTER(Status), C.POINTER(Status)]
+    L.is3d_multi_plan_shards.argtypes = [C.c_void_p]
+    L.is3d_multi_plan_output_size.argtypes = [C.c_void_p]
+    L.is3d_multi_plan_output_size.restype = C.c_int64
+    L.is3d_multi_plan_destroy.argtypes = [C.c_void_p]
+    L.is3d_multi_plan_destroy.restype = None
     _LIB = L
     return L
 
@@ -355,6 +371,55 @@ def smooth_spectra_multi(cells, species, grid, df, opts=None, devices=None, redu
     return out, st.as_dict(), [sst[i].as_dict() for i in range(nd or L.is3d_device_count())]
 
 
+class MultiPlan:
+    """is3d_multi_plan_*: the persistent form of smooth_spectra_multi -- per-shard plans, workspaces, streams, pinned staging and the
+    communicator set are created once; execute(cells) only uploads, runs and sums."""
+
+    def __init__(self, species, grid, df, opts=None, devices=None, reduce=REDUCE_ORDERED, max_cells=1, fq=None):
+        L = load()
+        sps, gs, ds, os_, self.output_size, self._keep = _pack_common(species, grid, df, opts)
+        nd = len(devices) if devices is not None else 0
+        dv = (C.c_int32 * nd)(*[int(d) for d in devices]) if nd else None
+        fqs = _pack_feqmod(fq, self._keep) if fq is not None else None
+        self._h = C.c_void_p()
+        _check(L.is3d_multi_plan_create(C.byref(self._h), C.byref(sps), C.byref(gs), C.byref(ds), C.byref(fqs) if fqs is not None else None,
+                                        C.byref(os_), dv, nd, int(reduce), int(max_cells)))
+        self.n_shards = L.is3d_multi_plan_shards(self._h)
+        assert L.is3d_multi_plan_output_size(self._h) == self.output_size
+
+    def execute(self, cells, out=None):
+        """cells: dict of host numpy arrays.  Returns (dN, aggregate status dict, [per-shard status dicts])."""
+        n = len(cells["tau"])
+        cs = Cells()
+        cs.n_cells = n
+        held = []
+        for f in CELL_FIELDS:
+            a = cells.get(f)
+            if a is not None:
+                a = _f64(a)
+                assert a.shape == (n,), f
+                held.append(a)
+                setattr(cs, f, a.ctypes.data)
+        if out is None:
+            out = np.zeros(self.output_size)
+        assert out.dtype == np.float64 and out.size == self.output_size and out.flags.c_contiguous
+        st = Status()
+        sst = (Status * self.n_shards)()
+        _check(load().is3d_multi_plan_execute(self._h, C.byref(cs), _p(out), C.byref(st), sst))
+        return out, st.as_dict(), [sst[i].as_dict() for i in range(self.n_shards)]
+
+    def close(self):
+        if self._h:
+            load().is3d_multi_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Comm:
     """is3d_comm: the library's RCCL communicator for one-process-per-GPU hosts.  Rank 0 makes the id (Comm.unique_id()),
     the host ships the 128 bytes to the other ranks, every rank constructs Comm(id, n_ranks, rank, device)."""
@@ -373,6 +438,31 @@ class Comm:
 
     def allreduce(self, dev_ptr, n, stream=0):
         _check(load().is3d_comm_allreduce(self._h, C.c_void_p(int(dev_ptr)), int(n), C.c_void_p(int(stream or 0))))
+
+    def rank_seen(self):
+        """(rank, n_ranks) as the library's communicator reports them (is3d_comm_rank)."""
+        r, n = C.c_int32(-1), C.c_int32(-1)
+        _check(load().is3d_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def check(self, stream=0):
+        """is3d_comm_check: raises Is3dError(IS3D_EPEER) if a rank's execute had failed before one of the all-reduces since the
+        last check (its n_failed attribute says how many); synchronises the stream."""
+        k = C.c_int32(0)
+        rc = load().is3d_comm_check(self._h, C.c_void_p(int(stream or 0)), C.byref(k))
+        if rc != 0:
+            e = Is3dError(rc, load().is3d_last_error().decode())
+            e.n_failed = k.value
+            raise e
+
+    def abort(self):
+        _check(load().is3d_comm_abort(self._h))
+
+    def allreduce_ms(self):
+        """Device time of the last collective on this rank (is3d_comm_timings)."""
+        ms = C.c_double(0.0)
+        _check(load().is3d_comm_timings(self._h, C.byref(ms)))
+        return ms.value
 
     def close(self):
         if self._h:
@@ -457,8 +547,9 @@ class Plan:
         """is3d_plan_check: raises Is3dError(IS3D_EDOMAIN) if an execute since the last check (status-less ones included) met a
         cell outside the coefficient table; synchronises the stream."""
         bad = C.c_int64(-1)
-        load().is3d_plan_check.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
-        _check(load().is3d_plan_check(self._h, C.c_void_p(int(stream or 0)), C.byref(bad)))
+        rc = load().is3d_plan_check(self._h, C.c_void_p(int(stream or 0)), C.byref(bad))
+        if rc != 0:
+            raise Is3dError(rc, load().is3d_last_error().decode(), bad_cell=bad.value)
 
     def timings(self):
         st = Status()

@@ -488,13 +488,13 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 // batch measure 6.5 / 5.7 / 5.5 ms per 1e5 cells -- occupancy is not what limits it)
 static int prep_batch_cells(int K) { return K <= 32 ? kPrepCB3 : kPrepCB; }
 
-size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec)
+size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int dim3)
 {
     const int cb = prep_batch_cells(K);
     const int nka = baryon ? 9 : 7, nja = baryon ? 8 : 6;
-    // the unit-level cull bounds ([cb][jtiles] + [cb][rblocks] <= cb ((J + 1) / 2 + K) doubles) exist for 3+1D grids only, where K is small;
-    // a 2+1D eta table of 241 rows must not pay 8 KB for them (two workgroups per CU need <= 80 KB each)
-    const size_t bounds = K <= 32 ? (size_t)cb * ((J + 1) / 2 + K) : 0;
+    // the unit-level cull bounds ([cb][jtiles] + [cb][rblocks] <= cb ((J + 1) / 2 + K) doubles) exist for 3+1D grids only -- the kernel's
+    // own predicate (p.dim3), whatever K is; a 2+1D eta table of 241 rows must not pay 8 KB for them (two workgroups per CU need <= 80 KB each)
+    const size_t bounds = dim3 ? (size_t)cb * ((J + 1) / 2 + K) : 0;
     // + one int2 per element of a unit record (rec doubles; 0 for the flat streams of variant 1)
     return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (nka * K + nja * J) + bounds + (size_t)rec) + sizeof(CellScal) * cb;
 }
@@ -505,7 +505,7 @@ hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
     const int cb = prep_batch_cells(p.K);
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
-    size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0);
+    size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0, p.dim3 ? 1 : 0);
     if (cb == kPrepCB3) hipLaunchKernelGGL(cf_prep<kPrepCB3>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     else hipLaunchKernelGGL(cf_prep<kPrepCB>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     return hipGetLastError();

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime_api.h>
 namespace is3d {
 constexpr int kWavesPerBlock = 4;
-size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec);
+size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int dim3);
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 void main_tile_shape(int variant, int dim3, int *JT, int *KT);
 hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st);  // a.g.baryon selects the B kernels

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -42,6 +43,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -78,6 +80,7 @@ Rccl &rccl()
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
@@ -130,6 +133,13 @@ hipError_t launch_add_spectrum(double *dst, const double *src, int64_t n, hipStr
 struct is3d_comm {
     ncclComm_t comm = nullptr;
     int32_t n_ranks = 1, rank = 0, device = 0;
+    // error word that travels with every is3d_plan_execute_allreduce: d_flag[0] = 1.0 on a rank whose execute failed, summed over the
+    // ranks next to the spectrum, read back into h_flag (pinned) on the same stream.  d_flag[1], d_flag[2] hold the constants 0.0, 1.0.
+    double *d_flag = nullptr, *h_flag = nullptr;
+    int64_t peer_errors = 0;          // sum of the error words of all collectives since the last is3d_comm_check
+    bool flag_in_flight = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last collective (is3d_comm_timings)
+    bool timed = false, aborted = false;
 };
 
 namespace is3d {
@@ -167,6 +177,64 @@ extern "C" int is3d_comm_unique_id(uint8_t id[IS3D_COMM_ID_BYTES])
     return IS3D_OK;
 }
 
+namespace {
+// the error word of a collective (is3d_comm): mode 0: f[0] = v before the sum; mode 1: f[3] += f[0] after it (the running total
+// is3d_comm_check reads); one thread
+__global__ void cf_comm_flag(double *f, int mode, double v)
+{
+    if (mode == 0) f[0] = v;
+    else f[3] += f[0];
+}
+
+void comm_abort(is3d_comm *c)
+{
+    if (c->comm && rccl().handle && rccl().CommAbort) {
+        (void)hipSetDevice(c->device);
+        (void)rccl().CommAbort(c->comm);   // frees the communicator; peers blocked in a collective with this rank get an error instead of waiting
+    }
+    c->comm = nullptr;
+    c->aborted = true;
+}
+
+// spectrum + error word in one group on the stream; on an RCCL failure the communicator is aborted
+int comm_allreduce_flagged(is3d_comm *c, double *dN_dev, int64_t n, bool local_error, hipStream_t st)
+{
+    hipLaunchKernelGGL(cf_comm_flag, dim3(1), dim3(1), 0, st, c->d_flag, 0, local_error ? 1.0 : 0.0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev0, st));
+    ncclResult_t r = rccl().GroupStart();
+    if (r == ncclSuccess && n > 0) r = rccl().AllReduce(dN_dev, dN_dev, (size_t)n, ncclDouble, ncclSum, c->comm, st);
+    if (r == ncclSuccess) r = rccl().AllReduce(c->d_flag, c->d_flag, 1, ncclDouble, ncclSum, c->comm, st);
+    const ncclResult_t r2 = rccl().GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) {
+        const std::string what = rccl().GetErrorString(r);
+        comm_abort(c);
+        return fail(IS3D_ENODEVICE, "ncclAllReduce failed on rank %d of %d: %s; the communicator was aborted", c->rank, c->n_ranks, what.c_str());
+    }
+    HIP_TRY(hipEventRecord(c->ev1, st));
+    c->timed = true;
+    hipLaunchKernelGGL(cf_comm_flag, dim3(1), dim3(1), 0, st, c->d_flag, 1, 0.0);
+    HIP_TRY(hipGetLastError());
+    c->flag_in_flight = true;
+    return IS3D_OK;
+}
+
+// running total of the error words since the last read; synchronises the stream
+int comm_read_errors(is3d_comm *c, hipStream_t st, double *total)
+{
+    *total = 0.0;
+    if (!c->flag_in_flight) return IS3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_flag + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(c->d_flag + 3, 0, sizeof(double), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *total = c->h_flag[0];
+    c->flag_in_flight = false;
+    return IS3D_OK;
+}
+}  // namespace
+
 extern "C" int is3d_comm_create(is3d_comm **out, const uint8_t id[IS3D_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int32_t device)
 {
     if (!out || !id) return fail(IS3D_EINVAL, "null argument");
@@ -185,6 +253,14 @@ extern "C" int is3d_comm_create(is3d_comm **out, const uint8_t id[IS3D_COMM_ID_B
         delete c;
         return fail(IS3D_ENODEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, n_ranks, dev, rccl().GetErrorString(r));
     }
+    const hipError_t e1 = hipMalloc((void **)&c->d_flag, 4 * sizeof(double));
+    const hipError_t e2 = hipHostMalloc((void **)&c->h_flag, sizeof(double), hipHostMallocDefault);
+    const hipError_t e3 = e1 == hipSuccess ? hipMemset(c->d_flag, 0, 4 * sizeof(double)) : e1;
+    const hipError_t e4 = hipEventCreate(&c->ev0), e5 = hipEventCreate(&c->ev1);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+        is3d_comm_destroy(c);
+        return fail(IS3D_ENODEVICE, "is3d_comm_create: cannot allocate the communicator's error word / events");
+    }
     *out = c;
     return IS3D_OK;
 }
@@ -200,35 +276,107 @@ extern "C" int is3d_comm_rank(const is3d_comm *c, int32_t *rank, int32_t *n_rank
 extern "C" int is3d_comm_allreduce(is3d_comm *c, double *dN_dev, int64_t n, void *hip_stream)
 {
     if (!c || !dN_dev || n < 0) return fail(IS3D_EINVAL, "is3d_comm_allreduce: bad argument");
+    if (c->aborted) return fail(IS3D_ENODEVICE, "is3d_comm_allreduce: the communicator was aborted");
     if (n == 0) return IS3D_OK;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, (hipStream_t)hip_stream));
     NCCL_TRY(rccl().AllReduce(dN_dev, dN_dev, (size_t)n, ncclDouble, ncclSum, c->comm, (hipStream_t)hip_stream));
+    HIP_TRY(hipEventRecord(c->ev1, (hipStream_t)hip_stream));
+    c->timed = true;
+    return IS3D_OK;
+}
+
+extern "C" int is3d_comm_abort(is3d_comm *c)
+{
+    if (!c) return fail(IS3D_EINVAL, "null communicator");
+    if (!c->aborted) comm_abort(c);
+    return IS3D_OK;
+}
+
+extern "C" int is3d_comm_check(is3d_comm *c, void *hip_stream, int32_t *n_failed)
+{
+    if (!c) return fail(IS3D_EINVAL, "null communicator");
+    if (n_failed) *n_failed = 0;
+    if (c->aborted) return fail(IS3D_ENODEVICE, "the communicator was aborted");
+    double total = 0.0;
+    if (int rc = comm_read_errors(c, (hipStream_t)hip_stream, &total)) return rc;
+    c->peer_errors += (int64_t)(total + 0.5);
+    const int64_t k = c->peer_errors;
+    c->peer_errors = 0;
+    if (n_failed) *n_failed = (int32_t)std::min<int64_t>(k, 0x7fffffff);
+    if (k > 0) return fail(IS3D_EPEER, "%lld rank-executes since the last check reported an error before their all-reduce: the summed spectra are incomplete", (long long)k);
+    return IS3D_OK;
+}
+
+extern "C" int is3d_comm_timings(is3d_comm *c, double *ms_allreduce)
+{
+    if (!c || !ms_allreduce) return fail(IS3D_EINVAL, "null argument");
+    *ms_allreduce = 0.0;
+    if (!c->timed || c->aborted) return IS3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_allreduce = ms;
     return IS3D_OK;
 }
 
 extern "C" void is3d_comm_destroy(is3d_comm *c)
 {
     if (!c) return;
-    if (c->comm && rccl().handle) {
-        (void)hipSetDevice(c->device);
-        (void)rccl().CommDestroy(c->comm);
-    }
+    (void)hipSetDevice(c->device);
+    if (c->comm && rccl().handle) (void)rccl().CommDestroy(c->comm);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
 }
 
 extern "C" int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *shard, double *dN_out, is3d_comm *comm, void *hip_stream,
                                            is3d_status *status)
 {
-    // the status read-back of is3d_plan_execute synchronises the stream: the collective is enqueued after it, so a rank whose
-    // shard has a domain error still takes part in the all-reduce (no rank is left waiting) and reports the error afterwards
-    const int rc = is3d_plan_execute(plan, shard, dN_out, hip_stream, status);
-    if (rc != IS3D_OK && rc != IS3D_EDOMAIN) return rc;
-    std::string kept = rc ? is3d_last_error() : "";
-    if (comm) {
-        const int rc2 = is3d_comm_allreduce(comm, dN_out, is3d_plan_output_size(plan), hip_stream);
-        if (rc2) return rc2;
+    if (!comm) return is3d_plan_execute(plan, shard, dN_out, hip_stream, status);
+    if (comm->aborted) return fail(IS3D_ENODEVICE, "is3d_plan_execute_allreduce: the communicator was aborted");
+    hipStream_t st = (hipStream_t)hip_stream;
+    // A rank must never leave its peers waiting in ncclAllReduce.  Whatever happens locally, it either joins the collective -- with its
+    // error word set, so that EVERY rank learns the sum is incomplete -- or, when it cannot (no buffer to reduce, a HIP error: the stream
+    // may be dead), aborts the communicator, which makes the peers' collective fail instead of hang.
+    if (!plan || !dN_out) {
+        comm_abort(comm);
+        return fail(IS3D_EINVAL, "is3d_plan_execute_allreduce: null plan or spectrum; the communicator was aborted so that the other ranks do not wait");
+    }
+    int rc;
+    if (is3d::plan_accumulate(plan))   // the old contents of dN_out would be summed n_ranks times
+        rc = fail(IS3D_EINVAL, "is3d_plan_execute_allreduce needs a plan with opts.accumulate = 0");
+    else
+        // the status read-back of is3d_plan_execute synchronises the stream: the collective is enqueued after it, so a rank whose
+        // shard has a domain error still takes part in the all-reduce and reports the error afterwards
+        rc = is3d_plan_execute(plan, shard, dN_out, hip_stream, status);
+    const std::string kept = rc ? is3d_last_error() : "";
+    const int64_t nout = is3d_plan_output_size(plan);
+    if (rc == IS3D_ENODEVICE) {
+        comm_abort(comm);
+        return fail(rc, "%s; the communicator was aborted so that the other ranks do not wait", kept.c_str());
+    }
+    if (hipSetDevice(comm->device) != hipSuccess ||
+        (rc != IS3D_OK && rc != IS3D_EDOMAIN && hipMemsetAsync(dN_out, 0, sizeof(double) * (size_t)nout, st) != hipSuccess)) {
+        comm_abort(comm);   // argument error and the neutral contribution cannot be enqueued either
+        return fail(rc ? rc : IS3D_ENODEVICE, "%s; the communicator was aborted so that the other ranks do not wait", kept.c_str());
+    }
+    if (int rc2 = comm_allreduce_flagged(comm, dN_out, nout, rc != IS3D_OK, st)) {
+        if (!comm->aborted) comm_abort(comm);
+        return rc2;
     }
     if (rc) return fail(rc, "%s", kept.c_str());
+    if (status) {   // the caller asked for a synchronous answer: include the other ranks'
+        double total = 0.0;
+        if (int rc3 = comm_read_errors(comm, st, &total)) return rc3;
+        if (total > 0.5) {
+            status->code = IS3D_EPEER;
+            return fail(IS3D_EPEER, "%d of the %d ranks reported an error before the all-reduce: the summed spectrum is incomplete", (int)(total + 0.5), comm->n_ranks);
+        }
+    }
     return IS3D_OK;
 }
 
@@ -237,16 +385,21 @@ extern "C" int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *sh
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int kCellArrays = 23;
+
+// everything a shard owns for the life of a multi-device plan
 struct Shard {
     int device = 0;
-    int64_t lo = 0, hi = 0;
+    int64_t cap = 0;                   // cells this shard's plan, device block and staging block are sized for
+    int64_t lo = 0, hi = 0;            // its cells in the current execute
     is3d_plan *plan = nullptr;
-    double *d_cells = nullptr, *d_out = nullptr;
+    double *d_cells = nullptr, *d_out = nullptr, *d_tmp = nullptr;   // d_tmp: the partner's spectrum in a round of the tree sum
+    double *h_stage = nullptr;         // pinned: the shard's slices of the caller's (pageable) arrays, packed, one DMA per execute
     hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e_sum = nullptr;
     is3d_status st{};
     int rc = IS3D_OK;
     std::string err;
-    float ms_h2d = 0.f;
 };
 
 void shard_release(Shard &s)
@@ -255,89 +408,125 @@ void shard_release(Shard &s)
     if (s.plan) is3d_plan_destroy(s.plan);
     if (s.d_cells) (void)hipFree(s.d_cells);
     if (s.d_out) (void)hipFree(s.d_out);
+    if (s.d_tmp) (void)hipFree(s.d_tmp);
+    if (s.h_stage) (void)hipHostFree(s.h_stage);
     if (s.stream) (void)hipStreamDestroy(s.stream);
-    s.plan = nullptr; s.d_cells = nullptr; s.d_out = nullptr; s.stream = nullptr;
+    for (hipEvent_t e : {s.e0, s.e1, s.e_sum})
+        if (e) (void)hipEventDestroy(e);
+    s = Shard{};
 }
 
-// upload the shard's slices, run the plan; the spectrum stays on the device (s.d_out), the stream is synchronised
-int shard_run(Shard &s, const is3d_cells *cells, const is3d_species *sp, const is3d_grid *grid, const is3d_df_tables *df,
-              const is3d_feqmod_tables *fq, const is3d_options *opts)
+// communicators of IS3D_REDUCE_RCCL are kept for the life of the process, keyed by the device list (creating one costs ~0.1-1 s)
+struct CommSet { std::vector<int> devices; std::vector<ncclComm_t> comms; };
+std::mutex g_commset_mutex;
+std::vector<CommSet *> g_commsets;
+
+int commset_for(const std::vector<int> &devs, CommSet **out)
+{
+    if (int rc = rccl_ready()) return rc;
+    std::vector<int> sorted = devs;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+        return fail(IS3D_EINVAL, "IS3D_REDUCE_RCCL needs distinct devices (a communicator holds one rank per GPU); use IS3D_REDUCE_ORDERED");
+    std::lock_guard<std::mutex> lock(g_commset_mutex);
+    for (CommSet *c : g_commsets)
+        if (c->devices == devs) { *out = c; return IS3D_OK; }
+    CommSet *n = new CommSet;
+    n->devices = devs;
+    n->comms.resize(devs.size());
+    ncclResult_t r = rccl().CommInitAll(n->comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) {
+        delete n;
+        return fail(IS3D_ENODEVICE, "ncclCommInitAll over %d devices failed: %s", (int)devs.size(), rccl().GetErrorString(r));
+    }
+    g_commsets.push_back(n);
+    *out = n;
+    return IS3D_OK;
+}
+
+}  // namespace
+
+struct is3d_multi_plan {
+    std::vector<Shard> sh;
+    int reduce = IS3D_REDUCE_ORDERED;
+    int64_t max_cells = 0, nout = 0;
+    bool diff = false, accumulate = false;
+    int n_arrays = 18;                 // cell arrays a shard uploads (23 with baryon diffusion)
+    CommSet *comms = nullptr;
+    std::vector<double> h_acc;         // accumulate: the device sum lands here first
+
+    ~is3d_multi_plan()
+    {
+        for (auto &s : sh) shard_release(s);
+    }
+};
+
+namespace {
+
+int shard_create(Shard &s, const is3d_species *sp, const is3d_grid *grid, const is3d_df_tables *df, const is3d_feqmod_tables *fq,
+                 const is3d_options *opts, bool need_tmp)
 {
     HIP_TRY(hipSetDevice(s.device));
     is3d_options o = *opts;
     o.device = s.device;
     o.accumulate = 0;
-    const int64_t n = s.hi - s.lo;
-    int rc = fq ? is3d_plan_create_feqmod(&s.plan, sp, grid, df, fq, &o, std::max<int64_t>(n, 1))
-                : is3d_plan_create(&s.plan, sp, grid, df, &o, std::max<int64_t>(n, 1));
+    int rc = fq ? is3d_plan_create_feqmod(&s.plan, sp, grid, df, fq, &o, s.cap) : is3d_plan_create(&s.plan, sp, grid, df, &o, s.cap);
     if (rc) return rc;
     (void)is3d_plan_set_timing(s.plan, 1);
     const int64_t nout = is3d_plan_output_size(s.plan);
     HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void **)&s.d_cells, sizeof(double) * 23 * (size_t)std::max<int64_t>(n, 1)));
+    HIP_TRY(hipMalloc((void **)&s.d_cells, sizeof(double) * kCellArrays * (size_t)s.cap));
+    HIP_TRY(hipHostMalloc((void **)&s.h_stage, sizeof(double) * kCellArrays * (size_t)s.cap, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&s.d_out, sizeof(double) * (size_t)nout));
-    const bool diff = opts->include_baryon && opts->include_baryondiff_deltaf;
-    const double *src[23] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
-                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
-                             diff ? cells->muB : nullptr, diff ? cells->nB : nullptr, diff ? cells->Vx : nullptr,
-                             diff ? cells->Vy : nullptr, diff ? cells->Vn : nullptr};
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
-    HIP_TRY(hipEventRecord(e0, s.stream));
-    const double *dptr[23];
-    for (int a = 0; a < 23; a++) {
+    if (need_tmp) HIP_TRY(hipMalloc((void **)&s.d_tmp, sizeof(double) * (size_t)nout));
+    HIP_TRY(hipEventCreate(&s.e0));
+    HIP_TRY(hipEventCreate(&s.e1));
+    HIP_TRY(hipEventCreateWithFlags(&s.e_sum, hipEventDisableTiming));
+    return IS3D_OK;
+}
+
+// pack the shard's slices into the pinned block, one DMA, run the plan; the spectrum stays on the device (s.d_out), the stream is
+// synchronised (is3d_plan_execute reads the status back)
+int shard_run(Shard &s, const is3d_cells *cells, bool diff)
+{
+    HIP_TRY(hipSetDevice(s.device));
+    const int64_t n = s.hi - s.lo;
+    const double *src[kCellArrays] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                                      cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
+                                      diff ? cells->muB : nullptr, diff ? cells->nB : nullptr, diff ? cells->Vx : nullptr,
+                                      diff ? cells->Vy : nullptr, diff ? cells->Vn : nullptr};
+    const double *dptr[kCellArrays];
+    int used = 0;
+    for (int a = 0; a < kCellArrays; a++) {
         dptr[a] = nullptr;
         if (src[a] && n > 0) {
-            HIP_TRY(hipMemcpyAsync(s.d_cells + (size_t)a * n, src[a] + s.lo, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s.stream));
-            dptr[a] = s.d_cells + (size_t)a * n;
+            memcpy(s.h_stage + (size_t)used * n, src[a] + s.lo, (size_t)n * sizeof(double));
+            dptr[a] = s.d_cells + (size_t)used * n;
+            used++;
         }
     }
-    HIP_TRY(hipEventRecord(e1, s.stream));
+    HIP_TRY(hipEventRecord(s.e0, s.stream));
+    if (used) HIP_TRY(hipMemcpyAsync(s.d_cells, s.h_stage, (size_t)used * n * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipEventRecord(s.e1, s.stream));
     is3d_cells dc{};
     dc.n_cells = n;
     dc.tau = dptr[0]; dc.eta = dptr[1]; dc.dat = dptr[2]; dc.dax = dptr[3]; dc.day = dptr[4]; dc.dan = dptr[5];
     dc.ux = dptr[6]; dc.uy = dptr[7]; dc.un = dptr[8]; dc.T = dptr[9]; dc.P = dptr[10]; dc.E = dptr[11];
     dc.pixx = dptr[12]; dc.pixy = dptr[13]; dc.pixn = dptr[14]; dc.piyy = dptr[15]; dc.piyn = dptr[16]; dc.bulkPi = dptr[17];
     dc.muB = dptr[18]; dc.nB = dptr[19]; dc.Vx = dptr[20]; dc.Vy = dptr[21]; dc.Vn = dptr[22];
-    rc = is3d_plan_execute(s.plan, &dc, s.d_out, s.stream, &s.st);
+    const int rc = is3d_plan_execute(s.plan, &dc, s.d_out, s.stream, &s.st);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s.stream));
     is3d_status t{};
     (void)is3d_plan_timings(s.plan, &t);
     s.st.ms_prep = t.ms_prep; s.st.ms_main = t.ms_main; s.st.ms_finalize = t.ms_finalize;
-    HIP_TRY(hipEventElapsedTime(&s.ms_h2d, e0, e1));
-    s.st.ms_h2d = s.ms_h2d;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
+    s.st.ms_h2d = ms;
     return IS3D_OK;
 }
 
-// communicators of IS3D_REDUCE_RCCL are kept for the life of the process, keyed by the device list (creating one costs ~0.1-1 s)
-struct CommSet { std::vector<int> devices; std::vector<ncclComm_t> comms; };
-std::mutex g_commset_mutex;
-std::vector<CommSet> g_commsets;
-
-int rccl_allreduce_shards(std::vector<Shard> &sh, int64_t nout)
+int rccl_allreduce_shards(std::vector<Shard> &sh, CommSet *cs, int64_t nout)
 {
-    if (int rc = rccl_ready()) return rc;
-    std::vector<int> devs;
-    for (auto &s : sh) devs.push_back(s.device);
-    std::vector<int> sorted = devs;
-    std::sort(sorted.begin(), sorted.end());
-    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
-        return fail(IS3D_EINVAL, "IS3D_REDUCE_RCCL needs distinct devices (a communicator holds one rank per GPU); use IS3D_REDUCE_ORDERED");
-    std::lock_guard<std::mutex> lock(g_commset_mutex);
-    CommSet *cs = nullptr;
-    for (auto &c : g_commsets)
-        if (c.devices == devs) cs = &c;
-    if (!cs) {
-        CommSet n;
-        n.devices = devs;
-        n.comms.resize(devs.size());
-        NCCL_TRY(rccl().CommInitAll(n.comms.data(), (int)devs.size(), devs.data()));
-        g_commsets.push_back(n);
-        cs = &g_commsets.back();
-    }
     NCCL_TRY(rccl().GroupStart());
     for (size_t i = 0; i < sh.size(); i++) {
         (void)hipSetDevice(sh[i].device);
@@ -355,73 +544,122 @@ int rccl_allreduce_shards(std::vector<Shard> &sh, int64_t nout)
     return IS3D_OK;
 }
 
-// ((s0 + s1) + s2) + ... on shard 0's device
-int ordered_sum_shards(std::vector<Shard> &sh, int64_t nout)
+// Pairwise tree in a fixed order: round r adds shard i + 2^r into shard i for every i that is a multiple of 2^(r+1); the pairs of a
+// round run concurrently on the streams of their receiving shards, a receiver waits for its partner's previous round through an event.
+// The sum ends in shard 0; the order of the additions depends on the shard count only.
+int tree_sum_shards(std::vector<Shard> &sh, int64_t nout)
 {
-    Shard &s0 = sh[0];
-    HIP_TRY(hipSetDevice(s0.device));
-    double *tmp = nullptr;
-    bool need_tmp = false;
-    for (size_t i = 1; i < sh.size(); i++) need_tmp |= sh[i].device != s0.device;
-    if (need_tmp) HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * (size_t)nout));
-    struct Guard { double *p; ~Guard() { if (p) (void)hipFree(p); } } guard{tmp};
-    for (size_t i = 1; i < sh.size(); i++) {
-        const double *src = sh[i].d_out;
-        if (sh[i].device != s0.device) {
-            HIP_TRY(hipMemcpyPeerAsync(tmp, s0.device, sh[i].d_out, sh[i].device, sizeof(double) * (size_t)nout, s0.stream));
-            src = tmp;
+    const size_t n = sh.size();
+    for (size_t stride = 1; stride < n; stride *= 2) {
+        for (size_t i = 0; i + stride < n; i += 2 * stride) {
+            Shard &dst = sh[i], &src = sh[i + stride];
+            HIP_TRY(hipSetDevice(dst.device));
+            if (stride > 1) HIP_TRY(hipStreamWaitEvent(dst.stream, src.e_sum, 0));   // round 0: every shard's stream is already synchronised
+            const double *from = src.d_out;
+            if (src.device != dst.device) {
+                HIP_TRY(hipMemcpyPeerAsync(dst.d_tmp, dst.device, src.d_out, src.device, sizeof(double) * (size_t)nout, dst.stream));
+                from = dst.d_tmp;
+            }
+            HIP_TRY(launch_add_spectrum(dst.d_out, from, nout, dst.stream));
+            HIP_TRY(hipEventRecord(dst.e_sum, dst.stream));
         }
-        HIP_TRY(launch_add_spectrum(s0.d_out, src, nout, s0.stream));
     }
-    HIP_TRY(hipStreamSynchronize(s0.stream));
+    HIP_TRY(hipSetDevice(sh[0].device));
+    HIP_TRY(hipStreamSynchronize(sh[0].stream));
+    return IS3D_OK;
+}
+
+int check_devices(const int32_t *devices, int32_t &n_devices, std::vector<int> &dev)
+{
+    const int visible = is3d_device_count();
+    if (visible < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (n_devices <= 0) { n_devices = visible; devices = nullptr; }
+    if (n_devices > 1024) return fail(IS3D_EINVAL, "n_devices = %d", n_devices);
+    dev.resize(n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        dev[i] = devices ? devices[i] : i;
+        if (dev[i] < 0 || dev[i] >= visible) return fail(IS3D_EINVAL, "device %d is not one of the %d visible HIP devices", dev[i], visible);
+    }
     return IS3D_OK;
 }
 
 }  // namespace
 
-extern "C" int is3d_smooth_spectra_multi(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
-                                         const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts,
-                                         const int32_t *devices, int32_t n_devices, int32_t reduce, double *dN_out,
-                                         is3d_status *status, is3d_status *shard_status)
+extern "C" int is3d_multi_plan_create(is3d_multi_plan **out, const is3d_species *species, const is3d_grid *grid, const is3d_df_tables *df,
+                                      const is3d_feqmod_tables *fq, const is3d_options *opts, const int32_t *devices, int32_t n_devices,
+                                      int32_t reduce, int64_t max_cells)
 {
-    if (!cells || !opts || !dN_out) return fail(IS3D_EINVAL, "null argument");
+    if (!out || !opts) return fail(IS3D_EINVAL, "null argument");
+    *out = nullptr;
     if (reduce != IS3D_REDUCE_ORDERED && reduce != IS3D_REDUCE_RCCL) return fail(IS3D_EINVAL, "reduce must be IS3D_REDUCE_ORDERED or IS3D_REDUCE_RCCL");
-    if (cells->n_cells < 0) return fail(IS3D_EINVAL, "n_cells < 0");
-    const int visible = is3d_device_count();
-    if (visible < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
-    if (n_devices <= 0) { n_devices = visible; devices = nullptr; }
-    if (n_devices > 1024) return fail(IS3D_EINVAL, "n_devices = %d", n_devices);
-    std::vector<int> dev(n_devices);
+    if (max_cells < 0) return fail(IS3D_EINVAL, "max_cells < 0");
+    std::vector<int> dev;
+    if (int rc = check_devices(devices, n_devices, dev)) return rc;
+    std::unique_ptr<is3d_multi_plan> M(new is3d_multi_plan);
+    M->reduce = reduce;
+    M->max_cells = max_cells;
+    M->accumulate = opts->accumulate != 0;
+    M->diff = opts->include_baryon && opts->include_baryondiff_deltaf;
+    M->sh.resize(n_devices);
+    if (reduce == IS3D_REDUCE_RCCL && n_devices > 1)
+        if (int rc = commset_for(dev, &M->comms)) return rc;
     for (int i = 0; i < n_devices; i++) {
-        dev[i] = devices ? devices[i] : i;
-        if (dev[i] < 0 || dev[i] >= visible) return fail(IS3D_EINVAL, "device %d is not one of the %d visible HIP devices", dev[i], visible);
+        M->sh[i].device = dev[i];
+        M->sh[i].cap = std::max<int64_t>((max_cells + n_devices - 1) / n_devices, 1);
+        M->sh[i].st.bad_cell = -1;
     }
-    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
-    if (shard_status) memset(shard_status, 0, sizeof(is3d_status) * (size_t)n_devices);
-
-    if (n_devices == 1 && reduce == IS3D_REDUCE_ORDERED) {
-        is3d_options o = *opts;
-        o.device = dev[0];
-        is3d_status st{};
-        const int rc = fq ? is3d_smooth_spectra_feqmod(cells, species, grid, df, fq, &o, dN_out, &st)
-                          : is3d_smooth_spectra(cells, species, grid, df, &o, dN_out, &st);
-        if (status) *status = st;
-        if (shard_status) shard_status[0] = st;
-        return rc;
-    }
-
-    std::vector<Shard> sh(n_devices);
-    for (int i = 0; i < n_devices; i++) {
-        sh[i].device = dev[i];
-        (void)is3d_shard_bounds(cells->n_cells, i, n_devices, &sh[i].lo, &sh[i].hi);
-        sh[i].st.bad_cell = -1;
-    }
-    struct Release { std::vector<Shard> &v; ~Release() { for (auto &s : v) shard_release(s); } } release{sh};
+    // a shard needs a receive buffer if it takes a partner from another device in some round of the tree
+    std::vector<char> need_tmp(n_devices, 0);
+    if (reduce == IS3D_REDUCE_ORDERED)
+        for (int stride = 1; stride < n_devices; stride *= 2)
+            for (int i = 0; i + stride < n_devices; i += 2 * stride)
+                if (dev[i] != dev[i + stride]) need_tmp[i] = 1;
     {
         std::vector<std::thread> th;
         for (int i = 0; i < n_devices; i++)
             th.emplace_back([&, i] {
-                sh[i].rc = shard_run(sh[i], cells, species, grid, df, fq, opts);
+                Shard &s = M->sh[i];
+                s.rc = shard_create(s, species, grid, df, fq, opts, need_tmp[i] != 0);
+                if (s.rc) s.err = is3d_last_error();
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < n_devices; i++)
+        if (M->sh[i].rc) return fail(M->sh[i].rc, "shard %d (device %d): %s", i, M->sh[i].device, M->sh[i].err.c_str());
+    M->nout = is3d_plan_output_size(M->sh[0].plan);
+    *out = M.release();
+    return IS3D_OK;
+}
+
+extern "C" int32_t is3d_multi_plan_shards(const is3d_multi_plan *M) { return M ? (int32_t)M->sh.size() : 0; }
+extern "C" int64_t is3d_multi_plan_output_size(const is3d_multi_plan *M) { return M ? M->nout : 0; }
+extern "C" void is3d_multi_plan_destroy(is3d_multi_plan *M) { delete M; }
+
+extern "C" int is3d_multi_plan_execute(is3d_multi_plan *M, const is3d_cells *cells, double *dN_out, is3d_status *status,
+                                       is3d_status *shard_status)
+{
+    if (!M || !cells || !dN_out) return fail(IS3D_EINVAL, "null argument");
+    const int n_devices = (int)M->sh.size();
+    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
+    if (shard_status) memset(shard_status, 0, sizeof(is3d_status) * (size_t)n_devices);
+    if (cells->n_cells < 0 || cells->n_cells > M->max_cells)
+        return fail(IS3D_EINVAL, "n_cells = %lld outside the multi-device plan's max_cells = %lld", (long long)cells->n_cells, (long long)M->max_cells);
+    std::vector<Shard> &sh = M->sh;
+    for (int i = 0; i < n_devices; i++) {
+        (void)is3d_shard_bounds(cells->n_cells, i, n_devices, &sh[i].lo, &sh[i].hi);
+        sh[i].st = is3d_status{};
+        sh[i].st.bad_cell = -1;
+        sh[i].rc = IS3D_OK;
+        sh[i].err.clear();
+    }
+    if (n_devices == 1) {
+        sh[0].rc = shard_run(sh[0], cells, M->diff);
+        if (sh[0].rc) sh[0].err = is3d_last_error();
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_devices; i++)
+            th.emplace_back([&, i] {
+                sh[i].rc = shard_run(sh[i], cells, M->diff);
                 if (sh[i].rc) sh[i].err = is3d_last_error();   // the error text is thread-local
             });
         for (auto &t : th) t.join();
@@ -454,30 +692,61 @@ extern "C" int is3d_smooth_spectra_multi(const is3d_cells *cells, const is3d_spe
         if (status) *status = agg;
         return fail(rc_first, "%s", err_first.c_str());
     }
-    const int64_t nout = is3d_plan_output_size(sh[0].plan);
-    hipEvent_t e0, e1;
+    const int64_t nout = M->nout;
     HIP_TRY(hipSetDevice(sh[0].device));
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
-    HIP_TRY(hipEventRecord(e0, sh[0].stream));
-    int rc = (reduce == IS3D_REDUCE_RCCL) ? rccl_allreduce_shards(sh, nout) : ordered_sum_shards(sh, nout);
+    HIP_TRY(hipEventRecord(sh[0].e0, sh[0].stream));
+    int rc = IS3D_OK;
+    if (n_devices > 1) rc = (M->reduce == IS3D_REDUCE_RCCL) ? rccl_allreduce_shards(sh, M->comms, nout) : tree_sum_shards(sh, nout);
     if (rc) { agg.code = rc; if (status) *status = agg; return rc; }
     HIP_TRY(hipSetDevice(sh[0].device));
-    if (opts->accumulate) {   // reference semantics: dN += result (smooth_kernels.cpp:375)
-        std::vector<double> h((size_t)nout);
-        HIP_TRY(hipMemcpyAsync(h.data(), sh[0].d_out, sizeof(double) * (size_t)nout, hipMemcpyDeviceToHost, sh[0].stream));
+    if (M->accumulate) {   // reference semantics: dN += result (smooth_kernels.cpp:375)
+        M->h_acc.resize((size_t)nout);
+        HIP_TRY(hipMemcpyAsync(M->h_acc.data(), sh[0].d_out, sizeof(double) * (size_t)nout, hipMemcpyDeviceToHost, sh[0].stream));
         HIP_TRY(hipStreamSynchronize(sh[0].stream));
-        for (int64_t i = 0; i < nout; i++) dN_out[i] += h[(size_t)i];
+        for (int64_t i = 0; i < nout; i++) dN_out[i] += M->h_acc[(size_t)i];
     } else {
         HIP_TRY(hipMemcpyAsync(dN_out, sh[0].d_out, sizeof(double) * (size_t)nout, hipMemcpyDeviceToHost, sh[0].stream));
     }
-    HIP_TRY(hipEventRecord(e1, sh[0].stream));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(sh[0].e1, sh[0].stream));
+    HIP_TRY(hipEventSynchronize(sh[0].e1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, sh[0].e0, sh[0].e1));
     agg.ms_d2h = ms;
     if (status) *status = agg;
+    return IS3D_OK;
+}
+
+extern "C" int is3d_smooth_spectra_multi(const is3d_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                                         const is3d_df_tables *df, const is3d_feqmod_tables *fq, const is3d_options *opts,
+                                         const int32_t *devices, int32_t n_devices, int32_t reduce, double *dN_out,
+                                         is3d_status *status, is3d_status *shard_status)
+{
+    if (!cells || !opts || !dN_out) return fail(IS3D_EINVAL, "null argument");
+    if (reduce != IS3D_REDUCE_ORDERED && reduce != IS3D_REDUCE_RCCL) return fail(IS3D_EINVAL, "reduce must be IS3D_REDUCE_ORDERED or IS3D_REDUCE_RCCL");
+    if (cells->n_cells < 0) return fail(IS3D_EINVAL, "n_cells < 0");
+    std::vector<int> dev;
+    if (int rc = check_devices(devices, n_devices, dev)) return rc;
+    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
+    if (shard_status) memset(shard_status, 0, sizeof(is3d_status) * (size_t)n_devices);
+
+    if (n_devices == 1 && reduce == IS3D_REDUCE_ORDERED) {
+        is3d_options o = *opts;
+        o.device = dev[0];
+        is3d_status st{};
+        const int rc = fq ? is3d_smooth_spectra_feqmod(cells, species, grid, df, fq, &o, dN_out, &st)
+                          : is3d_smooth_spectra(cells, species, grid, df, &o, dN_out, &st);
+        if (status) *status = st;
+        if (shard_status) shard_status[0] = st;
+        return rc;
+    }
+    // the one-shot form: a multi-device plan created, executed once and destroyed (hosts that call more than once keep the plan)
+    std::vector<int32_t> dev32(dev.begin(), dev.end());
+    is3d_multi_plan *M = nullptr;
+    if (int rc = is3d_multi_plan_create(&M, species, grid, df, fq, opts, dev32.data(), n_devices, reduce, cells->n_cells)) return rc;
+    const int rc = is3d_multi_plan_execute(M, cells, dN_out, status, shard_status);
+    const std::string kept = rc ? is3d_last_error() : "";
+    is3d_multi_plan_destroy(M);
+    if (rc) return fail(rc, "%s", kept.c_str());
     return IS3D_OK;
 }
 

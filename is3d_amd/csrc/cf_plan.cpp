@@ -427,7 +427,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     is3d::main_tile_shape(P->variant, P->dim3 ? 1 : 0, &P->JT, &P->KT);
     P->jtiles = (P->J + P->JT - 1) / P->JT;
     const bool tiled = P->variant != 1;
-    if (!fq && is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K, P->baryon ? 1 : 0, tiled ? is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0) : 0) > 160 * 1024)
+    if (!fq && is3d::prep_lds_bytes(df->n_T, nspl, P->J, P->K, P->baryon ? 1 : 0, tiled ? is3d::unit_rec_doubles(P->JT, P->KT, P->baryon ? 1 : 0) : 0, P->dim3 ? 1 : 0) > 160 * 1024)
         return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     P->rblocks = tiled ? (P->K + P->KT - 1) / P->KT : 1;
     P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;   // k tiles are separate tasks only in 3+1D
@@ -567,6 +567,9 @@ extern "C" int is3d_plan_set_timing(is3d_plan *P, int32_t enable)
     if (!P) return fail(IS3D_EINVAL, "null plan");
     P->timing = enable != 0;
     return IS3D_OK;
+}
+namespace is3d {
+int plan_accumulate(const is3d_plan *P) { return P && P->opts.accumulate != 0; }
 }
 extern "C" void is3d_plan_destroy(is3d_plan *P)
 {
@@ -741,7 +744,8 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[npasses * 3], st));
     }
 
-    if (n > 0) HIP_TRY(is3d::launch_fold_status(P->d_status.p, P->d_sticky.p, st));
+    // executes that return their domain errors through `status` do not leave them for a later is3d_plan_check as well
+    if (n > 0 && !status) HIP_TRY(is3d::launch_fold_status(P->d_status.p, P->d_sticky.p, st));
     if (status) {
         unsigned long long h[8];
         HIP_TRY(hipMemcpyAsync(h, P->d_status.p, sizeof h, hipMemcpyDeviceToHost, st));

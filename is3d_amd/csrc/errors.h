@@ -6,3 +6,8 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // a thread of its own while it parses the surface file (a cold context costs a quarter of a second).  Errors are left to the real calls.
 void warm_devices(const int *devices, int n);
 }
+struct is3d_plan;
+namespace is3d {
+// opts.accumulate of a plan (cf_multi.hip refuses it in front of a collective)
+int plan_accumulate(const is3d_plan *plan);
+}

@@ -135,3 +135,136 @@ def test_sampler_over_several_shards_gives_the_single_device_list(fx):
     with pytest.raises(api.Is3dError) as e:                                   # buffer too small: full count reported, IS3D_ENOMEM
         api.sample_particles(cells, sp, fx["df"], gla, o, n_events=7, seed=99, devices=[0, 0], capacity=10)
     assert e.value.code == api.IS3D_ENOMEM
+
+
+def test_persistent_multi_plan_is_bitwise_the_one_shot_and_cheaper_per_execute(fx):
+    """is3d_multi_plan_*: plans, workspaces, streams, pinned staging created once.  Two shards on one GPU through the persistent
+    plan == is3d_smooth_spectra_multi bitwise; a second execute no longer pays plan creation + workspace hipMalloc."""
+    import time
+    cells = synth.synth_surface(20000, 3, seed=12)
+    o = dict(dimension=3, df_mode=2)
+    one_shot, _, _ = api.smooth_spectra_multi(cells, fx["urqmd"], fx["grid"], fx["df"], o, devices=[0, 0])
+    t0 = time.perf_counter()
+    mp = api.MultiPlan(fx["urqmd"], fx["grid"], fx["df"], o, devices=[0, 0], max_cells=20000)
+    first, st, sh = mp.execute(cells)
+    t_first = time.perf_counter() - t0          # what the one-shot entry pays on every call
+    assert np.array_equal(first, one_shot) and mp.n_shards == 2 and len(sh) == 2 and st["code"] == 0
+    t0 = time.perf_counter()
+    second, st2, _ = mp.execute(cells)
+    t_second = time.perf_counter() - t0
+    assert np.array_equal(second, one_shot)
+    print("multi plan: create + first execute %.1f ms, second execute %.1f ms (kernels %.1f ms)" % (
+        t_first * 1e3, t_second * 1e3, st2["ms_prep"] + st2["ms_main"] + st2["ms_finalize"]))
+    assert t_second + 8e-3 < t_first
+    # fewer cells than max_cells, an odd count, an empty surface: the same plan
+    for n in (7777, 1, 0):
+        sub = {k: v[:n] for k, v in cells.items()}
+        got, _, _ = mp.execute(sub)
+        ref, _, _ = api.smooth_spectra_multi(sub, fx["urqmd"], fx["grid"], fx["df"], o, devices=[0, 0])
+        assert np.array_equal(got, ref), n
+    with pytest.raises(api.Is3dError) as e:
+        mp.execute(synth.synth_surface(20001, 3, seed=1))
+    assert e.value.code == api.IS3D_EINVAL
+    mp.close()
+
+
+@pytest.mark.parametrize("shards", [3, 4, 5, 8])
+def test_tree_sum_is_reproducible_and_matches_one_shard(fx, shards):
+    """IS3D_REDUCE_ORDERED is a fixed pairwise tree: bitwise reproducible for a given shard count, equal to the single-shard spectrum up
+    to the rounding of the different association, and equal to the host's own pairwise sum of the shard spectra in that order."""
+    cells = synth.synth_surface(shards * 130 + 3, 3, seed=40 + shards)
+    o = dict(dimension=3, df_mode=2)
+    one, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], o)
+    got, _, sh = api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], o, devices=[0] * shards)
+    again, _, _ = api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], o, devices=[0] * shards)
+    assert np.array_equal(got, again) and relerr(got, one) < 1e-13 and len(sh) == shards
+    parts = []
+    for r in range(shards):
+        lo, hi = api.shard_bounds(len(cells["tau"]), r, shards)
+        parts.append(api.smooth_spectra({k: v[lo:hi] for k, v in cells.items()}, fx["pikp"], fx["grid"], fx["df"], o)[0])
+    stride = 1
+    while stride < shards:
+        for i in range(0, shards - stride, 2 * stride):
+            parts[i] = parts[i] + parts[i + stride]
+        stride *= 2
+    assert np.array_equal(got, parts[0])
+
+
+def test_allreduce_error_word_and_refusals(fx):
+    """is3d_plan_execute_allreduce never leaves a peer waiting: a rank with an argument error still joins (zeros + error word), the
+    error word reaches is3d_comm_check, accumulate = 1 is refused in front of a collective, and an aborted communicator refuses
+    further use.  One rank here (a one-GPU box holds one RCCL rank); the first run with N > 1 RCCL ranks is the driver's SCALE run."""
+    import torch
+    dev = torch.device("cuda:0")
+    cells = synth.synth_surface(300, 3, seed=3)
+    o = dict(dimension=3, df_mode=2)
+    one, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], o)
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+    comm = api.Comm(api.Comm.unique_id(), 1, 0, 0)
+    assert comm.rank_seen() == (0, 1)
+    plan = api.Plan(fx["pikp"], fx["grid"], fx["df"], o, max_cells=300)
+    out = torch.full((plan.output_size,), 7.0, dtype=torch.float64, device=dev)
+    plan.execute_allreduce(300, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    comm.check(stream)                                   # clean
+    assert np.array_equal(out.cpu().numpy(), one) and comm.allreduce_ms() >= 0.0
+    # more cells than the plan holds: IS3D_EINVAL locally, the collective still happens with a neutral contribution
+    out.fill_(7.0)
+    with pytest.raises(api.Is3dError) as e:
+        plan.execute_allreduce(301, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    assert e.value.code == api.IS3D_EINVAL
+    torch.cuda.synchronize()
+    assert not out.cpu().numpy().any()
+    with pytest.raises(api.Is3dError) as e:
+        comm.check(stream)
+    assert e.value.code == api.IS3D_EPEER and e.value.n_failed == 1
+    comm.check(stream)                                   # cleared
+    # a domain error: the rank joins with what it could evaluate and returns its own code
+    tens["T"][17] = 0.3
+    with pytest.raises(api.Is3dError) as e:
+        plan.execute_allreduce(300, ptrs, out.data_ptr(), comm, stream)
+    assert e.value.code == api.IS3D_EDOMAIN and "cell 17" in str(e.value)
+    with pytest.raises(api.Is3dError) as e:
+        comm.check(stream)
+    assert e.value.code == api.IS3D_EPEER
+    tens["T"][17] = 0.15
+    plan.close()
+    # accumulate = 1 with a communicator
+    plan_acc = api.Plan(fx["pikp"], fx["grid"], fx["df"], dict(o, accumulate=1), max_cells=300)
+    with pytest.raises(api.Is3dError) as e:
+        plan_acc.execute_allreduce(300, ptrs, out.data_ptr(), comm, stream)
+    assert e.value.code == api.IS3D_EINVAL and "accumulate" in str(e.value)
+    plan_acc.execute_allreduce(300, ptrs, out.data_ptr(), None, stream)   # fine without one
+    plan_acc.close()
+    try:
+        comm.check(stream)
+    except api.Is3dError:
+        pass
+    # abort: the communicator refuses further use
+    plan = api.Plan(fx["pikp"], fx["grid"], fx["df"], o, max_cells=300)
+    comm.abort()
+    with pytest.raises(api.Is3dError) as e:
+        plan.execute_allreduce(300, ptrs, out.data_ptr(), comm, stream)
+    assert e.value.code == api.IS3D_ENODEVICE and "aborted" in str(e.value)
+    plan.close()
+    comm.close()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts the two rank processes itself (before it
+    imports torch), they share the one GPU through --backend gloo, and exactly one JSON line comes back -- strong scaling of ONE
+    surface (BASELINE config 4's shape: 2 x 1000 cells of a 2000-cell surface)."""
+    import json
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cells", "2000", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--no-clock-probe"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cells_total"] == 2000 and d["config"]["cells_per_gpu"] == 1000
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["cells"] for x in d["ranks"]] == [1000, 1000]
+    assert d["value"] > 0 and d["config"]["spectrum_finite"]

@@ -185,7 +185,9 @@ def test_odd_grids(fx):
     rng = np.random.default_rng(3)
     cells = synth.synth_surface(21, 3, seed=8)
     g = dict(pT=np.array([0.1, 0.7, 2.5]), phi=np.sort(rng.random(5) * 2 * np.pi), y=np.linspace(-2, 2, 5), eta=fx["grid"]["eta"], eta_w=fx["grid"]["eta_w"])
-    for ygrid in (np.linspace(-2, 2, 5), np.linspace(-3.5, 3.5, 29)):
+    # 41 and 67 rapidities: more than 32 rows in 3+1D -- cf_prep then runs 4-cell batches and must still reserve LDS for the unit-cull
+    # bounds behind the row arrays (prep_lds_bytes once sized them with K <= 32 while the kernel laid them out for p.dim3)
+    for ygrid in (np.linspace(-2, 2, 5), np.linspace(-3.5, 3.5, 29), np.linspace(-4, 4, 41), np.linspace(-5, 5, 67)):
         gg = dict(g, y=ygrid)
         for dfm in (1, 2):
             ref = oracle.dN_pTdpTdphidy(cells, fx["pikp"], gg, fx["df"], dict(dimension=3, df_mode=dfm))
