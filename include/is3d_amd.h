@@ -317,8 +317,8 @@ int is3d_comm_abort(is3d_comm *comm);
  * slowest rank).  Synchronises the closing event. */
 int is3d_comm_timings(is3d_comm *comm, double *ms_allreduce);
 
-/* Persistent form of is3d_smooth_spectra_multi: one plan, one workspace, one stream, pinned staging buffers and (IS3D_REDUCE_RCCL) the
- * communicator set per shard are created ONCE; every execute then only uploads its cells, runs the shards concurrently and sums the
+/* Persistent form of is3d_smooth_spectra_multi: one plan, one workspace, one stream, the device blocks for cells and spectrum and
+ * (IS3D_REDUCE_RCCL) the communicator set per shard are created ONCE; every execute then only uploads its cells, runs the shards concurrently and sums the
  * spectra.  max_cells bounds cells->n_cells of any execute.  The result of an execute is bitwise the one is3d_smooth_spectra_multi
  * returns for the same arguments. */
 typedef struct is3d_multi_plan is3d_multi_plan;
@@ -355,6 +355,60 @@ typedef struct {
 
 int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_species *species, const is3d_grid *grid,
                             const is3d_options *opts, double *dN_out, is3d_status *status);
+
+/* The anisotropic-hydro 14-moment coefficient tables deltaf_coefficients/vah/c{0..4}_vah1.dat.  src/cpp never loads them; the
+ * loader the reference has is the CUDA tree's load_df_coefficient_data, "df_mode == 4 // va hydro PL matching 14 moment"
+ * (src/cuda/deltafReader.cu:60-82 file names, :104-112 "n_Lambda\nn_alphaL\n" + one label line, :196-213 rows
+ * "Lambda [fm^-1]  alpha_L  value", alpha_L outer, Lambda inner).  Every table is [n_aL][n_L], Lambda fastest, file units. */
+typedef struct {
+    int32_t n_L, n_aL;
+    const double *L;                    /* Lambda nodes, fm^-1, ascending */
+    const double *aL;                   /* alpha_L nodes, ascending */
+    const double *c0, *c1, *c2, *c3, *c4;
+} is3d_vah_df_tables;
+/* Reads <dir>/c0_vah1.dat ... c4_vah1.dat (dir = "deltaf_coefficients/vah" in a run directory).  Two-call pattern: L == NULL ->
+ * only *n_L, *n_aL; otherwise L[n_L], aL[n_aL], c[5 * n_aL * n_L] (table k at c + k n_aL n_L), capacity in doubles of `c`.
+ * The node arrays are what the reference's scan leaves in L_array / aL_array (each row overwrites its entries; the c4 file is
+ * scanned last).  IS3D_EIO: a file is missing or short; IS3D_EINVAL: the five headers disagree or the nodes do not ascend. */
+int is3d_vah_df_read(const char *dir, int32_t *n_L, int32_t *n_aL, double *L, double *aL, double *c, int64_t capacity);
+/* Per-cell coefficients as src/cuda/deltafReader.cu:224-278 sets them, evaluated on the device (HOST pointers in and out; Lambda in
+ * GeV as the surface reader stores it, :228): the first alpha_L node i2 >= 1 with aL < aL[i2] and the first Lambda node i1 >= 1 with
+ * Lambda/hbarc < L[i1] select the cell of the grid; bilinear interpolation in (Lambda, alpha_L) -- which below the first node
+ * extrapolates, as the reference does -- and every coefficient divided by hbarc^3 (:262-266).  A cell with Lambda/hbarc >= L[n_L - 1]
+ * or aL >= aL[n_aL - 1] (or a NaN) finds no node: the reference leaves its c0..c4 unset there; this call returns IS3D_EDOMAIN with
+ * *bad_cell (may be NULL) = the lowest such index, and stores zeros for it.  c0..c4: n doubles each. */
+int is3d_vah_coefficients(const is3d_vah_df_tables *tab, int64_t n, const double *Lambda, const double *aL, double *c0, double *c1,
+                          double *c2, double *c3, double *c4, int32_t device, int64_t *bad_cell);
+/* is3d_smooth_spectra_vah with the coefficients taken from the tables: cells->c0..c4 are ignored (may be NULL), a device kernel
+ * interpolates them from (Lambda, aL) into the arrays the prep kernel reads.  IS3D_EDOMAIN + status->bad_cell for a cell outside
+ * the grid (see is3d_vah_coefficients).  tab == NULL: is3d_smooth_spectra_vah. */
+int is3d_smooth_spectra_vah_df(const is3d_vah_cells *cells, const is3d_species *species, const is3d_grid *grid,
+                               const is3d_vah_df_tables *tab, const is3d_options *opts, double *dN_out, is3d_status *status);
+
+/* Device-resident form (bench.py --workload config5, hosts whose surface is already in HBM): the plan holds the lane tables, the
+ * coefficient tables (tab may be NULL: cells->c0..c4 are then inputs) and the workspaces for up to max_cells cells per execute;
+ * cells->* and dN_out are DEVICE pointers on the plan's device, hip_stream a hipStream_t.  Asynchronous except for the status
+ * read-back when status != NULL.  is3d_vah_plan_timings: device time of the last execute's kernels (coefficients + prep in ms_prep,
+ * cf_main_vah in ms_main, reduction + species scatter in ms_finalize) when timing is enabled. */
+typedef struct is3d_vah_plan is3d_vah_plan;
+int is3d_vah_plan_create(is3d_vah_plan **plan, const is3d_species *species, const is3d_grid *grid, const is3d_vah_df_tables *tab,
+                         const is3d_options *opts, int64_t max_cells);
+int64_t is3d_vah_plan_output_size(const is3d_vah_plan *plan);
+int64_t is3d_vah_plan_workspace_bytes(const is3d_vah_plan *plan);
+int is3d_vah_plan_execute(is3d_vah_plan *plan, const is3d_vah_cells *cells, double *dN_out, void *hip_stream, is3d_status *status);
+int is3d_vah_plan_set_timing(is3d_vah_plan *plan, int32_t enable);
+int is3d_vah_plan_timings(is3d_vah_plan *plan, is3d_status *status);
+int is3d_vah_plan_tile_shape(const is3d_vah_plan *plan, int32_t *JT, int32_t *R);
+void is3d_vah_plan_destroy(is3d_vah_plan *plan);
+
+/* FO_data_reader::read_surf_VAH_PLMatch (mode 2; src/cpp/readindata.cpp:813-928): 31 numbers per cell -- tau x y eta | dat dax day
+ * dan | ut ux uy un | E T P PL | pitt pitx pity pitn pixx pixy pixn piyy piyn pinn | Wt Wx Wy Wn | bulkPi -- E, T, P, PL, pi, W and
+ * bulkPi multiplied by hbar*c, and the anisotropic variables inferred per cell: aL = aL_fit(PL/P), Lambda = T / (aL R200(aL) / 2)^(1/4)
+ * (src/cpp/arsenal.cpp:999-1065), Lambda stored in GeV.  PL/P >= 3 is fatal in the reference ("pl is too large", exit(-1)):
+ * IS3D_EINVAL naming the cell.  Two-call pattern as is3d_surface_read_vh (arrays == NULL -> only *n_cells).  arrays32: caller-allocated,
+ * in the order of is3d_vah_cells' first 25 members -- tau eta ux uy un dat dax day dan T pitt pitx pity pitn pixx pixy pixn piyy piyn
+ * pinn bulkPi Wx Wy Lambda aL -- then E P PL Wt Wn x y; the last seven may be NULL. */
+int is3d_surface_read_vah(const char *path, int32_t dimension, int64_t *n_cells, double *const *arrays32);
 
 /* ---------------------------------------------------------------------------------------------
  * Particle sampler (operation = 2): replaces EmissionFunctionArray::sample_dN_pTdpTdphidy

@@ -102,7 +102,10 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
            "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi",
            "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_multi_plan_create", "is3d_multi_plan_execute",
-           "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy"]
+           "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
+           "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
+           "is3d_vah_plan_workspace_bytes", "is3d_vah_plan_execute", "is3d_vah_plan_set_timing", "is3d_vah_plan_timings",
+           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
 IS3D_EPEER = -6
@@ -271,15 +274,33 @@ class VahCells(C.Structure):
     _fields_ = [("n_cells", C.c_int64)] + [(f, _dp) for f in VAH_FIELDS]
 
 
-def smooth_spectra_vah(cells, species, grid, opts=None, out=None):
-    """is3d_smooth_spectra_vah (the drop-in for calculate_dN_pTdpTdphidy_VAH_PL).  cells: dict of host arrays per VAH_FIELDS."""
-    L = load()
-    dummy_df = dict(T=[0.1, 0.15, 0.2], c0=[0, 0, 0], c2=[0, 0, 0], F=[0, 0, 0], betabulk=[1, 1, 1], betapi=[1, 1, 1])
-    sps, gs, _, os_, nout, keep = _pack_common(species, grid, dummy_df, opts)
-    n = len(cells["tau"])
+class VahDfTables(C.Structure):
+    _fields_ = [("n_L", C.c_int32), ("n_aL", C.c_int32), ("L", _dp), ("aL", _dp), ("c0", _dp), ("c1", _dp), ("c2", _dp), ("c3", _dp), ("c4", _dp)]
+
+
+def _pack_vah_tables(tab, keep):
+    """is3d_vah_df_tables from the dict of is3d_amd.inputs.vah_df_tables() / vah_df_read()."""
+    a = {k: _f64(tab[k]) for k in ("L", "aL", "c0", "c1", "c2", "c3", "c4")}
+    for k in ("c0", "c1", "c2", "c3", "c4"):
+        assert a[k].shape == (len(a["aL"]), len(a["L"])), k
+    keep["vah_tab"] = a
+    return VahDfTables(len(a["L"]), len(a["aL"]), _p(a["L"]), _p(a["aL"]), _p(a["c0"]), _p(a["c1"]), _p(a["c2"]), _p(a["c3"]), _p(a["c4"]))
+
+
+_VAH_DUMMY_DF = dict(T=[0.1, 0.15, 0.2], c0=[0, 0, 0], c2=[0, 0, 0], F=[0, 0, 0], betabulk=[1, 1, 1], betapi=[1, 1, 1])
+
+
+def _vah_cells_struct(cells, held, device=False):
     cs = VahCells()
+    if device:
+        cs.n_cells = int(cells["n_cells"])
+        for f in VAH_FIELDS:
+            p = cells.get(f)
+            if p:
+                setattr(cs, f, C.cast(C.c_void_p(int(p)), _dp))
+        return cs
+    n = len(cells["tau"])
     cs.n_cells = n
-    held = []
     for f in VAH_FIELDS:
         a = cells.get(f)
         if a is not None:
@@ -287,12 +308,139 @@ def smooth_spectra_vah(cells, species, grid, opts=None, out=None):
             assert a.shape == (n,), f
             held.append(a)
             setattr(cs, f, _p(a))
+    return cs
+
+
+def smooth_spectra_vah(cells, species, grid, opts=None, out=None, tab=None):
+    """is3d_smooth_spectra_vah (the drop-in for calculate_dN_pTdpTdphidy_VAH_PL).  cells: dict of host arrays per VAH_FIELDS.
+    tab (dict L, aL, c0..c4): is3d_smooth_spectra_vah_df -- the cells' c0..c4 are ignored, the coefficients come from the
+    (Lambda, alpha_L) tables (src/cuda/deltafReader.cu:224-278)."""
+    L = load()
+    sps, gs, _, os_, nout, keep = _pack_common(species, grid, _VAH_DUMMY_DF, opts)
+    held = []
+    if tab is not None:
+        cells = {k: v for k, v in cells.items() if k not in ("c0", "c1", "c2", "c3", "c4")}
+    cs = _vah_cells_struct(cells, held)
     if out is None:
         out = np.zeros(nout)
     st = Status()
     L.is3d_smooth_spectra_vah.argtypes = [C.POINTER(VahCells), C.POINTER(Species), C.POINTER(Grid), C.POINTER(Options), _dp, C.POINTER(Status)]
-    _check(L.is3d_smooth_spectra_vah(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(os_), _p(out), C.byref(st)))
+    L.is3d_smooth_spectra_vah_df.argtypes = [C.POINTER(VahCells), C.POINTER(Species), C.POINTER(Grid), C.POINTER(VahDfTables), C.POINTER(Options), _dp,
+                                             C.POINTER(Status)]
+    if tab is not None:
+        ts = _pack_vah_tables(tab, keep)
+        rc = L.is3d_smooth_spectra_vah_df(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(ts), C.byref(os_), _p(out), C.byref(st))
+    else:
+        rc = L.is3d_smooth_spectra_vah(C.byref(cs), C.byref(sps), C.byref(gs), C.byref(os_), _p(out), C.byref(st))
+    if rc != 0:
+        raise Is3dError(rc, L.is3d_last_error().decode(), bad_cell=st.bad_cell)
     return out, st.as_dict()
+
+
+def vah_coefficients(tab, Lambda, aL, device=-1):
+    """is3d_vah_coefficients: per-cell c0..c4 (divided by hbarc^3) from the tables, evaluated on the device.  Lambda in GeV.
+    Raises Is3dError(IS3D_EDOMAIN) with .bad_cell and .values (zeros at the offending cells) for a cell beyond the last node."""
+    L = load()
+    keep = {}
+    ts = _pack_vah_tables(tab, keep)
+    lam, al = _f64(Lambda), _f64(aL)
+    n = len(lam)
+    out = [np.zeros(n) for _ in range(5)]
+    bad = C.c_int64(-1)
+    L.is3d_vah_coefficients.argtypes = [C.POINTER(VahDfTables), C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_int64)]
+    rc = L.is3d_vah_coefficients(C.byref(ts), n, _p(lam), _p(al), *[_p(x) for x in out], int(device), C.byref(bad))
+    vals = {"c%d" % k: out[k] for k in range(5)}
+    if rc != 0:
+        e = Is3dError(rc, L.is3d_last_error().decode(), bad_cell=bad.value)
+        e.values = vals
+        raise e
+    return vals
+
+
+def vah_df_read(directory):
+    """is3d_vah_df_read: <dir>/c{0..4}_vah1.dat -> dict L, aL, c0..c4 ([n_aL][n_L])."""
+    L = load()
+    nL, naL = C.c_int32(), C.c_int32()
+    L.is3d_vah_df_read.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, C.c_int64]
+    _check(L.is3d_vah_df_read(directory.encode(), C.byref(nL), C.byref(naL), None, None, None, 0))
+    Lg, ag, c = np.zeros(nL.value), np.zeros(naL.value), np.zeros((5, naL.value, nL.value))
+    _check(L.is3d_vah_df_read(directory.encode(), C.byref(nL), C.byref(naL), _p(Lg), _p(ag), _p(c), c.size))
+    d = dict(L=Lg, aL=ag)
+    for k in range(5):
+        d["c%d" % k] = c[k].copy()
+    return d
+
+
+VAH_SURFACE_ORDER = VAH_FIELDS[:25] + ["E", "P", "PL", "Wt", "Wn", "x", "y"]
+
+
+def surface_read_vah(path, dimension=3):
+    """is3d_surface_read_vah (mode 2, read_surf_VAH_PLMatch) -> dict of the 32 arrays of VAH_SURFACE_ORDER."""
+    L = load()
+    n = C.c_int64(0)
+    L.is3d_surface_read_vah.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(_dp)]
+    _check(L.is3d_surface_read_vah(path.encode(), int(dimension), C.byref(n), None))
+    arrs = {f: np.zeros(n.value) for f in VAH_SURFACE_ORDER}
+    ptrs = (_dp * 32)(*[_p(arrs[f]) for f in VAH_SURFACE_ORDER])
+    if n.value > 0:
+        _check(L.is3d_surface_read_vah(path.encode(), int(dimension), C.byref(n), ptrs))
+    return arrs
+
+
+class VahPlan:
+    """Device-resident VAH plan (is3d_vah_plan_*): cell arrays and the output are device pointers (ints); with `tab` the
+    coefficients are interpolated on the device from (Lambda, aL) and c0..c4 need not be given."""
+
+    def __init__(self, species, grid, opts=None, tab=None, max_cells=1):
+        L = load()
+        sps, gs, _, os_, self.output_size, self._keep = _pack_common(species, grid, _VAH_DUMMY_DF, opts)
+        ts = _pack_vah_tables(tab, self._keep) if tab is not None else None
+        L.is3d_vah_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(Grid), C.POINTER(VahDfTables), C.POINTER(Options), C.c_int64]
+        L.is3d_vah_plan_execute.argtypes = [C.c_void_p, C.POINTER(VahCells), C.c_void_p, C.c_void_p, C.POINTER(Status)]
+        L.is3d_vah_plan_timings.argtypes = [C.c_void_p, C.POINTER(Status)]
+        L.is3d_vah_plan_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.is3d_vah_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.is3d_vah_plan_output_size.argtypes = [C.c_void_p]
+        L.is3d_vah_plan_output_size.restype = C.c_int64
+        L.is3d_vah_plan_workspace_bytes.argtypes = [C.c_void_p]
+        L.is3d_vah_plan_workspace_bytes.restype = C.c_int64
+        L.is3d_vah_plan_destroy.argtypes = [C.c_void_p]
+        L.is3d_vah_plan_destroy.restype = None
+        self._h = C.c_void_p()
+        _check(L.is3d_vah_plan_create(C.byref(self._h), C.byref(sps), C.byref(gs), C.byref(ts) if ts is not None else None, C.byref(os_), int(max_cells)))
+        assert L.is3d_vah_plan_output_size(self._h) == self.output_size
+        self.workspace_bytes = L.is3d_vah_plan_workspace_bytes(self._h)
+        jt, r = C.c_int32(), C.c_int32()
+        L.is3d_vah_plan_tile_shape(self._h, C.byref(jt), C.byref(r))
+        self.tile_shape = (jt.value, r.value)
+        self.main_kernel_name = "cf_main_vah"
+
+    def set_timing(self, enable=True):
+        _check(load().is3d_vah_plan_set_timing(self._h, 1 if enable else 0))
+
+    def execute(self, n_cells, cell_ptrs, out_ptr, stream=0, want_status=True):
+        cs = _vah_cells_struct(dict(cell_ptrs, n_cells=n_cells), None, device=True)
+        st = Status()
+        rc = load().is3d_vah_plan_execute(self._h, C.byref(cs), C.c_void_p(int(out_ptr)), C.c_void_p(int(stream or 0)), C.byref(st) if want_status else None)
+        if rc != 0:
+            raise Is3dError(rc, load().is3d_last_error().decode(), bad_cell=st.bad_cell)
+        return st.as_dict() if want_status else None
+
+    def timings(self):
+        st = Status()
+        _check(load().is3d_vah_plan_timings(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            load().is3d_vah_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _pack_feqmod(fq, keep):

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/is3d_amd.h"
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
 template <bool DIM3, bool REG, int JT, int R>
 __global__ void __launch_bounds__(512)
 cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
-            const double *__restrict__ lane_sign, double *__restrict__ partial, MainGeom g)
+            const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g)
 {
     constexpr int HDR = 4 * JT;
     constexpr int RW = 4 + 2 * JT;
@@ -221,6 +222,7 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+    int n_rows = 0, n_dead = 0;
 
     auto process_unit = [&](const double *U) {
         double pTB[JT], gx[JT], gd[JT];
@@ -244,7 +246,8 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
                 X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], ax + gx[jj]);
                 x2min = __builtin_fmin(x2min, X2[jj]);
             }
-            if (g.zskip && __all(x2min > 555400.0)) return;   // E_a/Lambda > 745.25: f_a == +0 for the whole wave-row
+            n_rows += 1;
+            if (g.zskip && __all(x2min > 555400.0)) { n_dead += 1; return; }   // E_a/Lambda > 745.25: f_a == +0 for the whole wave-row
 #pragma unroll
             for (int j0 = 0; j0 < JT; j0 += RB) {   // one v_rcp_f64 per RB evaluations (rcp_batch, cf_math.h)
                 double zz[RB], d[RB], inv[RB];
@@ -313,6 +316,10 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
         }
     }
     if (!wave_active) return;
+    if ((tid & 63) == 0) {
+        atomicAdd(&stats[2], (unsigned long long)n_rows);
+        atomicAdd(&stats[3], (unsigned long long)n_dead);
+    }
     const double unscale = REG ? 2.0 : 1.0;
     const int64_t JKacc = (int64_t)J * g.Kacc;
     double *pp = partial + (int64_t)chunk * JKacc * g.Lpad;
@@ -333,6 +340,62 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-cell 14-moment coefficients from the (Lambda, alpha_L) tables: src/cuda/deltafReader.cu:224-278.  The reference scans
+// i2 (alpha_L) outer, i1 (Lambda) inner for the first pair with i1 > 0 && Lambda < L[i1] && i2 > 0 && aL < aL[i2]: the two conditions
+// are independent, so that is the first i2 >= 1 with aL < aL[i2] and the first i1 >= 1 with Lambda < L[i1] (ascending nodes: an
+// upper bound, at least 1 -- below the first node the bilinear form extrapolates, as in the reference).  No such node: the reference
+// leaves the cell's c0..c4 unset; here the cell is reported (status[0] = lowest index) and gets zeros.  The arithmetic is the
+// reference's expression with every rounding written out (no contraction), so that the values agree with a host evaluation bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct VahCoefArgs {
+    int64_t n, cell0;                   // cells in this launch; index of the first one in the caller's arrays (for the report)
+    const double *Lambda, *aL;          // per cell: GeV, 1
+    int32_t nL, naL;
+    const double *L, *aLg, *tab[5];     // nodes (fm^-1, 1) and tables [naL][nL]
+    double *out[5];
+    unsigned long long *status;         // [0] min bad cell
+};
+
+__device__ __forceinline__ int first_node_above(const double *g, int n, double x)   // first i >= 1 with x < g[i], or n
+{
+    int lo = 1, hi = n;                 // invariant: every i in [1, lo) has !(x < g[i])
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (x < g[mid]) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) cf_vah_coeffs(VahCoefArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const double aL = a.aL[i];
+    const double Lam = __ddiv_rn(a.Lambda[i], kHbarC);                    // :228
+    const int i1 = first_node_above(a.L, a.nL, Lam), i2 = first_node_above(a.aLg, a.naL, aL);
+    if (i1 >= a.nL || i2 >= a.naL) {                                      // includes NaN: every comparison fails
+#pragma unroll
+        for (int k = 0; k < 5; k++) a.out[k][i] = 0.0;
+        atomicMin(a.status, (unsigned long long)(a.cell0 + i));
+        return;
+    }
+    const double L1 = a.L[i1 - 1], L2 = a.L[i1], A1 = a.aLg[i2 - 1], A2 = a.aLg[i2];
+    const double dL2 = __dsub_rn(L2, Lam), dL1 = __dsub_rn(Lam, L1), dA2 = __dsub_rn(A2, aL), dA1 = __dsub_rn(aL, A1);
+    const double den = __dmul_rn(__dsub_rn(A2, A1), __dsub_rn(L2, L1));
+    const double hbarC3 = __dmul_rn(__dmul_rn(kHbarC, kHbarC), kHbarC);   // :219
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const double *t = a.tab[k];
+        const double c00 = t[(i2 - 1) * a.nL + i1 - 1], c10 = t[(i2 - 1) * a.nL + i1], c01 = t[i2 * a.nL + i1 - 1], c11 = t[i2 * a.nL + i1];
+        const double lo = __dadd_rn(__dmul_rn(c00, dL2), __dmul_rn(c10, dL1));   // (c[i1-1][i2-1] (L2 - L) + c[i1][i2-1] (L - L1))
+        const double hi = __dadd_rn(__dmul_rn(c01, dL2), __dmul_rn(c11, dL1));
+        const double v = __ddiv_rn(__dadd_rn(__dmul_rn(lo, dA2), __dmul_rn(hi, dA1)), den);
+        a.out[k][i] = __ddiv_rn(v, hbarC3);                                       // :262-266
+    }
+}
+
 }  // namespace is3d
 
 namespace {
@@ -345,7 +408,8 @@ namespace {
 
 struct DevMem {
     void *p = nullptr;
-    hipError_t alloc(size_t bytes) { release(); return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+    size_t bytes = 0;
+    hipError_t alloc(size_t b) { release(); bytes = b; return b ? hipMalloc(&p, b) : hipSuccess; }
     template <class T>
     hipError_t upload(const std::vector<T> &h)
     {
@@ -353,7 +417,13 @@ struct DevMem {
         if (e != hipSuccess || h.empty()) return e;
         return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    hipError_t upload(const double *h, size_t n)
+    {
+        hipError_t e = alloc(n * sizeof(double));
+        if (e != hipSuccess || !n) return e;
+        return hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
     ~DevMem() { release(); }
     template <class T> T *as() const { return (T *)p; }
 };
@@ -361,44 +431,102 @@ struct DevMem {
 constexpr int kJT3 = 6, kR3 = 7, kJT2 = 8, kR2 = 61;   // the default tile shapes of the delta-f kernel
 
 template <bool DIM3>
-void launch_vah(bool reg, const double *TS, const double *mT, const double *pT, const double *sg, double *partial, const is3d::MainGeom &g)
+void launch_vah(bool reg, const double *TS, const double *mT, const double *pT, const double *sg, double *partial, unsigned long long *stats,
+                const is3d::MainGeom &g, hipStream_t st)
 {
     const int grid = ((g.NT + 7) / 8) * 8 * g.G;
     constexpr int JT = DIM3 ? kJT3 : kJT2, R = DIM3 ? kR3 : kR2;
-    if (reg) hipLaunchKernelGGL((is3d::cf_main_vah<DIM3, true, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, nullptr, TS, mT, pT, sg, partial, g);
-    else hipLaunchKernelGGL((is3d::cf_main_vah<DIM3, false, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, nullptr, TS, mT, pT, sg, partial, g);
+    if (reg) hipLaunchKernelGGL((is3d::cf_main_vah<DIM3, true, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g);
+    else hipLaunchKernelGGL((is3d::cf_main_vah<DIM3, false, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g);
 }
+
+int check_tables(const is3d_vah_df_tables *t)
+{
+    using is3d::set_error;
+    if (t->n_L < 2 || t->n_aL < 2 || !t->L || !t->aL || !t->c0 || !t->c1 || !t->c2 || !t->c3 || !t->c4)
+        return set_error(IS3D_EINVAL, "VAH coefficient tables need >= 2 x 2 nodes and all five tables");
+    for (int i = 1; i < t->n_L; i++)
+        if (!(t->L[i] > t->L[i - 1])) return set_error(IS3D_EINVAL, "VAH coefficient tables: Lambda nodes must ascend");
+    for (int i = 1; i < t->n_aL; i++)
+        if (!(t->aL[i] > t->aL[i - 1])) return set_error(IS3D_EINVAL, "VAH coefficient tables: alpha_L nodes must ascend");
+    return IS3D_OK;
+}
+
+// device copy of the coefficient tables
+struct TabDev {
+    DevMem L, aL, c;
+    int nL = 0, naL = 0;
+    int upload(const is3d_vah_df_tables *t)
+    {
+        nL = t->n_L; naL = t->n_aL;
+        const size_t n = (size_t)nL * naL;
+        std::vector<double> all(5 * n);
+        const double *src[5] = {t->c0, t->c1, t->c2, t->c3, t->c4};
+        for (int k = 0; k < 5; k++) memcpy(all.data() + k * n, src[k], n * sizeof(double));
+        VAH_TRY(L.upload(t->L, (size_t)nL));
+        VAH_TRY(aL.upload(t->aL, (size_t)naL));
+        VAH_TRY(c.upload(all));
+        return IS3D_OK;
+    }
+    void fill(is3d::VahCoefArgs &a) const
+    {
+        a.nL = nL; a.naL = naL; a.L = L.as<double>(); a.aLg = aL.as<double>();
+        for (int k = 0; k < 5; k++) a.tab[k] = c.as<double>() + (size_t)k * nL * naL;
+    }
+};
 
 }  // namespace
 
-extern "C" int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_species *sp, const is3d_grid *gr, const is3d_options *o,
-                                       double *dN_out, is3d_status *status)
+struct is3d_vah_plan {
+    is3d_options o{};
+    int device = 0;
+    bool three_d = true, tables = false, timing = false;
+    int npart = 0, npT = 0, J = 0, K = 0, Kacc = 1, ncls = 0, Lpad = 0;
+    int JT = 0, R = 0, jtiles = 0, rblocks = 0, ktiles = 0, upc = 0, REC = 0, wpb = 4, nch = 1;
+    int64_t nout = 0, max_cells = 0, pass_cells = 0;
+    size_t lds_prep = 0;
+    DevMem d_mT, d_pT, d_sg, d_lane, d_deg, d_cos, d_sin, d_kg, d_kw, d_TS, d_partial, d_coef, d_status;
+    TabDev tab;
+    std::vector<hipEvent_t> ev;   // [pass][0..2]: start, after coefficients + prep, after main; last: after finalize
+    int last_passes = 0;
+
+    ~is3d_vah_plan()
+    {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp, const is3d_grid *gr, const is3d_vah_df_tables *tab,
+                                    const is3d_options *o, int64_t max_cells)
 {
     using is3d::set_error;
-    if (!cells || !sp || !gr || !o || !dN_out) return set_error(IS3D_EINVAL, "null argument");
-    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
+    if (!out) return set_error(IS3D_EINVAL, "null plan pointer");
+    *out = nullptr;
+    if (!sp || !gr || !o) return set_error(IS3D_EINVAL, "null argument");
     if (o->dimension != 2 && o->dimension != 3) return set_error(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", o->dimension);
     if (sp->n < 1 || !sp->mass || !sp->sign || !sp->degeneracy) return set_error(IS3D_EINVAL, "empty species list");
     if (gr->n_pT < 1 || gr->n_phi < 1 || !gr->pT || !gr->phi) return set_error(IS3D_EINVAL, "empty pT/phi grid");
     const bool three_d = o->dimension == 3;
     if (three_d && (gr->n_y < 1 || !gr->y)) return set_error(IS3D_EINVAL, "dimension 3 needs a y grid");
     if (!three_d && (gr->n_eta < 2 || !gr->eta || !gr->eta_w)) return set_error(IS3D_EINVAL, "dimension 2 needs an eta table of >= 2 nodes");
-    const int64_t n = cells->n_cells;
-    if (n < 0 || n > 0x7fff0000LL) return set_error(IS3D_EINVAL, "n_cells out of range");
-    const double *src[30] = {cells->tau, cells->eta, cells->ux, cells->uy, cells->un, cells->dat, cells->dax, cells->day, cells->dan, cells->T,
-                             cells->pitt, cells->pitx, cells->pity, cells->pitn, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn,
-                             cells->pinn, cells->bulkPi, cells->Wx, cells->Wy, cells->Lambda, cells->aL, cells->c0, cells->c1, cells->c2,
-                             cells->c3, cells->c4};
-    if (n > 0)
-        for (int a = 0; a < 30; a++)
-            if (!src[a] && !(a == 1 && !three_d) && a != 9) return set_error(IS3D_EINVAL, "a required VAH cell array is NULL (index %d)", a);
+    if (tab)
+        if (int rc = check_tables(tab)) return rc;
+    if (max_cells < 1) max_cells = 1;
+    if (max_cells > 0x7fff0000LL) return set_error(IS3D_EINVAL, "max_cells out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    std::unique_ptr<is3d_vah_plan> P(new is3d_vah_plan);
+    P->o = *o;
     if (o->device >= 0) VAH_TRY(hipSetDevice(o->device));
+    VAH_TRY(hipGetDevice(&P->device));
+    P->three_d = three_d;
+    P->max_cells = max_cells;
 
     // ---- species classes and lanes sorted by mT (as cf_plan.cpp) ----
     const int npart = sp->n, npT = gr->n_pT, J = gr->n_phi, K = three_d ? gr->n_y : gr->n_eta, Kacc = three_d ? K : 1;
-    const int64_t nout = (int64_t)npart * npT * J * Kacc;
+    P->npart = npart; P->npT = npT; P->J = J; P->K = K; P->Kacc = Kacc;
+    P->nout = (int64_t)npart * npT * J * Kacc;
     std::vector<int> cls(npart);
     std::vector<double> cmass, csign;
     for (int s = 0; s < npart; s++) {
@@ -410,6 +538,7 @@ extern "C" int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_s
         cls[s] = found;
     }
     const int ncls = (int)cmass.size(), L = ncls * npT, Lpad = ((L + 63) / 64) * 64;
+    P->ncls = ncls; P->Lpad = Lpad;
     std::vector<double> mT(Lpad, 1.0), pT(Lpad, 0.0), sg(Lpad, 1.0), mT_nat(L);
     std::vector<int> order(L), slot_of(L), lane_sp((size_t)npart * npT);
     for (int c = 0; c < ncls; c++)
@@ -424,83 +553,261 @@ extern "C" int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_s
         kgrid[k] = three_d ? gr->y[k] : gr->eta[k];
         if (!three_d) kweight[k] = gr->eta_w[k] * (gr->eta[1] - gr->eta[0]);          // :2178-2187
     }
-    if (status) status->n_classes = ncls;
-    if (n == 0) {
-        if (!o->accumulate) memset(dN_out, 0, sizeof(double) * (size_t)nout);
-        return IS3D_OK;
+    VAH_TRY(P->d_mT.upload(mT)); VAH_TRY(P->d_pT.upload(pT)); VAH_TRY(P->d_sg.upload(sg)); VAH_TRY(P->d_lane.upload(lane_sp)); VAH_TRY(P->d_deg.upload(deg));
+    VAH_TRY(P->d_cos.upload(cosphi)); VAH_TRY(P->d_sin.upload(sinphi)); VAH_TRY(P->d_kg.upload(kgrid)); VAH_TRY(P->d_kw.upload(kweight));
+    if (tab) {
+        if (int rc = P->tab.upload(tab)) return rc;
+        P->tables = true;
+        VAH_TRY(P->d_coef.alloc(sizeof(double) * 5 * (size_t)max_cells));
     }
-    DevMem d_mT, d_pT, d_sg, d_lane, d_deg, d_cos, d_sin, d_kg, d_kw, d_cell[30], d_TS, d_partial, d_out;
-    VAH_TRY(d_mT.upload(mT)); VAH_TRY(d_pT.upload(pT)); VAH_TRY(d_sg.upload(sg)); VAH_TRY(d_lane.upload(lane_sp)); VAH_TRY(d_deg.upload(deg));
-    VAH_TRY(d_cos.upload(cosphi)); VAH_TRY(d_sin.upload(sinphi)); VAH_TRY(d_kg.upload(kgrid)); VAH_TRY(d_kw.upload(kweight));
+    P->JT = three_d ? kJT3 : kJT2; P->R = three_d ? kR3 : kR2;
+    P->jtiles = (J + P->JT - 1) / P->JT; P->rblocks = (K + P->R - 1) / P->R;
+    P->ktiles = three_d ? P->rblocks : 1; P->upc = three_d ? 1 : P->rblocks;
+    P->REC = 4 * P->JT + P->R * (4 + 2 * P->JT);
+    P->lds_prep = sizeof(is3d::VahScal) * is3d::kVahCB + sizeof(double) * (size_t)is3d::kVahCB * (9 * K + 7 * J);
+    if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
+    // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
+    const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
+    const int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
+    P->pass_cells = std::max<int64_t>(1, std::min<int64_t>(max_cells, ws / (int64_t)bytes_per_cell));
+    const int lane_waves = Lpad / 64;
+    int best = 1 << 30;
+    for (int w : {8, 4, 2}) { const int waste = ((lane_waves + w - 1) / w) * w - lane_waves; if (waste < best) { best = waste; P->wpb = w; } }
+    int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24LL * 4096 + (int64_t)lane_waves * P->jtiles * P->ktiles - 1) / ((int64_t)lane_waves * P->jtiles * P->ktiles);
+    nch = std::min<int64_t>(nch, std::max<int64_t>(1, P->pass_cells / 64));
+    nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)2 << 30) / ((int64_t)J * Kacc * Lpad * 8)));
+    P->nch = (int)nch;
+    VAH_TRY(P->d_TS.alloc((size_t)P->pass_cells * bytes_per_cell + 64 * 1024));   // + slack: the staging pieces of the last batch over-read the stream
+    VAH_TRY(P->d_partial.alloc((size_t)nch * J * Kacc * Lpad * sizeof(double)));
+    VAH_TRY(P->d_status.alloc(8 * sizeof(unsigned long long)));
+    *out = P.release();
+    return IS3D_OK;
+}
+
+extern "C" int64_t is3d_vah_plan_output_size(const is3d_vah_plan *P) { return P ? P->nout : 0; }
+extern "C" int64_t is3d_vah_plan_workspace_bytes(const is3d_vah_plan *P) { return P ? (int64_t)(P->d_TS.bytes + P->d_partial.bytes + P->d_coef.bytes) : 0; }
+extern "C" int is3d_vah_plan_set_timing(is3d_vah_plan *P, int32_t enable)
+{
+    if (!P) return is3d::set_error(IS3D_EINVAL, "null plan");
+    P->timing = enable != 0;
+    return IS3D_OK;
+}
+extern "C" int is3d_vah_plan_tile_shape(const is3d_vah_plan *P, int32_t *JT, int32_t *R)
+{
+    if (!P || !JT || !R) return is3d::set_error(IS3D_EINVAL, "null argument");
+    *JT = P->JT; *R = P->R;
+    return IS3D_OK;
+}
+extern "C" void is3d_vah_plan_destroy(is3d_vah_plan *P)
+{
+    if (!P) return;
+    (void)hipSetDevice(P->device);
+    delete P;
+}
+
+extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cells, double *dN_out, void *hip_stream, is3d_status *status)
+{
+    using is3d::set_error;
+    if (!P || !cells || !dN_out) return set_error(IS3D_EINVAL, "null argument");
+    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; status->n_classes = P->ncls; }
+    const int64_t n = cells->n_cells;
+    if (n < 0 || n > P->max_cells) return set_error(IS3D_EINVAL, "n_cells = %lld exceeds the plan's max_cells = %lld", (long long)n, (long long)P->max_cells);
+    const double *src[30] = {cells->tau, cells->eta, cells->ux, cells->uy, cells->un, cells->dat, cells->dax, cells->day, cells->dan, cells->T,
+                             cells->pitt, cells->pitx, cells->pity, cells->pitn, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn,
+                             cells->pinn, cells->bulkPi, cells->Wx, cells->Wy, cells->Lambda, cells->aL, cells->c0, cells->c1, cells->c2,
+                             cells->c3, cells->c4};
+    if (n > 0)
+        for (int a = 0; a < 30; a++)
+            if (!src[a] && !(a == 1 && !P->three_d) && a != 9 && !(a >= 25 && P->tables))
+                return set_error(IS3D_EINVAL, "a required VAH cell array is NULL (index %d)", a);
+    hipStream_t st = (hipStream_t)hip_stream;
+    VAH_TRY(hipSetDevice(P->device));
+    const is3d_options &o = P->o;
+    const int npasses = n == 0 ? 0 : (int)((n + P->pass_cells - 1) / P->pass_cells);
+    if (P->timing)
+        while (P->ev.size() < (size_t)npasses * 3 + 1) {
+            hipEvent_t e;
+            VAH_TRY(hipEventCreate(&e));
+            P->ev.push_back(e);
+        }
+    P->last_passes = npasses;
+    unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0, ~0ULL};
+    unsigned long long *d_st = P->d_status.as<unsigned long long>();
+    VAH_TRY(hipMemcpyAsync(d_st, init, sizeof init, hipMemcpyHostToDevice, st));
+    if (n == 0) {
+        if (!o.accumulate) VAH_TRY(hipMemsetAsync(dN_out, 0, (size_t)P->nout * sizeof(double), st));
+    }
+    const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(P->nch, std::min<int64_t>(n, P->pass_cells) / 64));
+    for (int pass = 0; pass < npasses; pass++) {
+        const int64_t c0 = (int64_t)pass * P->pass_cells;
+        const int32_t nc = (int32_t)std::min<int64_t>(P->pass_cells, n - c0);
+        const double *q[30];
+        for (int a = 0; a < 30; a++) q[a] = src[a] ? src[a] + c0 : nullptr;
+        if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 0], st));
+        if (P->tables) {
+            is3d::VahCoefArgs ca{};
+            ca.n = nc; ca.Lambda = q[23]; ca.aL = q[24];
+            P->tab.fill(ca);
+            for (int k = 0; k < 5; k++) { ca.out[k] = P->d_coef.as<double>() + (size_t)k * P->max_cells + c0; q[25 + k] = ca.out[k]; }
+            ca.status = d_st;
+            ca.cell0 = c0;
+            hipLaunchKernelGGL(is3d::cf_vah_coeffs, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, ca);
+            VAH_TRY(hipGetLastError());
+        }
+        is3d::VahPrepParams pp{};
+        pp.cells = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[10], q[11], q[12], q[13], q[14], q[15], q[16], q[17], q[18], q[19],
+                    q[20], q[21], q[22], q[23], q[24], q[25], q[26], q[27], q[28], q[29]};
+        pp.n_cells = nc; pp.J = P->J; pp.K = P->K; pp.dim3 = P->three_d;
+        pp.include_bulk = o.include_bulk_deltaf != 0; pp.include_shear = o.include_shear_deltaf != 0;
+        pp.cosphi = P->d_cos.as<double>(); pp.sinphi = P->d_sin.as<double>(); pp.kgrid = P->d_kg.as<double>(); pp.kweight = P->d_kw.as<double>();
+        pp.JT = P->JT; pp.R = P->R; pp.jtiles = P->jtiles; pp.rblocks = P->rblocks; pp.TS = P->d_TS.as<double>();
+        const int nbatch = (nc + is3d::kVahCB - 1) / is3d::kVahCB;
+        hipLaunchKernelGGL(is3d::cf_prep_vah, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), P->lds_prep, st, pp);
+        VAH_TRY(hipGetLastError());
+        if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 1], st));
+        is3d::MainGeom g{};
+        g.n_cells = nc; g.J = P->J; g.K = P->K; g.Lpad = P->Lpad; g.wpb = P->wpb; g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
+        g.jtiles = P->jtiles; g.ktiles = P->ktiles; g.nch = nch; g.NT = P->jtiles * P->ktiles * nch; g.Kacc = P->Kacc;
+        g.first_pass = 1; g.upc = P->upc; g.zskip = (o.zero_skip != 2); g.baryon = 0;
+        if (P->three_d) launch_vah<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
+        else launch_vah<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
+        VAH_TRY(hipGetLastError());
+        if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 2], st));
+        // each pass finalises into the output (accumulating after the first): the partial slots are rewritten per pass
+        const double prefactor = 1.0 / (8.0 * (M_PI * M_PI * M_PI)) / is3d::kHbarC / is3d::kHbarC / is3d::kHbarC;   // :2147
+        VAH_TRY(is3d::launch_finalize(P->d_partial.as<double>(), P->d_lane.as<int>(), P->d_deg.as<double>(), dN_out, P->nout, P->npart, P->npT, P->J,
+                                      P->Kacc, P->Lpad, nch, prefactor, (pass > 0 || o.accumulate) ? 1 : 0, nullptr, st));
+    }
+    if (P->timing && npasses) VAH_TRY(hipEventRecord(P->ev[npasses * 3], st));
+    if (status) {
+        unsigned long long h[8];
+        VAH_TRY(hipMemcpyAsync(h, d_st, sizeof h, hipMemcpyDeviceToHost, st));
+        VAH_TRY(hipStreamSynchronize(st));
+        status->n_passes = npasses;
+        status->kernel_variant = 2;
+        status->n_wave_rows = (int64_t)h[2];
+        status->n_wave_rows_culled = (int64_t)h[3];
+        if (h[0] != ~0ULL) {
+            status->bad_cell = (int64_t)h[0];
+            status->code = IS3D_EDOMAIN;
+            return set_error(IS3D_EDOMAIN, "cell %lld: (Lambda, alpha_L) beyond the last node of the VAH coefficient tables (the reference leaves the "
+                             "cell's c0..c4 unset there, src/cuda/deltafReader.cu:237-276)", (long long)status->bad_cell);
+        }
+    }
+    return IS3D_OK;
+}
+
+extern "C" int is3d_vah_plan_timings(is3d_vah_plan *P, is3d_status *status)
+{
+    if (!P || !status) return is3d::set_error(IS3D_EINVAL, "null argument");
+    status->ms_prep = status->ms_main = status->ms_finalize = 0.0;
+    if (!P->timing || P->last_passes == 0) return IS3D_OK;
+    VAH_TRY(hipSetDevice(P->device));
+    VAH_TRY(hipEventSynchronize(P->ev[P->last_passes * 3]));
+    for (int pass = 0; pass < P->last_passes; pass++) {
+        float a = 0, b = 0, c = 0;
+        VAH_TRY(hipEventElapsedTime(&a, P->ev[pass * 3 + 0], P->ev[pass * 3 + 1]));
+        VAH_TRY(hipEventElapsedTime(&b, P->ev[pass * 3 + 1], P->ev[pass * 3 + 2]));
+        VAH_TRY(hipEventElapsedTime(&c, P->ev[pass * 3 + 2], P->ev[pass * 3 + 3]));   // the next pass's start, or the closing event
+        status->ms_prep += a; status->ms_main += b; status->ms_finalize += c;
+    }
+    status->n_passes = P->last_passes;
+    status->kernel_variant = 2;
+    status->n_classes = P->ncls;
+    return IS3D_OK;
+}
+
+extern "C" int is3d_vah_coefficients(const is3d_vah_df_tables *tab, int64_t n, const double *Lambda, const double *aL, double *c0, double *c1,
+                                     double *c2, double *c3, double *c4, int32_t device, int64_t *bad_cell)
+{
+    using is3d::set_error;
+    if (bad_cell) *bad_cell = -1;
+    if (!tab || n < 0 || (n > 0 && (!Lambda || !aL || !c0 || !c1 || !c2 || !c3 || !c4))) return set_error(IS3D_EINVAL, "null argument");
+    if (int rc = check_tables(tab)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (n == 0) return IS3D_OK;
+    if (device >= 0) VAH_TRY(hipSetDevice(device));
+    TabDev td;
+    if (int rc = td.upload(tab)) return rc;
+    DevMem d_in, d_out, d_st;
+    VAH_TRY(d_in.alloc(sizeof(double) * 2 * (size_t)n));
+    VAH_TRY(d_out.alloc(sizeof(double) * 5 * (size_t)n));
+    VAH_TRY(d_st.alloc(sizeof(unsigned long long)));
+    const unsigned long long init = ~0ULL;
+    VAH_TRY(hipMemcpy(d_st.p, &init, sizeof init, hipMemcpyHostToDevice));
+    VAH_TRY(hipMemcpy(d_in.p, Lambda, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    VAH_TRY(hipMemcpy(d_in.as<double>() + n, aL, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    is3d::VahCoefArgs ca{};
+    ca.n = n; ca.Lambda = d_in.as<double>(); ca.aL = d_in.as<double>() + n;
+    td.fill(ca);
+    for (int k = 0; k < 5; k++) ca.out[k] = d_out.as<double>() + (size_t)k * n;
+    ca.status = d_st.as<unsigned long long>();
+    hipLaunchKernelGGL(is3d::cf_vah_coeffs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, ca);
+    VAH_TRY(hipGetLastError());
+    double *dst[5] = {c0, c1, c2, c3, c4};
+    for (int k = 0; k < 5; k++) VAH_TRY(hipMemcpy(dst[k], ca.out[k], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    unsigned long long bad = ~0ULL;
+    VAH_TRY(hipMemcpy(&bad, d_st.p, sizeof bad, hipMemcpyDeviceToHost));
+    if (bad != ~0ULL) {
+        if (bad_cell) *bad_cell = (int64_t)bad;
+        return set_error(IS3D_EDOMAIN, "cell %llu: (Lambda, alpha_L) beyond the last node of the VAH coefficient tables (the reference leaves the "
+                         "cell's c0..c4 unset there, src/cuda/deltafReader.cu:237-276)", bad);
+    }
+    return IS3D_OK;
+}
+
+extern "C" int is3d_smooth_spectra_vah_df(const is3d_vah_cells *cells, const is3d_species *sp, const is3d_grid *gr, const is3d_vah_df_tables *tab,
+                                          const is3d_options *o, double *dN_out, is3d_status *status)
+{
+    using is3d::set_error;
+    if (!cells || !sp || !gr || !o || !dN_out) return set_error(IS3D_EINVAL, "null argument");
+    if (status) { memset(status, 0, sizeof *status); status->bad_cell = -1; }
+    const int64_t n = cells->n_cells;
+    if (n < 0 || n > 0x7fff0000LL) return set_error(IS3D_EINVAL, "n_cells out of range");
+    is3d_vah_plan *P = nullptr;
+    if (int rc = is3d_vah_plan_create(&P, sp, gr, tab, o, std::max<int64_t>(n, 1))) return rc;
+    struct Guard { is3d_vah_plan *p; ~Guard() { is3d_vah_plan_destroy(p); } } guard{P};
+    (void)is3d_vah_plan_set_timing(P, 1);
+    const double *src[30] = {cells->tau, cells->eta, cells->ux, cells->uy, cells->un, cells->dat, cells->dax, cells->day, cells->dan, cells->T,
+                             cells->pitt, cells->pitx, cells->pity, cells->pitn, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn,
+                             cells->pinn, cells->bulkPi, cells->Wx, cells->Wy, cells->Lambda, cells->aL, cells->c0, cells->c1, cells->c2,
+                             cells->c3, cells->c4};
+    if (n > 0)
+        for (int a = 0; a < 30; a++)
+            if (!src[a] && !(a == 1 && o->dimension == 2) && a != 9 && !(a >= 25 && tab)) return set_error(IS3D_EINVAL, "a required VAH cell array is NULL (index %d)", a);
+    DevMem d_cell, d_out;
+    VAH_TRY(d_cell.alloc(sizeof(double) * 30 * (size_t)std::max<int64_t>(n, 1)));
+    VAH_TRY(d_out.alloc(sizeof(double) * (size_t)P->nout));
     const double *dp[30];
     for (int a = 0; a < 30; a++) {
         dp[a] = nullptr;
-        if (src[a] && a != 9) {
-            VAH_TRY(d_cell[a].alloc((size_t)n * sizeof(double)));
-            VAH_TRY(hipMemcpyAsync(d_cell[a].p, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
-            dp[a] = d_cell[a].as<double>();
+        if (src[a] && a != 9 && !(a >= 25 && tab) && n > 0) {
+            VAH_TRY(hipMemcpyAsync(d_cell.as<double>() + (size_t)a * n, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+            dp[a] = d_cell.as<double>() + (size_t)a * n;
         }
     }
-    const int JT = three_d ? kJT3 : kJT2, R = three_d ? kR3 : kR2;
-    const int jtiles = (J + JT - 1) / JT, rblocks = (K + R - 1) / R, ktiles = three_d ? rblocks : 1, upc = three_d ? 1 : rblocks;
-    const int REC = 4 * JT + R * (4 + 2 * JT);
-    const size_t lds = sizeof(is3d::VahScal) * is3d::kVahCB + sizeof(double) * (size_t)is3d::kVahCB * (9 * K + 7 * J);
-    if (lds > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
-    // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
-    const size_t bytes_per_cell = sizeof(double) * (size_t)jtiles * rblocks * REC;
-    const int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
-    const int64_t pass_cells = std::max<int64_t>(1, std::min<int64_t>(n, ws / (int64_t)bytes_per_cell));
-    const int lane_waves = Lpad / 64;
-    int wpb = 4, best = 1 << 30;
-    for (int w : {8, 4, 2}) { const int waste = ((lane_waves + w - 1) / w) * w - lane_waves; if (waste < best) { best = waste; wpb = w; } }
-    int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24LL * 4096 + (int64_t)lane_waves * jtiles * ktiles - 1) / ((int64_t)lane_waves * jtiles * ktiles);
-    nch = std::min<int64_t>(nch, std::max<int64_t>(1, pass_cells / 64));
-    nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)2 << 30) / ((int64_t)J * Kacc * Lpad * 8)));
-    VAH_TRY(d_TS.alloc((size_t)pass_cells * bytes_per_cell + 64 * 1024));   // + slack: the staging pieces of the last batch over-read the stream
-    VAH_TRY(d_partial.alloc((size_t)nch * J * Kacc * Lpad * sizeof(double)));
-    VAH_TRY(d_out.alloc((size_t)nout * sizeof(double)));
-    if (o->accumulate) VAH_TRY(hipMemcpyAsync(d_out.p, dN_out, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, nullptr));
-    hipEvent_t ev[3];
-    for (auto &e : ev) VAH_TRY(hipEventCreate(&e));
-    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]); } } evg{ev};
-    const int npasses = (int)((n + pass_cells - 1) / pass_cells);
-    double ms_prep = 0.0, ms_main = 0.0;
-    for (int pass = 0; pass < npasses; pass++) {
-        const int64_t c0 = (int64_t)pass * pass_cells;
-        const int32_t nc = (int32_t)std::min<int64_t>(pass_cells, n - c0);
-        is3d::VahPrepParams pp{};
-        const double *q[30];
-        for (int a = 0; a < 30; a++) q[a] = dp[a] ? dp[a] + c0 : nullptr;
-        pp.cells = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[10], q[11], q[12], q[13], q[14], q[15], q[16], q[17], q[18], q[19],
-                    q[20], q[21], q[22], q[23], q[24], q[25], q[26], q[27], q[28], q[29]};
-        pp.n_cells = nc; pp.J = J; pp.K = K; pp.dim3 = three_d;
-        pp.include_bulk = o->include_bulk_deltaf != 0; pp.include_shear = o->include_shear_deltaf != 0;
-        pp.cosphi = d_cos.as<double>(); pp.sinphi = d_sin.as<double>(); pp.kgrid = d_kg.as<double>(); pp.kweight = d_kw.as<double>();
-        pp.JT = JT; pp.R = R; pp.jtiles = jtiles; pp.rblocks = rblocks; pp.TS = d_TS.as<double>();
-        VAH_TRY(hipEventRecord(ev[0], nullptr));
-        const int nbatch = (nc + is3d::kVahCB - 1) / is3d::kVahCB;
-        hipLaunchKernelGGL(is3d::cf_prep_vah, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), lds, nullptr, pp);
-        VAH_TRY(hipGetLastError());
-        VAH_TRY(hipEventRecord(ev[1], nullptr));
-        is3d::MainGeom g{};
-        g.n_cells = nc; g.J = J; g.K = K; g.Lpad = Lpad; g.wpb = wpb; g.G = (lane_waves + wpb - 1) / wpb;
-        g.jtiles = jtiles; g.ktiles = ktiles; g.nch = (int)nch; g.NT = jtiles * ktiles * (int)nch; g.Kacc = Kacc;
-        g.first_pass = 1; g.upc = upc; g.zskip = (o->zero_skip != 2); g.baryon = 0;
-        if (three_d) launch_vah<true>(o->regulate_deltaf != 0, d_TS.as<double>(), d_mT.as<double>(), d_pT.as<double>(), d_sg.as<double>(), d_partial.as<double>(), g);
-        else launch_vah<false>(o->regulate_deltaf != 0, d_TS.as<double>(), d_mT.as<double>(), d_pT.as<double>(), d_sg.as<double>(), d_partial.as<double>(), g);
-        VAH_TRY(hipGetLastError());
-        // each pass finalises into the output (accumulating after the first): the partial slots are rewritten per pass
-        const double prefactor = 1.0 / (8.0 * (M_PI * M_PI * M_PI)) / is3d::kHbarC / is3d::kHbarC / is3d::kHbarC;   // :2147
-        VAH_TRY(is3d::launch_finalize(d_partial.as<double>(), d_lane.as<int>(), d_deg.as<double>(), d_out.as<double>(), nout, npart, npT, J, Kacc,
-                                      Lpad, (int)nch, prefactor, (pass > 0 || o->accumulate) ? 1 : 0, nullptr, nullptr));
-        VAH_TRY(hipEventRecord(ev[2], nullptr));
-        VAH_TRY(hipEventSynchronize(ev[2]));
-        float a = 0, b2 = 0;
-        VAH_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
-        VAH_TRY(hipEventElapsedTime(&b2, ev[1], ev[2]));
-        ms_prep += a; ms_main += b2;
-    }
-    VAH_TRY(hipMemcpy(dN_out, d_out.p, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost));
-    if (status) { status->n_passes = npasses; status->kernel_variant = 2; status->ms_prep = ms_prep; status->ms_main = ms_main; }
+    if (o->accumulate) VAH_TRY(hipMemcpyAsync(d_out.p, dN_out, (size_t)P->nout * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    is3d_vah_cells dc{};
+    dc.n_cells = n;
+    dc.tau = dp[0]; dc.eta = dp[1]; dc.ux = dp[2]; dc.uy = dp[3]; dc.un = dp[4]; dc.dat = dp[5]; dc.dax = dp[6]; dc.day = dp[7]; dc.dan = dp[8];
+    dc.T = nullptr; dc.pitt = dp[10]; dc.pitx = dp[11]; dc.pity = dp[12]; dc.pitn = dp[13]; dc.pixx = dp[14]; dc.pixy = dp[15]; dc.pixn = dp[16];
+    dc.piyy = dp[17]; dc.piyn = dp[18]; dc.pinn = dp[19]; dc.bulkPi = dp[20]; dc.Wx = dp[21]; dc.Wy = dp[22]; dc.Lambda = dp[23]; dc.aL = dp[24];
+    dc.c0 = dp[25]; dc.c1 = dp[26]; dc.c2 = dp[27]; dc.c3 = dp[28]; dc.c4 = dp[29];
+    is3d_status st{};
+    const int rc = is3d_vah_plan_execute(P, &dc, d_out.as<double>(), nullptr, &st);
+    if (rc) { if (status) *status = st; return rc; }
+    VAH_TRY(hipMemcpy(dN_out, d_out.p, (size_t)P->nout * sizeof(double), hipMemcpyDeviceToHost));
+    is3d_status t{};
+    (void)is3d_vah_plan_timings(P, &t);
+    st.ms_prep = t.ms_prep; st.ms_main = t.ms_main; st.ms_finalize = t.ms_finalize;
+    st.code = IS3D_OK;
+    if (status) *status = st;
     return IS3D_OK;
+}
+
+extern "C" int is3d_smooth_spectra_vah(const is3d_vah_cells *cells, const is3d_species *sp, const is3d_grid *gr, const is3d_options *o,
+                                       double *dN_out, is3d_status *status)
+{
+    return is3d_smooth_spectra_vah_df(cells, sp, gr, nullptr, o, dN_out, status);
 }

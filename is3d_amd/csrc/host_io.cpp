@@ -449,6 +449,164 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
 }
 
 // ---------------------------------------------------------------------------------------------
+// FO_data_reader::read_surf_VAH_PLMatch (mode 2; src/cpp/readindata.cpp:813-928) with aL_fit and R200
+// (src/cpp/arsenal.cpp:999-1065): 31 numbers per cell, hbar*c on E, T, P, PL, pi^{mu nu}, W^mu, bulkPi, and the anisotropic
+// variables (aL, Lambda) inferred from PL/P by the conformal factorisation fit.
+// ---------------------------------------------------------------------------------------------
+namespace {
+// arsenal.cpp:999-1028: rational fit of alpha_L(PL/Peq), coefficients and operation order as written there
+double aL_fit(double x)
+{
+    const double x2 = x * x, x3 = x2 * x, x4 = x3 * x, x5 = x4 * x, x6 = x5 * x, x7 = x6 * x, x8 = x7 * x, x9 = x8 * x, x10 = x9 * x;
+    const double x11 = x10 * x, x12 = x11 * x, x13 = x12 * x, x14 = x13 * x;
+    return (2.307660683188896e-22 + 1.7179667824677117e-16 * x + 7.2725449826862375e-12 * x2 + 4.2846163672079405e-8 * x3 + 0.00004757224421671691 * x4 +
+            0.011776118846199547 * x5 + 0.7235583305942909 * x6 + 11.582755440134724 * x7 + 44.45243622597357 * x8 + 12.673594148032494 * x9 -
+            33.75866652773691 * x10 + 8.04299287188939 * x11 + 1.462901772148128 * x12 - 0.6320131889637761 * x13 + 0.048528166213735346 * x14) /
+           (5.595674409987461e-19 + 8.059757191879689e-14 * x + 1.2033043382301483e-9 * x2 + 2.9819348588423508e-6 * x3 + 0.0015212379997299082 * x4 +
+            0.18185453852532632 * x5 + 5.466199358534425 * x6 + 40.1581708710626 * x7 + 44.38310108782752 * x8 - 55.213789667214364 * x9 +
+            1.5449108423263358 * x10 + 11.636087951096759 * x11 - 4.005934533735304 * x12 + 0.4703844693488544 * x13 - 0.014599143701745957 * x14);
+}
+// arsenal.cpp:1031-1065: R200(aL) = aL t200(xi), xi = 1/aL^2 - 1; *ok = false where the reference exits ("x is out of bounds!")
+double R200(double aL, bool *ok)
+{
+    const double x = (1.0 / (aL * aL)) - 1.0;
+    const double delta = 0.01;
+    double t200 = 0.0;
+    if (x > delta) t200 = 1.0 + (1.0 + x) * atan(sqrt(x)) / sqrt(x);
+    else if (x < -delta && x > -1.0) t200 = 1.0 + (1.0 + x) * atanh(sqrt(-x)) / sqrt(-x);
+    else if (x >= -delta && x <= delta)
+        t200 = 2.0 + x * (0.6666666666666667 + x * (-0.1333333333333333 + x * (0.05714285714285716 + x * (-0.031746031746031744 + x * (0.020202020202020193 +
+               x * (-0.013986013986013984 + (0.010256410256410262 - 0.00784313725490196 * x) * x))))));
+    else *ok = false;   // x <= -1 (or NaN)
+    return aL * t200;
+}
+}  // namespace
+
+extern "C" int is3d_surface_read_vah(const char *path, int32_t dimension, int64_t *n_cells, double *const *A)
+{
+    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    int64_t rows;
+    int32_t cols;
+    std::vector<double> tab;
+    bool exact = false;
+    int rc = parse_table(text, path, &rows, &cols, A ? &tab : nullptr, &exact);
+    if (rc) return rc;
+    if (!A) { *n_cells = rows; return IS3D_OK; }
+    if (*n_cells < rows) return io_fail(IS3D_EINVAL, "%s: arrays hold %lld cells, file has %lld", path, (long long)*n_cells, (long long)rows);
+    *n_cells = rows;
+    enum { itau, ieta, iux, iuy, iun, idat, idax, iday, idan, iT, ipitt, ipitx, ipity, ipitn, ipixx, ipixy, ipixn, ipiyy, ipiyn, ipinn, ibulk,
+           iWx, iWy, iLambda, iaL, iE, iP, iPL, iWt, iWn, ix, iy };
+    for (int a = 0; a <= iaL; a++)
+        if (!A[a]) return io_fail(IS3D_EINVAL, "VAH cell array %d is NULL", a);
+    const char *p = text.c_str();
+    bool short_read = false;
+    size_t ti = 0;
+    auto next = [&]() -> double {   // the whitespace token stream (surface_data >> ...)
+        if (exact) {
+            if (ti >= tab.size()) { short_read = true; return 0.0; }
+            return tab[ti++];
+        }
+        char *q;
+        double x = strtod(p, &q);
+        if (q == p) { short_read = true; return 0.0; }
+        p = q;
+        return x;
+    };
+    (void)dimension;   // dan != 0 in 2+1D: the reference prints a warning only (its exit is commented out, :853-857)
+    for (int64_t i = 0; i < rows; i++) {
+        const double tau = next(), x = next(), y = next(), eta = next();
+        const double dat = next(), dax = next(), day = next(), dan = next();
+        (void)next();   // ut: read and never used (the kernel recomputes it, smooth_kernels.cpp:2213)
+        const double ux = next(), uy = next(), un = next();
+        const double E = next(), T = next(), P = next(), PL = next();   // fm^-4, fm^-1
+        double pi[10], W[4];
+        for (double &v : pi) v = next() * kHbarC;
+        for (double &v : W) v = next() * kHbarC;
+        const double bulkPi = next() * kHbarC;
+        if (short_read) return io_fail(IS3D_EIO, "%s: ran out of numbers at cell %lld (mode 2)", path, (long long)i);
+        if (!((PL / P) < 3.0))   // :910-921: "pl is too large, stopping anisotropic variables..." exit(-1)
+            return io_fail(IS3D_EINVAL, "%s: cell %lld: PL/P = %.6g is too large for the anisotropic variables (needs < 3)", path, (long long)i, PL / P);
+        const double aL = aL_fit(PL / P);
+        bool ok = true;
+        const double r200 = R200(aL, &ok);
+        if (!ok) return io_fail(IS3D_EINVAL, "%s: cell %lld: alpha_L = %.6g is out of bounds for R200", path, (long long)i, aL);
+        const double Lambda = T / pow(0.5 * aL * r200, 0.25);
+        A[itau][i] = tau; A[ieta][i] = eta; A[iux][i] = ux; A[iuy][i] = uy; A[iun][i] = un;
+        A[idat][i] = dat; A[idax][i] = dax; A[iday][i] = day; A[idan][i] = dan;
+        A[iT][i] = T * kHbarC;
+        for (int k = 0; k < 10; k++) A[ipitt + k][i] = pi[k];
+        A[ibulk][i] = bulkPi;
+        A[iWx][i] = W[1]; A[iWy][i] = W[2];
+        A[iLambda][i] = Lambda * kHbarC; A[iaL][i] = aL;
+        if (A[iE]) A[iE][i] = E * kHbarC;
+        if (A[iP]) A[iP][i] = P * kHbarC;
+        if (A[iPL]) A[iPL][i] = PL * kHbarC;
+        if (A[iWt]) A[iWt][i] = W[0];
+        if (A[iWn]) A[iWn][i] = W[3];
+        if (A[ix]) A[ix][i] = x;
+        if (A[iy]) A[iy][i] = y;
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The anisotropic-hydro branch of load_df_coefficient_data in the CUDA tree (src/cuda/deltafReader.cu): file names :74-81,
+// fscanf("%d\n%d\n") of the two dimensions :104-112, fgets(header, 100) :122-127, then for i2 (alpha_L) outer, i1 (Lambda) inner
+// fscanf("%lf\t\t%lf\t\t%lf\n", &L_array[i1], &aL_array[i2], &c[i1][i2]) on the five files in turn (:196-213): every row
+// overwrites its node entries, the c4 file's scan comes last.
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_vah_df_read(const char *dir, int32_t *n_L, int32_t *n_aL, double *L, double *aL, double *c, int64_t capacity)
+{
+    if (!dir || !n_L || !n_aL) return io_fail(IS3D_EINVAL, "null argument");
+    long nL0 = -1, naL0 = -1;
+    for (int k = 0; k < 5; k++) {
+        const std::string path = std::string(dir) + "/c" + std::to_string(k) + "_vah1.dat";
+        std::string text;
+        if (!slurp(path.c_str(), text)) return io_fail(IS3D_EIO, "Couldn't open c%d coefficient file %s", k, path.c_str());
+        const char *p = text.c_str();
+        char *q;
+        const long nL = strtol(p, &q, 10);
+        if (q == p || nL < 2) return io_fail(IS3D_EIO, "%s: bad Lambda dimension", path.c_str());
+        p = q;
+        const long naL = strtol(p, &q, 10);
+        if (q == p || naL < 2) return io_fail(IS3D_EIO, "%s: bad alpha_L dimension", path.c_str());
+        p = q;
+        if (k == 0) { nL0 = nL; naL0 = naL; }
+        else if (nL != nL0 || naL != naL0)   // the reference reads all five headers into the same two ints: the last one would win silently
+            return io_fail(IS3D_EINVAL, "%s: dimensions %ld x %ld differ from c0's %ld x %ld", path.c_str(), nL, naL, nL0, naL0);
+        if (!L) continue;
+        if ((int64_t)5 * nL * naL > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %lld < %lld", path.c_str(), (long long)capacity, (long long)(5 * nL * naL));
+        while (*p && isspace((unsigned char)*p)) p++;                         // fscanf("%d\n%d\n") eats the white space
+        for (int got = 0; *p && got < 99; got++) { if (*p++ == '\n') break; }   // fgets(header, 100, file): at most 99 characters
+        double *tab = c + (size_t)k * nL * naL;
+        for (long i2 = 0; i2 < naL; i2++)
+            for (long i1 = 0; i1 < nL; i1++) {
+                double v[3];
+                for (double &x : v) {
+                    x = strtod(p, &q);
+                    if (q == p) return io_fail(IS3D_EIO, "%s: ran out of numbers at row %ld", path.c_str(), i2 * nL + i1);
+                    p = q;
+                }
+                L[i1] = v[0];
+                if (aL) aL[i2] = v[1];
+                tab[i2 * nL + i1] = v[2];
+            }
+    }
+    *n_L = (int32_t)nL0;
+    *n_aL = (int32_t)naL0;
+    if (L) {
+        for (long i = 1; i < nL0; i++)
+            if (!(L[i] > L[i - 1])) return io_fail(IS3D_EINVAL, "%s: Lambda nodes do not ascend at %ld", dir, i);
+        if (aL)
+            for (long i = 1; i < naL0; i++)
+                if (!(aL[i] > aL[i - 1])) return io_fail(IS3D_EINVAL, "%s: alpha_L nodes do not ascend at %ld", dir, i);
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // PDG_Data::read_resonances_conventional  (src/cpp/readindata.cpp:1440-1568)
 //   token stream: 12 header fields + decays x 8 fields; an antiparticle entry follows each
 //   baryon > 0; the entry produced by the read attempt that hits EOF is dropped (Nparticle =

@@ -46,6 +46,14 @@ def df_tables_full():
     return d
 
 
+def vah_df_tables():
+    """The anisotropic-hydro (P_L matching) 14-moment coefficient tables deltaf_coefficients/vah/c{0..4}_vah1.dat as the CUDA tree's
+    reader holds them (src/cuda/deltafReader.cu:60-82, :196-213): L [fm^-1] (80 nodes), aL (180 nodes), c0..c4 each [n_aL][n_L] in file
+    units (the per-cell values are divided by hbarc^3 after the interpolation, :262-266)."""
+    z = np.load(os.path.join(_DATA, "df_vah.npz"))
+    return {k: np.ascontiguousarray(z[k]) for k in ("L", "aL", "c0", "c1", "c2", "c3", "c4")}
+
+
 def species(which="pikp"):
     """which: 'pikp' (chosen_particles_pikp.dat) | 'urqmd' (chosen_particles_urqmd_v3.3+.dat, 305) |
     list of mc_ids.  Order = order of the chosen list (emissionfunction.cpp:336-351)."""

@@ -139,7 +139,27 @@ def synth_vah_surface(n_cells, dimension, seed=None, first_cell=0):
     v["c1"] = -8.0 / T ** 4 * (0.5 + U(8))
     v["c2"] = 6.0 / T ** 4 * (0.5 + U(9))
     v["x"], v["y"] = s["x"], s["y"]
+    # what a mode-2 surface file carries besides (write_surface_vah_dat): E, P and a longitudinal pressure with PL/P in [0.5, 1.5] --
+    # the reader infers (alpha_L, Lambda) from (T, P, PL), so a surface read back from such a file has ITS OWN Lambda, aL, not the
+    # ones drawn above
+    v["E"], v["P"] = E, P
+    v["PL"] = P * (0.5 + U(10))
     return {k: np.ascontiguousarray(a, dtype=np.float64) for k, a in v.items()}
+
+
+def write_surface_vah_dat(path, s):
+    """Mode-2 (`read_surf_VAH_PLMatch`, src/cpp/readindata.cpp:813-928) text surface: 31 columns -- tau x y eta | dat dax day dan |
+    ut ux uy un | E T P PL | ten pi_perp^{mu nu} | Wt Wx Wy Wn | bulkPi -- 17 significant digits, thermodynamic, viscous and W
+    columns in fm^-n (divided by hbar*c).  W^tau and W^eta as the kernel reconstructs them (smooth_kernels.cpp:2244-2245)."""
+    h = HBARC
+    tau, ux, uy, un = s["tau"], s["ux"], s["uy"], s["un"]
+    ut = np.sqrt(1.0 + ux * ux + uy * uy + tau * tau * un * un)
+    Wt = (ux * s["Wx"] + uy * s["Wy"]) * ut / (1.0 + ux * ux + uy * uy)
+    Wn = Wt * un / ut
+    cols = [tau, s["x"], s["y"], s["eta"], s["dat"], s["dax"], s["day"], s["dan"], ut, ux, uy, un,
+            s["E"] / h, s["T"] / h, s["P"] / h, s["PL"] / h] + [s[k] / h for k in ("pitt", "pitx", "pity", "pitn", "pixx", "pixy", "pixn", "piyy", "piyn", "pinn")] + \
+           [Wt / h, s["Wx"] / h, s["Wy"] / h, Wn / h, s["bulkPi"] / h]
+    np.savetxt(path, np.column_stack(cols), fmt="%.17e", delimiter=" ")
 
 
 def write_surface_dat(path, s):

@@ -1748,3 +1748,50 @@ int oracle_dN_pTdpTdphidy_vah(long FO_length, int npart, const double *Mass, con
     free(part); free(cosphi); free(sinphi); free(etaW);
     return 0;
 }
+
+/* ==========================================================================================
+ * VAH coefficient loading, per cell: src/cuda/deltafReader.cu:216-278 (the CUDA tree's load_df_coefficient_data, branch
+ * "df_mode == 4 // va hydro PL matching"; src/cpp never loads these tables).  Same loops, same search, same expression:
+ *   for i2 (alpha_L) { for i1 (Lambda) { if (i1 > 0 && Lambda < L[i1] && i2 > 0 && aL < aL[i2]) { bilinear; /= hbarC^3; found } } }
+ * with Lambda = surface.Lambda / hbarC (:228).  The reference indexes c[i1][i2] (Lambda first); the tables here are stored
+ * [i2][i1] as the file lists them (alpha_L outer), c(i1, i2) = tab[i2 * nL + i1].  found[icell] = 0 where the reference's
+ * loops end without a hit -- it then leaves surface[icell].c0..c4 untouched (unset memory); the outputs are left untouched here too.
+ * PARITY UNPINNED like the rest of this file: no fixture of the reference covers it.
+ * ========================================================================================== */
+int oracle_vah_coefficients(int nL, int naL, const double *L_array, const double *aL_array, const double *c0, const double *c1,
+                            const double *c2, const double *c3, const double *c4, long FO_length, const double *Lambda_GeV,
+                            const double *aL_cell, double *o0, double *o1, double *o2, double *o3, double *o4, int *found_out)
+{
+    const double hbarC = ORACLE_HBARC;
+    const double hbarC3 = (hbarC * hbarC * hbarC);                                  /* :219 */
+    const double *tab[5] = {c0, c1, c2, c3, c4};
+    double *out[5] = {o0, o1, o2, o3, o4};
+    const int n1 = nL, n2 = naL;
+    for (long icell = 0; icell < FO_length; icell++) {
+        double aL = aL_cell[icell];
+        double Lambda = Lambda_GeV[icell] / hbarC;                                  /* :228 */
+        int found = 0;
+        for (int i2 = 0; i2 < n2; i2++) {                                           /* aL, :232 */
+            for (int i1 = 0; i1 < n1; i1++) {                                       /* Lambda, :236 */
+                if ((i1 > 0) && (Lambda < L_array[i1]) && (i2 > 0) && (aL < aL_array[i2])) {   /* :238 */
+                    double Lambda1 = L_array[i1 - 1], Lambda2 = L_array[i1];
+                    double aL1 = aL_array[i2 - 1], aL2 = aL_array[i2];
+                    for (int k = 0; k < 5; k++) {
+                        const double *c = tab[k];
+#define CC(a, b) c[(size_t)(b) * nL + (a)]
+                        double v = ((CC(i1 - 1, i2 - 1) * (Lambda2 - Lambda) + CC(i1, i2 - 1) * (Lambda - Lambda1)) * (aL2 - aL)
+                                    + (CC(i1 - 1, i2) * (Lambda2 - Lambda) + CC(i1, i2) * (Lambda - Lambda1)) * (aL - aL1)) / ((aL2 - aL1) * (Lambda2 - Lambda1));   /* :248-261 */
+#undef CC
+                        v /= hbarC3;                                                /* :262-266 */
+                        out[k][icell] = v;
+                    }
+                    found = 1;
+                    break;
+                }
+            }
+            if (found == 1) break;
+        }
+        if (found_out) found_out[icell] = found;
+    }
+    return 0;
+}

@@ -379,3 +379,76 @@ def dN_pTdpTdphidy_vah(cells, species, grid, opts):
     if rc:
         raise RuntimeError("oracle_dN_pTdpTdphidy_vah failed rc=%d" % rc)
     return out
+
+
+def vah_coefficients(tab, Lambda, aL):
+    """oracle_vah_coefficients: src/cuda/deltafReader.cu:216-278 per cell.  tab: dict L, aL, c0..c4 ([n_aL][n_L]); Lambda in GeV.
+    Returns (dict c0..c4, found mask): where found is False the reference leaves the cell's coefficients unset (NaN here)."""
+    L = lib()
+    Lg, ag = _f64(tab["L"]), _f64(tab["aL"])
+    t = [_f64(tab["c%d" % k]) for k in range(5)]
+    for x in t:
+        assert x.shape == (len(ag), len(Lg))
+    lam, al = _f64(Lambda), _f64(aL)
+    n = len(lam)
+    out = [np.full(n, np.nan) for _ in range(5)]
+    found = np.zeros(n, dtype=np.int32)
+    L.oracle_vah_coefficients.argtypes = [C.c_int, C.c_int] + [_dp] * 7 + [C.c_long, _dp, _dp] + [_dp] * 5 + [C.POINTER(C.c_int32)]
+    rc = L.oracle_vah_coefficients(len(Lg), len(ag), _p(Lg), _p(ag), *[_p(x) for x in t], n, _p(lam), _p(al), *[_p(x) for x in out],
+                                   found.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0
+    return {"c%d" % k: out[k] for k in range(5)}, found.astype(bool)
+
+
+def aL_fit(x):
+    """src/cpp/arsenal.cpp:999-1028: alpha_L(PL/Peq), conformal factorisation fit, the reference's operation order."""
+    x = np.asarray(x, dtype=np.float64)
+    p = [x ** 0]
+    for _ in range(14):
+        p.append(p[-1] * x)
+    x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14 = p[1:]
+    num = (2.307660683188896e-22 + 1.7179667824677117e-16 * x1 + 7.2725449826862375e-12 * x2 + 4.2846163672079405e-8 * x3 + 0.00004757224421671691 * x4 +
+           0.011776118846199547 * x5 + 0.7235583305942909 * x6 + 11.582755440134724 * x7 + 44.45243622597357 * x8 + 12.673594148032494 * x9 -
+           33.75866652773691 * x10 + 8.04299287188939 * x11 + 1.462901772148128 * x12 - 0.6320131889637761 * x13 + 0.048528166213735346 * x14)
+    den = (5.595674409987461e-19 + 8.059757191879689e-14 * x1 + 1.2033043382301483e-9 * x2 + 2.9819348588423508e-6 * x3 + 0.0015212379997299082 * x4 +
+           0.18185453852532632 * x5 + 5.466199358534425 * x6 + 40.1581708710626 * x7 + 44.38310108782752 * x8 - 55.213789667214364 * x9 +
+           1.5449108423263358 * x10 + 11.636087951096759 * x11 - 4.005934533735304 * x12 + 0.4703844693488544 * x13 - 0.014599143701745957 * x14)
+    return num / den
+
+
+def R200(aL):
+    """src/cpp/arsenal.cpp:1031-1065: R200(alpha_L) = alpha_L t200(xi), xi = 1/alpha_L^2 - 1 (three branches around xi = 0)."""
+    aL = np.asarray(aL, dtype=np.float64)
+    x = (1.0 / (aL * aL)) - 1.0
+    delta = 0.01
+    t = np.full(x.shape, np.nan)
+    hi = x > delta
+    lo = (x < -delta) & (x > -1.0)
+    mid = (x >= -delta) & (x <= delta)
+    with np.errstate(invalid="ignore"):
+        t[hi] = 1.0 + (1.0 + x[hi]) * np.arctan(np.sqrt(x[hi])) / np.sqrt(x[hi])
+        t[lo] = 1.0 + (1.0 + x[lo]) * np.arctanh(np.sqrt(-x[lo])) / np.sqrt(-x[lo])
+    xm = x[mid]
+    t[mid] = 2.0 + xm * (0.6666666666666667 + xm * (-0.1333333333333333 + xm * (0.05714285714285716 + xm * (-0.031746031746031744 + xm * (0.020202020202020193 +
+             xm * (-0.013986013986013984 + (0.010256410256410262 - 0.00784313725490196 * xm) * xm))))))
+    return aL * t
+
+
+def read_surf_VAH_PLMatch(path):
+    """FO_data_reader::read_surf_VAH_PLMatch (src/cpp/readindata.cpp:813-928) in numpy: 31 columns per cell -> the VAH cell arrays
+    (GeV units) with aL = aL_fit(PL/P), Lambda = T / (aL R200(aL) / 2)^(1/4) hbarc.  Cells with PL/P >= 3 make the reference exit."""
+    a = np.loadtxt(path, ndmin=2)
+    assert a.shape[1] == 31, a.shape
+    h = 0.197327053   # src/cpp/iS3D.h:9
+    names = ["tau", "x", "y", "eta", "dat", "dax", "day", "dan", "ut", "ux", "uy", "un", "E", "T", "P", "PL",
+             "pitt", "pitx", "pity", "pitn", "pixx", "pixy", "pixn", "piyy", "piyn", "pinn", "Wt", "Wx", "Wy", "Wn", "bulkPi"]
+    s = {n: a[:, i].copy() for i, n in enumerate(names)}
+    T, P, PL = s["T"].copy(), s["P"].copy(), s["PL"].copy()          # fm^-1, fm^-4: kept for the (aL, Lambda) inference (:874-882)
+    if not np.all(PL / P < 3.0):
+        raise ValueError("pl is too large, stopping anisotropic variables...")
+    for n in names[12:]:
+        s[n] = s[n] * h
+    aL = aL_fit(PL / P)
+    s["aL"] = aL
+    s["Lambda"] = (T / np.power(0.5 * aL * R200(aL), 0.25)) * h
+    return s

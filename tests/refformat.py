@@ -75,6 +75,19 @@ def write_df_table(path, T, values, label, n_muB=2):
                 f.write("%.6f\t\t%.6f\t\t%s\n" % (t, 0.01 * ib, repr(float(v) * (1.0 + 0.5 * ib))))
 
 
+def write_vah_df_tables(directory, tab, header_pad=0):
+    """deltaf_coefficients/vah/c{0..4}_vah1.dat in the shipped layout (src/cuda/deltafReader.cu:104-127, :196-213): "n_L\\nn_aL\\n",
+    one label line, rows "L\\t\\taL\\t\\tvalue" with alpha_L outer and Lambda inner."""
+    os.makedirs(directory, exist_ok=True)
+    for k in range(5):
+        with open(os.path.join(directory, "c%d_vah1.dat" % k), "w") as f:
+            f.write("%d\n%d\n" % (len(tab["L"]), len(tab["aL"])))
+            f.write("L [fm^-1]\t\taL\t\tc%d_vah1 [...]%s\n" % (k, " x" * header_pad))
+            for i2, al in enumerate(tab["aL"]):
+                for i1, lam in enumerate(tab["L"]):
+                    f.write("%s\t\t%s\t\t%s\n" % (repr(float(lam)), repr(float(al)), repr(float(tab["c%d" % k][i2, i1]))))
+
+
 def make_run_dir(root, cells, species_ids, params):
     """An iS3D-style run directory: iS3D_parameters.dat, input/, PDG/, tables/, deltaf_coefficients/, results/."""
     fx = inputs.load_fixture()

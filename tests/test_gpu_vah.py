@@ -91,3 +91,100 @@ def test_vah_full_size_properties(fx):
     ref, _ = api.smooth_spectra(vh, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=1, include_bulk_deltaf=0, include_shear_deltaf=0, outflow=0))
     assert relerr(got, ref, floor=1e-250) < 1e-9
     print("vah main kernel ms", st["ms_main"], "prep", st["ms_prep"])
+
+
+def test_vah_device_coefficients_are_the_oracles_bit_for_bit():
+    """is3d_vah_coefficients (device kernel cf_vah_coeffs) == oracle_vah_coefficients (src/cuda/deltafReader.cu:216-278): the same
+    node search and the same expression with every rounding written out -- bitwise equal, extrapolation below the first node
+    included; beyond the last node (and NaN) the reference leaves the coefficients unset: IS3D_EDOMAIN with the lowest such cell."""
+    tab = inputs.vah_df_tables()
+    h = 0.197327053
+    rng = np.random.default_rng(5)
+    n = 100003
+    lam = (0.55 + 0.69 * rng.random(n)) * h
+    al = 0.15 + 1.84 * rng.random(n)
+    ref, found = oracle.vah_coefficients(tab, lam, al)
+    assert found.all() and ((lam / h) < 0.6).any() and (al < 0.2).any()      # all inside or below: every cell gets a value
+    got = api.vah_coefficients(tab, lam, al)
+    for k in range(5):
+        assert np.array_equal(got["c%d" % k], ref["c%d" % k]), k
+    lam[[70001, 313]] = 1.2501 * h            # beyond the last Lambda node
+    al[90000] = 2.0                           # exactly the last alpha_L node: aL < aL[i2] fails for every i2
+    lam[95000] = np.nan
+    ref, found = oracle.vah_coefficients(tab, lam, al)
+    assert list(np.nonzero(~found)[0]) == [313, 70001, 90000, 95000]
+    with pytest.raises(api.Is3dError) as e:
+        api.vah_coefficients(tab, lam, al)
+    assert e.value.code == api.IS3D_EDOMAIN and e.value.bad_cell == 313 and "cell 313" in str(e.value)
+    for k in range(5):
+        v = e.value.values["c%d" % k]
+        assert np.array_equal(v[found], ref["c%d" % k][found]) and not v[~found].any()
+    with pytest.raises(api.Is3dError) as e:   # tables must ascend
+        api.vah_coefficients(dict(tab, aL=tab["aL"][::-1].copy()), lam[:4], al[:4])
+    assert e.value.code == api.IS3D_EINVAL
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_vah_spectrum_from_the_coefficient_tables(fx, dim):
+    """BASELINE config 5 from files: the cells carry (Lambda, alpha_L) only, c0..c4 come from the tables on the device == the oracle
+    kernel fed with the oracle's coefficients; the device-resident plan gives the same bits as the host entry; a cell outside the
+    tables is IS3D_EDOMAIN with its index."""
+    import torch
+    tab = inputs.vah_df_tables()
+    cells = synth.synth_vah_surface(120 if dim == 3 else 9, dim, seed=940 + dim)
+    n = len(cells["tau"])
+    sp = inputs.species([211, 321, 2212, 3122]) if dim == 3 else fx["pikp"]
+    coef, found = oracle.vah_coefficients(tab, cells["Lambda"], cells["aL"])
+    assert found.all()
+    o = dict(dimension=dim)
+    ref = oracle.dN_pTdpTdphidy_vah(dict(cells, **coef), sp, fx["grid"], o)
+    got, st = api.smooth_spectra_vah(cells, sp, fx["grid"], o, tab=inputs.vah_df_tables())
+    assert relerr(got, ref, floor=1e-270) < TOL, relerr(got, ref, floor=1e-270)
+    same, _ = api.smooth_spectra_vah(dict(cells, **coef), sp, fx["grid"], o)       # coefficients as inputs: the same kernel, the same bits
+    assert np.array_equal(same, got)
+    assert st["n_wave_rows"] > 0
+    # device-resident plan, torch-owned memory, a non-default stream
+    dev = torch.device("cuda:0")
+    fields = [f for f in api.VAH_FIELDS[:25] if f != "T"]
+    tens = {k: torch.from_numpy(np.ascontiguousarray(cells[k])).to(dev) for k in fields}
+    plan = api.VahPlan(sp, fx["grid"], o, tab=tab, max_cells=n + 5)
+    plan.set_timing(True)
+    out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        st2 = plan.execute(n, {k: v.data_ptr() for k, v in tens.items()}, out.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(out.cpu().numpy(), got) and st2["code"] == 0 and st2["n_wave_rows"] == st["n_wave_rows"]
+    t = plan.timings()
+    assert t["ms_main"] > 0 and t["ms_prep"] > 0
+    tens["aL"][7] = 2.5
+    with pytest.raises(api.Is3dError) as e:
+        plan.execute(n, {k: v.data_ptr() for k, v in tens.items()}, out.data_ptr(), 0)
+    assert e.value.code == api.IS3D_EDOMAIN and e.value.bad_cell == 7
+    with pytest.raises(api.Is3dError) as e:
+        plan.execute(n + 6, {k: v.data_ptr() for k, v in tens.items()}, out.data_ptr(), 0)
+    assert e.value.code == api.IS3D_EINVAL
+    plan.close()
+    # passes over the cell axis keep the global index of an offending cell
+    bad = {k: v.copy() for k, v in cells.items()}
+    bad["Lambda"][n - 2] = 0.3
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra_vah(bad, sp, fx["grid"], dict(o, workspace_bytes=1 << 18), tab=tab)
+    assert e.value.code == api.IS3D_EDOMAIN and e.value.bad_cell == n - 2
+
+
+def test_vah_surface_file_to_spectrum(fx, tmp_path):
+    """Mode-2 surface file -> is3d_surface_read_vah -> spectrum with table coefficients == oracle reader -> oracle coefficients ->
+    oracle kernel."""
+    tab = inputs.vah_df_tables()
+    path = str(tmp_path / "surface.dat")
+    src = synth.synth_vah_surface(64, 3, seed=77)
+    synth.write_surface_vah_dat(path, src)
+    cells = api.surface_read_vah(path, 3)
+    o = dict(dimension=3)
+    got, _ = api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], o, tab=tab)
+    rc = oracle.read_surf_VAH_PLMatch(path)
+    coef, found = oracle.vah_coefficients(tab, rc["Lambda"], rc["aL"])
+    assert found.all()
+    ref = oracle.dN_pTdpTdphidy_vah(dict(rc, **coef), fx["pikp"], fx["grid"], o)
+    assert relerr(got, ref, floor=1e-270) < TOL

@@ -342,3 +342,80 @@ def test_readers_on_the_reference_files():
     surf, _ = api.surface_read_vh(os.path.join(REFERENCE, "input/surface.dat"))
     assert len(surf["tau"]) == 1 and surf["P"][0] == 0.270 * 0.197327053
     assert api.param_get(os.path.join(REFERENCE, "iS3D_parameters.dat"), "df_mode") == 4.0
+
+
+def test_vah_table_reader(tmp_path):
+    """is3d_vah_df_read on files in the shipped layout (src/cuda/deltafReader.cu:104-127, :196-213): dimensions, one label line read by
+    fgets(header, 100), rows with alpha_L outer and Lambda inner; the node arrays are what the LAST rows leave behind."""
+    tab = inputs.vah_df_tables()
+    d = str(tmp_path / "vah")
+    refformat.write_vah_df_tables(d, tab)
+    got = api.vah_df_read(d)
+    for k in ("L", "aL", "c0", "c1", "c2", "c3", "c4"):
+        assert np.array_equal(got[k], tab[k]), k
+    assert got["c3"].shape == (180, 80)
+    # a label line of more than 99 characters: fgets(header, 100, file) stops after 99 and the scan then starts inside the label --
+    # the reference's fscanf fails there silently; here it is an error
+    refformat.write_vah_df_tables(d, tab, header_pad=120)
+    with pytest.raises(api.Is3dError) as e:
+        api.vah_df_read(d)
+    assert e.value.code == api.IS3D_EIO
+    refformat.write_vah_df_tables(d, tab)
+    os.remove(os.path.join(d, "c3_vah1.dat"))
+    with pytest.raises(api.Is3dError) as e:
+        api.vah_df_read(d)
+    assert e.value.code == api.IS3D_EIO and "c3" in str(e.value)
+    small = {k: (v[:7] if k == "L" else v[:5] if k == "aL" else v[:5, :7]) for k, v in tab.items()}
+    refformat.write_vah_df_tables(d, small)
+    with open(os.path.join(d, "c1_vah1.dat"), "r+") as f:   # a header that disagrees with c0's
+        f.write("6")
+    with pytest.raises(api.Is3dError) as e:
+        api.vah_df_read(d)
+    assert e.value.code == api.IS3D_EINVAL
+    small["L"] = small["L"][::-1].copy()
+    refformat.write_vah_df_tables(d, small)
+    with pytest.raises(api.Is3dError) as e:
+        api.vah_df_read(d)
+    assert e.value.code == api.IS3D_EINVAL and "ascend" in str(e.value)
+
+
+def test_surface_reader_mode2(tmp_path):
+    """is3d_surface_read_vah == the numpy restatement of read_surf_VAH_PLMatch (readindata.cpp:813-928, arsenal.cpp:999-1065): hbar*c
+    conversions, u^tau dropped, (alpha_L, Lambda) from the conformal-factorisation fit; PL/P >= 3 is fatal."""
+    from oracle import oracle
+    path = str(tmp_path / "surface.dat")
+    for dim, n in ((3, 57), (2, 11)):
+        cells = synth.synth_vah_surface(n, dim, seed=300 + dim)
+        synth.write_surface_vah_dat(path, cells)
+        got = api.surface_read_vah(path, dim)
+        ref = oracle.read_surf_VAH_PLMatch(path)
+        for k in api.VAH_SURFACE_ORDER:
+            assert np.allclose(got[k], ref[k], rtol=4e-15, atol=0), k
+        for k in ("tau", "eta", "ux", "uy", "un", "dat", "dax", "day", "dan", "x", "y"):
+            assert np.allclose(got[k], cells[k], rtol=1e-15, atol=0), k
+        for k in ("T", "E", "P", "PL", "pitt", "pitn", "pinn", "piyn", "Wx", "Wy", "bulkPi"):
+            assert np.allclose(got[k], cells[k], rtol=5e-16, atol=0), k
+        assert (got["aL"] > 0.6).all() and (got["aL"] < 1.6).all()
+        # isotropic pressure: alpha_L = 1 and Lambda = T (the fit is exact to 2e-8 there)
+        iso = dict(cells, PL=cells["P"].copy())
+        synth.write_surface_vah_dat(path, iso)
+        g2 = api.surface_read_vah(path, dim)
+        assert np.allclose(g2["aL"], 1.0, rtol=1e-7) and np.allclose(g2["Lambda"], g2["T"], rtol=1e-7)
+    bad = dict(cells, PL=cells["P"] * np.where(np.arange(n) == 4, 3.5, 1.0))
+    synth.write_surface_vah_dat(path, bad)
+    with pytest.raises(api.Is3dError) as e:
+        api.surface_read_vah(path, 2)
+    assert e.value.code == api.IS3D_EINVAL and "cell 4" in str(e.value)
+    with open(path, "w") as f:
+        f.write("1 2 3\n")
+    with pytest.raises(api.Is3dError) as e:
+        api.surface_read_vah(path, 3)
+    assert e.value.code == api.IS3D_EIO
+
+
+@pytest.mark.reference
+def test_vah_tables_of_the_reference_parse_to_the_fixture():
+    got = api.vah_df_read(os.path.join(REFERENCE, "deltaf_coefficients/vah"))
+    tab = inputs.vah_df_tables()
+    for k in ("L", "aL", "c0", "c1", "c2", "c3", "c4"):
+        assert np.array_equal(got[k], tab[k]), k

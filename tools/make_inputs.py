@@ -10,6 +10,8 @@ with small independent Python parsers that follow the reference readers' semanti
                                             only if its line is newline-terminated
   deltaf_coefficients/vh/urqmd/*.dat        Deltaf_Data::load_df_coefficient_data (src/cpp/deltafReader.cpp:120-197)
   PDG/pdg-urqmd_v3.3+.dat                   PDG_Data::read_resonances_conventional (src/cpp/readindata.cpp:1440-1568)
+  deltaf_coefficients/vah/c{0..4}_vah1.dat  the anisotropic-hydro branch of load_df_coefficient_data in the CUDA tree
+                                            (src/cuda/deltafReader.cu:60-82 names, :104-112 header, :196-213 scan order)
 
 Run here (container) only:  python tools/make_inputs.py
 """
@@ -57,6 +59,19 @@ def read_df_table_full(path):
         f.readline()
         a = np.array([[float(x) for x in f.readline().split()] for _ in range(nT * nB)])
     return a[:nT, 0].copy(), a[::nT, 1].copy(), a[:, 2].reshape(nB, nT).copy()
+
+
+def read_vah_table(path):
+    """deltaf_coefficients/vah/c*_vah1.dat: line 1 = number of Lambda nodes, line 2 = number of alpha_L nodes, one label line,
+    then rows "Lambda [fm^-1]  alpha_L  value" with alpha_L OUTER and Lambda inner (src/cuda/deltafReader.cu:104-112, :196-213)
+    -> L[nL], aL[naL], values[naL][nL]."""
+    import numpy as np
+    with open(path) as f:
+        nL = int(f.readline())
+        naL = int(f.readline())
+        f.readline()
+        a = np.array([[float(x) for x in f.readline().split()] for _ in range(nL * naL)])
+    return a[(naL - 1) * nL:, 0].copy(), a[nL - 1::nL, 1].copy(), a[:, 2].reshape(naL, nL).copy()   # the arrays as the LAST rows leave them
 
 
 def read_pdg(path):
@@ -119,6 +134,12 @@ def main():
         T, muB, v = read_df_table_full(os.path.join(REF, "deltaf_coefficients/vh/urqmd", name + ".dat"))
         full["T"], full["muB"], full[name] = T, muB, v
     np.savez_compressed(os.path.join(os.path.dirname(OUT), "df_urqmd_full.npz"), **full)
+    # anisotropic-hydro 14-moment coefficient tables (BASELINE config 5): 5 x 180 x 80
+    vah = {}
+    for k in range(5):
+        L, aL, v = read_vah_table(os.path.join(REF, "deltaf_coefficients/vah/c%d_vah1.dat" % k))
+        vah["L"], vah["aL"], vah["c%d" % k] = L, aL, v
+    np.savez_compressed(os.path.join(os.path.dirname(OUT), "df_vah.npz"), **vah)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(pdg), "pdg entries;",
           {k: len(v["x"]) for k, v in grids.items()}, len(d["chosen_urqmd"]), "chosen")
 
