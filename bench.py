@@ -14,7 +14,8 @@ its cell axis in N contiguous shards (8 x 125 000 cells at N = 8) -- strong scal
 RCCL all-reduce of the 39 MB spectrum ends the step (the sum over chunks of cells of
 /root/reference/src/cpp/emissionfunction_smooth_kernels.cpp:363-375 is what makes the split exact).  `--scaling weak` gives
 every rank its own 1e6-cell slice of the (infinite, counter-based) seeded surface instead.  `--workload config2` gives
-the 1e5-cell 2+1D case.
+the 1e5-cell 2+1D case, `--workload config5` the smooth leg of BASELINE config 5: the anisotropic-hydro (VAH) kernel on a 1e6-cell
+surface with its 14-moment coefficients interpolated on the device from the deltaf_coefficients/vah tables.
 
 One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   roofline        the contract's object for the dominant kernel, HBM view: algorithmic bytes / kernel time
@@ -53,6 +54,11 @@ def workload(name):
         return dict(name="config3", dimension=3, df_mode=2, species="urqmd", cells=1000000,
                     text="BASELINE config 3: 1e6-cell synthetic 3+1D surface (seed 20260002), Chapman-Enskog delta-f, "
                          "305-species pdg-urqmd_v3.3+ list, 32x24x21 (pT,phi,y) bins")
+    if name == "config5":
+        return dict(name="config5", dimension=3, df_mode=4, species="urqmd", cells=1000000,
+                    text="BASELINE config 5 (smooth leg): 1e6-cell synthetic 3+1D anisotropic-hydro (VAH, P_L matching) surface (seed 20260002), "
+                         "14-moment delta-f with c0..c4 interpolated on the device from the deltaf_coefficients/vah tables, "
+                         "305-species pdg-urqmd_v3.3+ list, 32x24x21 (pT,phi,y) bins")
     if name == "config2":
         return dict(name="config2", dimension=2, df_mode=1, species="pikp", cells=100000,
                     text="BASELINE config 2: 1e5-cell synthetic 2+1D boost-invariant surface (seed 20260001), 14-moment "
@@ -68,6 +74,8 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
     if kernel_name == "cf_main_feqmod":
         key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1])
+    elif kernel_name == "cf_main_vah":
+        key = "cf_main_vah:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_tile3e":
         key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,MODE=%d" % (ce, JT_R[0], JT_R[1], 0 if variant == 5 else 1)
     elif kernel_name == "cf_main_tile":
@@ -85,27 +93,37 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     nbins = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if wl["dimension"] == 3 else 1)
     per_cell = nbins * len(sp["mass"])
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"])
+    vah_tab = df if wl["name"] == "config5" else None   # config5: `df` is the VAH (Lambda, alpha_L) table set
     # a 1-GPU box owns a 16-core share of the host (and the oracle keeps one 39 MB partial spectrum per thread)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = oracle.set_num_threads(min(16, avail))
-    if fq is not None:
+    make = synth.synth_surface
+    if vah_tab is not None:
+        make = synth.synth_vah_surface
+
+        def run(c, **kw):   # the reference's order: coefficients into the surface (deltafReader.cu:224-278), then the kernel
+            coef, found = oracle.vah_coefficients(vah_tab, c["Lambda"], c["aL"])
+            assert found.all()
+            return oracle.dN_pTdpTdphidy_vah(dict(c, **coef), sp, grid, dict(dimension=wl["dimension"]))
+    elif fq is not None:
         run = lambda c, **kw: oracle.dN_pTdpTdphidy_feqmod(c, sp, grid, df, fq, opts)
     else:
         run = lambda c, **kw: oracle.dN_pTdpTdphidy(c, sp, grid, df, opts, **kw)
-    probe = synth.synth_surface(2 * threads, wl["dimension"])
+    probe = make(2 * threads, wl["dimension"])
     t0 = time.time()
     run(probe)
     t_probe = max(time.time() - t0, 1e-3)
     n = int(max(2 * threads, min(8192, 2 * threads * (0.5 * seconds_budget / t_probe))))
     n -= n % threads
-    cells = synth.synth_surface(n, wl["dimension"])
+    cells = make(n, wl["dimension"])
     t0 = time.time()
     run(cells)
     tb = time.time() - t0
     res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, kind="port",
                sample="first %d cells of the workload surface x all %d species x %d bins, oracle %s, %.1f s" % (
-                   n, len(sp["mass"]), nbins, "feqmod restatement" if fq is not None else "variant B (no scratch)", tb))
-    if fq is not None:
+                   n, len(sp["mass"]), nbins, "VAH restatement (coefficients + kernel)" if vah_tab is not None else
+                   "feqmod restatement" if fq is not None else "variant B (no scratch)", tb))
+    if fq is not None or vah_tab is not None:
         return res
     # variant A: the reference's own structure; scratch = npart*chunk*bins*8 B must fit
     na = n
@@ -159,7 +177,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"])
     ap.add_argument("--df-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
     ap.add_argument("--cells", type=int, default=0, help="override the surface size: total cells (strong scaling) / cells per GPU (weak)")
@@ -238,13 +256,27 @@ def main():
     n_total = (a.cells or wl["cells"]) * (world if a.scaling == "weak" else 1)
     lo, hi = idist.shard_bounds(n_total, rank, world)
     n_loc = hi - lo
-    cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
-    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}   # resident in HBM before timing
+    vah = wl["name"] == "config5"
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local, zero_skip=a.zero_skip, cell_chunks=a.cell_chunks)
     fq = None
-    if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, the surface-average temperature (all ranks' cells)
-        fq = inputs.feqmod_tables(idist.surface_average_T_global(cells))
-    plan = api.Plan(sp, grid, df, opts, max_cells=max(n_loc, 1), fq=fq)
+    if vah:
+        # anisotropic hydro: 24 cell arrays (no T, no c0..c4: the coefficients are interpolated on the device from the tables)
+        if a.df_mode:
+            raise SystemExit("--df-mode does not apply to --workload config5")
+        cells = synth.synth_vah_surface(n_loc, 3, first_cell=lo)
+        cell_fields = [f for f in api.VAH_FIELDS[:25] if f != "T"]
+        df = inputs.vah_df_tables()
+        opts = dict(dimension=3, device=local, zero_skip=a.zero_skip, cell_chunks=a.cell_chunks)
+        tens = {k: torch.from_numpy(cells[k]).to(dev) for k in cell_fields}   # resident in HBM before timing
+        make_plan = lambda o: api.VahPlan(sp, grid, o, tab=df, max_cells=max(n_loc, 1))
+    else:
+        cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
+        cell_fields = list(synth.CELL_FIELDS)
+        tens = {k: torch.from_numpy(cells[k]).to(dev) for k in cell_fields}   # resident in HBM before timing
+        if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, the surface-average temperature (all ranks' cells)
+            fq = inputs.feqmod_tables(idist.surface_average_T_global(cells))
+        make_plan = lambda o: api.Plan(sp, grid, df, o, max_cells=max(n_loc, 1), fq=fq)
+    plan = make_plan(opts)
     plan.set_timing(True)
     out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
     ptrs = {k: v.data_ptr() for k, v in tens.items()}
@@ -253,7 +285,10 @@ def main():
     ms = dict(prep=[], main=[], finalize=[], allreduce=[])
 
     def step(record):
-        if comm is not None:
+        if comm is not None and vah:
+            plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
+            comm.allreduce(out.data_ptr(), plan.output_size, stream)   # is3d_comm_allreduce: the VAH plan has no fused form
+        elif comm is not None:
             plan.execute_allreduce(n_loc, ptrs, out.data_ptr(), comm, stream, want_status=False)
         else:
             plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
@@ -291,8 +326,9 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    plan.check(stream)   # the timed steps ran without status read-back: any cell outside the coefficient table surfaces here
-    if comm is not None:
+    if not vah:
+        plan.check(stream)   # the timed steps ran without status read-back: any cell outside the coefficient table surfaces here
+    if comm is not None and not vah:
         comm.check(stream)   # ... and so does any rank whose execute failed before a collective (the error word summed beside the spectrum)
     st = plan.execute(n_loc, ptrs, out.data_ptr(), stream)   # untimed: status (classes, skipped cells) + sanity
     torch.cuda.synchronize()
@@ -313,7 +349,7 @@ def main():
     # region (pinned host buffers, as a host that cares would hold them); N = 1 only
     incl = None
     if world == 1:
-        used = [k for k in synth.CELL_FIELDS if k in ptrs and (k != "eta" or wl["dimension"] == 3)]
+        used = [k for k in cell_fields if k in ptrs and (k != "eta" or wl["dimension"] == 3)]
         hpin = {k: torch.from_numpy(cells[k]).pin_memory() for k in used}
         hout = torch.empty(plan.output_size, dtype=torch.float64).pin_memory()
 
@@ -332,16 +368,20 @@ def main():
         # and the one-shot host entry a maintainer would call from calculate_dN_pTdpTdphidy: pageable host arrays, plan creation and
         # workspace allocation included
         t1 = time.perf_counter()
-        _, st_host = api.smooth_spectra(cells, sp, grid, df, opts, fq=fq)
+        if vah:
+            _, st_host = api.smooth_spectra_vah(cells, sp, grid, opts, tab=df)
+        else:
+            _, st_host = api.smooth_spectra(cells, sp, grid, df, opts, fq=fq)
         host_entry = dict(ms=(time.perf_counter() - t1) * 1e3, ms_h2d=st_host["ms_h2d"], ms_d2h=st_host["ms_d2h"],
                           ms_kernels=st_host["ms_prep"] + st_host["ms_main"] + st_host["ms_finalize"],
-                          note="is3d_smooth_spectra, one call: plan creation + workspace hipMalloc + pageable H->D + kernels + D->H")
+                          note="%s, one call: plan creation + workspace hipMalloc + pageable H->D + kernels + D->H" % (
+                              "is3d_smooth_spectra_vah_df" if vah else "is3d_smooth_spectra"))
         del hpin, hout
     # untimed: the row / unit culling skips only work that cannot change a bit of the spectrum -- check it here against the same
     # kernels with culling off (zero_skip = 2) on the same resident surface
     cull_identical, ms_no_cull = None, None
     if world == 1 and not a.no_cull_check:
-        plan2 = api.Plan(sp, grid, df, dict(opts, zero_skip=2), max_cells=max(n_loc, 1), fq=fq)
+        plan2 = make_plan(dict(opts, zero_skip=2))
         plan2.set_timing(True)
         out2 = torch.zeros(plan2.output_size, dtype=torch.float64, device=dev)
         plan2.execute(n_loc, ptrs, out2.data_ptr(), stream, want_status=False)
@@ -377,7 +417,7 @@ def main():
         value = evals_step * a.steps / elapsed
         ms_main = float(np.mean(ms["main"]))
         # ---- roofline (contract form, HBM): algorithmic bytes of the launch = cell arrays read once + spectrum written once
-        ncell_arrays = 18 if wl["dimension"] == 3 else 17
+        ncell_arrays = len(cell_fields) - (0 if wl["dimension"] == 3 else 1)   # 18 (17 in 2+1D: no eta); VAH: 24
         b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
         traffic, traffic_source = None, None
         for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC counters need their own rocprofv3 passes: not this run

@@ -370,10 +370,13 @@ __device__ __forceinline__ int first_node_above(const double *g, int n, double x
 
 __global__ void __launch_bounds__(256) cf_vah_coeffs(VahCoefArgs a)
 {
+    // every product and sum below is its own rounding, as in the reference's host code: the pragma applies to the operators written
+    // in THIS block (the __dmul_rn / __dadd_rn wrappers are inlined plain operators and would still be fused into FMAs)
+#pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const double aL = a.aL[i];
-    const double Lam = __ddiv_rn(a.Lambda[i], kHbarC);                    // :228
+    const double Lam = a.Lambda[i] / kHbarC;                              // :228
     const int i1 = first_node_above(a.L, a.nL, Lam), i2 = first_node_above(a.aLg, a.naL, aL);
     if (i1 >= a.nL || i2 >= a.naL) {                                      // includes NaN: every comparison fails
 #pragma unroll
@@ -382,17 +385,19 @@ __global__ void __launch_bounds__(256) cf_vah_coeffs(VahCoefArgs a)
         return;
     }
     const double L1 = a.L[i1 - 1], L2 = a.L[i1], A1 = a.aLg[i2 - 1], A2 = a.aLg[i2];
-    const double dL2 = __dsub_rn(L2, Lam), dL1 = __dsub_rn(Lam, L1), dA2 = __dsub_rn(A2, aL), dA1 = __dsub_rn(aL, A1);
-    const double den = __dmul_rn(__dsub_rn(A2, A1), __dsub_rn(L2, L1));
-    const double hbarC3 = __dmul_rn(__dmul_rn(kHbarC, kHbarC), kHbarC);   // :219
+    const double dL2 = L2 - Lam, dL1 = Lam - L1, dA2 = A2 - aL, dA1 = aL - A1;
+    const double den = (A2 - A1) * (L2 - L1);
+    const double hbarC3 = (kHbarC * kHbarC) * kHbarC;                     // :219
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const double *t = a.tab[k];
         const double c00 = t[(i2 - 1) * a.nL + i1 - 1], c10 = t[(i2 - 1) * a.nL + i1], c01 = t[i2 * a.nL + i1 - 1], c11 = t[i2 * a.nL + i1];
-        const double lo = __dadd_rn(__dmul_rn(c00, dL2), __dmul_rn(c10, dL1));   // (c[i1-1][i2-1] (L2 - L) + c[i1][i2-1] (L - L1))
-        const double hi = __dadd_rn(__dmul_rn(c01, dL2), __dmul_rn(c11, dL1));
-        const double v = __ddiv_rn(__dadd_rn(__dmul_rn(lo, dA2), __dmul_rn(hi, dA1)), den);
-        a.out[k][i] = __ddiv_rn(v, hbarC3);                                       // :262-266
+        const double p00 = c00 * dL2, p10 = c10 * dL1, p01 = c01 * dL2, p11 = c11 * dL1;
+        const double lo = p00 + p10;                                      // (c[i1-1][i2-1] (L2 - L) + c[i1][i2-1] (L - L1))
+        const double hi = p01 + p11;
+        const double q0 = lo * dA2, q1 = hi * dA1;
+        const double v = (q0 + q1) / den;
+        a.out[k][i] = v / hbarC3;                                         // :262-266
     }
 }
 

@@ -12,6 +12,10 @@
 // average_thermodynamic_quantities.dat (readindata.cpp:464-466).
 // operation = 2 (particle sampler; df_mode 1-4, fast in {0, 1}, include_baryon = 1 with df_mode 1-3) writes
 // results/particle_list_osc.dat (write_particle_list_OSC, emissionfunction.cpp:863-901) and results/dN_dy_*.dat is skipped.
+// mode = 2 (anisotropic hydro, P_L matching; BASELINE config 5): operation = 1 with df_mode = 4 -- the combination for which the
+// reference allocates the per-cell c0..c4 (emissionfunction.cpp:1397-1418) and the CUDA tree loads the VAH tables
+// (src/cuda/deltafReader.cu:74-81) -- reads input/surface.dat with read_surf_VAH_PLMatch and deltaf_coefficients/vah/c{0..4}_vah1.dat,
+// runs what the commented-out call site would (emissionfunction.cpp:1650-1654) and writes the same three result files.
 // Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2, 3} with include_baryon in {0, 1}, df_mode 4
 // (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
 // averages it has just written, as the reference does) with include_baryon = 0.  Anything else is refused
@@ -160,11 +164,16 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (get_param("do_resonance_decays", &decays, false) == IS3D_OK && (int)decays)
             DIE("do_resonance_decays = 1: resonance decays are not on this path; set do_resonance_decays = 0");
     }
-    if (!mem && mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
-        DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 (2, 3 = VAH and 5 = vorticity are other paths)", mode);
+    const bool vah = !mem && mode == 2;
+    if (vah) {
+        if (operation != 1) DIE("mode = 2 (anisotropic hydro): only operation = 1; the reference's VAH sampler is an empty stub (emissionfunction_sampling_kernels.cpp:1231-1239)");
+        if (df_mode != 4) DIE("mode = 2 (anisotropic hydro) needs df_mode = 4: the per-cell 14-moment coefficients c0..c4 exist for that combination only (emissionfunction.cpp:1410-1418)");
+    }
+    if (!mem && !vah && mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
+        DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 and the anisotropic-hydro format 2 (3 = VAH P_L, P_T matching and 5 = vorticity are other paths)", mode);
     if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
-    const bool feqmod = df_mode == 3 || df_mode == 4;
-    if (df_mode == 4 && include_baryon)   // deltafReader.cpp:470-474
+    const bool feqmod = !vah && (df_mode == 3 || df_mode == 4);
+    if (df_mode == 4 && include_baryon && !vah)   // deltafReader.cpp:470-474
         DIE("Bilinear interpolation error: Jonah df doesn't work for nonzero muB (df_mode = 4 with include_baryon = 1)");
     const char *pdg_path, *df_dir;
     if (hrg_eos == 1) { pdg_path = "PDG/pdg-urqmd_v3.3+.dat"; df_dir = "deltaf_coefficients/vh/urqmd/"; }
@@ -182,7 +191,13 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     std::vector<std::vector<double>> arr(23);
     double *ptr[23];
     double avg[5] = {0, 0, 0, 0, 0};
-    if (mem) {
+    std::vector<std::vector<double>> varr(32);   // mode 2: the arrays of is3d_surface_read_vah
+    if (vah) {
+        if (is3d_surface_read_vah("input/surface.dat", dimension, &n_cells, nullptr)) DIE("%s", is3d_last_error());
+        double *vp[32];
+        for (int a = 0; a < 32; a++) { varr[a].assign((size_t)n_cells, 0.0); vp[a] = varr[a].data(); }
+        if (n_cells > 0 && is3d_surface_read_vah("input/surface.dat", dimension, &n_cells, vp)) DIE("%s", is3d_last_error());
+    } else if (mem) {
         // iS3D.cpp:100-134: the surface comes from the caller's vectors, already in GeV / fm units (no hbar*c conversion)
         printf("Reading in freezeout surface from memory \n");
         n_cells = mem->n_cells;
@@ -201,7 +216,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         }
         if (n_cells > 0 && is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
     }
-    {
+    if (!vah) {   // read_surf_VAH_PLMatch accumulates no averages (readindata.cpp:813-928)
         std::ofstream f("average_thermodynamic_quantities.dat", std::ios_base::out);
         f << std::setprecision(15) << avg[0] << "\n" << avg[1] << "\n" << avg[2] << "\n" << avg[3] << "\n" << avg[4];
     }
@@ -235,7 +250,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     //      include_baryon = 0: the mu_B = 0 rows; include_baryon = 1: the full (mu_B, T) grids (deltafReader.cpp:134)
     const char *names[10] = {"c0.dat", "c1.dat", "c2.dat", "c3.dat", "c4.dat", "F.dat", "G.dat", "betabulk.dat", "betaV.dat", "betapi.dat"};
     std::vector<double> Tk, Bk, tab[10];
-    for (int t = 0; t < 10; t++) {
+    for (int t = 0; t < 10 && !vah; t++) {
         std::string p = std::string(df_dir) + names[t];
         int32_t nT = 0, nB = 0;
         const bool spline_table = (t == 0 || t == 2 || t == 5 || t == 7 || t == 9);   // c0 c2 F betabulk betapi
@@ -418,9 +433,26 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         return IS3D_OK;
     }
     is3d_status st{};
-    printf(feqmod ? "computing thermal spectra from vhydro with feqmod...\n" : "computing thermal spectra from vhydro with df...\n");
     int rc;
-    if (feqmod) {
+    if (vah) {
+        // the call the reference has commented out (emissionfunction.cpp:1650-1654), with the coefficients the CUDA tree's reader
+        // would have put into the surface (src/cuda/deltafReader.cu:224-278)
+        printf("computing thermal spectra from vahydro (P_L matching) with df...\n");
+        int32_t nL = 0, naL = 0;
+        if (is3d_vah_df_read("deltaf_coefficients/vah", &nL, &naL, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+        std::vector<double> Lg((size_t)nL), ag((size_t)naL), ct((size_t)5 * nL * naL);
+        if (is3d_vah_df_read("deltaf_coefficients/vah", &nL, &naL, Lg.data(), ag.data(), ct.data(), (int64_t)ct.size())) DIE("%s", is3d_last_error());
+        const size_t tn = (size_t)nL * naL;
+        is3d_vah_df_tables vt{nL, naL, Lg.data(), ag.data(), ct.data(), ct.data() + tn, ct.data() + 2 * tn, ct.data() + 3 * tn, ct.data() + 4 * tn};
+        is3d_vah_cells vc{};
+        vc.n_cells = n_cells;
+        const double **vf[25] = {&vc.tau, &vc.eta, &vc.ux, &vc.uy, &vc.un, &vc.dat, &vc.dax, &vc.day, &vc.dan, &vc.T, &vc.pitt, &vc.pitx, &vc.pity,
+                                 &vc.pitn, &vc.pixx, &vc.pixy, &vc.pixn, &vc.piyy, &vc.piyn, &vc.pinn, &vc.bulkPi, &vc.Wx, &vc.Wy, &vc.Lambda, &vc.aL};
+        for (int a = 0; a < 25; a++) *vf[a] = varr[a].data();
+        rc = is3d_smooth_spectra_vah_df(&vc, &sp, &grid, &vt, &opts, dN.data(), &st);
+        st.kernel_variant = 2;
+    } else if (feqmod) {
+        printf("computing thermal spectra from vhydro with feqmod...\n");
         // emissionfunction.cpp:1309-1319: Gauss-Laguerre tables, Plasma::load_thermodynamic_averages (the file written
         // above, read back as text), parameters deta_min and mass_pion0 (:184, :188)
         int32_t n_alpha = 0, n_pts = 0;
@@ -445,10 +477,11 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         rc = is3d_smooth_spectra_multi(&cells, &sp, &grid, &df, &fq, &opts, rd.list.empty() ? nullptr : rd.list.data(), (int32_t)rd.list.size(),
                                        rd.reduce, dN.data(), &st, nullptr);
     } else {
+        printf("computing thermal spectra from vhydro with df...\n");
         rc = is3d_smooth_spectra_multi(&cells, &sp, &grid, &df, nullptr, &opts, rd.list.empty() ? nullptr : rd.list.data(), (int32_t)rd.list.size(),
                                        rd.reduce, dN.data(), &st, nullptr);
     }
-    {
+    if (!vah) {
         const int nd = rd.list.empty() ? is3d_device_count() : (int)rd.list.size();
         printf("devices: %d (cell-axis shards of ~%lld cells%s)\n", nd, (long long)((n_cells + nd - 1) / std::max(nd, 1)),
                nd > 1 ? (rd.reduce == IS3D_REDUCE_RCCL ? ", RCCL all-reduce of the spectrum" : ", shard-ordered device sum of the spectrum") : "");
@@ -457,7 +490,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         const std::string msg = is3d_last_error();
         DIE("is3d_smooth_spectra failed (%d): %s", rc, msg.c_str());
     }
-    if (feqmod) printf("\nfeqmod breaks down for %lld cells\n\n", (long long)st.n_cells_breakdown);   // smooth_kernels.cpp:989
+    if (feqmod && !vah) printf("\nfeqmod breaks down for %lld cells\n\n", (long long)st.n_cells_breakdown);   // smooth_kernels.cpp:989
     double t2 = now_s();
     if (is3d_write_results("results", dimension, sp.n, mcid.data(), grid.n_pT, pT.data(), pTw.data(), grid.n_phi, phi.data(),
                            phiw.data(), grid.n_y, y.data(), dN.data()))

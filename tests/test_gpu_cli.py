@@ -268,3 +268,40 @@ def test_cli_shipped_default_shape(tmp_path, fx):
     assert np.allclose(got[:, 1], h / (2 * np.pi * 1.4 * 0.1 * 0.5 * (e[1:] + e[:-1]) * n_events), rtol=6e-6)
     ylist = [int(v) for v in open(os.path.join(root, "results", "yield_list.dat")).read().split()[3:]]
     assert len(ylist) == n_events and sum(ylist) == len(ref["E"])
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_cli_mode2_anisotropic_hydro(tmp_path, fx, dim):
+    """mode = 2, df_mode = 4, operation = 1: a read_surf_VAH_PLMatch surface and the deltaf_coefficients/vah tables in, the three
+    result files out == oracle reader -> oracle coefficients -> oracle VAH kernel (BASELINE config 5 from files).  The reference's own
+    binary writes zeros here (its call site is commented out, emissionfunction.cpp:1650-1654)."""
+    ids = [211, 321, 2212]
+    cells = synth.synth_vah_surface(19 if dim == 3 else 5, dim, seed=60 + dim)
+    vh = synth.synth_surface(3, dim)            # make_run_dir wants a mode-1 surface to write first; it is replaced below
+    root = refformat.make_run_dir(str(tmp_path), vh, ids, dict(dimension=dim, df_mode=4, mode=2))
+    synth.write_surface_vah_dat(os.path.join(root, "input", "surface.dat"), cells)
+    tab = inputs.vah_df_tables()
+    refformat.write_vah_df_tables(os.path.join(root, "deltaf_coefficients", "vah"), tab)
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "vahydro" in r.stdout and "Total number of freezeout cells: %d" % len(cells["tau"]) in r.stdout
+    rc = oracle.read_surf_VAH_PLMatch(os.path.join(root, "input", "surface.dat"))
+    coef, found = oracle.vah_coefficients(tab, rc["Lambda"], rc["aL"])
+    assert found.all()
+    sp = inputs.species(ids)
+    ref = oracle.dN_pTdpTdphidy_vah(dict(rc, **coef), sp, fx["grid"], dict(dimension=dim))
+    ny = 21 if dim == 3 else 1
+    ref4 = ref.reshape(ny, 24, 32, 3)
+    allsp = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy.dat"))
+    want = np.transpose(ref4, (3, 0, 1, 2)).reshape(-1)
+    assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8
+    assert os.path.exists(os.path.join(root, "results", "dN_dy_2212.dat")) and os.path.exists(os.path.join(root, "results", "vn_continuous", "vn_321.dat"))
+    # refusals: the sampler (an empty stub in the reference), another df_mode, a cell outside the tables
+    for bad, msg in ((dict(operation=2), "stub"), (dict(df_mode=1), "df_mode = 4")):
+        root2 = refformat.make_run_dir(str(tmp_path / ("bad%d" % len(msg))), vh, ids, dict(dict(dimension=dim, df_mode=4, mode=2), **bad))
+        r = subprocess.run([api.CLI_PATH], cwd=root2, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and msg in r.stderr
+    hot = dict(cells, T=cells["T"] * 2.5)       # Lambda ~ T beyond the last node of the tables
+    synth.write_surface_vah_dat(os.path.join(root, "input", "surface.dat"), hot)
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "beyond the last node" in r.stderr

@@ -107,7 +107,7 @@ def test_vah_device_coefficients_are_the_oracles_bit_for_bit():
     assert found.all() and ((lam / h) < 0.6).any() and (al < 0.2).any()      # all inside or below: every cell gets a value
     got = api.vah_coefficients(tab, lam, al)
     for k in range(5):
-        assert np.array_equal(got["c%d" % k], ref["c%d" % k]), k
+        assert np.array_equal(got["c%d" % k], ref["c%d" % k]), (k, relerr(got["c%d" % k], ref["c%d" % k]))
     lam[[70001, 313]] = 1.2501 * h            # beyond the last Lambda node
     al[90000] = 2.0                           # exactly the last alpha_L node: aL < aL[i2] fails for every i2
     lam[95000] = np.nan

@@ -1,0 +1,33 @@
+"""CPU: is3d_amd/csrc/isa_counts.json (tools/count_isa.py), the table bench.py's fp64-VALU roofline is priced with.  The number of
+evaluations a kernel's hot loop covers is read from the emitted ISA (accumulate-FMAs into registers nothing else writes), not re-derived
+from the template rules; this test holds the table to that and to a sanity band."""
+import json
+import os
+import re
+
+from conftest import ROOT
+
+
+def test_isa_counts_are_read_from_the_isa_and_sane():
+    d = json.load(open(os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")))
+    assert len(d) >= 100
+    names = set()
+    for key, v in d.items():
+        assert key.startswith("cf_main_"), key
+        names.add(key.split(":")[0])
+        assert v["evals_counted_from_isa"], key
+        assert 20.0 <= v["flop_per_eval"] <= 70.0, (key, v["flop_per_eval"])
+        assert 13.0 <= v["valu_f64_instr_per_eval"] <= 45.0, (key, v["valu_f64_instr_per_eval"])
+        m = re.search(r"JT=(\d+)", key)
+        if m:
+            assert v["evals_in_loop"] % int(m.group(1)) == 0, key       # evaluations come in whole rows of JT
+        assert v["evals_in_loop"] == v["evals_per_rcp"] * v["histogram"]["v_rcp_f64"], key
+    assert {"cf_main_tile", "cf_main_tile3e", "cf_main_feqmod", "cf_main_vah", "cf_main_direct"} <= names
+    # the instantiation a re-stated template rule got wrong (round 2): the Chapman-Enskog 8 x 31 tile shares a reciprocal among 4
+    # evaluations (cf_kernels.hip), the 14-moment one among 8
+    ce = d["cf_main_tile:CE=1,DIM3=0,OUTFLOW=1,REG=1,BARYON=0,JT=8,R=31"]
+    m14 = d["cf_main_tile:CE=0,DIM3=0,OUTFLOW=1,REG=1,BARYON=0,JT=8,R=31"]
+    assert ce["evals_per_rcp"] == 4 and m14["evals_per_rcp"] == 8 and ce["flop_per_eval"] > m14["flop_per_eval"]
+    # BASELINE config 3's kernel
+    k3 = d["cf_main_tile3e:CE=1,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1"]
+    assert k3["evals_in_loop"] == 56 and k3["evals_per_rcp"] == 4

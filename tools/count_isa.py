@@ -3,8 +3,13 @@
 emits for is3d_amd/csrc/cf_kernels.hip, cf_feqmod.hip and cf_vah.hip, and write is3d_amd/csrc/isa_counts.json (read by bench.py for the
 fp64-VALU roofline).  Method: for every cf_main_* instantiation take the basic blocks of the innermost loop
 that contains v_rcp_f64 (exactly one v_rcp_f64 is issued per evaluation) and divide the opcode histogram of
-those blocks by the number of evaluations they cover = their v_rcp_f64 count x RB, where RB evaluations share one
-reciprocal (rcp_batch in cf_math.h; RB follows from the tile shape exactly as in the kernels; cf_main_direct: 1).
+those blocks by the number of evaluations they cover.  That number is READ FROM THE ISA: every evaluation ends in exactly one
+accumulate `acc = fma(p.dsigma, w, acc)`, and the accumulators are the registers of the loop that nothing but such an in-place
+FMA ever writes (v_fmac_f64 D, A, B or v_fma_f64 D, A, B, D: destination == addend) -- temporaries that also happen to be updated in
+place (Newton steps, Horner chains) are initialised by some other instruction inside the loop and drop out.  The reciprocal batch
+evals_per_rcp = evaluations / v_rcp_f64 follows (4 for the 3+1D 8 x 7 tiles, 8 for the 14-moment 2+1D 8-wide tiles, 4 for the
+Chapman-Enskog 8 x 31 tile, ...); the template rule the kernels use is kept beside it as evals_per_rcp_template, and the two are
+compared by tests/test_isa_counts.py.
 For the 3+1D tile kernel that loop is the whole unit (header + rows),
 so the amortised exponentials are included; for 2+1D the per-unit header (<2 %) is outside the counted loop.
 
@@ -48,6 +53,46 @@ def demangle_params(sym):
     return name, dict(zip(keys, vals))
 
 
+def vregs(tok):
+    """VGPR numbers an operand names: v12 -> [12], v[10:11] -> [10, 11], anything else -> []."""
+    tok = tok.strip().lstrip("-").strip("|")
+    m = re.match(r"^v(\d+)$", tok)
+    if m:
+        return [int(m.group(1))]
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return []
+
+
+def count_evaluations(ins):
+    """Accumulate-FMAs of the loop body `ins` ([(mnemonic, operand text)]): in-place FMAs (destination == addend) into registers that no
+    other instruction of the loop writes."""
+    writers = collections.defaultdict(set)     # vgpr -> set of instruction indices that write it
+    cand = {}                                  # instruction index -> tuple of its destination registers
+    for i, (op, args) in enumerate(ins):
+        ops = [a.strip() for a in args.split(",")]
+        if not ops or op.startswith(("ds_write", "global_store", "scratch_store", "buffer_store", "s_", "v_cmp", "v_readfirstlane", "v_readlane")):
+            continue
+        if op.startswith("global_load_lds"):
+            continue
+        dst = vregs(ops[0])
+        if op.startswith(("v_", "ds_read", "global_load", "scratch_load", "buffer_load")):
+            for r in dst:
+                writers[r].add(i)
+        if op == "v_fmac_f64" and len(dst) == 2:
+            cand[i] = tuple(dst)
+        elif op == "v_fma_f64" and len(ops) >= 4 and len(dst) == 2:
+            add = ops[3].split()[0]            # drop a trailing modifier ("clamp", "mul:2")
+            if vregs(add) == dst and not ops[3].strip().startswith("-") and "clamp" not in args:
+                cand[i] = tuple(dst)
+    n = 0
+    for i, dst in cand.items():
+        if all(all(j in cand and cand[j] == dst for j in writers[r]) for r in dst):
+            n += 1
+    return n
+
+
 def main():
     text = []
     with tempfile.TemporaryDirectory() as td:
@@ -75,9 +120,10 @@ def main():
             d = re.search(r"Depth=(\d+)", m.group(1))
             blocks.append(dict(depth=int(d.group(1)) if d else 0, ops=collections.Counter()))
             continue
-        m = re.match(r"^\s+([vs]_[a-z0-9_]+|ds_[a-z0-9_]+|global_[a-z0-9_]+)", ln)
+        m = re.match(r"^\s+([vs]_[a-z0-9_]+|ds_[a-z0-9_]+|global_[a-z0-9_]+|scratch_[a-z0-9_]+|buffer_[a-z0-9_]+)\s*(.*)", ln)
         if m:
             blocks[-1]["ops"][m.group(1).replace("_e32", "").replace("_e64", "")] += 1
+            blocks[-1].setdefault("ins", []).append((m.group(1).replace("_e32", "").replace("_e64", ""), m.group(2)))
     out = {}
     for sym, blocks in kernels.items():
         p = demangle_params(sym)
@@ -95,17 +141,23 @@ def main():
             continue
         dmax = max(b["depth"] for b in rb)
         hot = collections.Counter()
+        hot_ins = []
         for b in blocks:
             if b["depth"] >= dmax and dmax > 0:
                 hot.update(b["ops"])
+                hot_ins += b.get("ins", [])
         if hot["v_rcp_f64"] == 0:
             continue
         if name == "cf_main_direct":
-            rbatch = 1
+            rbatch_t = 1
         else:
             jt = params["JT"]
-            rbatch = (4 if jt % 4 == 0 else (3 if jt % 3 == 0 else 2)) if params.get("DIM3", 1) else (8 if jt % 8 == 0 else 4)
-        n_eval = hot["v_rcp_f64"] * rbatch
+            rbatch_t = (4 if jt % 4 == 0 else (3 if jt % 3 == 0 else 2)) if params.get("DIM3", 1) else (8 if jt % 8 == 0 else 4)
+        n_eval = count_evaluations(hot_ins)
+        from_isa = n_eval > 0 and n_eval % hot["v_rcp_f64"] == 0
+        if not from_isa:   # accumulators spilled or renamed inside the loop: fall back to the template rule and say so
+            n_eval = hot["v_rcp_f64"] * rbatch_t
+        rbatch = n_eval // hot["v_rcp_f64"]
         f64 = {k: v for k, v in hot.items() if k.endswith("_f64") or k == "v_mov_b64"}
         fma = hot["v_fma_f64"] + hot["v_fmac_f64"]
         other = sum(v for k, v in f64.items() if k not in ("v_fma_f64", "v_fmac_f64", "v_mov_b64"))
@@ -119,7 +171,7 @@ def main():
         if name == "cf_main_tile3e" and params.pop("BARYON", 0):
             name = "cf_main_tile3e_baryon"
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
-        out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
+        out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
                         histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
     with open(OUT, "w") as f:
