@@ -76,6 +76,8 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
         key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_vah":
         key = "cf_main_vah:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
+    elif kernel_name == "cf_main_vah3":
+        key = "cf_main_vah3:REG=1,JT=%d,R=%d" % (JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_tile3e":
         key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,MODE=%d" % (ce, JT_R[0], JT_R[1], 0 if variant == 5 else 1)
     elif kernel_name == "cf_main_tile":

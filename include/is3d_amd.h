@@ -399,6 +399,9 @@ int is3d_vah_plan_execute(is3d_vah_plan *plan, const is3d_vah_cells *cells, doub
 int is3d_vah_plan_set_timing(is3d_vah_plan *plan, int32_t enable);
 int is3d_vah_plan_timings(is3d_vah_plan *plan, is3d_status *status);
 int is3d_vah_plan_tile_shape(const is3d_vah_plan *plan, int32_t *JT, int32_t *R);
+/* "cf_main_vah3" (3+1D, opts.kernel_variant 0 | 3: factored exponent, 8 x 7 tile) or "cf_main_vah" (2+1D; 3+1D with kernel_variant 2: the
+ * round-1 kernel on the 6 x 7 tile, kept for A/B) as it appears in rocprofv3 traces */
+const char *is3d_vah_plan_main_kernel_name(const is3d_vah_plan *plan);
 void is3d_vah_plan_destroy(is3d_vah_plan *plan);
 
 /* FO_data_reader::read_surf_VAH_PLMatch (mode 2; src/cpp/readindata.cpp:813-928): 31 numbers per cell -- tau x y eta | dat dax day

@@ -105,7 +105,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
            "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
            "is3d_vah_plan_workspace_bytes", "is3d_vah_plan_execute", "is3d_vah_plan_set_timing", "is3d_vah_plan_timings",
-           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah"]
+           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah", "is3d_vah_plan_main_kernel_name"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
 IS3D_EPEER = -6
@@ -413,7 +413,9 @@ class VahPlan:
         jt, r = C.c_int32(), C.c_int32()
         L.is3d_vah_plan_tile_shape(self._h, C.byref(jt), C.byref(r))
         self.tile_shape = (jt.value, r.value)
-        self.main_kernel_name = "cf_main_vah"
+        L.is3d_vah_plan_main_kernel_name.argtypes = [C.c_void_p]
+        L.is3d_vah_plan_main_kernel_name.restype = C.c_char_p
+        self.main_kernel_name = L.is3d_vah_plan_main_kernel_name(self._h).decode()
 
     def set_timing(self, enable=True):
         _check(load().is3d_vah_plan_set_timing(self._h, 1 if enable else 0))

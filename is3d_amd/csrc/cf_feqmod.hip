@@ -695,7 +695,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const double X = sqrt_g1(X2[j0 + i]);   // 3e-15 relative: e^-X moves by X * 3e-15
-                    zz[i] = exp_full_sat(BARYON ? cm - X : -X);   // X = |A^-1 p|/T_mod is unbounded for nearly singular A
+                    zz[i] = exp_p9_sat(BARYON ? cm - X : -X);   // saturating: X = |A^-1 p|/T_mod is unbounded for nearly singular A; degree 9 + one-fma reduction (cf_math.h): 7e-14
                     d[i] = __builtin_fma(sign, zz[i], 1.0);
                 }
                 rcp_batch<RB>(d, inv);

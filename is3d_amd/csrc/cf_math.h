@@ -113,6 +113,44 @@ __device__ __forceinline__ double exp_full(double v)
     return ldexp_fast(f, n);
 }
 
+// e^v for the kernels that pay one exponential PER EVALUATION (modified equilibrium, anisotropic hydro: the square root in the
+// exponent does not factorise).  Two instructions shorter than exp_full: the reduction subtracts n ln2 in ONE fma with the double
+// nearest ln2 (its 2.3e-17 error times |n| <= 1075 moves the reduced argument by <= 2.5e-14), and e^r is a degree-9 polynomial
+// (Chebyshev-node interpolant of (e^r - 1)/r on |r| <= 1.02 ln2/2 computed in long double: max relative error 4.5e-14).  Worst
+// case 7e-14 relative -- five orders of magnitude inside the 2e-9 the parity tests assert, seven inside north_star's 1e-6 -- and the
+// argument itself (a one-step square root) already carries 3e-15 |v|.  Same domain as exp_core: |v| < 1.4e9.
+__attribute__((weak)) __constant__ double kExpD[9] = {2.76278435747019428533e-06, 2.48791812002179739231e-05, 1.98412037179905744030e-04,
+    1.38888161319893847084e-03, 8.33333335629010685253e-03, 4.16666669192741895289e-02, 1.66666666666451496193e-01,
+    4.99999999997632282867e-01, 1.00000000000000000000e+00};
+#define IS3D_LN2 0.693147180559945286
+__device__ __forceinline__ double exp_p9_poly(double r)
+{
+    double p = kExpD[0];
+    p = __builtin_fma(p, r, kExpD[1]);
+    p = __builtin_fma(p, r, kExpD[2]);
+    p = __builtin_fma(p, r, kExpD[3]);
+    p = __builtin_fma(p, r, kExpD[4]);
+    p = __builtin_fma(p, r, kExpD[5]);
+    p = __builtin_fma(p, r, kExpD[6]);
+    p = __builtin_fma(p, r, kExpD[7]);
+    p = __builtin_fma(p, r, kExpD[8]);
+    return __builtin_fma(p, r, 1.0);
+}
+__device__ __forceinline__ double exp_p9(double v)   // |v| < 1.4e9 (shift trick, see exp_core)
+{
+    const double shift = 6755399441055744.0;   // 0x1.8p52
+    const double t = __builtin_fma(v, IS3D_LOG2E, shift);
+    const double dn = t - shift;
+    const double r = __builtin_fma(-dn, IS3D_LN2, v);
+    return ldexp_fast(exp_p9_poly(r), __double2loint(t));
+}
+__device__ __forceinline__ double exp_p9_sat(double v)   // any v: v_cvt_i32_f64 saturates, e^-huge = +0
+{
+    const double dn = __builtin_rint(v * IS3D_LOG2E);
+    const double r = __builtin_fma(-dn, IS3D_LN2, v);
+    return ldexp_fast(exp_p9_poly(r), (int)dn);
+}
+
 // 1/d: v_rcp_f64 seed + two Newton steps (each squares the relative error)
 __device__ __forceinline__ double rcp_nr(double d)
 {

@@ -42,6 +42,11 @@ struct VahPrepParams {
     const double *cosphi, *sinphi, *kgrid, *kweight;
     int32_t JT, R, jtiles, rblocks;
     double *TS;
+    // "F" records (3+1D, kernel variant 3; layout at cf_main_vah3): the exponent travels factored, (E_a/Lambda)^2 = (mT c_k - pT d_j)^2 + mT^2 e_k
+    int32_t fact;
+    int64_t cell0;                      // index of the pass's first cell in the caller's arrays (domain report)
+    double mTmax, pTmax;                // largest lane mT, pT: bound of E_a/Lambda for the exponential's domain (exp_p9: < 1.4e9)
+    unsigned long long *status;         // [7] min cell whose E_a/Lambda can exceed 1e9
 };
 
 constexpr int kVahCB = 4;
@@ -50,7 +55,7 @@ constexpr int kVahThreads = 256;
 struct VahScal {
     double dat, dax, day, dan_tau, eta, ut, ux, uy, tau_un, zt, tzn;
     double pitt, pitx, pity, tpitn, pixx, pixy, tpixn, piyy, tpiyn, t2pinn;
-    double Wt, Wx, Wy, tWn, invL2, xi, Pi, c0, c1, c2, c3, c4;
+    double Wt, Wx, Wy, tWn, invL2, xi, Pi, c0, c1, c2, c3, c4, invL;
 };
 
 __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
@@ -60,10 +65,13 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
     VahScal *cs = (VahScal *)lds;                     // [CB]
     double *lk = (double *)(cs + kVahCB);             // [9][CB][K]: A, ax, ad, W, ch, sh, C, Z, V1
     double *lj = lk + 9 * kVahCB * K;                 // [7][CB][J]: B, gx, gd, D, V2, E, F
+    double *l_dmx = lj + 7 * kVahCB * J;              // [CB][jtiles] F records: max_j d_j of a phi tile
     const int CK = kVahCB * K, CJ = kVahCB * J;
     double *l_A = lk, *l_ax = lk + CK, *l_ad = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK;
     double *l_C = lk + 6 * CK, *l_Z = lk + 7 * CK, *l_V1 = lk + 8 * CK;
     double *l_B = lj, *l_gx = lj + CJ, *l_gd = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_V2 = lj + 4 * CJ, *l_E = lj + 5 * CJ, *l_F = lj + 6 * CJ;
+    // F records: the slots of ax_k, W_k (= 1 in 3+1D) and gx_j carry the factored exponent's c_k = C_k / Lambda, e_k = xi Z_k^2 / Lambda^2, d_j = D_j / Lambda
+    double *l_ck = l_ax, *l_ek = l_W, *l_dj = l_gx;
     const int tid = threadIdx.x;
     const int nbatch = (p.n_cells + kVahCB - 1) / kVahCB;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
@@ -89,6 +97,7 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             s.Wt = Wt; s.Wx = Wx; s.Wy = Wy; s.tWn = tau * (Wt * un / ut);
             const double Lambda = p.cells.Lambda[gi], aL = p.cells.aL[gi];
             s.invL2 = 1.0 / (Lambda * Lambda);
+            s.invL = 1.0 / Lambda;
             s.xi = 1.0 / (aL * aL) - 1.0;
             s.Pi = p.include_bulk ? p.cells.bulkPi[gi] : 0.0;
             s.c0 = p.cells.c0[gi]; s.c1 = p.cells.c1[gi]; s.c2 = p.cells.c2[gi];
@@ -109,8 +118,13 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             const double V1 = ch * s.Wt - sh * s.tWn;                               // p.W = mT V1 - pT V2
             const double Q0 = s.pitt * ch * ch + s.t2pinn * sh * sh - 2.0 * s.tpitn * ch * sh;
             l_A[idx] = w * (ch * s.dat + sh * s.dan_tau);
-            l_W[idx] = w;
-            l_ax[idx] = (C * C + s.xi * Z * Z) * s.invL2;
+            if (p.fact) {
+                l_ck[idx] = C * s.invL;
+                l_ek[idx] = s.xi * Z * Z * s.invL2;
+            } else {
+                l_W[idx] = w;
+                l_ax[idx] = (C * C + s.xi * Z * Z) * s.invL2;
+            }
             l_ad[idx] = s.c3 * Z * V1 + s.c4 * Q0 + s.Pi * (s.c0 + s.c1 * Z * Z + s.c2 * C * C);
             l_ch[idx] = ch; l_sh[idx] = sh; l_C[idx] = C; l_Z[idx] = Z; l_V1[idx] = V1;
         }
@@ -121,7 +135,8 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             const double D = cp * s.ux + sp * s.uy;
             const double Q2 = s.pixx * cp * cp + s.piyy * sp * sp + 2.0 * s.pixy * cp * sp;
             l_B[idx] = cp * s.dax + sp * s.day;
-            l_gx[idx] = D * D * s.invL2;
+            if (p.fact) l_dj[idx] = D * s.invL;
+            else l_gx[idx] = D * D * s.invL2;
             l_gd[idx] = s.c4 * Q2 + s.Pi * (s.c2 * D * D - s.c0);
             l_D[idx] = D;
             l_V2[idx] = cp * s.Wx + sp * s.Wy;
@@ -129,7 +144,59 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             l_F[idx] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
         }
         __syncthreads();
-        {
+        if (p.fact) {
+            // ---- F records (cf_main_vah3): header jj {B_j, d_j, gd_j, x}, x of jj = 0, 1, 2 = min_k c_k, min_k e_k over the unit's rows and
+            // max_j d_j over its phi tile (the bounds of the unit- and row-level culls); row r {A_k, c_k, ad_k, e_k, bd_{j0..,k}}
+            const int JT = p.JT, R = p.R;
+            for (int idx = tid; idx < ncb * p.jtiles; idx += kVahThreads) {
+                const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
+                double v = -1.0e300;
+                for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_dj[c * J + min(jt * JT + q2, J - 1)]);
+                l_dmx[idx] = v;
+            }
+            if (tid < ncb) {   // domain of the main kernel's exponential: E_a/Lambda <= mTmax max_k sqrt(c_k^2 + |e_k|) + pTmax max_j |d_j|
+                double ck = 0.0, dj = 0.0;
+                for (int k = 0; k < K; k++) ck = fmax(ck, sqrt(l_ck[tid * K + k] * l_ck[tid * K + k] + fabs(l_ek[tid * K + k])));
+                for (int j = 0; j < J; j++) dj = fmax(dj, fabs(l_dj[tid * J + j]));
+                if (!(p.mTmax * ck + p.pTmax * dj < 1.0e9)) atomicMin(&p.status[7], (unsigned long long)(p.cell0 + cbase + tid));
+            }
+            __syncthreads();
+            const int HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
+            const int units_per_cell = p.jtiles * p.rblocks, per_cell = units_per_cell * REC;
+            for (int idx = tid; idx < ncb * per_cell; idx += kVahThreads) {
+                const int c = idx / per_cell;
+                const int rem = idx - c * per_cell;
+                const int ut = rem / REC, e = rem - ut * REC;
+                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
+                const VahScal &s = cs[c];
+                double v = 0.0;
+                if (e < HDR) {
+                    const int jj = e >> 2, f = e & 3;
+                    const int j = min(jt * JT + jj, J - 1);
+                    if (f == 0) v = l_B[c * J + j];
+                    else if (f == 1) v = l_dj[c * J + j];
+                    else if (f == 2) v = l_gd[c * J + j];
+                    else if (jj == 0) { v = 1.0e300; for (int r = 0; r < R; r++) v = fmin(v, l_ck[c * K + min(rb * R + r, K - 1)]); }
+                    else if (jj == 1) { v = 1.0e300; for (int r = 0; r < R; r++) v = fmin(v, l_ek[c * K + min(rb * R + r, K - 1)]); }
+                    else if (jj == 2) v = l_dmx[c * p.jtiles + jt];
+                } else {
+                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
+                    const int k = rb * R + r, kc = min(k, K - 1);     // padding rows: the forms of row K-1 with p.dsigma = 0
+                    if (f == 0) v = (k < K) ? l_A[c * K + kc] : 0.0;
+                    else if (f == 1) v = l_ck[c * K + kc];
+                    else if (f == 2) v = l_ad[c * K + kc];
+                    else if (f == 3) v = l_ek[c * K + kc];
+                    else {
+                        const int j = min(jt * JT + (f - 4), J - 1);
+                        const double X = l_E[c * J + j] * l_ch[c * K + kc] + l_F[c * J + j] * l_sh[c * K + kc];
+                        v = s.c4 * X - s.c3 * l_Z[c * K + kc] * l_V2[c * J + j] - 2.0 * s.Pi * s.c2 * l_C[c * K + kc] * l_D[c * J + j];
+                    }
+                }
+                const int64_t cell = cbase + c;
+                const int64_t unit = (int64_t)ut * p.n_cells + cell;
+                __builtin_nontemporal_store(v, &p.TS[unit * REC + e]);
+            }
+        } else {
             const int JT = p.JT, R = p.R;
             const int HDR = 4 * JT, RWD = 4 + 2 * JT, REC = HDR + R * RWD;
             const int units_per_cell = p.jtiles * p.rblocks, per_cell = units_per_cell * REC;
@@ -341,6 +408,169 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// cf_main_vah3 (3+1D, kernel variant 3, the default): the round-1 kernel above brought up to the toolbox of cf_main_tile3e /
+// cf_main_feqmod.
+//   * "F" unit records, REC = 4 JT + R (4 + JT) doubles (116 for the 8 x 7 tile, as the delta-f tile's): the exponent travels FACTORED,
+//       (E_a/Lambda)^2 = (p.u/Lambda)^2 + xi (p.z/Lambda)^2 = (mT c_k - pT d_j)^2 + mT^2 e_k,
+//     so a row carries {A_k, c_k, ad_k, e_k, bd_jk...} instead of {A_k, ax_k, ad_k, W_k, bx_jk..., bd_jk...}: 12 instead of 20 doubles through
+//     LDS and registers per row (W_k = 1 in 3+1D), which is what lets the 8 x 7 tile fit 256 VGPRs with four evaluations per v_rcp_f64
+//     (the 6 x 7 tile shared one among three).  p.u = mT C_k - pT D_j is formed as the difference it is in the reference (:2290) rather
+//     than through the expanded quadratic form: the same instruction count (one add, one fma) and no cancellation between squares.
+//   * a row is tested BEFORE its evaluations from a lower bound: p.u/Lambda >= mT c_k - pT max_j d_j >= 0 (u timelike, pT >= 0, monotone
+//     roundings), X^2 >= lb^2 + mT^2 e_k: three instructions per row instead of a minimum per evaluation, and a dead row forms no X^2;
+//     a unit whose bound (min_k c_k, min_k e_k in free header slots) is dead skips its header and its R row fetches.  The rule is the
+//     exact-zero rule of the round-1 kernel (E_a/Lambda > 745.25: f_a == +0): bitwise the same spectrum with zero_skip on or off.
+//   * exp_p9 (cf_math.h): one fma for the range reduction, degree 9 -- two instructions fewer per evaluation, 7e-14 relative.
+//     cf_prep_vah refuses cells whose E_a/Lambda could exceed 1e9 (status[7]) so that the shift-trick conversion is in its domain.
+// ------------------------------------------------------------------------------------------------
+template <bool REG, int JT, int R>
+__global__ void __launch_bounds__(512)
+cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
+             const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g)
+{
+    constexpr int HDR = 4 * JT;
+    constexpr int RW = 4 + JT;
+    constexpr int REC = HDR + R * RW;
+    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
+    constexpr int BUF2 = UB * REC / 2;
+    constexpr int RB = JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2);
+    static_assert(REC % 2 == 0 && JT % RB == 0 && JT >= 3, "unit records must be 16-byte multiples; the cull bounds sit in header slots jj = 0, 1, 2");
+    constexpr int BUFP = ((BUF2 * 16 + 1023) / 1024) * 64;   // the batch as whole 1-KiB staging pieces (64 double2 each)
+    __shared__ double2 lbuf[2][BUFP + RW / 2 + 1];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int stream = (q / g.G) * 8 + xcd;
+    if (stream >= g.NT) return;
+    int sidx = stream;
+    const int jt = sidx % g.jtiles; sidx /= g.jtiles;
+    const int kt = sidx % g.ktiles; sidx /= g.ktiles;
+    const int chunk = sidx;
+    const int nthr = blockDim.x;
+    const int lw = grp * g.wpb + (tid >> 6);
+    const bool wave_active = lw * 64 < g.Lpad;
+    const int l = wave_active ? lw * 64 + (tid & 63) : 0;
+
+    const int J = g.J, K = g.K;
+    const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    const double mT2 = mT * mT;
+    const double hs = REG ? 0.5 : 1.0;   // u = (1 + fbar df) * hs, clamped to [0, 1] by the VOP3 clamp modifier when REG
+    const double mT2s = hs * mT2, mTpTs = hs * (mT * pT), pT2s = hs * (pT * pT);
+    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
+    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    const int n_units = c1 - c0;
+    const int s_tile = jt * g.ktiles + kt;
+    const double2 *src = (const double2 *)(TS + ((int64_t)s_tile * g.n_cells + c0) * REC);
+    const int nb = (n_units + UB - 1) / UB;
+
+    double acc[JT * R];
+#pragma unroll
+    for (int i = 0; i < JT * R; i++) acc[i] = 0.0;
+    int n_rows = 0, n_dead = 0;
+    constexpr double X2CUT = 555400.0;   // E_a/Lambda > 745.25: exp(-E_a/Lambda) == +0
+
+    auto process_unit = [&](const double *U) {
+        const double pTdmax = pT * U[11];
+        if (g.zskip) {   // unit-level cull: every row of the unit would fail its own test below
+            const double lbu = __builtin_fmax(__builtin_fma(mT, U[3], -pTdmax), 0.0);
+            const double x2lb_u = __builtin_fma(lbu, lbu, mT2 * U[7]);
+            if (__all(x2lb_u > X2CUT)) { n_rows += R; n_dead += R; return; }
+        }
+        double pTB[JT], pTd[JT], gd[JT];
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) {
+            pTB[jj] = pT * U[4 * jj + 0];
+            pTd[jj] = pT * U[4 * jj + 1];
+            gd[jj] = pT2s * U[4 * jj + 2];
+        }
+        struct Row { double v[RW]; };
+        auto fetch = [&](Row &rw, const double *row) {
+#pragma unroll
+            for (int i = 0; i < RW; i++) rw.v[i] = row[i];
+        };
+        auto evals = [&](const Row &rw, int r) {
+            const double mTc = mT * rw.v[1], mT2e = mT2 * rw.v[3];
+            n_rows += 1;
+            const double lb = __builtin_fmax(mTc - pTdmax, 0.0);
+            const double x2lb = __builtin_fma(lb, lb, mT2e);
+            if (g.zskip && __all(x2lb > X2CUT)) { n_dead += 1; return; }
+            const double mTA = mT * rw.v[0], ad = mT2s * rw.v[2];
+#pragma unroll
+            for (int j0 = 0; j0 < JT; j0 += RB) {   // one v_rcp_f64 per RB evaluations (rcp_batch, cf_math.h)
+                double zz[RB], d[RB], inv[RB];
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const double t = mTc - pTd[j0 + i];                      // p.u / Lambda
+                    const double X = sqrt_g1(__builtin_fma(t, t, mT2e));     // E_a / Lambda
+                    zz[i] = exp_p9(-X);
+                    d[i] = __builtin_fma(sign, zz[i], 1.0);
+                }
+                rcp_batch<RB>(d, inv);                                                         // fbar_a
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int jj = j0 + i;
+                    const double rr = inv[i];
+                    const double br = __builtin_fma(mTpTs, rw.v[4 + jj], ad + gd[jj]);         // hs * df/(f_a fbar_a)
+                    const double u = REG ? fma_clamp01_half(rr, br) : __builtin_fma(rr, br, 1.0);
+                    const double pds = pTB[jj] + mTA;                                          // W_k = 1 in 3+1D
+                    const double w = (zz[i] * rr) * u;
+                    acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                }
+            }
+        };
+        const double *rows = U + HDR;
+        Row cur, nxt;
+        fetch(cur, rows);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
+            evals(cur, r);
+            if (r + 1 < R) cur = nxt;
+        }
+    };
+
+    // staging: the next batch by direct-to-LDS loads (stage_pieces, cf_math.h), issued before the current batch is consumed
+    auto stage = [&](int ib, int buf) { stage_pieces<BUFP / 64>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
+    // the lane constants must have ARRIVED before the batch loop (see cf_main_vah)
+    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2s), "v"(mTpTs), "v"(pT2s), "v"(mT2) : "memory");
+    if (nb > 0) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ib = 0; ib < nb; ib++) {
+            if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
+            if (wave_active) {
+                const int nu = min(UB, n_units - ib * UB);
+                const double *base = (const double *)lbuf[ib & 1];
+                for (int u = 0; u < nu; u++) process_unit(base + u * REC);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (!wave_active) return;
+    if ((tid & 63) == 0) {
+        atomicAdd(&stats[2], (unsigned long long)n_rows);
+        atomicAdd(&stats[3], (unsigned long long)n_dead);
+    }
+    const double unscale = REG ? 2.0 : 1.0;
+    double *pp = partial + (int64_t)chunk * J * g.Kacc * g.Lpad;
+#pragma unroll
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = jt * JT + jj;
+        if (j < J) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int k = kt * R + r;
+                if (k < K) pp[((int64_t)j * g.Kacc + k) * g.Lpad + l] = unscale * acc[jj * R + r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-cell 14-moment coefficients from the (Lambda, alpha_L) tables: src/cuda/deltafReader.cu:224-278.  The reference scans
 // i2 (alpha_L) outer, i1 (Lambda) inner for the first pair with i1 > 0 && Lambda < L[i1] && i2 > 0 && aL < aL[i2]: the two conditions
 // are independent, so that is the first i2 >= 1 with aL < aL[i2] and the first i1 >= 1 with Lambda < L[i1] (ascending nodes: an
@@ -433,7 +663,16 @@ struct DevMem {
     template <class T> T *as() const { return (T *)p; }
 };
 
-constexpr int kJT3 = 6, kR3 = 7, kJT2 = 8, kR2 = 61;   // the default tile shapes of the delta-f kernel
+constexpr int kJT3 = 6, kR3 = 7, kJT2 = 8, kR2 = 61;   // the round-1 kernel's tile shapes (kernel variant 2; 2+1D always)
+constexpr int kJT3F = 8, kR3F = 7;                       // cf_main_vah3 (3+1D default, kernel variant 3)
+
+void launch_vah3(bool reg, const double *TS, const double *mT, const double *pT, const double *sg, double *partial, unsigned long long *stats,
+                 const is3d::MainGeom &g, hipStream_t st)
+{
+    const int grid = ((g.NT + 7) / 8) * 8 * g.G;
+    if (reg) hipLaunchKernelGGL((is3d::cf_main_vah3<true, kJT3F, kR3F>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g);
+    else hipLaunchKernelGGL((is3d::cf_main_vah3<false, kJT3F, kR3F>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g);
+}
 
 template <bool DIM3>
 void launch_vah(bool reg, const double *TS, const double *mT, const double *pT, const double *sg, double *partial, unsigned long long *stats,
@@ -486,6 +725,8 @@ struct is3d_vah_plan {
     is3d_options o{};
     int device = 0;
     bool three_d = true, tables = false, timing = false;
+    bool fact = false;            // F records + cf_main_vah3 (3+1D, kernel variant 0 / 3)
+    double mTmax = 0.0, pTmax = 0.0;
     int npart = 0, npT = 0, J = 0, K = 0, Kacc = 1, ncls = 0, Lpad = 0;
     int JT = 0, R = 0, jtiles = 0, rblocks = 0, ktiles = 0, upc = 0, REC = 0, wpb = 4, nch = 1;
     int64_t nout = 0, max_cells = 0, pass_cells = 0;
@@ -565,11 +806,15 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
         P->tables = true;
         VAH_TRY(P->d_coef.alloc(sizeof(double) * 5 * (size_t)max_cells));
     }
-    P->JT = three_d ? kJT3 : kJT2; P->R = three_d ? kR3 : kR2;
+    if (o->kernel_variant != 0 && o->kernel_variant != 2 && o->kernel_variant != 3)
+        return set_error(IS3D_EINVAL, "VAH kernel_variant %d: 0 (default), 2 (round-1 kernel, 6 x 7 tile) or 3 (factored exponent, 8 x 7 tile; 3+1D)", o->kernel_variant);
+    P->fact = three_d && o->kernel_variant != 2;
+    for (int s2 = 0; s2 < L; s2++) { P->mTmax = std::max(P->mTmax, mT[s2]); P->pTmax = std::max(P->pTmax, pT[s2]); }
+    P->JT = three_d ? (P->fact ? kJT3F : kJT3) : kJT2; P->R = three_d ? (P->fact ? kR3F : kR3) : kR2;
     P->jtiles = (J + P->JT - 1) / P->JT; P->rblocks = (K + P->R - 1) / P->R;
     P->ktiles = three_d ? P->rblocks : 1; P->upc = three_d ? 1 : P->rblocks;
-    P->REC = 4 * P->JT + P->R * (4 + 2 * P->JT);
-    P->lds_prep = sizeof(is3d::VahScal) * is3d::kVahCB + sizeof(double) * (size_t)is3d::kVahCB * (9 * K + 7 * J);
+    P->REC = P->fact ? 4 * P->JT + P->R * (4 + P->JT) : 4 * P->JT + P->R * (4 + 2 * P->JT);
+    P->lds_prep = sizeof(is3d::VahScal) * is3d::kVahCB + sizeof(double) * (size_t)is3d::kVahCB * (9 * K + 8 * J);   // + [CB][jtiles <= J] tile maxima of the F records
     if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
@@ -603,6 +848,7 @@ extern "C" int is3d_vah_plan_tile_shape(const is3d_vah_plan *P, int32_t *JT, int
     *JT = P->JT; *R = P->R;
     return IS3D_OK;
 }
+extern "C" const char *is3d_vah_plan_main_kernel_name(const is3d_vah_plan *P) { return (P && P->fact) ? "cf_main_vah3" : "cf_main_vah"; }
 extern "C" void is3d_vah_plan_destroy(is3d_vah_plan *P)
 {
     if (!P) return;
@@ -666,6 +912,7 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         pp.include_bulk = o.include_bulk_deltaf != 0; pp.include_shear = o.include_shear_deltaf != 0;
         pp.cosphi = P->d_cos.as<double>(); pp.sinphi = P->d_sin.as<double>(); pp.kgrid = P->d_kg.as<double>(); pp.kweight = P->d_kw.as<double>();
         pp.JT = P->JT; pp.R = P->R; pp.jtiles = P->jtiles; pp.rblocks = P->rblocks; pp.TS = P->d_TS.as<double>();
+        pp.fact = P->fact; pp.cell0 = c0; pp.mTmax = P->mTmax; pp.pTmax = P->pTmax; pp.status = d_st;
         const int nbatch = (nc + is3d::kVahCB - 1) / is3d::kVahCB;
         hipLaunchKernelGGL(is3d::cf_prep_vah, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), P->lds_prep, st, pp);
         VAH_TRY(hipGetLastError());
@@ -674,7 +921,8 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         g.n_cells = nc; g.J = P->J; g.K = P->K; g.Lpad = P->Lpad; g.wpb = P->wpb; g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
         g.jtiles = P->jtiles; g.ktiles = P->ktiles; g.nch = nch; g.NT = P->jtiles * P->ktiles * nch; g.Kacc = P->Kacc;
         g.first_pass = 1; g.upc = P->upc; g.zskip = (o.zero_skip != 2); g.baryon = 0;
-        if (P->three_d) launch_vah<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
+        if (P->fact) launch_vah3(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
+        else if (P->three_d) launch_vah<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
         else launch_vah<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
         VAH_TRY(hipGetLastError());
         if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 2], st));
@@ -689,9 +937,15 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         VAH_TRY(hipMemcpyAsync(h, d_st, sizeof h, hipMemcpyDeviceToHost, st));
         VAH_TRY(hipStreamSynchronize(st));
         status->n_passes = npasses;
-        status->kernel_variant = 2;
+        status->kernel_variant = P->fact ? 3 : 2;
         status->n_wave_rows = (int64_t)h[2];
         status->n_wave_rows_culled = (int64_t)h[3];
+        if (h[7] != ~0ULL && (h[0] == ~0ULL || h[7] < h[0])) {
+            status->bad_cell = (int64_t)h[7];
+            status->code = IS3D_EDOMAIN;
+            return set_error(IS3D_EDOMAIN, "cell %lld: E_a/Lambda can exceed 1e9 for the momentum grid (flow, Lambda or alpha_L outside the kernel's "
+                             "exponent range; the reference's exp() overflows to inf there)", (long long)status->bad_cell);
+        }
         if (h[0] != ~0ULL) {
             status->bad_cell = (int64_t)h[0];
             status->code = IS3D_EDOMAIN;
@@ -717,7 +971,7 @@ extern "C" int is3d_vah_plan_timings(is3d_vah_plan *P, is3d_status *status)
         status->ms_prep += a; status->ms_main += b; status->ms_finalize += c;
     }
     status->n_passes = P->last_passes;
-    status->kernel_variant = 2;
+    status->kernel_variant = P->fact ? 3 : 2;
     status->n_classes = P->ncls;
     return IS3D_OK;
 }

@@ -450,7 +450,6 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
                                  &vc.pitn, &vc.pixx, &vc.pixy, &vc.pixn, &vc.piyy, &vc.piyn, &vc.pinn, &vc.bulkPi, &vc.Wx, &vc.Wy, &vc.Lambda, &vc.aL};
         for (int a = 0; a < 25; a++) *vf[a] = varr[a].data();
         rc = is3d_smooth_spectra_vah_df(&vc, &sp, &grid, &vt, &opts, dN.data(), &st);
-        st.kernel_variant = 2;
     } else if (feqmod) {
         printf("computing thermal spectra from vhydro with feqmod...\n");
         // emissionfunction.cpp:1309-1319: Gauss-Laguerre tables, Plasma::load_thermodynamic_averages (the file written

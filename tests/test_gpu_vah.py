@@ -19,9 +19,28 @@ def test_vah_parity(fx, dim, flags):
     sp = inputs.species([211, 321, 2212, -2212, 3122, 333]) if dim == 3 else fx["pikp"]
     o = dict(dimension=dim, **flags)
     ref = oracle.dN_pTdpTdphidy_vah(cells, sp, fx["grid"], o)
-    got, st = api.smooth_spectra_vah(cells, sp, fx["grid"], o)
-    assert relerr(got, ref, floor=1e-270) < TOL, relerr(got, ref, floor=1e-270)
+    for variant in (0, 2, 3):                    # 3 (= the 3+1D default): cf_main_vah3, factored exponent on the 8 x 7 tile; 2: the round-1 kernel
+        got, st = api.smooth_spectra_vah(cells, sp, fx["grid"], dict(o, kernel_variant=variant))
+        assert relerr(got, ref, floor=1e-270) < TOL, (variant, relerr(got, ref, floor=1e-270))
+        assert st["kernel_variant"] == (2 if (dim == 2 or variant == 2) else 3)
+        off, _ = api.smooth_spectra_vah(cells, sp, fx["grid"], dict(o, kernel_variant=variant, zero_skip=2))
+        assert np.array_equal(off, got), variant         # the row / unit culls skip exact zeros only
     assert (ref < 0).any() or dim == 2
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra_vah(cells, sp, fx["grid"], dict(o, kernel_variant=5))
+    assert e.value.code == api.IS3D_EINVAL
+
+
+def test_vah_exponent_domain_is_refused(fx):
+    """cf_main_vah3's exponential takes its integer part by the shift trick (|E_a/Lambda| < 1.4e9): cf_prep_vah reports a cell that could
+    exceed 1e9 (a Lambda of 1e-12 GeV here) instead of wrapping an exponent; the reference's exp() overflows to inf there."""
+    cells = synth.synth_vah_surface(40, 3, seed=3)
+    cells["Lambda"][11] = 1e-12
+    with pytest.raises(api.Is3dError) as e:
+        api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], dict(dimension=3))
+    assert e.value.code == api.IS3D_EDOMAIN and e.value.bad_cell == 11 and "1e9" in str(e.value)
+    got, _ = api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], dict(dimension=3, kernel_variant=2))   # the saturating exponential of the round-1 kernel
+    assert np.isfinite(got).all()
 
 
 def test_vah_species_collapse_passes_and_accumulate(fx):
@@ -32,7 +51,7 @@ def test_vah_species_collapse_passes_and_accumulate(fx):
     ref = oracle.dN_pTdpTdphidy_vah(cells, sp, g, o)
     one, st = api.smooth_spectra_vah(cells, sp, g, o)
     assert st["n_classes"] == 75 and relerr(one, ref, floor=1e-270) < TOL
-    for extra in (dict(workspace_bytes=1 << 20), dict(cell_chunks=3), dict(zero_skip=2), dict(collapse_species=2)):
+    for extra in (dict(workspace_bytes=1 << 19), dict(cell_chunks=3), dict(zero_skip=2), dict(collapse_species=2), dict(kernel_variant=2)):
         got, st2 = api.smooth_spectra_vah(cells, sp, g, dict(o, **extra))
         if "workspace_bytes" in extra:
             assert st2["n_passes"] > 1

@@ -48,6 +48,8 @@ def demangle_params(sym):
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON"]
     elif name == "cf_main_vah":
         keys = ["DIM3", "REG", "JT", "R"]
+    elif name == "cf_main_vah3":
+        keys = ["REG", "JT", "R"]
     else:
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
     return name, dict(zip(keys, vals))
