@@ -239,6 +239,16 @@ def main():
             except Exception as e:   # keep the scaling run alive: torch's RCCL group does the same sum
                 print("bench.py rank %d: library communicator unavailable (%s); falling back to torch.distributed.all_reduce" % (rank, e),
                       file=sys.stderr, flush=True)
+        if comm is not None:
+            # RCCL builds its rings / connections lazily at the first collective: pay that here, not in a timed step (--warmup 0 included)
+            try:
+                prime = torch.zeros(1024, dtype=torch.float64, device=dev)
+                comm.allreduce(prime.data_ptr(), prime.numel(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            except Exception as e:
+                print("bench.py rank %d: priming all-reduce failed (%s); falling back to torch.distributed.all_reduce" % (rank, e), file=sys.stderr, flush=True)
+                comm.close()
+                comm = None
         ok = torch.tensor([1 if comm is not None else 0], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:

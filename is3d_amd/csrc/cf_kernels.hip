@@ -486,7 +486,13 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 
 // cells per batch: 16 while (9 K + 8 J) doubles per cell stay small (3+1D grids), else 4 (2+1D, 241 eta rows: 1 / 2 / 4 cells per
 // batch measure 6.5 / 5.7 / 5.5 ms per 1e5 cells -- occupancy is not what limits it)
-static int prep_batch_cells(int K) { return K <= 32 ? kPrepCB3 : kPrepCB; }
+static int prep_batch_cells(int K)
+{
+    if (K > 32) return kPrepCB;
+    // dev switch (A/B only): IS3D_PREP_CB3 = 4 | 8 | 16 cells per workgroup batch in 3+1D
+    static const int env = [] { const char *e = getenv("IS3D_PREP_CB3"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16) ? v : 0; }();
+    return env ? env : kPrepCB3;
+}
 
 size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int dim3)
 {
@@ -506,7 +512,8 @@ hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
     size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0, p.dim3 ? 1 : 0);
-    if (cb == kPrepCB3) hipLaunchKernelGGL(cf_prep<kPrepCB3>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
+    if (cb == 16) hipLaunchKernelGGL(cf_prep<16>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
+    else if (cb == 8) hipLaunchKernelGGL(cf_prep<8>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     else hipLaunchKernelGGL(cf_prep<kPrepCB>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     return hipGetLastError();
 }
@@ -1130,7 +1137,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
             rw.live = !(g.zskip && __all(earg < cull_thr));
             n_rows += 1;
             n_dead += rw.live ? 0 : 1;
-            rw.E1 = exp_full(earg);
+            rw.E1 = exp_p9(earg);   // degree 9, one-fma reduction (cf_math.h): 7e-14, two instructions fewer per row
         };
         auto evals = [&](const Row &rw, int r) {
             const double mTA = mT * rw.v[0];
@@ -1190,7 +1197,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                     Row rw;
                     rw.v = rows + r * RW;
                     rw.mTC = mT * cn[r];   // C'_k is already here (read with the unit bounds): the exponential starts before the row's own reads return
-                    rw.E1 = exp_full(BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC);
+                    rw.E1 = exp_p9(BARYON ? (bmax - rw.mTC) + baB : bmax - rw.mTC);   // degree 9, one-fma reduction (cf_math.h): 7e-14
                     rw.live = true;
                     evals(rw, r);
                 }

@@ -440,7 +440,15 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if (P->feqmod)   // fallback record, flag, list entry; df_mode 3: cell record + |renorm| per class
         P->bytes_per_cell += sizeof(double) * is3d::kFbRec + 2 * sizeof(int32_t) +
                              (o->df_mode == 3 ? sizeof(double) * ((size_t)is3d::kCrRec + P->ncls) : 0);
-    int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
+    // cap on the derived streams of one pass: the caller's, else 16 GiB or half of the device memory that is free right now, whichever
+    // is larger (288 GB of HBM: a 1e6-cell surface with baryon slots -- 20.6 KB per cell -- stays a single pass; only what max_cells
+    // needs is allocated)
+    int64_t ws = o->workspace_bytes;
+    if (ws <= 0) {
+        ws = (int64_t)16 << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)(free_b / 2));
+    }
     int64_t pc = ws / (int64_t)P->bytes_per_cell;
     if (pc < 1) pc = 1;
     if (pc > max_cells) pc = max_cells;

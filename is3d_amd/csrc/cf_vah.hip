@@ -818,7 +818,12 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
-    const int64_t ws = o->workspace_bytes > 0 ? o->workspace_bytes : ((int64_t)16 << 30);
+    int64_t ws = o->workspace_bytes;
+    if (ws <= 0) {   // as cf_plan.cpp: 16 GiB or half of the free device memory
+        ws = (int64_t)16 << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)(free_b / 2));
+    }
     P->pass_cells = std::max<int64_t>(1, std::min<int64_t>(max_cells, ws / (int64_t)bytes_per_cell));
     const int lane_waves = Lpad / 64;
     int best = 1 << 30;

@@ -31,6 +31,11 @@ def main():
     ap.add_argument("--order", default="mT", choices=["mT", "pT", "pTpad", "band8", "band4", "band16"],
                     help="lane order: sorted by mT (the plan's), pT-major with the classes sorted by mass inside, or pT-major with "
                          "every pT padded to whole waves")
+    ap.add_argument("--eta-bin", type=float, default=None,
+                    help="eta-binned chunk (VERDICT round 2, item 5): take only cells with |eta - ETA_BIN| < half the y spacing, i.e. what a chunk "
+                         "would hold if cf_prep binned the cells by eta")
+    ap.add_argument("--origin", default="0", help="row-block origin: an integer row, or 'eta': the row nearest the bin's eta minus R // 2, so that the "
+                                                  "live window of the chunk's cells sits in one block (blocks then cover rows origin + R m, clipped to the grid)")
     a = ap.parse_args()
     g = inputs.grid()
     sp = inputs.species("urqmd")
@@ -61,7 +66,14 @@ def main():
     pe = np.ceil(np.log2(np.maximum(mT / mTmax, pTl / pTmax))).astype(int)
     pe = np.minimum(pe, 0)
 
-    s = synth.synth_surface(a.cells, 3, first_cell=a.first)
+    if a.eta_bin is None:
+        s = synth.synth_surface(a.cells, 3, first_cell=a.first)
+    else:
+        hw = 0.5 * (yv[1] - yv[0])
+        big = synth.synth_surface(a.cells * 24, 3, first_cell=a.first)
+        sel = np.nonzero(np.abs(big["eta"] - a.eta_bin) < hw)[0][:a.cells]
+        s = {k: v[sel] for k, v in big.items()}
+        a.cells = len(sel)
     tau, eta, T = s["tau"], s["eta"], s["T"]
     ut = np.sqrt(1 + s["ux"] ** 2 + s["uy"] ** 2 + tau ** 2 * s["un"] ** 2)
     dy = yv[None, :] - eta[:, None]                       # [c][k]
@@ -76,7 +88,14 @@ def main():
     e_sc = int(np.frexp(bound)[1])
     psc = 2.0 ** -e_sc
     J, K, JT, R = len(phi), len(yv), a.JT, a.R
-    jt_n, kt_n = (J + JT - 1) // JT, (K + R - 1) // R
+    if a.origin == "eta":
+        center = int(round(((a.eta_bin if a.eta_bin is not None else 0.0) - yv[0]) / (yv[1] - yv[0])))
+        origin = (center - R // 2) % R
+        origin = origin - R if origin > 0 else origin          # first block starts at or before row 0
+    else:
+        origin = -(int(a.origin) % R) if int(a.origin) % R else 0
+    blocks = [(max(o, 0), min(o + R, K)) for o in range(origin, K, R) if min(o + R, K) > max(o, 0)]
+    jt_n, kt_n = (J + JT - 1) // JT, len(blocks)
     C = a.cells
 
     # accumulators acc[l][j][k] (equilibrium, u = 1/2) and the exponent bounds
@@ -103,7 +122,7 @@ def main():
         js = slice(jt * JT, min(J, (jt + 1) * JT))
         Dmax = Dp[:, js].max(axis=1)                                     # [c]
         for kt in range(kt_n):
-            ks = slice(kt * R, min(K, (kt + 1) * R))
+            ks = slice(blocks[kt][0], blocks[kt][1])
             earg = pTl[:, None, None] * Dmax[None, :, None] - mT[:, None, None] * Cp[None, :, ks]      # [l][c][r]
             eA = e_acc[:, js, ks].min(axis=(1, 2))                        # [l]
             eB = e_acc[:, js, ks].min(axis=1)                             # [l][r]
@@ -125,13 +144,20 @@ def main():
                 live[key] += int(w.sum())
                 unit_live[key] += int(w.any(axis=2).sum())
                 if key in per_kt:
-                    per_kt[key][kt] += w.sum()
+                    per_kt[key][kt] += w.sum() * R / nr
                     lane_live[key] += int(lv.sum())
     units = nw * C * jt_n * kt_n
-    print("cells %d  lanes %d (%d waves)  tiles %d x %d  scale 2^-%d" % (C, L, nw, jt_n, kt_n, e_sc))
+    print("cells %d  lanes %d (%d waves)  tiles %d x %d  row blocks %s  scale 2^-%d" % (C, L, nw, jt_n, kt_n, blocks, e_sc))
     for key in "ABC":
         print("rule %s: live wave-rows %.4f  live units %.4f  rows per live unit %.2f" % (
             key, live[key] / total_rows, unit_live[key] / units, live[key] / max(unit_live[key], 1)))
+    # issued fp64-VALU instructions per (wave, cell, phi tile) under rule A, priced with the instruction counts of cf_main_tile3e (DESIGN.md
+    # section 5): a live row 8 x 14 + 25 (operands, row exponential), a live unit's header 59 (24 multiplications, 21 row-test instructions,
+    # 14 v_readfirstlane), a dead row inside a live unit 3, a unit culled whole 3
+    lr, lu = live["A"], unit_live["A"]
+    dead_rows_in_live_units = lu * R - lr
+    instr = lr * (8 * 14 + 25) + lu * 59 + max(dead_rows_in_live_units, 0) * 3 + (units - lu) * 3
+    print("rule A: modelled issued instructions per (wave, cell, phi tile): %.1f   (units per cell and tile: %d)" % (instr / (nw * C * jt_n), kt_n))
     for key in "AB":
         print("rule %s: live (lane, row) pairs %.4f;  live wave-rows by row block: %s" % (
             key, lane_live[key] / (L * C * jt_n * K), np.round(per_kt[key] / (nw * C * jt_n * R), 4)))

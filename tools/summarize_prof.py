@@ -103,3 +103,41 @@ if c2:
                           rocprof_avg_kernel_ms=[float(r[3]) / 1e6 for r in rows[1:] if "cf_main" in r[0]][:1],
                           sq_counters_per_launch={k: agg2[k] / cnt2[k] for k in sorted(agg2)})
     json.dump(old, open(tp, "w"), indent=1)
+
+# optional third workload (tools/profile_r03.sh: the smooth leg of BASELINE config 5, cf_main_vah3): kernel stats, every counter of
+# its c5pmc_* passes, and the same traffic derivation
+c5 = glob.glob(os.path.join(src, "trace_c5", "*", "*_kernel_stats.csv"))
+if c5:
+    rows = list(csv.reader(open(max(c5, key=os.path.getmtime))))
+    with open(os.path.join(dst, tag + "_kernel_stats_vah.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        for r in rows:
+            r[0] = r[0][:120]
+            w.writerow(r)
+    b5 = json.load(open(os.path.join(src, "trace_c5_bench.json")))
+    json.dump(b5, open(os.path.join(dst, tag + "_bench_config5_under_rocprof.json"), "w"), indent=1)
+    agg5, cnt5 = collections.defaultdict(float), collections.Counter()
+    for d in sorted(glob.glob(os.path.join(src, "c5pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                if name.startswith("is3d::"):
+                    agg5[(name[:60], r["Counter_Name"])] += float(r["Counter_Value"])
+                    cnt5[(name[:60], r["Counter_Name"])] += 1
+    with open(os.path.join(dst, tag + "_pmc_summary_vah.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "launches", "value_per_launch"])
+        for k in sorted(agg5):
+            w.writerow([k[0], k[1], cnt5[k], "%.6g" % (agg5[k] / cnt5[k])])
+    main5 = {k[1]: agg5[k] / cnt5[k] for k in agg5 if "cf_main" in k[0]}
+    avg5 = [float(r[3]) for r in rows[1:] if "cf_main" in r[0]][:1]
+    old = json.load(open(tp))
+    if "FETCH_SIZE" in main5 and "WRITE_SIZE" in main5:
+        old["config5"] = dict(cells=b5["config"]["cells_per_gpu"], kernel=b5["config"]["kernel"], FETCH_SIZE_KiB=main5["FETCH_SIZE"],
+                              WRITE_SIZE_KiB=main5["WRITE_SIZE"], fetch_correction=2.0,
+                              hbm_bytes_per_launch=(2.0 * main5["FETCH_SIZE"] + main5["WRITE_SIZE"]) * 1024.0,
+                              rocprof_avg_kernel_ms=avg5[0] / 1e6 if avg5 else None, bench_hip_event_kernel_ms=b5["kernel_ms"]["main"],
+                              sq_counters_per_launch={k: v for k, v in sorted(main5.items()) if k not in ("FETCH_SIZE", "WRITE_SIZE")})
+    json.dump(old, open(tp, "w"), indent=1)
