@@ -65,6 +65,7 @@ struct PrepParams {
     double mTmax, kmin, kmax;       // largest lane mT; range of the k grid (y in 3+1D, eta nodes in 2+1D): bound of p.u/T
     unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count, [7] min cell whose p.u/T can exceed 1e9
     // E2 table stream (kernel variant 5, see "TE" below); TE == nullptr: not written
+    int32_t pair_writer;            // tiled stream: the record writer handles two elements per lane and trip (set by launch_prep)
     double *TE;
     const double *pTgrid;           // [npT] the pT grid (the lanes' pT values are exactly these)
     int32_t npT;

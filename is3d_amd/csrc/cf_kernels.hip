@@ -114,6 +114,7 @@ hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3,
 constexpr int kPrepCB = 4;          // cells per workgroup batch (2+1D: K = 241 rows per cell fill the LDS)
 constexpr int kPrepCB3 = 16;       // 3+1D: larger batches give longer contiguous runs per stream of the tiled output
 constexpr int kPrepThreads = 256;
+constexpr bool kPrepPairDefault = true;   // record writer: two elements per lane and trip (A/B: IS3D_PREP_PAIR)
 
 struct CellScal {
     double dat, dax, day, dan_tau, ut, ux, uy, tau_un, invT, eta;
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *l_bD = lj + NJA * CJ;              // [CB][jtiles] max_j Dp_j of a phi tile   (unit-level cull bounds, 3+1D)
     double *l_bC = l_bD + CB * ((J + 1) / 2);  // [CB][rblocks] min_k Cp_k of a row block
     // element descriptors of a unit record (tiled stream), one int2 per record element, filled once per workgroup (below)
-    int2 *desc = (int2 *)(p.dim3 ? l_bC + CB * K : l_bD);
+    int2 *desc = (int2 *)(((uintptr_t)(p.dim3 ? l_bC + CB * K : l_bD) + 15) & ~(uintptr_t)15);   // 16-byte aligned: read two descriptors at a time
 
     const int tid = threadIdx.x;
     for (int i = tid; i < nT; i += kPrepThreads) {
@@ -426,12 +427,24 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             const double psc = pds_scale(p.pds_bound, nullptr);
             const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
             const int wave = tid >> 6, lane = tid & 63;
-            int n = 0;
-            for (int c = 0; c < ncb; c++) {
+            // units in (stream, cell) order, a contiguous range per wave: a wave writes the records of consecutive cells of ONE stream
+            // back to back (ncb x REC x 8 bytes contiguous in 3+1D) instead of hopping to another stream after every 928-byte record
+            const int n_units_b = ncb * p.jtiles * p.rblocks;
+            const int n_lo = (n_units_b * wave) / (kPrepThreads / 64), n_hi = (n_units_b * (wave + 1)) / (kPrepThreads / 64);
+            for (int n = n_lo; n < n_hi; n++) {
+                int jt, rb, c;
+                if (p.dim3) {         // stream = (jt, rb): the cells of the batch are consecutive records
+                    const int sidx = n / ncb;
+                    c = n - sidx * ncb; jt = sidx / p.rblocks; rb = sidx - jt * p.rblocks;
+                } else {              // stream = jt: a cell's eta row blocks are consecutive records, then the next cell's
+                    const int per_jt = ncb * p.rblocks;
+                    jt = n / per_jt;
+                    const int r2 = n - jt * per_jt;
+                    c = r2 / p.rblocks; rb = r2 - c * p.rblocks;
+                }
                 const int64_t cell = cbase + c;
-                for (int jt = 0; jt < p.jtiles; jt++) {
-                    for (int rb = 0; rb < p.rblocks; rb++, n++) {
-                        if ((n & (kPrepThreads / 64 - 1)) != wave) continue;
+                {
+                    {
                         int64_t unit;
                         if (p.dim3) unit = (int64_t)(jt * p.rblocks + rb) * p.n_cells + cell;       // s = jt*rblocks + rb
                         else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;              // s = jt
@@ -439,8 +452,9 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                         // one LDS round trip per 64 elements: the descriptor, then the source double next to the six reads of a
                         // (clamped) beta_of; no divergent branch
                         const int cJ = c * J, cK = c * K, cT = c * p.jtiles + jt, cR = c * p.rblocks + rb, cS = c * (int)(sizeof(CellScal) / sizeof(double));
-                        for (int e = lane; e < REC; e += 64) {
-                            const int2 d = desc[e];
+                        // two consecutive elements per lane: one 16-byte descriptor read, one 16-byte store (records are 16-byte
+                        // multiples, cf_device.h), the two elements' LDS reads in flight together -- half the trips per record
+                        auto element = [&](const int2 d) {
                             const int jj = d.y & 0xffff, r = d.y >> 16;
                             const int jcl = min(jt * JT + jj, J - 1);
                             const int k = rb * R + r, kcl = min(k, K - 1);
@@ -451,7 +465,20 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                             const double bet = beta_of(c, jcl, kcl);
                             double v = ((d.x >> 19) & 1) ? raw * psc : raw;
                             v = ((d.x >> 20) & 1) ? bet : v;
-                            __builtin_nontemporal_store(zero ? 0.0 : v, &o[e]);
+                            return zero ? 0.0 : v;
+                        };
+                        if (p.pair_writer) {
+                            const int4 *desc2 = (const int4 *)desc;
+                            for (int e2 = lane; e2 < REC / 2; e2 += 64) {
+                                const int4 dd = desc2[e2];
+                                double2 v2;
+                                v2.x = element(int2{dd.x, dd.y});
+                                v2.y = element(int2{dd.z, dd.w});
+                                __builtin_nontemporal_store(v2.x, &o[2 * e2]);
+                                __builtin_nontemporal_store(v2.y, &o[2 * e2 + 1]);
+                            }
+                        } else {
+                            for (int e = lane; e < REC; e += 64) __builtin_nontemporal_store(element(desc[e]), &o[e]);
                         }
                     }
                 }
@@ -465,10 +492,11 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 static_assert(kE2Stride == 32, "lane -> (jj, ipT) decode below");
                 const int wv = tid >> 6, ln = tid & 63;
                 const double pTl = p.pTgrid[min(ln & 31, p.npT - 1)];           // [jj][ipT], columns past the grid repeat the last
-                int m = 0;
-                for (int c = 0; c < ncb; c++) {
-                    for (int jt = 0; jt < p.jtiles; jt++, m++) {
-                        if ((m & (kPrepThreads / 64 - 1)) != wv) continue;
+                const int n_tab_b = ncb * p.jtiles;
+                const int m_lo = (n_tab_b * wv) / (kPrepThreads / 64), m_hi = (n_tab_b * (wv + 1)) / (kPrepThreads / 64);
+                for (int m = m_lo; m < m_hi; m++) {   // (phi tile, cell) order: consecutive tables of one tile stream per wave
+                    const int jt = m / ncb, c = m - jt * ncb;
+                    {
                         const double bmax = __dmul_rn(pTl, l_bD[c * p.jtiles + jt]);
                         double *t = p.TE + ((int64_t)jt * p.n_cells + (cbase + c)) * NPJ;
                         for (int e = ln; e < NPJ; e += 64) {
@@ -502,15 +530,20 @@ size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int d
     // own predicate (p.dim3), whatever K is; a 2+1D eta table of 241 rows must not pay 8 KB for them (two workgroups per CU need <= 80 KB each)
     const size_t bounds = dim3 ? (size_t)cb * ((J + 1) / 2 + K) : 0;
     // + one int2 per element of a unit record (rec doubles; 0 for the flat streams of variant 1)
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (nka * K + nja * J) + bounds + (size_t)rec) + sizeof(CellScal) * cb;
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (nka * K + nja * J) + bounds + (size_t)rec + 2) + sizeof(CellScal) * cb;   // + 2: descriptor alignment
 }
 
-hipError_t launch_prep(const PrepParams &p, hipStream_t stream)
+hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
 {
-    if (p.n_cells <= 0) return hipSuccess;
+    if (p_in.n_cells <= 0) return hipSuccess;
+    PrepParams p = p_in;
     const int cb = prep_batch_cells(p.K);
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
+    {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1, read per launch so that one process can alternate
+        const char *e = getenv("IS3D_PREP_PAIR");
+        p.pair_writer = e ? (atoi(e) != 0) : kPrepPairDefault;
+    }
     size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0, p.dim3 ? 1 : 0);
     if (cb == 16) hipLaunchKernelGGL(cf_prep<16>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
     else if (cb == 8) hipLaunchKernelGGL(cf_prep<8>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
