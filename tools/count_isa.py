@@ -5,8 +5,9 @@ fp64-VALU roofline).  Method: for every cf_main_* instantiation take the basic b
 that contains v_rcp_f64 (exactly one v_rcp_f64 is issued per evaluation) and divide the opcode histogram of
 those blocks by the number of evaluations they cover.  That number is READ FROM THE ISA: every evaluation ends in exactly one
 accumulate `acc = fma(p.dsigma, w, acc)`, and the accumulators are the registers of the loop that nothing but such an in-place
-FMA ever writes (v_fmac_f64 D, A, B or v_fma_f64 D, A, B, D: destination == addend) -- temporaries that also happen to be updated in
-place (Newton steps, Horner chains) are initialised by some other instruction inside the loop and drop out.  The reciprocal batch
+FMA ever writes (v_fmac_f64 D, A, B or v_fma_f64 D, A, B, D: destination == addend; the reload of a spilled accumulator does not count as a
+write) -- temporaries that also happen to be updated in place (Newton steps, Horner chains) are initialised by some other instruction inside
+the loop and drop out.  The reciprocal batch
 evals_per_rcp = evaluations / v_rcp_f64 follows (4 for the 3+1D 8 x 7 tiles, 8 for the 14-moment 2+1D 8-wide tiles, 4 for the
 Chapman-Enskog 8 x 31 tile, ...); the template rule the kernels use is kept beside it as evals_per_rcp_template, and the two are
 compared by tests/test_isa_counts.py.
@@ -88,10 +89,32 @@ def count_evaluations(ins):
             add = ops[3].split()[0]            # drop a trailing modifier ("clamp", "mul:2")
             if vregs(add) == dst and not ops[3].strip().startswith("-") and "clamp" not in args:
                 cand[i] = tuple(dst)
+    # a spilled accumulator comes back through a reload (scratch_load / v_accvgpr_read into the same registers): that is not an initialisation
+    reload = {i for i, (op, _) in enumerate(ins) if op.startswith(("scratch_load", "v_accvgpr_read"))}
     n = 0
+    counted = set()
     for i, dst in cand.items():
-        if all(all(j in cand and cand[j] == dst for j in writers[r]) for r in dst):
+        if all(all((j in cand and cand[j] == dst) or j in reload for j in writers[r]) for r in dst):
             n += 1
+            counted.add(i)
+    # an accumulator that LIVES in a spill slot: reload into a scratch register that other code also uses, accumulate, store back to the same slot
+    def slot(args):
+        m = re.search(r"offset:(\d+)", args)
+        return int(m.group(1)) if m else 0
+    for i, dst in cand.items():
+        if i in counted:
+            continue
+        prev = max((j for r in dst for j in writers[r] if j < i), default=None)
+        if prev is None or not ins[prev][0].startswith("scratch_load") or tuple(vregs(ins[prev][1].split(",")[0])) != dst:
+            continue
+        for j in range(i + 1, len(ins)):
+            op, args = ins[j]
+            if op.startswith("scratch_store") and tuple(vregs(args.split(",")[1])) == dst:
+                if slot(args) == slot(ins[prev][1]):
+                    n += 1
+                break
+            if any(j in writers[r] for r in dst):
+                break
     return n
 
 
