@@ -795,7 +795,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             bmax = __builtin_fmax(bmax, pTD[jj]);
         }
 #pragma unroll
-        for (int jj = 0; jj < JT; jj++) E2[jj] = exp_full(pTD[jj] - bmax);
+        for (int jj = 0; jj < JT; jj++) E2[jj] = exp_p9(pTD[jj] - bmax);
         // Rows are software-pipelined by hand: the operands and the exponential of row r+1 are fetched / computed
         // before the evaluations of row r, so that neither LDS latency nor the 13-deep FMA chain of exp_core sits
         // at the head of a row.  Exact-zero culling: exp(earg) == +0 below -745.2; then z = 0 for every phi of the
@@ -820,7 +820,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             rw.live = !(g.zskip && __all(earg < cull_thr));
             n_rows += 1;
             n_dead += rw.live ? 0 : 1;
-            rw.E1 = exp_full(earg);
+            rw.E1 = exp_p9(earg);
         };
         auto evals = [&](const Row &rw, int r) {
             const double mTA = mT * rw.v[0];
@@ -889,7 +889,7 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 n_rows += 1;
                 if (g.zskip && __all(earg < cull_thr)) { n_dead += 1; continue; }
                 rw.live = true;
-                rw.E1 = exp_full(earg);
+                rw.E1 = exp_p9(earg);
                 evals(rw, 0);
             }
         } else {

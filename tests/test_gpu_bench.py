@@ -1,0 +1,35 @@
+"""GPU (-m gpu): the bench.py contract on small surfaces -- one JSON line on stdout with the contract's fields, the `roofline` and
+`roofline_valu` objects, for every workload bench.py knows (BASELINE configs 3, 2 and the smooth leg of 5).  Sizes are tiny: this guards the
+plumbing, the numbers come from the full-size runs under profiles/."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload,kernel,extra", [("config3", "cf_main_tile3e", []), ("config2", "cf_main_tile", []), ("config5", "cf_main_vah3", []),
+                                                   ("config3", "cf_main_feqmod", ["--df-mode", "4"])])
+def test_bench_line(workload, kernel, extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--cells", "6000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-clock-probe"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "roofline_valu", "kernel_ms", "executed_evals_per_s"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["value"] > 0
+    assert d["config"]["kernel"] == kernel and d["config"]["cells_total"] == 6000 and d["config"]["spectrum_finite"]
+    assert d["config"]["culled_rows_change_no_bit"] is True
+    ro, rv = d["roofline"], d["roofline_valu"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    assert rv is not None and rv["bound"] == "fp64_valu" and 20 <= rv["executed_flop_per_eval"] <= 70 and 0 < rv["frac"] < 1
+    assert d["kernel_ms"]["main"] > 0 and d["kernel_ms"]["prep"] > 0

@@ -207,3 +207,30 @@ def test_vah_surface_file_to_spectrum(fx, tmp_path):
     assert found.all()
     ref = oracle.dN_pTdpTdphidy_vah(dict(rc, **coef), fx["pikp"], fx["grid"], o)
     assert relerr(got, ref, floor=1e-270) < TOL
+
+
+def test_vah_odd_grids(fx):
+    """Grid lengths that are not multiples of the tiles (phi 5, pT 3, y 5 / 29 / 41 -- more than 32 rows; eta 41 and 7 in 2+1D), both 3+1D kernels,
+    with the coefficients from the tables."""
+    rng = np.random.default_rng(3)
+    tab = inputs.vah_df_tables()
+    cells = synth.synth_vah_surface(21, 3, seed=8)
+    g = dict(pT=np.array([0.1, 0.7, 2.5]), phi=np.sort(rng.random(5) * 2 * np.pi), y=np.linspace(-2, 2, 5), eta=fx["grid"]["eta"], eta_w=fx["grid"]["eta_w"])
+    coef, found = oracle.vah_coefficients(tab, cells["Lambda"], cells["aL"])
+    assert found.all()
+    for ygrid in (np.linspace(-2, 2, 5), np.linspace(-3.5, 3.5, 29), np.linspace(-4, 4, 41)):
+        gg = dict(g, y=ygrid)
+        ref = oracle.dN_pTdpTdphidy_vah(dict(cells, **coef), fx["pikp"], gg, dict(dimension=3))
+        for variant in (2, 3):
+            got, _ = api.smooth_spectra_vah(cells, fx["pikp"], gg, dict(dimension=3, kernel_variant=variant), tab=tab)
+            assert relerr(got, ref, floor=1e-270) < TOL, (len(ygrid), variant)
+    c2 = synth.synth_vah_surface(5, 2, seed=9)
+    coef2, _ = oracle.vah_coefficients(tab, c2["Lambda"], c2["aL"])
+    for neta in (41, 7):
+        eta = np.linspace(-2.0, 2.0, neta)
+        w = np.full(neta, 1.0)
+        w[[0, -1]] *= 0.5
+        gg = dict(g, eta=eta, eta_w=w)
+        ref = oracle.dN_pTdpTdphidy_vah(dict(c2, **coef2), fx["pikp"], gg, dict(dimension=2))
+        got, _ = api.smooth_spectra_vah(c2, fx["pikp"], gg, dict(dimension=2), tab=tab)
+        assert relerr(got, ref, floor=1e-270) < TOL, neta
