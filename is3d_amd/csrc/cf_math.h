@@ -21,7 +21,11 @@ namespace is3d {
 template <int OFF>
 __device__ __forceinline__ void glds16a(const void *g, unsigned l32)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(l32), "n"(OFF) : "memory");   // M0 is not allocatable: the compiler keeps nothing in it across the statement
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2" : : "v"(g), "s"(l32), "n"(OFF) : "memory");
+    // M0 is a RESERVED register to the compiler: it is never allocated, a value is materialised into it immediately in front of each
+    // compiler-generated user (movrel, sendmsg, LDS-direct), and naming it in the clobber list is refused ("clobber list contains reserved
+    // registers ... not modelled").  tools/count_isa.py records every instruction that reads M0 in the kernels that use this helper and
+    // tests/test_isa_counts.py asserts there is none besides global_load_lds itself.
 }
 __device__ __forceinline__ unsigned lds_addr32(const void *p)
 {

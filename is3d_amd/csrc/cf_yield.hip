@@ -190,7 +190,10 @@ extern "C" int is3d_total_yield(const is3d_cells *cells, const is3d_species *spe
     // ---- Deltaf_Data::compute_particle_densities at the averages (deltafReader.cpp:536-650) ----
     const int npart = species->n;
     const double two_pi2_hbarC3 = 2.0 * std::pow(M_PI, 2) * std::pow(is3d::kHbarC, 3);
-    const double T = avg->T, E = avg->E, P = avg->P, muB = baryon ? avg->muB : 0.0, nB = baryon ? avg->nB : 0.0;
+    // the averages as Plasma::load_thermodynamic_averages reads them, muB and nB included whatever include_baryon says (deltafReader.cpp:541-552:
+    // alphaB = muB_avg / T enters every density integrand through the species' own baryon number; the readers of modes 0 and 1 write muB_avg = 0
+    // without include_baryon, the MUSIC / hic-eventgen readers always carry it)
+    const double T = avg->T, E = avg->E, P = avg->P, muB = avg->muB, nB = avg->nB;
     const std::vector<double> xs(df->T, df->T + df->n_T);
     for (int i = 1; i < df->n_T; i++)
         if (!(xs[i] > xs[i - 1])) return set_error(IS3D_EINVAL, "coefficient table temperatures must ascend");
@@ -241,7 +244,7 @@ extern "C" int is3d_total_yield(const is3d_cells *cells, const is3d_species *spe
     auto J31_i = [](double pbar, double Ebar, double qstat, double chem) { return pbar * std::exp(pbar + Ebar - chem) / (qstat * qstat); };
     for (int i = 0; i < npart; i++) {
         const double mass = species->mass[i], g = species->degeneracy[i], sign = species->sign[i];
-        // the particle's own baryon number, whatever include_baryon says (deltafReader.cpp:575); alpha_B = 0 without include_baryon
+        // the particle's own baryon number, whatever include_baryon says (deltafReader.cpp:575); alpha_B = muB_avg / T of the averages file
         const double b = species->baryon ? species->baryon[i] : 0.0, mbar = mass / T, chem = b * alphaB;
         const double f3 = g * std::pow(T, 3) / two_pi2_hbarC3, f4 = g * std::pow(T, 4) / two_pi2_hbarC3, f5 = g * std::pow(T, 5) / two_pi2_hbarC3;
         const double neq = f3 * gauss_thermal(r1, w1, ng, mbar, chem, sign, neq_i);

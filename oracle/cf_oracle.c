@@ -1531,7 +1531,7 @@ int oracle_total_yield(long FO_length, int npart, const double *Mass, const doub
     /* ---- compute_particle_densities (deltafReader.cpp:536-650) ---- */
     {
         const double T = avg5[0], E = avg5[1], P = avg5[2];
-        const double muB = o->include_baryon ? avg5[3] : 0.0, nB = o->include_baryon ? avg5[4] : 0.0;
+        const double muB = avg5[3], nB = avg5[4];   /* :545-546: read from the averages file whatever include_baryon says */
         df_coeff df;
         memset(&df, 0, sizeof df);
         if (o->include_baryon) {

@@ -22,7 +22,13 @@ def test_isa_counts_are_read_from_the_isa_and_sane():
         if m:
             assert v["evals_in_loop"] % int(m.group(1)) == 0, key       # evaluations come in whole rows of JT
         assert v["evals_in_loop"] == v["evals_per_rcp"] * v["histogram"]["v_rcp_f64"], key
-    assert {"cf_main_tile", "cf_main_tile3e", "cf_main_feqmod", "cf_main_vah", "cf_main_direct"} <= names
+    assert {"cf_main_tile", "cf_main_tile3e", "cf_main_feqmod", "cf_main_vah", "cf_main_vah3", "cf_main_direct"} <= names
+    # M0 audit: the direct-to-LDS helper (cf_math.h::glds16a) sets M0 inside an asm statement; no other instruction of a kernel that stages
+    # this way may read M0 (a compiler-generated user would have been handed the helper's value or have had its own overwritten)
+    staged = [k for k, v in d.items() if v["global_load_lds"] > 0]
+    assert len(staged) > 50 and "cf_main_tile3e:CE=1,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1" in staged
+    for k in staged:
+        assert d[k]["m0_other_users"] == [] and d[k]["m0_writes"] >= 1, (k, d[k]["m0_other_users"])
     # the instantiation a re-stated template rule got wrong (round 2): the Chapman-Enskog 8 x 31 tile shares a reciprocal among 4
     # evaluations (cf_kernels.hip), the 14-moment one among 8
     ce = d["cf_main_tile:CE=1,DIM3=0,OUTFLOW=1,REG=1,BARYON=0,JT=8,R=31"]

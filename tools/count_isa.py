@@ -161,6 +161,14 @@ def main():
             params.pop("LAZY", None)
             if not params.pop("DMA", 1):   # the register-staged copy kept for A/B (variant 8)
                 continue
+        # M0 audit (cf_math.h::glds16a writes M0 inside an asm statement the compiler cannot be told about): every instruction of the kernel that
+        # names m0 or uses it implicitly, besides the helper's own s_mov_b32 m0 / global_load_lds pair
+        all_ins = [x for b in blocks for x in b.get("ins", [])]
+        m0_set = sum(1 for op, args in all_ins if op == "s_mov_b32" and args.split(",")[0].strip() == "m0")
+        glds = sum(1 for op, _ in all_ins if op.startswith("global_load_lds"))
+        implicit = ("v_movrel", "s_movrel", "v_interp", "s_sendmsg", "ds_gws", "ds_read_addtid", "ds_write_addtid", "buffer_load_lds", "s_ttrace")
+        m0_other = [op for op, args in all_ins if (re.search(r"\bm0\b", args) and not (op == "s_mov_b32" and args.split(",")[0].strip() == "m0"))
+                    or op.startswith(implicit)]
         rb = [b for b in blocks if b["ops"].get("v_rcp_f64", 0) > 0]
         if not rb:
             continue
@@ -196,7 +204,7 @@ def main():
         if name == "cf_main_tile3e" and params.pop("BARYON", 0):
             name = "cf_main_tile3e_baryon"
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
-        out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
+        out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), m0_writes=m0_set, global_load_lds=glds, m0_other_users=m0_other, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
                         histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
     with open(OUT, "w") as f:
