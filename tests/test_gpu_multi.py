@@ -276,3 +276,37 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cells_total"] == 2000 and d["config"]["cells_per_gpu"] == 1000
     assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["cells"] for x in d["ranks"]] == [1000, 1000]
     assert d["value"] > 0 and d["config"]["spectrum_finite"]
+
+
+def test_persistent_multi_plan_other_modes(fx):
+    """The persistent plan for the modified-equilibrium kernel (df_mode 4), for the 2+1D kernel, with accumulate = 1, and with the RCCL
+    reduction over the one device of a test box: each equals the one-shot entry bitwise."""
+    cells = synth.synth_surface(900, 3, seed=15)
+    fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
+    o = dict(dimension=3, df_mode=4)
+    one, st1, _ = api.smooth_spectra_multi(cells, fx["pikp"], fx["grid"], fx["df"], o, devices=[0, 0, 0], fq=fq)
+    mp = api.MultiPlan(fx["pikp"], fx["grid"], fx["df"], o, devices=[0, 0, 0], max_cells=1000, fq=fq)
+    got, st, sh = mp.execute(cells)
+    assert np.array_equal(got, one) and st["n_cells_narrow"] == st1["n_cells_narrow"] and len(sh) == 3
+    mp.close()
+    c2 = synth.synth_surface(50, 2, seed=16)
+    o2 = dict(dimension=2, df_mode=1)
+    one2, _, _ = api.smooth_spectra_multi(c2, fx["pikp"], fx["grid"], fx["df"], o2, devices=[0, 0])
+    mp = api.MultiPlan(fx["pikp"], fx["grid"], fx["df"], dict(o2, accumulate=1), devices=[0, 0], max_cells=50)
+    acc = one2.copy()
+    mp.execute(c2, out=acc)
+    mp.execute(c2, out=acc)
+    assert relerr(acc, 3.0 * one2) < 1e-14
+    mp.close()
+    o3 = dict(dimension=3, df_mode=2)
+    ref, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], o3)
+    mp = api.MultiPlan(fx["pikp"], fx["grid"], fx["df"], o3, devices=[0], reduce=api.REDUCE_RCCL, max_cells=900)
+    got, _, _ = mp.execute(cells)
+    assert np.array_equal(got, ref)
+    mp.close()
+    with pytest.raises(api.Is3dError) as e:
+        api.MultiPlan(fx["pikp"], fx["grid"], fx["df"], o3, devices=[0, 0], reduce=api.REDUCE_RCCL, max_cells=900)
+    assert e.value.code == api.IS3D_EINVAL and "distinct" in str(e.value)
+    with pytest.raises(api.Is3dError) as e:
+        api.MultiPlan(fx["pikp"], fx["grid"], fx["df"], o3, devices=[0, 7], max_cells=900)
+    assert e.value.code == api.IS3D_EINVAL
