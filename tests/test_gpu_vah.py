@@ -234,3 +234,23 @@ def test_vah_odd_grids(fx):
         ref = oracle.dN_pTdpTdphidy_vah(dict(c2, **coef2), fx["pikp"], gg, dict(dimension=2))
         got, _ = api.smooth_spectra_vah(c2, fx["pikp"], gg, dict(dimension=2), tab=tab)
         assert relerr(got, ref, floor=1e-270) < TOL, neta
+
+
+def test_vah_golden_vectors_on_device():
+    """The committed independent vectors (tests/golden/golden_vah.npz: scipy coefficients, numpy long-double spectra) against the device:
+    coefficients to 2e-12, spectra -- with the coefficients interpolated on the device from the tables -- to the parity tolerance."""
+    import os
+    from conftest import ROOT
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_vah.npz"))
+    tab = inputs.vah_df_tables()
+    c = api.vah_coefficients(tab, z["coef_Lambda"], z["coef_aL"])
+    for k in range(5):
+        assert relerr(c["c%d" % k], z["coef_c%d" % k], floor=1e-300) < 2e-12, k
+    sp = inputs.species([int(i) for i in z["species"]])
+    for dim in (3, 2):
+        cells = {k[len("cells%d_" % dim):]: z[k] for k in z.files if k.startswith("cells%d_" % dim)}
+        grid = {k[len("grid%d_" % dim):]: z[k] for k in z.files if k.startswith("grid%d_" % dim)}
+        for reg in (1, 0):
+            for variant in ((0, 2) if dim == 3 else (0,)):
+                got, _ = api.smooth_spectra_vah(cells, sp, grid, dict(dimension=dim, regulate_deltaf=reg, kernel_variant=variant), tab=tab)
+                assert relerr(got, z["dN%d_reg%d" % (dim, reg)], floor=1e-270) < TOL, (dim, reg, variant)

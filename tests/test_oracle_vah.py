@@ -115,3 +115,27 @@ def test_anisotropic_variable_fit():
     aL = 1.0 / np.sqrt(1.0 + xi)
     series = 2.0 + xi * (2.0 / 3 - xi * (2.0 / 15 - xi * (2.0 / 35 - xi * (2.0 / 63))))
     assert np.max(np.abs(oracle.R200(aL) / aL - series)) < 1e-10
+
+
+def _golden_vah():
+    import os
+    from conftest import ROOT
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_vah.npz"))
+
+
+def test_golden_vah_vectors_pin_the_oracle():
+    """tests/golden/golden_vah.npz (tests/golden/make_golden_vah.py): coefficients from scipy's independent multilinear interpolator and spectra
+    from an independent numpy long-double restatement of calculate_dN_pTdpTdphidy_VAH_PL -- both against the C oracle."""
+    z = _golden_vah()
+    tab = inputs.vah_df_tables()
+    c, found = oracle.vah_coefficients(tab, z["coef_Lambda"], z["coef_aL"])
+    assert found.all()
+    for k in range(5):
+        assert relerr(c["c%d" % k], z["coef_c%d" % k], floor=1e-300) < 2e-12, k
+    sp = inputs.species([int(i) for i in z["species"]])
+    for dim in (3, 2):
+        cells = {k[len("cells%d_" % dim):]: z[k] for k in z.files if k.startswith("cells%d_" % dim)}
+        grid = {k[len("grid%d_" % dim):]: z[k] for k in z.files if k.startswith("grid%d_" % dim)}
+        for reg in (1, 0):
+            got = oracle.dN_pTdpTdphidy_vah(cells, sp, grid, dict(dimension=dim, regulate_deltaf=reg))
+            assert relerr(got, z["dN%d_reg%d" % (dim, reg)], floor=1e-270) < 5e-11, (dim, reg, relerr(got, z["dN%d_reg%d" % (dim, reg)], floor=1e-270))
