@@ -321,7 +321,7 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const double X = sqrt_g1(X2[j0 + i]);
-                    zz[i] = exp_full_sat(-X);
+                    zz[i] = DIM3 ? exp_full_sat(-X) : exp_p9_sat(-X);   // 3+1D here is the round-1 kernel kept as it was for A/B; 2+1D takes the shorter exponential (cf_math.h)
                     d[i] = __builtin_fma(sign, zz[i], 1.0);
                 }
                 rcp_batch<RB>(d, inv);                                                         // fbar_a
