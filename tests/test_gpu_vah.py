@@ -254,3 +254,43 @@ def test_vah_golden_vectors_on_device():
             for variant in ((0, 2) if dim == 3 else (0,)):
                 got, _ = api.smooth_spectra_vah(cells, sp, grid, dict(dimension=dim, regulate_deltaf=reg, kernel_variant=variant), tab=tab)
                 assert relerr(got, z["dN%d_reg%d" % (dim, reg)], floor=1e-270) < TOL, (dim, reg, variant)
+
+
+def test_vah_full_size_config5_from_tables_stratified_oracle_sample(fx):
+    """BASELINE config 5, smooth leg, as bench.py --workload config5 runs it: 1e6-cell anisotropic-hydro surface, coefficients from the
+    tables.  (i) the whole surface: finite, additive over two shards; (ii) a stratified oracle sample on a 1e5-cell slice: one species of
+    EVERY one of the 75 (mass, sign) classes x 4 pT x 3 phi (one per phi tile) x all 21 rapidities = 18 900 bins against oracle
+    coefficients -> oracle kernel; species of a class follow from their representative exactly."""
+    tab = inputs.vah_df_tables()
+    n = 1000000
+    cells = synth.synth_vah_surface(n, 3)
+    sp = fx["urqmd"]
+    o = dict(dimension=3)
+    whole, st = api.smooth_spectra_vah(cells, sp, fx["grid"], o, tab=tab)
+    assert np.isfinite(whole).all() and st["n_classes"] == 75 and st["kernel_variant"] == 3
+    lo, _ = api.smooth_spectra_vah({k: v[:400000] for k, v in cells.items()}, sp, fx["grid"], o, tab=tab)
+    hi, _ = api.smooth_spectra_vah({k: v[400000:] for k, v in cells.items()}, sp, fx["grid"], o, tab=tab)
+    assert relerr(lo + hi, whole, floor=1e-250) < 1e-10
+    sl = {k: v[600000:700000] for k, v in cells.items()}
+    got, _ = api.smooth_spectra_vah(sl, sp, fx["grid"], o, tab=tab)
+    seen, reps = set(), []
+    for s, (m, sg) in enumerate(zip(sp["mass"], sp["sign"])):
+        if (m, sg) not in seen:
+            seen.add((m, sg))
+            reps.append(s)
+    assert len(reps) == 75
+    ipT, iphi = [0, 9, 20, 31], [2, 11, 21]
+    coef, found = oracle.vah_coefficients(tab, sl["Lambda"], sl["aL"])
+    assert found.all()
+    sub_grid = dict(fx["grid"], pT=fx["grid"]["pT"][ipT], phi=fx["grid"]["phi"][iphi])
+    ref = oracle.dN_pTdpTdphidy_vah(dict(sl, **coef), inputs.species([int(sp["mc_id"][s]) for s in reps]), sub_grid, o).reshape(21, 3, 4, 75)
+    g5 = got.reshape(21, 24, 32, 305)
+    sub = g5[:, iphi][:, :, ipT][:, :, :, reps]
+    assert sub.size == 18900
+    assert relerr(sub, ref, floor=1e-250) < TOL, relerr(sub, ref, floor=1e-250)
+    cls_of = {}
+    for s, (m, sg) in enumerate(zip(sp["mass"], sp["sign"])):
+        cls_of.setdefault((m, sg), s)
+    for s in (7, 150, 299):
+        r = cls_of[(sp["mass"][s], sp["sign"][s])]
+        assert relerr(g5[..., s] * sp["degeneracy"][r], g5[..., r] * sp["degeneracy"][s], floor=1e-250) < 1e-15
