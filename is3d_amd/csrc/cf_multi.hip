@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -55,11 +56,23 @@ Rccl &rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // a copy the host process has already mapped (e.g. the one PyTorch bundles) is reused, so that the process holds ONE RCCL
-        for (const char *name : {"librccl.so", "librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-            if (r.handle) break;
+        // IS3D_RCCL_LIBRARY: an explicit path (sites that keep RCCL elsewhere; the test suite's process-level test double, tests/cpp/fake_rccl.cpp)
+        if (const char *path = getenv("IS3D_RCCL_LIBRARY")) {
+            if (*path) {
+                r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+                if (!r.handle) {
+                    const char *e = dlerror();
+                    r.error = std::string("IS3D_RCCL_LIBRARY = ") + path + " cannot be loaded: " + (e ? e : "?");
+                    return;
+                }
+            }
         }
+        // a copy the host process has already mapped (e.g. the one PyTorch bundles) is reused, so that the process holds ONE RCCL
+        if (!r.handle)
+            for (const char *name : {"librccl.so", "librccl.so.1"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+                if (r.handle) break;
+            }
         if (!r.handle)
             for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
                 r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);

@@ -310,3 +310,38 @@ def test_persistent_multi_plan_other_modes(fx):
     with pytest.raises(api.Is3dError) as e:
         api.MultiPlan(fx["pikp"], fx["grid"], fx["df"], o3, devices=[0, 7], max_cells=900)
     assert e.value.code == api.IS3D_EINVAL
+
+
+def test_two_ranks_through_a_stub_communicator(tmp_path):
+    """is3d_plan_execute_allreduce with TWO ranks.  RCCL refuses two ranks on one device, and a test box has one GPU, so the library's
+    communicator is pointed (IS3D_RCCL_LIBRARY) at a process-level test double of the nine RCCL entry points it binds
+    (tests/cpp/fake_rccl.cpp: shared-memory slots, a barrier, an abort flag).  What this exercises for real is the library's own
+    multi-rank logic: the sum over ranks, the error word (a failed rank joins with zeros, every rank learns), IS3D_EPEER on the
+    synchronous path, survival of the communicator, and ncclCommAbort making a peer's collective fail instead of hang.  It is not a
+    test of RCCL; the first run with more than one real RCCL rank is the driver's SCALE run."""
+    import json
+    import sys
+    from conftest import ROOT
+    so = str(tmp_path / "libfakerccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "fake_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread"])
+    env = dict(os.environ, IS3D_RCCL_LIBRARY=so)
+    uid = str(tmp_path / "uid.bin")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multi_rank_worker.py"), str(r), "2", uid], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    res = []
+    for p, (so_, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+        line = [ln for ln in so_.splitlines() if ln.startswith("RESULT ")]
+        assert len(line) == 1, so_ + se[-2000:]
+        res.append(json.loads(line[0][7:]))
+    r0, r1 = sorted(res, key=lambda d: d["rank"])
+    assert r0["seen"] == [0, 2] and r1["seen"] == [1, 2]
+    for r in (r0, r1):
+        assert r["clean_check"] == 0 and r["clean_relerr"] < 1e-13          # 1: the sum over two ranks is the whole surface
+        assert r["s2_check"] == api.IS3D_EPEER and r["s2_sum_is_rank0_only"]  # 2: everybody learns; the failed rank contributed zeros
+        assert r["s4_check"] == 0 and r["s4_relerr"] < 1e-13                # 4: the communicator survived
+    assert r0["s2_exec"] == 0 and r1["s2_exec"] == api.IS3D_EINVAL
+    assert r0["s3_exec"] == api.IS3D_EDOMAIN and r0["s3_text_has_cell"] and r1["s3_exec"] == api.IS3D_EPEER   # 3
+    assert r0["s5_exec"] == api.IS3D_ENODEVICE and "abort" in r0["s5_text"] and r0["s5_seconds"] < 30        # 5: fails, does not hang
