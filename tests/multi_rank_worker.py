@@ -67,12 +67,13 @@ def main():
     only0, _ = api.smooth_spectra({k: v[:api.shard_bounds(n, 0, n_ranks)[1]] for k, v in cells.items()}, sp, grid, df, o)
     res["s2_sum_is_rank0_only"] = bool(np.max(np.abs(got - only0) / np.maximum(np.abs(only0), 1e-280)) < 1e-13)
     # 3. rank 0 meets a cell outside the coefficient table (synchronous call): its own code there, IS3D_EPEER on the other rank
+    t3 = float(tens["T"][3].item())
     if rank == 0:
         tens["T"][3] = 0.3
     c3 = code(lambda: plan.execute_allreduce(hi - lo, ptrs, out.data_ptr(), comm, stream))
     res["s3_exec"], res["s3_text_has_cell"] = c3[0], ("cell 3" in c3[1])
     if rank == 0:
-        tens["T"][3] = 0.15
+        tens["T"][3] = t3
     comm_state = code(lambda: comm.check(stream))[0]   # the synchronous call already consumed the word on the peer; rank 0 still holds it
     res["s3_check_after"] = comm_state
     # 4. a clean step again: the communicator survived both failures
