@@ -231,8 +231,9 @@ def main():
         else:
             idist.init_process_group(a.backend)
             import torch.distributed as dist
-        if a.backend == "nccl":
+        if a.backend == "nccl" or os.environ.get("IS3D_RCCL_LIBRARY"):
             # the data-path collective is the library's: an is3d_comm (RCCL) built from an id made through the C ABI
+            # (with --backend gloo only when IS3D_RCCL_LIBRARY names the communicator library: the test suite's two-ranks-on-one-GPU rehearsal)
             try:
                 comm = idist.library_comm(local)
                 allreduce_by = "is3d_plan_execute_allreduce (librccl ncclAllReduce called by libis3d_amd.so)"

@@ -25,7 +25,7 @@
 #include <vector>
 
 namespace {
-constexpr size_t kSlotDoubles = 1 << 20;   // 8 MB per rank: the tests' spectra are far smaller
+constexpr size_t kSlotDoubles = (size_t)5 << 20;   // 42 MB per rank (pages are committed when touched): the config-3 spectrum is 4.92e6 doubles
 constexpr int kMaxRanks = 8;
 struct Shared {
     std::atomic<int> arrived, generation, aborted, attached;

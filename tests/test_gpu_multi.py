@@ -345,3 +345,26 @@ def test_two_ranks_through_a_stub_communicator(tmp_path):
     assert r0["s2_exec"] == 0 and r1["s2_exec"] == api.IS3D_EINVAL
     assert r0["s3_exec"] == api.IS3D_EDOMAIN and r0["s3_text_has_cell"] and r1["s3_exec"] == api.IS3D_EPEER   # 3
     assert r0["s5_exec"] == api.IS3D_ENODEVICE and "abort" in r0["s5_text"] and r0["s5_seconds"] < 30        # 5: fails, does not hang
+
+
+def test_bench_two_ranks_through_the_library_communicator(tmp_path):
+    """bench.py's N > 1 path end to end with two self-started ranks on the one GPU: process group on gloo (rendezvous and barrier only), the
+    data-path collective through the LIBRARY's communicator (is3d_plan_execute_allreduce) backed by the test double of RCCL -- the code path
+    the driver's SCALE run takes with real RCCL, minus RCCL."""
+    import json
+    import sys
+    from conftest import ROOT
+    so = str(tmp_path / "libfakerccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "fake_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IS3D_RCCL_LIBRARY"] = so
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cells", "3000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-clock-probe"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["allreduce"].startswith("is3d_plan_execute_allreduce")
+    assert d["ranks_seen"] == [0, 1] and [x["comm_rank_seen"] for x in d["ranks"]] == [[0, 2], [1, 2]]
+    assert all(x["allreduce_ms"] is not None and x["allreduce_ms"] >= 0 for x in d["ranks"]) and d["config"]["spectrum_finite"]
