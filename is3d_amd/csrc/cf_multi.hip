@@ -359,6 +359,12 @@ extern "C" int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *sh
         comm_abort(comm);
         return fail(IS3D_EINVAL, "is3d_plan_execute_allreduce: null plan or spectrum; the communicator was aborted so that the other ranks do not wait");
     }
+    if (is3d::plan_device(plan) != comm->device) {   // the spectrum would live on another device than the communicator's rank: it cannot be reduced
+        const int pd = is3d::plan_device(plan), cd = comm->device;
+        comm_abort(comm);
+        return fail(IS3D_EINVAL, "is3d_plan_execute_allreduce: the plan is on device %d, the communicator on device %d; the communicator was aborted so that "
+                    "the other ranks do not wait", pd, cd);
+    }
     int rc;
     if (is3d::plan_accumulate(plan))   // the old contents of dN_out would be summed n_ranks times
         rc = fail(IS3D_EINVAL, "is3d_plan_execute_allreduce needs a plan with opts.accumulate = 0");

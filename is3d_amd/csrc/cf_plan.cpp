@@ -578,6 +578,7 @@ extern "C" int is3d_plan_set_timing(is3d_plan *P, int32_t enable)
 }
 namespace is3d {
 int plan_accumulate(const is3d_plan *P) { return P && P->opts.accumulate != 0; }
+int plan_device(const is3d_plan *P) { return P ? P->device : -1; }
 }
 extern "C" void is3d_plan_destroy(is3d_plan *P)
 {

@@ -10,4 +10,6 @@ struct is3d_plan;
 namespace is3d {
 // opts.accumulate of a plan (cf_multi.hip refuses it in front of a collective)
 int plan_accumulate(const is3d_plan *plan);
+// HIP device ordinal the plan lives on
+int plan_device(const is3d_plan *plan);
 }
