@@ -338,7 +338,10 @@ void is3d_multi_plan_destroy(is3d_multi_plan *mplan);
  * 14-moment coefficients c0..c4 are inputs, as in the method's own signature.  All ten pi_perp^{mu nu} components are inputs
  * too (this kernel does not reconstruct them); T is accepted and unused.  No outflow cut, no skipped cells.  opts: dimension,
  * include_bulk_deltaf, include_shear_deltaf, regulate_deltaf, accumulate, device, workspace_bytes, cell_chunks, collapse_species,
- * zero_skip.  HOST pointers; dN_out as for is3d_smooth_spectra.
+ * zero_skip (exact zeros only on this path: 0 and 1 are the same), kernel_variant (0 default = 3 in 3+1D: factored exponent on the 8 x 7
+ * tile, cf_main_vah3 | 2: the round-1 kernel on the 6 x 7 tile, kept for A/B; 2+1D always runs the 8 x 61 tile).  A cell whose
+ * E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (kernel_variant 3; the reference's exp overflows there).
+ * HOST pointers; dN_out as for is3d_smooth_spectra.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
     int64_t n_cells;

@@ -13,6 +13,12 @@
 // delta-f of the tile kernel (cf_kernels.hip).  Unit record (JT phi's x R rows): header jj {B_j, gx_j, gd_j, 0}; row r
 // {A_k, ax_k, ad_k, W_k, bx_{j0..,k}, bd_{j0..,k}}.  No outflow cut and no skipped cells on this path; in 2+1D the eta
 // weights are the table weights times the node spacing (:2180-2188).
+//
+// Round 3.  (i) The 3+1D default is cf_main_vah3 on "F" records: the exponent factored, (E_a/Lambda)^2 = (mT c_k - pT d_j)^2 + mT^2 e_k, on the
+// 8 x 7 tile with lower-bound row / unit culls and the shorter exponential (see the comment at the kernel); the kernel above stays for
+// 2+1D and as kernel_variant 2.  (ii) The coefficients can come from the reference's tables instead of the cell arrays: cf_vah_coeffs is
+// the per-cell bilinear of the CUDA tree's loader (src/cuda/deltafReader.cu:224-278; src/cpp has none).  (iii) The host side is a
+// device-resident plan (is3d_vah_plan_*): is3d_smooth_spectra_vah[_df] = create + upload + execute + download.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
