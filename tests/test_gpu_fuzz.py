@@ -95,3 +95,28 @@ def test_random_configuration_matches_the_oracle(fx, case):
         for v in (0, 2):
             got, st = api.smooth_spectra_vah(cells, sp, g, dict(o, kernel_variant=v, **extra), tab=tab)
             assert relerr(got, ref, floor=1e-270) < TOL, (case, v, relerr(got, ref, floor=1e-270), {k: len(x) for k, x in g.items()}, n)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_sampler_configuration_gives_the_oracles_list(fx, case):
+    """The particle sampler on random small configurations (dimension, df_mode 1-4, fast mode, species subsets, event counts, seeds, y_cut,
+    shard offsets, event batching): the device list is the oracle's list -- same hadrons, same order, momenta to rounding."""
+    rng = np.random.default_rng(8000 + case)
+    dim = int(rng.choice([3, 2]))
+    dfm = int(rng.choice([1, 2, 3, 4]))
+    n = int(rng.integers(1, 500))
+    cells = synth.synth_surface(n, dim, seed=9500 + case)
+    sp = _species(rng, fx)
+    T_avg = inputs.surface_average_T(cells)
+    fq = inputs.feqmod_tables(T_avg)
+    fast = int(rng.random() < 0.4)
+    o = dict(dimension=dim, df_mode=dfm, include_bulk_deltaf=int(rng.random() < 0.8), include_shear_deltaf=int(rng.random() < 0.8))
+    kw = dict(n_events=int(rng.integers(1, 40)), seed=int(rng.integers(1, 1 << 40)), y_cut=float(rng.uniform(0.3, 2.0)),
+              first_cell=int(rng.integers(0, 10 ** 9)), fq=fq if (dfm >= 3 or fast) else None, fast=fast, T_avg=fq["T_avg"])
+    ref, rst = oracle.sample_particles(cells, sp, fx["df"], fq, o, **kw)
+    got, st = api.sample_particles(cells, sp, fx["df"], fq, o, batch_events=int(rng.choice([0, 1, 3])), **kw)
+    assert len(got) == len(ref["E"]), (case, len(got), len(ref["E"]))
+    assert np.array_equal(got["cell"], ref["cell"]) and np.array_equal(got["event"], ref["event"]) and np.array_equal(got["species"], ref["species"])
+    for f in ("tau", "x", "y", "eta", "t", "z", "E", "px", "py", "pz"):
+        assert np.allclose(got[f], ref[f], rtol=1e-11, atol=1e-13), (case, f)
+    assert st["n_hadrons_drawn"] == rst["drawn"] and st["n_momentum_samples"] == rst["samples"]
