@@ -245,6 +245,11 @@ int is3d_plan_timings(is3d_plan *plan, is3d_status *status);
  * spectra kernel runs on another stream, it gives the clock that kernel's fp64 roofline should be priced at
  * (bench.py: roofline_valu.shader_clock_ghz).  *ghz = 0 if the two counters tick at the same rate on this device. */
 int is3d_probe_shader_clock(int32_t device, double seconds, double *ghz);
+/* Diagnostic (no reference counterpart): the elementary functions the kernels are built from (is3d_amd/csrc/cf_math.h), evaluated on the
+ * device, y[i] = f(x[i]) for HOST arrays of n doubles -- so that their accuracy is a tested number, not a comment.  which: 0 exp_full
+ * (Cody-Waite, degree 10) | 1 exp_p9 (one-fma reduction, degree 9; |x| < 1.4e9) | 2 exp_p9_sat | 3 exp_full_sat (any x) | 4 sqrt_g1 (v_rsq_f64 +
+ * one Goldschmidt step) | 5 sqrt_nr | 6 rcp_nr1 (v_rcp_f64 + one Newton step) | 7 rcp_nr (two steps). */
+int is3d_math_probe(int32_t which, int64_t n, const double *x, double *y, int32_t device);
 /* Name of the dominant kernel as it appears in rocprofv3 traces, for the variant in use. */
 const char *is3d_plan_main_kernel_name(const is3d_plan *plan);
 /* tile of the main kernel: *JT phi's x *R rows (y's in 3+1D, eta nodes in 2+1D) */

@@ -105,7 +105,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
            "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
            "is3d_vah_plan_workspace_bytes", "is3d_vah_plan_execute", "is3d_vah_plan_set_timing", "is3d_vah_plan_timings",
-           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah", "is3d_vah_plan_main_kernel_name"]
+           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah", "is3d_vah_plan_main_kernel_name", "is3d_math_probe"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
 IS3D_EPEER = -6
@@ -624,6 +624,19 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+MATH_FUNCS = dict(exp_full=0, exp_p9=1, exp_p9_sat=2, exp_full_sat=3, sqrt_g1=4, sqrt_nr=5, rcp_nr1=6, rcp_nr=7)
+
+
+def math_probe(which, x, device=-1):
+    """is3d_math_probe: the device's elementary function `which` (a key of MATH_FUNCS) at the host array x."""
+    xs = _f64(x)
+    y = np.zeros_like(xs)
+    L = load()
+    L.is3d_math_probe.argtypes = [C.c_int32, C.c_int64, _dp, _dp, C.c_int32]
+    _check(L.is3d_math_probe(MATH_FUNCS[which], xs.size, _p(xs), _p(y), int(device)))
+    return y
 
 
 def probe_shader_clock(seconds=0.3, device=0):

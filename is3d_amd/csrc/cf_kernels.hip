@@ -1688,3 +1688,36 @@ hipError_t launch_observables(const double *dN, const double *phi_w, const doubl
 }
 
 }  // namespace is3d
+
+// ------------------------------------------------------------------------------------------------
+// Diagnostic: the elementary functions of cf_math.h, one evaluation per element (is3d_math_probe, include/is3d_amd.h).  The kernels'
+// accuracy claims -- exp_full 1.4e-15, exp_p9 7e-14, the one-step square root 3e-15, rcp_nr1 2e-15 -- are checked against glibc / numpy
+// through this entry in tests/test_gpu_math.py instead of being taken from the comments.
+// ------------------------------------------------------------------------------------------------
+namespace is3d {
+__global__ void __launch_bounds__(256) cf_math_probe(int which, int64_t n, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double r;
+    switch (which) {
+    case 0: r = exp_full(v); break;
+    case 1: r = exp_p9(v); break;
+    case 2: r = exp_p9_sat(v); break;
+    case 3: r = exp_full_sat(v); break;
+    case 4: r = sqrt_g1(v); break;
+    case 5: r = sqrt_nr(v); break;
+    case 6: r = rcp_nr1(v); break;
+    default: r = rcp_nr(v); break;
+    }
+    y[i] = r;
+}
+
+hipError_t launch_math_probe(int which, int64_t n, const double *x, double *y, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cf_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, which, n, x, y);
+    return hipGetLastError();
+}
+}  // namespace is3d

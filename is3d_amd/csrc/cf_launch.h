@@ -20,6 +20,8 @@ int tile3e_stream_slack_doubles(int JT, int R);                  // variant 5: o
 hipError_t launch_observables(const double *dN, const double *phi_w, const double *pT_w, const double *coskphi,
                               const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
                               int ny, hipStream_t st);
+// which: 0 exp_full | 1 exp_p9 | 2 exp_p9_sat | 3 exp_full_sat | 4 sqrt_g1 | 5 sqrt_nr | 6 rcp_nr1 | 7 rcp_nr  (cf_math.h), y[i] = f(x[i])
+hipError_t launch_math_probe(int which, int64_t n, const double *x, double *y, hipStream_t st);
 hipError_t launch_clock_probe(unsigned long long ref_ticks, unsigned long long *out /* 2 x 8 */, hipStream_t st);
 hipError_t launch_fold_status(const unsigned long long *status /* [8] */, unsigned long long *sticky /* [2] */, hipStream_t st);
 }  // namespace is3d

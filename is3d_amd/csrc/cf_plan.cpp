@@ -556,6 +556,21 @@ extern "C" int is3d_probe_shader_clock(int32_t device, double seconds, double *g
     return IS3D_OK;
 }
 
+extern "C" int is3d_math_probe(int32_t which, int64_t n, const double *x, double *y, int32_t device)
+{
+    if (which < 0 || which > 7 || n < 0 || (n > 0 && (!x || !y))) return fail(IS3D_EINVAL, "is3d_math_probe: which in 0..7, n >= 0, non-null arrays");
+    if (is3d_device_count() < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    if (n == 0) return IS3D_OK;
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    DevBuf<double> dx, dy;
+    HIP_TRY(dx.alloc((size_t)n));
+    HIP_TRY(dy.alloc((size_t)n));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(is3d::launch_math_probe(which, n, dx.p, dy.p, nullptr));
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return IS3D_OK;
+}
+
 extern "C" int64_t is3d_plan_output_size(const is3d_plan *P) { return P ? P->nout : 0; }
 extern "C" int64_t is3d_plan_workspace_bytes(const is3d_plan *P) { return P ? P->workspace : 0; }
 extern "C" const char *is3d_plan_main_kernel_name(const is3d_plan *P)
