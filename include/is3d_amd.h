@@ -247,7 +247,7 @@ int is3d_plan_timings(is3d_plan *plan, is3d_status *status);
 int is3d_probe_shader_clock(int32_t device, double seconds, double *ghz);
 /* Diagnostic (no reference counterpart): the elementary functions the kernels are built from (is3d_amd/csrc/cf_math.h), evaluated on the
  * device, y[i] = f(x[i]) for HOST arrays of n doubles -- so that their accuracy is a tested number, not a comment.  which: 0 exp_full
- * (Cody-Waite, degree 10) | 1 exp_p9 (one-fma reduction, degree 9; |x| < 1.4e9) | 2 exp_p9_sat | 3 exp_full_sat (any x) | 4 sqrt_g1 (v_rsq_f64 +
+ * (Cody-Waite, degree 10) | 1 exp_p9 (one-fma reduction, degree 9; |x| < 1.4e9) | 2 exp_p9_sat | 3 exp_full_sat (|x| up to ~1e45) | 4 sqrt_g1 (v_rsq_f64 +
  * one Goldschmidt step) | 5 sqrt_nr | 6 rcp_nr1 (v_rcp_f64 + one Newton step) | 7 rcp_nr (two steps). */
 int is3d_math_probe(int32_t which, int64_t n, const double *x, double *y, int32_t device);
 /* Name of the dominant kernel as it appears in rocprofv3 traces, for the variant in use. */
@@ -345,7 +345,7 @@ void is3d_multi_plan_destroy(is3d_multi_plan *mplan);
  * include_bulk_deltaf, include_shear_deltaf, regulate_deltaf, accumulate, device, workspace_bytes, cell_chunks, collapse_species,
  * zero_skip (exact zeros only on this path: 0 and 1 are the same), kernel_variant (0 default = 3 in 3+1D: factored exponent on the 8 x 7
  * tile, cf_main_vah3 | 2: the round-1 kernel on the 6 x 7 tile, kept for A/B; 2+1D always runs the 8 x 61 tile).  A cell whose
- * E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (kernel_variant 3; the reference's exp overflows there).
+ * E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (the reference's exp overflows there).
  * HOST pointers; dN_out as for is3d_smooth_spectra.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -50,7 +50,8 @@ struct FqPrepParams {
     double *CR;                         // [n_cells][kCrRec], df_mode 3
     double *FB;                         // [n_cells][kFbRec], written for flagged cells only
     int32_t *flag;                      // [n_cells] 0 feqmod | 1 breakdown (all rows linear) | 2 detA < 0.01 (narrow rows linear)
-    unsigned long long *status;         // [0] min bad cell, [1] skipped
+    unsigned long long *status;         // [0] min bad cell, [1] skipped, [7] min cell whose E_mod/T_mod can exceed 1e9
+    double mTmax, kmin, kmax;           // largest lane mT; range of the k grid: bound of E_mod/T_mod for the exponential's domain (exp_p9: < 1.4e9)
 };
 
 struct FqMainArgs {

@@ -273,11 +273,28 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                     rn = fabs(rn);
                     if (isnan(rn) || isinf(rn)) rn = 0.0;                             // :768-772: every species skipped
                 }
-                const bool narrow = p.dim3 && !breakdown && detA < 0.01;              // :807-813
+                // Exponent range of the main kernel's exponential (exp_p9, |v| < 1.4e9): E_mod/T_mod <= (1 + ||A^-1||_F) E_LRF / T_mod with
+                // E_LRF = p.u <= mTmax (u^tau + |tau u^eta|) cosh(max |y - eta|).  A cell beyond it -- a singular or nearly singular A that the
+                // breakdown test did not catch, a vanishing T_mod -- is reported (status[7]) and left out; the reference's LU solve returns
+                // inf / nan there.  df_mode 4 with a renormalisation that is nan or inf: the reference skips every species (:768-772) -- the cell
+                // is neutral here too, silently, whatever its A^-1 holds.
+                bool leave_out = (p.mode == 4 && !(rn > 0.0));
+                if (!breakdown && !leave_out) {
+                    double an = 0.0;
+                    for (int i = 0; i < 9; i++) an += s.Ai[i] * s.Ai[i];
+                    const double eta0 = p.dim3 ? p.cells.eta[gi] : 0.0;
+                    const double xb = p.mTmax * (ut + fabs(tau * un)) * cosh(fmax(fabs(p.kmin - eta0), fabs(p.kmax - eta0))) * (1.0 + sqrt(an)) / fabs(T_mod);
+                    if (!(xb < 1.0e9)) {
+                        atomicMin(&p.status[7], (unsigned long long)gi);
+                        leave_out = true;
+                    }
+                }
+                if (leave_out) breakdown = false;
+                const bool narrow = p.dim3 && !breakdown && !leave_out && detA < 0.01;   // :807-813
                 s.dat = dat; s.dax = dax; s.day = day; s.dan_tau = dan / tau;
                 s.eta = p.dim3 ? p.cells.eta[gi] : 0.0;
                 s.eta_scale = eta_scale;
-                s.live = breakdown ? 0.0 : 1.0;
+                s.live = (breakdown || leave_out) ? 0.0 : 1.0;
                 s.rn = rn;
                 s.invTm2 = 1.0 / (T_mod * T_mod);
                 s.Xt = Xt; s.tXn = tau * Xn; s.Zt = Zt; s.tZn = tau * Zn;
@@ -695,7 +712,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const double X = sqrt_g1(X2[j0 + i]);   // 3e-15 relative: e^-X moves by X * 3e-15
-                    zz[i] = exp_p9_sat(BARYON ? cm - X : -X);   // saturating: X = |A^-1 p|/T_mod is unbounded for nearly singular A; degree 9 + one-fma reduction (cf_math.h): 7e-14
+                    zz[i] = exp_p9(BARYON ? cm - X : -X);   // degree 9 + one-fma reduction (cf_math.h): 7e-14; cf_prep_feqmod keeps X = |A^-1 p|/T_mod below 1e9 (status[7])
                     d[i] = __builtin_fma(sign, zz[i], 1.0);
                 }
                 rcp_batch<RB>(d, inv);

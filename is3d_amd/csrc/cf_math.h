@@ -106,7 +106,7 @@ __device__ __forceinline__ double exp_full_sat(double v)
     p = __builtin_fma(p, r, kExpC[7]);
     p = __builtin_fma(p, r, kExpC[8]);
     p = __builtin_fma(p, r, kExpC[9]);
-    return ldexp_fast(__builtin_fma(p, r, 1.0), (int)dn);   // v_cvt_i32_f64 saturates: e^-huge = +0, never a wrapped exponent
+    return ldexp_fast(__builtin_fma(p, r, 1.0), (int)dn);   // v_cvt_i32_f64 saturates: e^-huge = +0, never a wrapped exponent (|v| up to ~1e45; tests/test_gpu_math.py)
 }
 
 // e^v; exactly +0 for v < -745.2 (v_ldexp_f64 underflow)
@@ -148,7 +148,7 @@ __device__ __forceinline__ double exp_p9(double v)   // |v| < 1.4e9 (shift trick
     const double r = __builtin_fma(-dn, IS3D_LN2, v);
     return ldexp_fast(exp_p9_poly(r), __double2loint(t));
 }
-__device__ __forceinline__ double exp_p9_sat(double v)   // any v: v_cvt_i32_f64 saturates, e^-huge = +0
+__device__ __forceinline__ double exp_p9_sat(double v)   // |v| up to ~1e45: v_cvt_i32_f64 saturates, e^-huge = +0 (beyond that the reduced argument's polynomial overflows)
 {
     const double dn = __builtin_rint(v * IS3D_LOG2E);
     const double r = __builtin_fma(-dn, IS3D_LN2, v);

@@ -673,6 +673,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 fp.nj = P->nj;
                 fp.jx = P->d_jonah.p; fp.jl2 = fp.jx + P->nj; fp.jz = fp.jx + 2 * P->nj; fp.jcl = fp.jx + 3 * P->nj; fp.jcz = fp.jx + 4 * P->nj;
                 fp.bp_max = P->bp_max;
+                fp.mTmax = P->mTmax; fp.kmin = P->kmin; fp.kmax = P->kmax;
                 fp.ngl = P->ngl; fp.gl = P->d_gl.p;
                 fp.detA_min = P->detA_min; fp.mass_pion0 = P->mass_pion0;
                 fp.JT = P->JT; fp.R = P->KT; fp.jtiles = P->jtiles; fp.rblocks = P->rblocks;

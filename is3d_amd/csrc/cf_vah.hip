@@ -150,6 +150,14 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             l_F[idx] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
         }
         __syncthreads();
+        if (tid < ncb) {
+            // domain of the main kernels' exponential (exp_p9: |v| < 1.4e9): E_a/Lambda <= (mTmax max_k sqrt(C_k^2 + |xi| Z_k^2) + pTmax max_j |D_j|) / Lambda
+            const VahScal &s = cs[tid];
+            double ck = 0.0, dj = 0.0;
+            for (int k = 0; k < K; k++) ck = fmax(ck, sqrt(l_C[tid * K + k] * l_C[tid * K + k] + fabs(s.xi) * l_Z[tid * K + k] * l_Z[tid * K + k]));
+            for (int j = 0; j < J; j++) dj = fmax(dj, fabs(l_D[tid * J + j]));
+            if (!((p.mTmax * ck + p.pTmax * dj) * fabs(s.invL) < 1.0e9)) atomicMin(&p.status[7], (unsigned long long)(p.cell0 + cbase + tid));
+        }
         if (p.fact) {
             // ---- F records (cf_main_vah3): header jj {B_j, d_j, gd_j, x}, x of jj = 0, 1, 2 = min_k c_k, min_k e_k over the unit's rows and
             // max_j d_j over its phi tile (the bounds of the unit- and row-level culls); row r {A_k, c_k, ad_k, e_k, bd_{j0..,k}}
@@ -159,12 +167,6 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
                 double v = -1.0e300;
                 for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_dj[c * J + min(jt * JT + q2, J - 1)]);
                 l_dmx[idx] = v;
-            }
-            if (tid < ncb) {   // domain of the main kernel's exponential: E_a/Lambda <= mTmax max_k sqrt(c_k^2 + |e_k|) + pTmax max_j |d_j|
-                double ck = 0.0, dj = 0.0;
-                for (int k = 0; k < K; k++) ck = fmax(ck, sqrt(l_ck[tid * K + k] * l_ck[tid * K + k] + fabs(l_ek[tid * K + k])));
-                for (int j = 0; j < J; j++) dj = fmax(dj, fabs(l_dj[tid * J + j]));
-                if (!(p.mTmax * ck + p.pTmax * dj < 1.0e9)) atomicMin(&p.status[7], (unsigned long long)(p.cell0 + cbase + tid));
             }
             __syncthreads();
             const int HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
@@ -327,7 +329,7 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const double X = sqrt_g1(X2[j0 + i]);
-                    zz[i] = DIM3 ? exp_full_sat(-X) : exp_p9_sat(-X);   // 3+1D here is the round-1 kernel kept as it was for A/B; 2+1D takes the shorter exponential (cf_math.h)
+                    zz[i] = DIM3 ? exp_full_sat(-X) : exp_p9(-X);   // 3+1D here is the round-1 kernel kept AS IT WAS for A/B; 2+1D takes the shorter exponential (cf_math.h); cf_prep_vah keeps X below 1e9
                     d[i] = __builtin_fma(sign, zz[i], 1.0);
                 }
                 rcp_batch<RB>(d, inv);                                                         // fbar_a

@@ -32,15 +32,17 @@ def test_vah_parity(fx, dim, flags):
 
 
 def test_vah_exponent_domain_is_refused(fx):
-    """cf_main_vah3's exponential takes its integer part by the shift trick (|E_a/Lambda| < 1.4e9): cf_prep_vah reports a cell that could
+    """The VAH kernels' exponential takes its integer part by the shift trick (|E_a/Lambda| < 1.4e9): cf_prep_vah reports a cell that could
     exceed 1e9 (a Lambda of 1e-12 GeV here) instead of wrapping an exponent; the reference's exp() overflows to inf there."""
     cells = synth.synth_vah_surface(40, 3, seed=3)
     cells["Lambda"][11] = 1e-12
     with pytest.raises(api.Is3dError) as e:
         api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], dict(dimension=3))
     assert e.value.code == api.IS3D_EDOMAIN and e.value.bad_cell == 11 and "1e9" in str(e.value)
-    got, _ = api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], dict(dimension=3, kernel_variant=2))   # the saturating exponential of the round-1 kernel
-    assert np.isfinite(got).all()
+    for o in (dict(dimension=3, kernel_variant=2), dict(dimension=2)):                                    # every VAH kernel shares the check
+        with pytest.raises(api.Is3dError) as e:
+            api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], o)
+        assert e.value.code == api.IS3D_EDOMAIN and e.value.bad_cell == 11
 
 
 def test_vah_species_collapse_passes_and_accumulate(fx):
