@@ -66,6 +66,7 @@ struct PrepParams {
     unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count, [7] min cell whose p.u/T can exceed 1e9
     // E2 table stream (kernel variant 5, see "TE" below); TE == nullptr: not written
     int32_t pair_writer;            // tiled stream: the record writer handles two elements per lane and trip (set by launch_prep)
+    int32_t dev_skip;               // dev (IS3D_PREP_SKIP, timing only, results invalid): bit 0 no unit records, bit 1 no E2 tables, bit 2 no phase 2
     double *TE;
     const double *pTgrid;           // [npT] the pT grid (the lanes' pT values are exactly these)
     int32_t npT;

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
         __syncthreads();
 
         // ---- phase 2: (cell, k) quantities ----
-        for (int idx = tid; idx < ncb * K; idx += kPrepThreads) {
+        for (int idx = tid; idx < ((p.dev_skip & 4) ? 0 : ncb * K); idx += kPrepThreads) {
             const int c = idx / K, k = idx - c * K;
             const CellScal &s = cs[c];
             double dlt, w;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             l_ch[c * K + k] = ch; l_sh[c * K + k] = sh; l_C[c * K + k] = C;
         }
         // ---- phase 2b: (cell, j) quantities ----
-        for (int idx = tid; idx < ncb * J; idx += kPrepThreads) {
+        for (int idx = tid; idx < ((p.dev_skip & 4) ? 0 : ncb * J); idx += kPrepThreads) {
             const int c = idx / J, j = idx - c * J;
             const CellScal &s = cs[c];
             double cp = p.cosphi[j], sp = p.sinphi[j];
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             // back to back (ncb x REC x 8 bytes contiguous in 3+1D) instead of hopping to another stream after every 928-byte record
             const int n_units_b = ncb * p.jtiles * p.rblocks;
             const int n_lo = (n_units_b * wave) / (kPrepThreads / 64), n_hi = (n_units_b * (wave + 1)) / (kPrepThreads / 64);
-            for (int n = n_lo; n < n_hi; n++) {
+            for (int n = n_lo; n < ((p.dev_skip & 1) ? n_lo : n_hi); n++) {
                 int jt, rb, c;
                 if (p.dim3) {         // stream = (jt, rb): the cells of the batch are consecutive records
                     const int sidx = n / ncb;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                     }
                 }
             }
-            if (p.TE && unit_bounds) {
+            if (p.TE && unit_bounds && !(p.dev_skip & 2)) {
                 // E2 table stream (cf_device.h): exp(pT Dp_j - pT Dmax) for every pT of the grid, with the roundings the main
                 // kernel's own header used (explicit mul / sub, no contraction): pT Dmax == max_j (pT Dp_j) for pT >= 0
                 // One (cell, phi tile) table per wave at a time, lanes <-> (jj, ipT) with ipT fastest (kE2Stride = 32: shifts, no division;
@@ -543,6 +543,8 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
     {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1, read per launch so that one process can alternate
         const char *e = getenv("IS3D_PREP_PAIR");
         p.pair_writer = e ? (atoi(e) != 0) : kPrepPairDefault;
+        const char *k = getenv("IS3D_PREP_SKIP");
+        p.dev_skip = k ? atoi(k) : 0;
     }
     size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0, p.dim3 ? 1 : 0);
     if (cb == 16) hipLaunchKernelGGL(cf_prep<16>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
