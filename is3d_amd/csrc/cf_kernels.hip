@@ -467,7 +467,32 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                             v = ((d.x >> 20) & 1) ? bet : v;
                             return zero ? 0.0 : v;
                         };
-                        if (p.pair_writer) {
+                        if (p.pair_writer == 2) {
+                            // split writer (A/B): the record's raw elements (header + row scalars: one LDS read each) and its beta elements
+                            // (six LDS reads each) in separate trips, so that no lane computes a beta_of it does not store and no beta lane
+                            // reads a descriptor
+                            const int NRAW = HDR + R * RS, NBETA = R * JT;
+                            for (int q = lane; q < NRAW; q += 64) {
+                                int e = q;
+                                if (q >= HDR) { const int qq = q - HDR, r = qq / RS; e = HDR + r * RWD + (qq - r * RS); }
+                                const int2 d = desc[e];
+                                const int jj = d.y & 0xffff, r = d.y >> 16;
+                                const int jcl = min(jt * JT + jj, J - 1);
+                                const int k = rb * R + r, kcl = min(k, K - 1);
+                                const int msel = (d.x >> 16) & 7;
+                                const int add = msel == 0 ? cJ + jcl : msel == 1 ? cK + kcl : msel == 2 ? cT : msel == 3 ? cR : cS;
+                                const bool zero = ((d.x >> 22) & 1) | (((d.x >> 21) & 1) & (k >= K));
+                                const double raw = lds[zero ? 0 : (d.x & 0xffff) + add];
+                                const double v = ((d.x >> 19) & 1) ? raw * psc : raw;
+                                __builtin_nontemporal_store(zero ? 0.0 : v, &o[e]);
+                            }
+                            for (int q = lane; q < NBETA; q += 64) {
+                                const int r = q / JT, jj = q - r * JT;
+                                const int k = rb * R + r;
+                                const double bet = beta_of(c, min(jt * JT + jj, J - 1), min(k, K - 1));
+                                __builtin_nontemporal_store(k >= K ? 0.0 : bet, &o[HDR + r * RWD + RS + jj]);
+                            }
+                        } else if (p.pair_writer) {
                             const int4 *desc2 = (const int4 *)desc;
                             for (int e2 = lane; e2 < REC / 2; e2 += 64) {
                                 const int4 dd = desc2[e2];
@@ -542,7 +567,7 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
     int grid = nbatch < 4096 ? nbatch : 4096;
     {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1, read per launch so that one process can alternate
         const char *e = getenv("IS3D_PREP_PAIR");
-        p.pair_writer = e ? (atoi(e) != 0) : kPrepPairDefault;
+        p.pair_writer = e ? atoi(e) : (kPrepPairDefault ? 1 : 0);
         const char *k = getenv("IS3D_PREP_SKIP");
         p.dev_skip = k ? atoi(k) : 0;
     }

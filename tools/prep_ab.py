@@ -24,17 +24,18 @@ def main():
         ptrs = {k: v.data_ptr() for k, v in tens.items()}
         plan = api.Plan(sp, grid, df, dict(dimension=dim, df_mode=dfm), max_cells=n)
         plan.set_timing(True)
-        outs = [torch.zeros(plan.output_size, dtype=torch.float64, device=dev) for _ in range(2)]
-        t = {0: [], 1: []}
+        outs = [torch.zeros(plan.output_size, dtype=torch.float64, device=dev) for _ in range(3)]
+        t = {0: [], 1: [], 2: []}
         for r in range(5):
-            for pair in (0, 1):
+            for pair in (0, 1, 2):
                 os.environ["IS3D_PREP_PAIR"] = str(pair)
                 plan.execute(n, ptrs, outs[pair].data_ptr(), 0, want_status=False)
                 ms = plan.timings()["ms_prep"]
                 if r:
                     t[pair].append(ms)
-        print("dim %d, %d cells: prep ms  one element per lane %.3f (min %.3f)   two per lane %.3f (min %.3f)   bitwise %s" % (
-            dim, n, np.median(t[0]), min(t[0]), np.median(t[1]), min(t[1]), bool(torch.equal(outs[0], outs[1]))), flush=True)
+        print("dim %d, %d cells: prep ms  one element per lane %.3f (min %.3f)   two per lane %.3f (min %.3f)   raw / beta trips %.3f (min %.3f)   bitwise %s %s" % (
+            dim, n, np.median(t[0]), min(t[0]), np.median(t[1]), min(t[1]), np.median(t[2]), min(t[2]), bool(torch.equal(outs[0], outs[1])),
+            bool(torch.equal(outs[0], outs[2]))), flush=True)
         plan.close()
 
 
