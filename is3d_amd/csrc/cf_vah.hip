@@ -836,9 +836,11 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     const int lane_waves = Lpad / 64;
     int best = 1 << 30;
     for (int w : {8, 4, 2}) { const int waste = ((lane_waves + w - 1) / w) * w - lane_waves; if (waste < best) { best = waste; P->wpb = w; } }
-    int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : (24LL * 4096 + (int64_t)lane_waves * P->jtiles * P->ktiles - 1) / ((int64_t)lane_waves * P->jtiles * P->ktiles);
+    // chunk count as in cf_plan.cpp: ~24 rounds of the chip, chunks of at most ~1152 cells (the streams of a chunk stay near the XCD's L2), partials <= 12 GiB
+    const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
+    int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : std::max<int64_t>((24LL * 4096 + tasks_per_chunk - 1) / tasks_per_chunk, (P->pass_cells + 1151) / 1152);
     nch = std::min<int64_t>(nch, std::max<int64_t>(1, P->pass_cells / 64));
-    nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)2 << 30) / ((int64_t)J * Kacc * Lpad * 8)));
+    nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)(o->cell_chunks > 0 ? 32 : 12) << 30) / ((int64_t)J * Kacc * Lpad * 8)));
     P->nch = (int)nch;
     VAH_TRY(P->d_TS.alloc((size_t)P->pass_cells * bytes_per_cell + 64 * 1024));   // + slack: the staging pieces of the last batch over-read the stream
     VAH_TRY(P->d_partial.alloc((size_t)nch * J * Kacc * Lpad * sizeof(double)));
