@@ -120,7 +120,7 @@ if c5:
     for d in sorted(glob.glob(os.path.join(src, "c5pmc_*"))):
         if not os.path.isdir(d):
             continue
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for f in [max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)]:   # gpurun merges every call's files: newest only
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 if name.startswith("is3d::"):
