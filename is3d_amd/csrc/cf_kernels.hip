@@ -431,6 +431,11 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             // back to back (ncb x REC x 8 bytes contiguous in 3+1D) instead of hopping to another stream after every 928-byte record
             const int n_units_b = ncb * p.jtiles * p.rblocks;
             const int n_lo = (n_units_b * wave) / (kPrepThreads / 64), n_hi = (n_units_b * (wave + 1)) / (kPrepThreads / 64);
+            // a record of at most 128 doubles (3+1D: 116) is ONE trip of the pair writer, lane <-> element pair fixed for every unit: its
+            // descriptors are read and decoded once, outside the unit loop
+            const bool one_trip = p.pair_writer == 1 && REC / 2 <= 64;
+            int4 dd0 = int4{1 << 22, 0, 1 << 22, 0};
+            if (one_trip && lane < REC / 2) dd0 = ((const int4 *)desc)[lane];
             for (int n = n_lo; n < ((p.dev_skip & 1) ? n_lo : n_hi); n++) {
                 int jt, rb, c;
                 if (p.dim3) {         // stream = (jt, rb): the cells of the batch are consecutive records
@@ -491,6 +496,12 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                                 const int k = rb * R + r;
                                 const double bet = beta_of(c, min(jt * JT + jj, J - 1), min(k, K - 1));
                                 __builtin_nontemporal_store(k >= K ? 0.0 : bet, &o[HDR + r * RWD + RS + jj]);
+                            }
+                        } else if (one_trip) {
+                            if (lane < REC / 2) {
+                                const double vx = element(int2{dd0.x, dd0.y}), vy = element(int2{dd0.z, dd0.w});
+                                __builtin_nontemporal_store(vx, &o[2 * lane]);
+                                __builtin_nontemporal_store(vy, &o[2 * lane + 1]);
                             }
                         } else if (p.pair_writer) {
                             const int4 *desc2 = (const int4 *)desc;
