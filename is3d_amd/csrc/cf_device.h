@@ -65,6 +65,7 @@ struct PrepParams {
     double mTmax, kmin, kmax;       // largest lane mT; range of the k grid (y in 3+1D, eta nodes in 2+1D): bound of p.u/T
     unsigned long long *status;     // [0] min bad cell (global index), [1] skipped count, [7] min cell whose p.u/T can exceed 1e9
     // E2 table stream (kernel variant 5, see "TE" below); TE == nullptr: not written
+    int32_t w0_share;               // wave 0's share of a batch's units (% of another wave's) while it runs the next batch's phase 1
     int32_t pair_writer;            // tiled stream: the record writer handles two elements per lane and trip (set by launch_prep)
     int32_t dev_skip;               // dev (IS3D_PREP_SKIP, timing only, results invalid): bit 0 no unit records, bit 1 no E2 tables, bit 2 no phase 2
     double *TE;

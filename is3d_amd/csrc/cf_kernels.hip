@@ -114,7 +114,8 @@ hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3,
 constexpr int kPrepCB = 4;          // cells per workgroup batch (2+1D: K = 241 rows per cell fill the LDS)
 constexpr int kPrepCB3 = 16;       // 3+1D: larger batches give longer contiguous runs per stream of the tiled output
 constexpr int kPrepThreads = 256;
-constexpr bool kPrepPairDefault = true;   // record writer: two elements per lane and trip (A/B: IS3D_PREP_PAIR)
+constexpr int kPrepW0Share = 60;    // measured 40 / 60 / 77 / 100: 4.27 / 4.17 / 4.23 / 4.27 ms (1e6 cells, 3+1D)
+constexpr int kPrepWriterDefault = 3;   // record writer: 3 = two units per trip, raw / beta trips (where eligible, else 1) | 1 = two elements per lane and trip | 0 | 2 (A/B: IS3D_PREP_PAIR)
 
 struct CellScal {
     double dat, dax, day, dan_tau, ut, ux, uy, tau_un, invT, eta;
@@ -135,12 +136,12 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     double *sx = lds;                         // [nT]
     double *sy = sx + nT;                     // [nspl][nT]
     double *sc = sy + nspl * nT;              // [nspl][nT]
-    CellScal *cs = (CellScal *)(sc + nspl * nT);  // [CB]
+    CellScal *cs = (CellScal *)(sc + nspl * nT);  // [2][CB]
     // per (cell, k): A, Cp, alpha, W, ch, sh, C ; per (cell, j): B, Dp, gamma, D, E, F
     // (the two last arrays of each group exist with include_baryon only: a 241-row eta table would pay 15 KB for them, and two
     // workgroups per CU need <= 80 KB each)
     const int NKA = p.baryon ? 9 : 7, NJA = p.baryon ? 8 : 6;
-    double *lk = (double *)(cs + CB);    // [NKA][CB][K]
+    double *lk = (double *)(cs + 2 * CB);    // [NKA][CB][K]   (cs: two buffers, the batch in hand and the next one's)
     double *lj = lk + NKA * CB * K;      // [NJA][CB][J]
     const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_Cp = lk + CK, *l_al = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK, *l_C = lk + 6 * CK;
@@ -200,12 +201,12 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
     }
 
     const int nbatch = (p.n_cells + CB - 1) / CB;
-    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-        const int cbase = batch * CB;
-        const int ncb = min(CB, p.n_cells - cbase);
-
-        // ---- phase 1: per-cell scalars (smooth_kernels.cpp:118-242) ----
-        if (tid < ncb) {
+    // ---- phase 1: per-cell scalars (smooth_kernels.cpp:118-242), one lane per cell of the batch ----
+    // A serial chain (22 loads, a square root, seven divisions, three spline searches, a cosh: ~7 us) that only 16 lanes of the workgroup
+    // work on: the batch loop below runs it for the NEXT batch on wave 0 while the other waves write the current batch's records
+    // (two CellScal buffers; wave 0 takes a smaller share of the records), so only a workgroup's first batch waits for it.
+    auto phase1 = [&](const int cbase, CellScal *dst) {
+        {
             const int64_t gi = p.cell0 + cbase + tid;
             CellScal s;
             double tau = p.cells.tau[gi], tau2 = tau * tau;
@@ -311,9 +312,18 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 s.alphaB = s.Vt = s.Vx = s.Vy = s.tVn = s.b1P = s.cLin = s.cQ = 0.0;
                 s.wvalid = 0.0;
             }
-            cs[tid] = s;
+            dst[tid] = s;
         }
-        __syncthreads();
+    };
+    CellScal *const cs_base = cs;
+    if ((int)blockIdx.x < nbatch && tid < min(CB, p.n_cells - (int)blockIdx.x * CB)) phase1(blockIdx.x * CB, cs);
+    __syncthreads();
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int cbase = batch * CB;
+        const int ncb = min(CB, p.n_cells - cbase);
+        const int cs_cur = (int)((const double *)cs - (const double *)cs_base);      // the buffer in use, as an offset in doubles
+        const int batch_next = batch + gridDim.x;
+        const bool prefetch = batch_next < nbatch;
 
         // ---- phase 2: (cell, k) quantities ----
         for (int idx = tid; idx < ((p.dev_skip & 4) ? 0 : ncb * K); idx += kPrepThreads) {
@@ -373,18 +383,42 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             l_F[c * J + j] = 2.0 * (s.tpixn * cp + s.tpiyn * sp);
         }
         __syncthreads();
+        // 3+1D records carry the bounds of the main kernel's unit-level cull in free slots: without baryon slots the x of header
+        // entries jj = 0, 1; "B" records the free double behind alpha_B and the free scalar of row 0 (cf_device.h)
+        if (p.tiled && p.dim3 && p.JT >= 2) {
+            const int JT = p.JT, R = p.R;
+            for (int idx = tid; idx < ncb * p.jtiles; idx += kPrepThreads) {
+                const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
+                double v = -1.0e300;
+                for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_Dp[c * J + min(jt * JT + q2, J - 1)]);
+                l_bD[idx] = v;
+            }
+            for (int idx = tid; idx < ncb * p.rblocks; idx += kPrepThreads) {
+                const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
+                double v = 1.0e300;
+                for (int q2 = 0; q2 < R; q2++) v = fmin(v, l_Cp[c * K + min(rb * R + q2, K - 1)]);   // padding rows repeat row K-1
+                l_bC[idx] = v;
+            }
+            __syncthreads();
+        }
+        // phase 1 of the workgroup's next batch, on wave 0, under the other waves' record writing
+        if (prefetch && tid < min(CB, p.n_cells - batch_next * CB)) phase1(batch_next * CB, cs == cs_base ? cs_base + CB : cs_base);
+        // units (and E2 tables) per wave: wave 0 takes w0 % of another wave's share while it has a phase 1 to run
+        const int w0 = prefetch ? p.w0_share : 100;
+        auto wave_lo = [&](int n_items, int w) { return w == 0 ? 0 : (int)(((int64_t)n_items * (w0 + 100 * (w - 1))) / (w0 + 100 * (kPrepThreads / 64 - 1))); };
         // beta_jk = shear X_jk - 2 Pi b2 C_k D_j (14-moment) | shear X_jk / T (Chapman-Enskog)
-        auto beta_of = [&](int c, int j, int k) {
-            const CellScal &s = cs[c];
-            double X = l_E[c * J + j] * l_ch[c * K + k] + l_F[c * J + j] * l_sh[c * K + k];
-            double beta = p.ce ? (s.shear * X * s.invT - 2.0 * s.kappa * l_Cp[c * K + k] * l_Dp[c * J + j])
-                               : (s.shear * X - 2.0 * s.Pb2 * l_C[c * K + k] * l_D[c * J + j]);
+        // ij = c J + j, ik = c K + k (the duo writer forms them with 24-bit multiplies)
+        auto beta_at = [&](const CellScal &s, int ij, int ik) {
+            double X = l_E[ij] * l_ch[ik] + l_F[ij] * l_sh[ik];
+            double beta = p.ce ? (s.shear * X * s.invT - 2.0 * s.kappa * l_Cp[ik] * l_Dp[ij])
+                               : (s.shear * X - 2.0 * s.Pb2 * l_C[ik] * l_D[ij]);
             if (p.baryon) {
-                const double Cq = p.ce ? l_Cp[c * K + k] : l_C[c * K + k], Dq = p.ce ? l_Dp[c * J + j] : l_D[c * J + j];
-                beta -= s.cQ * (Cq * l_V2[c * J + j] + Dq * l_V1[c * K + k]);
+                const double Cq = p.ce ? l_Cp[ik] : l_C[ik], Dq = p.ce ? l_Dp[ij] : l_D[ij];
+                beta -= s.cQ * (Cq * l_V2[ij] + Dq * l_V1[ik]);
             }
             return beta;
         };
+        auto beta_of = [&](int c, int j, int k) { return beta_at(cs[c], c * J + j, c * K + k); };
         if (!p.tiled) {
             // ---- phase 3 (flat): S1[cell][k][4], S2[cell][j][4], S3[cell][j][k] ----
             for (int idx = tid; idx < ncb * K; idx += kPrepThreads) {
@@ -406,37 +440,113 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             // (q < 2^15, RWD < 64: q * ceil(2^20 / RWD) >> 20 is exact); decoding a flat index with five runtime divisions per
             // element made this kernel VALU-bound (200 instructions per double written).
             const int JT = p.JT, R = p.R;
-            // 3+1D records carry the bounds of the main kernel's unit-level cull in free slots: without baryon slots the x of header
-            // entries jj = 0, 1; "B" records the free double behind alpha_B and the free scalar of row 0 (cf_device.h)
             const bool unit_bounds = p.dim3 && JT >= 2;
-            if (unit_bounds) {
-                for (int idx = tid; idx < ncb * p.jtiles; idx += kPrepThreads) {
-                    const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
-                    double v = -1.0e300;
-                    for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_Dp[c * J + min(jt * JT + q2, J - 1)]);
-                    l_bD[idx] = v;
-                }
-                for (int idx = tid; idx < ncb * p.rblocks; idx += kPrepThreads) {
-                    const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
-                    double v = 1.0e300;
-                    for (int q2 = 0; q2 < R; q2++) v = fmin(v, l_Cp[c * K + min(rb * R + q2, K - 1)]);   // padding rows repeat row K-1
-                    l_bC[idx] = v;
-                }
-                __syncthreads();
-            }
             const double psc = pds_scale(p.pds_bound, nullptr);
             const int HDR = 4 * JT + (p.baryon ? 2 : 0), RS = p.baryon ? 6 : 4, RWD = RS + JT, REC = HDR + R * RWD;
             const int wave = tid >> 6, lane = tid & 63;
             // units in (stream, cell) order, a contiguous range per wave: a wave writes the records of consecutive cells of ONE stream
             // back to back (ncb x REC x 8 bytes contiguous in 3+1D) instead of hopping to another stream after every 928-byte record
             const int n_units_b = ncb * p.jtiles * p.rblocks;
-            const int n_lo = (n_units_b * wave) / (kPrepThreads / 64), n_hi = (n_units_b * (wave + 1)) / (kPrepThreads / 64);
+            const int n_lo = wave_lo(n_units_b, wave), n_hi = wave_lo(n_units_b, wave + 1);
             // a record of at most 128 doubles (3+1D: 116) is ONE trip of the pair writer, lane <-> element pair fixed for every unit: its
             // descriptors are read and decoded once, outside the unit loop
-            const bool one_trip = p.pair_writer == 1 && REC / 2 <= 64;
+            // duo writer (pair_writer 3): TWO unit records per trip, one per half wave, and a record's raw elements (header + row scalars: one
+            // LDS read each) and its beta elements (six LDS reads each) in separate trips of 16-byte stores -- no lane computes a beta_of it
+            // does not store, no beta lane decodes a descriptor, and both trips run with ~60 of 64 lanes busy (the one-trip pair writer: 58 of
+            // 64 lanes, every lane paying for a beta_of).  Needs pairs that stay inside a field group: JT even, no baryon slots.
+            const int NRAWP = (HDR + R * RS) / 2, NBETAP = (R * JT) / 2;
+            const bool duo = p.pair_writer == 3 && !p.baryon && !(JT & 1) && NRAWP <= 32 && NBETAP <= 32;
+            // otherwise: a record of at most 128 doubles is ONE trip of the pair writer, lane <-> element pair fixed for every unit: its
+            // descriptors are read and decoded once, outside the unit loop
+            const bool one_trip = (p.pair_writer == 1 || p.pair_writer == 3) && !duo && REC / 2 <= 64;
             int4 dd0 = int4{1 << 22, 0, 1 << 22, 0};
             if (one_trip && lane < REC / 2) dd0 = ((const int4 *)desc)[lane];
-            for (int n = n_lo; n < ((p.dev_skip & 1) ? n_lo : n_hi); n++) {
+            if (duo && !(p.dev_skip & 1)) {
+                const int l = lane & 31, half = lane >> 5;
+                const int lr = min(l, NRAWP - 1), lb = min(l, NBETAP - 1);
+                const int eR = lr < HDR / 2 ? 2 * lr : HDR + ((lr - HDR / 2) >> 1) * RWD + ((lr - HDR / 2) & 1) * 2;
+                // the lane's two raw elements never change: their descriptors are decoded ONCE into a branch-free address rule
+                //   lds[off + c mc + min(jt a + rb b + q, lim)] * mul,   zero when (always | padding row and rb R + r >= K)
+                struct RawRule { int off, mc, a, b, q, lim, r, zero, padz; double mul; };
+                auto rule_of = [&](const int2 d) {
+                    RawRule u;
+                    const int jj = d.y & 0xffff, r = d.y >> 16, msel = (d.x >> 16) & 7;
+                    u.off = (d.x & 0xffff) + (msel == 4 ? cs_cur : 0); u.r = r;
+                    u.mc = msel == 0 ? J : msel == 1 ? K : msel == 2 ? p.jtiles : msel == 3 ? p.rblocks : (int)(sizeof(CellScal) / sizeof(double));
+                    u.a = msel == 0 ? JT : msel == 2 ? 1 : 0;
+                    u.b = msel == 1 ? R : msel == 3 ? 1 : 0;
+                    u.q = msel == 0 ? jj : msel == 1 ? r : 0;
+                    u.lim = msel == 0 ? J - 1 : msel == 1 ? K - 1 : 0x7fffffff;
+                    u.zero = (d.x >> 22) & 1; u.padz = (d.x >> 21) & 1;
+                    u.mul = ((d.x >> 19) & 1) ? psc : 1.0;
+                    return u;
+                };
+                const RawRule u0 = rule_of(desc[eR]), u1 = rule_of(desc[eR + 1]);
+                const int rB = (2 * lb) / JT, jB = 2 * lb - rB * JT, eB = HDR + rB * RWD + RS + jB;
+                // the half wave's unit (jt, rb, c): decoded once, then stepped (two units per trip) -- per-lane integer divisions in the
+                // loop would cost more than the record's arithmetic
+                int jt, rb, c;
+                {
+                    const int nn = min(n_lo + half, max(n_hi - 1, n_lo));
+                    if (p.dim3) {
+                        const int sidx = nn / ncb;
+                        c = nn - sidx * ncb; jt = sidx / p.rblocks; rb = sidx - jt * p.rblocks;
+                    } else {
+                        const int per_jt = ncb * p.rblocks;
+                        jt = nn / per_jt;
+                        const int r2 = nn - jt * per_jt;
+                        c = r2 / p.rblocks; rb = r2 - c * p.rblocks;
+                    }
+                }
+                const bool raw_lane = l < NRAWP, beta_lane = l < NBETAP;
+                // the record pointer is stepped with the unit (a 64-bit multiply per trip otherwise), and every index product of the loop is a
+                // 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate and the loop is bound by VALU issue): all factors are < 2^15
+                const int64_t unit0 = p.dim3 ? (int64_t)(jt * p.rblocks + rb) * p.n_cells + (cbase + c) : ((int64_t)jt * p.n_cells + (cbase + c)) * p.rblocks + rb;
+                double *o = p.TS + unit0 * REC;
+                const int64_t wrap_stride = p.dim3 ? (int64_t)(p.n_cells - ncb + 1) * REC : (int64_t)(1 + (int64_t)(p.n_cells - ncb) * p.rblocks) * REC;
+                auto step = [&]() {   // selects, no branches: (stream, cell) order in 3+1D, (phi tile, cell, row block) order in 2+1D
+                    bool wrap;
+                    if (p.dim3) {
+                        const int c1 = c + 1; wrap = c1 == ncb;
+                        c = wrap ? 0 : c1;
+                        const int rb1 = rb + (wrap ? 1 : 0); const bool w2 = rb1 == p.rblocks;
+                        rb = w2 ? 0 : rb1; jt += w2 ? 1 : 0;
+                    } else {
+                        const int rb1 = rb + 1; const bool w1 = rb1 == p.rblocks;
+                        rb = w1 ? 0 : rb1;
+                        const int c1 = c + (w1 ? 1 : 0); wrap = c1 == ncb;
+                        c = wrap ? 0 : c1; jt += wrap ? 1 : 0;
+                    }
+                    o += wrap ? wrap_stride : (int64_t)REC;
+                };
+                constexpr int CSD = (int)(sizeof(CellScal) / sizeof(double));
+                const int cs_off = (int)((const double *)cs - lds);
+                for (int n = n_lo; n < n_hi; n += 2, step(), step()) {
+                    if (n + half >= n_hi) continue;          // an odd range's last trip: the upper half wave has no unit
+                    const int rbR = __mul24(rb, R), jtJT = __mul24(jt, JT);
+                    auto raw_element = [&](const RawRule &u) {
+                        const bool zero = u.zero | (u.padz & (rbR + u.r >= K));
+                        const int at = u.off + __mul24(c, u.mc) + min(__mul24(jt, u.a) + __mul24(rb, u.b) + u.q, u.lim);
+                        const double v = lds[zero ? 0 : at] * u.mul;
+                        return zero ? 0.0 : v;
+                    };
+                    // both trips' LDS reads are issued before either store
+                    const double vx = raw_element(u0), vy = raw_element(u1);
+                    const int k = rbR + rB, ik = __mul24(c, K) + min(k, K - 1), cJ = __mul24(c, J);
+                    const int j0 = min(jtJT + jB, J - 1), j1 = min(jtJT + jB + 1, J - 1);
+                    const CellScal &sc_ = *(const CellScal *)(lds + (cs_off + __mul24(c, CSD)));
+                    const double b0 = beta_at(sc_, cJ + j0, ik), b1 = beta_at(sc_, cJ + j1, ik);
+                    if (raw_lane) {
+                        __builtin_nontemporal_store(vx, &o[eR]);
+                        __builtin_nontemporal_store(vy, &o[eR + 1]);
+                    }
+                    if (beta_lane) {
+                        __builtin_nontemporal_store(k >= K ? 0.0 : b0, &o[eB]);
+                        __builtin_nontemporal_store(k >= K ? 0.0 : b1, &o[eB + 1]);
+                    }
+                }
+            }
+            for (int n = n_lo; n < (((p.dev_skip & 1) || duo) ? n_lo : n_hi); n++) {
                 int jt, rb, c;
                 if (p.dim3) {         // stream = (jt, rb): the cells of the batch are consecutive records
                     const int sidx = n / ncb;
@@ -456,7 +566,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                         double *o = p.TS + unit * REC;
                         // one LDS round trip per 64 elements: the descriptor, then the source double next to the six reads of a
                         // (clamped) beta_of; no divergent branch
-                        const int cJ = c * J, cK = c * K, cT = c * p.jtiles + jt, cR = c * p.rblocks + rb, cS = c * (int)(sizeof(CellScal) / sizeof(double));
+                        const int cJ = c * J, cK = c * K, cT = c * p.jtiles + jt, cR = c * p.rblocks + rb, cS = cs_cur + c * (int)(sizeof(CellScal) / sizeof(double));
                         // two consecutive elements per lane: one 16-byte descriptor read, one 16-byte store (records are 16-byte
                         // multiples, cf_device.h), the two elements' LDS reads in flight together -- half the trips per record
                         auto element = [&](const int2 d) {
@@ -529,7 +639,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                 const int wv = tid >> 6, ln = tid & 63;
                 const double pTl = p.pTgrid[min(ln & 31, p.npT - 1)];           // [jj][ipT], columns past the grid repeat the last
                 const int n_tab_b = ncb * p.jtiles;
-                const int m_lo = (n_tab_b * wv) / (kPrepThreads / 64), m_hi = (n_tab_b * (wv + 1)) / (kPrepThreads / 64);
+                const int m_lo = wave_lo(n_tab_b, wv), m_hi = wave_lo(n_tab_b, wv + 1);
                 for (int m = m_lo; m < m_hi; m++) {   // (phi tile, cell) order: consecutive tables of one tile stream per wave
                     const int jt = m / ncb, c = m - jt * ncb;
                     {
@@ -545,6 +655,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
             }
         }
         __syncthreads();
+        cs = cs == cs_base ? cs_base + CB : cs_base;
     }
 }
 
@@ -566,7 +677,7 @@ size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int d
     // own predicate (p.dim3), whatever K is; a 2+1D eta table of 241 rows must not pay 8 KB for them (two workgroups per CU need <= 80 KB each)
     const size_t bounds = dim3 ? (size_t)cb * ((J + 1) / 2 + K) : 0;
     // + one int2 per element of a unit record (rec doubles; 0 for the flat streams of variant 1)
-    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (nka * K + nja * J) + bounds + (size_t)rec + 2) + sizeof(CellScal) * cb;   // + 2: descriptor alignment
+    return sizeof(double) * ((size_t)nT * (1 + 2 * nspl) + (size_t)cb * (nka * K + nja * J) + bounds + (size_t)rec + 2) + sizeof(CellScal) * cb * 2;   // + 2: descriptor alignment; two CellScal buffers
 }
 
 hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
@@ -576,11 +687,14 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
     const int cb = prep_batch_cells(p.K);
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
-    {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1, read per launch so that one process can alternate
+    {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1 | 2 | 3, read per launch so that one process can alternate
         const char *e = getenv("IS3D_PREP_PAIR");
-        p.pair_writer = e ? atoi(e) : (kPrepPairDefault ? 1 : 0);
+        p.pair_writer = e ? atoi(e) : kPrepWriterDefault;
         const char *k = getenv("IS3D_PREP_SKIP");
         p.dev_skip = k ? atoi(k) : 0;
+        const char *w = getenv("IS3D_PREP_W0");          // wave 0's share of the units while it runs the next batch's phase 1, in %
+        p.w0_share = w ? atoi(w) : kPrepW0Share;
+        if (p.w0_share < 1 || p.w0_share > 100) p.w0_share = kPrepW0Share;
     }
     size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0, p.dim3 ? 1 : 0);
     if (cb == 16) hipLaunchKernelGGL(cf_prep<16>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
