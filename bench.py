@@ -184,7 +184,7 @@ def main():
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
     ap.add_argument("--cells", type=int, default=0, help="override the surface size: total cells (strong scaling) / cells per GPU (weak)")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--zero-skip", type=int, default=0, choices=[0, 1, 2], help="dev: culling mode of the main kernel (2 = off)")
+    ap.add_argument("--zero-skip", type=int, default=0, choices=[0, 1, 2, 3], help="dev: culling mode of the main kernel (2 = off; 3 = surface-relative floors, bounded instead of bitwise: include/is3d_amd.h)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N > 1: strong (default) = BASELINE config 4, ONE surface in N shards; weak = every rank its own surface")
     ap.add_argument("--cell-chunks", type=int, default=0, help="dev: override the number of cell chunks of the main kernel's grid")

@@ -116,6 +116,7 @@ struct MainGeom {
     int32_t npT;       // variant 5: rows of the E2 table
     int32_t ub;        // variant 5: units per LDS batch (from the LDS budget of the workgroup)
     int32_t split;     // 2+1D: lane slots per momentum bin (unit-strided lanes, cf_main_tile); 1 = off
+    int32_t ch0, nch_run;  // cf_main_tile3e: this launch runs chunks [ch0, ch0 + nch_run) of the nch (nch_run 0 = all of them)
 };
 
 struct MainArgs {
@@ -127,6 +128,8 @@ struct MainArgs {
     const double *TE = nullptr;         // variant 5: E2 table stream
     const int32_t *lane_ipT = nullptr;  // variant 5: per lane, the index of its pT in the grid
     const int32_t *lane_sub = nullptr;  // unit-strided lanes: per lane slot, which units (u = sub mod split) it takes
+    const double *cull_floor = nullptr; // cf_main_tile3e, surface-relative cull: [jtiles * ktiles][Lpad] lower bounds of the row-cull threshold
+                                        // (cf_cull_floor, from the partial spectrum of the chunks that ran first)
 };
 
 }  // namespace is3d

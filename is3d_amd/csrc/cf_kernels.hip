@@ -114,7 +114,10 @@ hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3,
 constexpr int kPrepCB = 4;          // cells per workgroup batch (2+1D: K = 241 rows per cell fill the LDS)
 constexpr int kPrepCB3 = 16;       // 3+1D: larger batches give longer contiguous runs per stream of the tiled output
 constexpr int kPrepThreads = 256;
-constexpr int kPrepW0Share = 60;    // measured 40 / 60 / 77 / 100: 4.27 / 4.17 / 4.23 / 4.27 ms (1e6 cells, 3+1D)
+// wave 0's share of a batch's units, in % of another wave's, while it runs the next batch's phase 1: measured 40 / 60 / 77 / 100:
+// 4.27 / 4.17 / 4.23 / 4.27 ms (3+1D, 1e6 cells, 16 cells per batch); 2+1D (4 cells per batch, 24 x 404-double records per cell: the
+// phase 1 is a tenth of a wave's batch): 60 / 85 / 93 / 100: 4.17 / 3.98 / 3.95 / 3.96 ms per 1e5 cells
+constexpr int kPrepW0Share3 = 60, kPrepW0Share2 = 93;
 constexpr int kPrepWriterDefault = 3;   // record writer: 3 = two units per trip, raw / beta trips (where eligible, else 1) | 1 = two elements per lane and trip | 0 | 2 (A/B: IS3D_PREP_PAIR)
 
 struct CellScal {
@@ -693,8 +696,8 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
         const char *k = getenv("IS3D_PREP_SKIP");
         p.dev_skip = k ? atoi(k) : 0;
         const char *w = getenv("IS3D_PREP_W0");          // wave 0's share of the units while it runs the next batch's phase 1, in %
-        p.w0_share = w ? atoi(w) : kPrepW0Share;
-        if (p.w0_share < 1 || p.w0_share > 100) p.w0_share = kPrepW0Share;
+        p.w0_share = w ? atoi(w) : 0;
+        if (p.w0_share < 1 || p.w0_share > 100) p.w0_share = p.dim3 ? kPrepW0Share3 : kPrepW0Share2;
     }
     size_t lds = prep_lds_bytes(p.spl.n, p.spl.nspl, p.J, p.K, p.baryon, p.tiled ? unit_rec_doubles(p.JT, p.R, p.baryon) : 0, p.dim3 ? 1 : 0);
     if (cb == 16) hipLaunchKernelGGL(cf_prep<16>, dim3(grid), dim3(kPrepThreads), lds, stream, p);
@@ -1200,7 +1203,7 @@ __global__ void __launch_bounds__(512)
 cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
                const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
                double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
-               const double *__restrict__ lane_b)
+               const double *__restrict__ lane_b, const double *__restrict__ cull_floor)
 {
     // "B" records (include_baryon, cf_device.h): alpha_B and Dmax behind the header, {L_k, Cmin (row 0)} behind W in every row, L2_j in
     // the header's x; the lane's baryon number b enters the exponent (b alpha_B) and the b-linear part of df (cf_main_tile)
@@ -1239,9 +1242,9 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     const int m = q / g.G;
     const int kt = m % g.ktiles;
     const int pair = (m / g.ktiles) * 8 + xcd;
-    if (pair >= g.jtiles * g.nch) return;  // uniform for the whole workgroup
+    if (pair >= g.jtiles * g.nch_run) return;  // uniform for the whole workgroup
     const int jt = pair % g.jtiles;
-    const int chunk = pair / g.jtiles;
+    const int chunk = g.ch0 + pair / g.jtiles;
     const int nthr = blockDim.x;
     const int lw = grp * g.wpb + (tid >> 6);
     const bool wave_active = lw * 64 < g.Lpad;
@@ -1272,7 +1275,9 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
 
     int n_rows = 0, n_dead = 0;
     constexpr bool RELCULL = OUTFLOW && REG;      // accumulator-relative culling, see cf_main_tile
-    double cull_thr = -745.2;
+    // surface-relative cull: the threshold never falls below what the partial spectrum of the chunks that ran first allows (cf_cull_floor)
+    const double thr_floor = (RELCULL && cull_floor && g.zskip == 2) ? cull_floor[(int64_t)s_tile * g.Lpad + l] : -745.2;
+    double cull_thr = thr_floor;
     const int pe = (RELCULL && lane_pe) ? lane_pe[l] : 0;
 
     unsigned long long pf_stage = 0, pf_wait = 0, pf_dead = 0, pf_live = 0, pf_hdr = 0, pf_nd = 0, pf_nl = 0, pf_thr = 0, pf_t0 = 0, pf_u0 = 0, pf_vm = 0, pf_pro = 0, pf_mid = 0, pf_ts = 0;
@@ -1458,7 +1463,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
 #pragma unroll
             for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
             const int e = __builtin_amdgcn_frexp_exp(m);
-            cull_thr = (m > 1.0e-290) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
+            cull_thr = (m > 1.0e-290) ? __builtin_fmax(thr_floor, (double)(e - 58 - pe) * 0.6931471805599453) : thr_floor;
         }
         if constexpr (PROF) pf_thr += clock64() - pa;
     };
@@ -1585,6 +1590,45 @@ cf_reduce_chunks(double *__restrict__ partial, int64_t n_per_chunk, int nch)
     partial[i] = s;
 }
 
+// Surface-relative cull (cf_main_tile3e): the chunks that ran first give a partial spectrum P_A <= the final one (every term is >= 0 under
+// outflow && regulate_deltaf); a row whose every term is below 2^-58 of the smallest P_A accumulator of its (lane, tile) can change the final
+// sum by less than 2^-57 of it per cell.  floor[s_tile][l] = the row-test threshold that follows from min over the tile of P_A, in the
+// units of the kernel's own (cull_thr: natural log of the half-scaled accumulator, lane exponent pe removed).
+__global__ void __launch_bounds__(256)
+cf_cull_floor(const double *__restrict__ partial, int nA, int J, int K, int Kacc, int Lpad, int JT, int R, int jtiles, int ktiles,
+              const int32_t *__restrict__ lane_pe, double unscale, double *__restrict__ floor_out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)jtiles * ktiles * Lpad) return;
+    const int l = (int)(idx % Lpad), s_tile = (int)(idx / Lpad), jt = s_tile / ktiles, kt = s_tile - jt * ktiles;
+    const int64_t per_chunk = (int64_t)J * Kacc * Lpad;
+    double m = 1.0e300;
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = jt * JT + jj;
+        if (j >= J) break;
+        for (int r = 0; r < R; r++) {
+            const int k = kt * R + r;
+            if (k >= K) break;
+            double sum = 0.0;
+            for (int c = 0; c < nA; c++) sum += partial[c * per_chunk + ((int64_t)j * Kacc + k) * Lpad + l];
+            m = __builtin_fmin(m, sum);
+        }
+    }
+    m /= unscale;
+    const int e = __builtin_amdgcn_frexp_exp(m);
+    const int pe = lane_pe ? lane_pe[l] : 0;
+    floor_out[idx] = (m > 1.0e-290 && m < 1.0e299) ? __builtin_fmax(-745.2, (double)(e - 58 - pe) * 0.6931471805599453) : -745.2;
+}
+
+hipError_t launch_cull_floor(const double *partial, int nA, int J, int K, int Kacc, int Lpad, int JT, int R, int jtiles, int ktiles,
+                             const int32_t *lane_pe, double unscale, double *floor_out, hipStream_t stream)
+{
+    const int64_t n = (int64_t)jtiles * ktiles * Lpad;
+    hipLaunchKernelGGL(cf_cull_floor, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, nA, J, K, Kacc, Lpad, JT, R, jtiles, ktiles,
+                       lane_pe, unscale, floor_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_finalize(double *partial, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
                            int accumulate, const unsigned long long *pds_bound, hipStream_t stream, int split, int Lbins)
@@ -1650,9 +1694,11 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 }
 
 template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false>
-static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
+static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
 {
-    const int pairs = a.g.jtiles * a.g.nch;                                   // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
+    MainArgs a = a_in;
+    if (a.g.nch_run <= 0) { a.g.ch0 = 0; a.g.nch_run = a.g.nch; }
+    const int pairs = a.g.jtiles * a.g.nch_run;                               // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
     const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
     const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0);
     if constexpr (CE && OF && RG && MODE >= 1 && !BARYON) {
@@ -1662,7 +1708,7 @@ static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
             unsigned long long h[16] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof3e), h, sizeof h);
             hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, true>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
-                               a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b);
+                               a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b, a.cull_floor);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof3e), sizeof h);
             const double T = (double)h[1];
@@ -1674,7 +1720,7 @@ static void launch_tile3e_t(const MainArgs &a, hipStream_t st)
         }
     }
     hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
-                       a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b);
+                       a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b, a.cull_floor);
 }
 
 template <bool CE, bool DIM3, bool OF, bool RG>

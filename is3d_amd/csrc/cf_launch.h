@@ -8,6 +8,8 @@ size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int d
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 void main_tile_shape(int variant, int dim3, int *JT, int *KT);
 hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, const MainArgs &a, hipStream_t st);  // a.g.baryon selects the B kernels
+hipError_t launch_cull_floor(const double *partial, int nA, int J, int K, int Kacc, int Lpad, int JT, int R, int jtiles, int ktiles,
+                             const int32_t *lane_pe, double unscale, double *floor_out, hipStream_t stream);
 hipError_t launch_finalize(double *partial /* chunk 0 receives the sum over chunks */, const int *cls, const double *degeneracy, double *out,
                            int64_t nout, int npart, int npT, int J, int Kacc, int Lpad, int nch, double prefactor,
                            int accumulate, const unsigned long long *pds_bound, hipStream_t stream, int split = 1, int Lbins = 0);

@@ -84,6 +84,7 @@ struct is3d_plan {
     bool baryon = false, baryondiff = false;
     DevBuf<int> d_cls;
     DevBuf<int32_t> d_lane_pe;      // per lane: max(mT/mTmax, pT/pTmax) < 2^pe
+    DevBuf<double> d_cull_floor;    // zero_skip 3 (cf_main_tile3e): [jtiles * ktiles][Lpad] threshold floors from the chunks that ran first
     DevBuf<double> d_splx, d_sply[3], d_splc[3];
     DevBuf<double> d_S1, d_S2, d_S3, d_TS, d_partial;
     DevBuf<double> d_TE, d_pTgrid;   // variant 5: E2 table stream (cf_device.h), the pT grid for cf_prep
@@ -505,6 +506,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
     }
     HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
+    if (P->e2tab) HIP_TRY(P->d_cull_floor.alloc((size_t)P->jtiles * P->ktiles * P->Lpad));
     HIP_TRY(P->d_status.alloc(8));
     HIP_TRY(P->d_sticky.upload(std::vector<unsigned long long>{~0ULL, ~0ULL}));
     if (P->feqmod) {
@@ -750,7 +752,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             is3d::MainArgs a{};
             a.S1 = P->d_S1.p; a.S2 = P->d_S2.p; a.S3 = P->d_S3.p; a.TS = P->d_TS.p;
             a.g.upc = P->upc;
-            a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2);   // 0 default: exact-zero + accumulator-relative culling
+            a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2);   // 0 default: exact-zero + accumulator-relative culling; 3: + surface-relative floors (below)
             a.lane_mT = P->d_mT.p; a.lane_pT = P->d_pT.p; a.lane_sign = P->d_sign.p; a.lane_b = P->d_lane_b.p;
             a.g.baryon = P->baryon;
             a.lane_pe = P->d_lane_pe.p;
@@ -768,7 +770,23 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.g.first_pass = (pass == 0);
             a.TE = P->e2tab ? P->d_TE.p : nullptr; a.lane_ipT = P->d_lane_ipT.p; a.g.npT = P->npT; a.g.ub = P->ub3e;
             a.g.split = P->split; a.lane_sub = P->d_lane_sub.p;
-            HIP_TRY(is3d::launch_main(P->variant, P->ce, P->dim3, o.outflow != 0, o.regulate_deltaf != 0, a, st));
+            // zero_skip 3, surface-relative cull (cf_main_tile3e with outflow && regulate_deltaf; include/is3d_amd.h): an eighth of the chunks
+            // runs first with the accumulator-relative rule; their partial spectrum is a lower bound of the final one (all terms >= 0) and
+            // floors the row-cull thresholds of the other chunks, which would otherwise each start from an empty accumulator
+            static const int surf_den = [] { const char *e = getenv("IS3D_SURFCULL_DEN"); const int v = e ? atoi(e) : 0; return v >= 2 ? v : 8; }();
+            const bool surf = o.zero_skip == 3 && P->e2tab && o.outflow != 0 && o.regulate_deltaf != 0 && nch_used >= 2 * surf_den;
+            if (surf) {
+                const int nA = nch_used / surf_den;
+                a.g.ch0 = 0; a.g.nch_run = nA;
+                HIP_TRY(is3d::launch_main(P->variant, P->ce, P->dim3, true, true, a, st));
+                HIP_TRY(is3d::launch_cull_floor(P->d_partial.p, nA, P->J, P->K, P->Kacc, P->Lpad, P->JT, P->KT, P->jtiles, P->ktiles, P->d_lane_pe.p,
+                                                2.0, P->d_cull_floor.p, st));
+                a.g.ch0 = nA; a.g.nch_run = nch_used - nA;
+                a.cull_floor = P->d_cull_floor.p;
+                HIP_TRY(is3d::launch_main(P->variant, P->ce, P->dim3, true, true, a, st));
+            } else {
+                HIP_TRY(is3d::launch_main(P->variant, P->ce, P->dim3, o.outflow != 0, o.regulate_deltaf != 0, a, st));
+            }
             if (P->timing) HIP_TRY(hipEventRecord(P->ev_list[pass * 3 + 2], st));
         }
         HIP_TRY(is3d::launch_finalize(P->d_partial.p, P->d_cls.p, P->d_degeneracy.p, dN_out, P->nout, P->npart, P->npT, P->J,

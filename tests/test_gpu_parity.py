@@ -288,6 +288,31 @@ def test_workgroup_sizes_and_batch_tails_change_no_bit(fx):
     assert relerr(got, ref) < TOL
 
 
+def test_surface_relative_cull_is_bounded_not_bitwise(fx):
+    """zero_skip 3 (cf_main_tile3e with outflow && regulate_deltaf): an eighth of the chunks runs first, its partial spectrum floors the
+    row-cull thresholds of the rest.  Not bitwise: a skipped term is below 2^-57 of the FINAL accumulator per cell, so the spectrum may
+    lose at most N_cells 2^-57 of a bin, one-sided; it culls more rows than the accumulator-relative rule.  Where the rule does not apply
+    (too few chunks, no outflow clamp) zero_skip 3 is zero_skip 0."""
+    n = 24000
+    cells = synth.synth_surface(n, 3, seed=91)
+    sp = inputs.species("urqmd")
+    o = dict(dimension=3, df_mode=2, cell_chunks=64)
+    full, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2))
+    rel, s0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0))
+    surf, s3 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=3))
+    assert np.array_equal(rel, full)
+    assert s3["n_wave_rows"] == s0["n_wave_rows"] and s3["n_wave_rows_culled"] > s0["n_wave_rows_culled"]
+    assert (surf <= full).all()
+    err = np.abs(surf - full) / np.maximum(np.abs(full), 1e-300)
+    assert err.max() <= n * 2.0 ** -57 and err.max() < 1e-12
+    few, sf = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=3, cell_chunks=4))
+    few0, sf0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0, cell_chunks=4))
+    assert np.array_equal(few, few0) and sf["n_wave_rows_culled"] == sf0["n_wave_rows_culled"]
+    a, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=3, outflow=0))
+    b, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2, outflow=0))
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("dim,df_mode,species", [(3, 2, "urqmd"), (3, 1, "pikp"), (2, 1, "pikp"), (2, 2, "urqmd")])
 def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
     """zero_skip: 2 evaluates every row; 1 skips wave-rows whose exp(-p.u/T) is exactly +0; 0 (default) also skips rows whose
