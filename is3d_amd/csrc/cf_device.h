@@ -67,7 +67,7 @@ struct PrepParams {
     // E2 table stream (kernel variant 5, see "TE" below); TE == nullptr: not written
     int32_t w0_share;               // wave 0's share of a batch's units (% of another wave's) while it runs the next batch's phase 1
     int32_t pair_writer;            // tiled stream: the record writer handles two elements per lane and trip (set by launch_prep)
-    int32_t dev_skip;               // dev (IS3D_PREP_SKIP, timing only, results invalid): bit 0 no unit records, bit 1 no E2 tables, bit 2 no phase 2
+    int32_t dev_skip;               // dev (IS3D_PREP_SKIP, timing only, results invalid): bit 0 no unit records, bit 1 no E2 tables, bit 2 no phase 2; bit 4 (results valid): non-temporal record stores
     double *TE;
     const double *pTgrid;           // [npT] the pT grid (the lanes' pT values are exactly these)
     int32_t npT;
