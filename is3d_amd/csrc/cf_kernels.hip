@@ -118,7 +118,7 @@ constexpr int kPrepThreads = 256;
 // 4.27 / 4.17 / 4.23 / 4.27 ms (3+1D, 1e6 cells, 16 cells per batch); 2+1D (4 cells per batch, 24 x 404-double records per cell: the
 // phase 1 is a tenth of a wave's batch): 60 / 85 / 93 / 100: 4.17 / 3.98 / 3.95 / 3.96 ms per 1e5 cells
 constexpr int kPrepW0Share3 = 60, kPrepW0Share2 = 93;
-constexpr int kPrepWriterDefault = 3;   // record writer: 3 = two units per trip, raw / beta trips (where eligible, else 1) | 1 = two elements per lane and trip | 0 | 2 (A/B: IS3D_PREP_PAIR)
+constexpr int kPrepWriterDefault = 3;   // record writer: 3 = duo / rows writers (raw and beta elements in separate trips with fixed lane roles; where eligible, else 1) | 1 = two elements per lane and trip | 0 = one (A/B: IS3D_PREP_PAIR)
 
 struct CellScal {
     double dat, dax, day, dan_tau, ut, ux, uy, tau_un, invT, eta;
@@ -678,32 +678,7 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
                             v = ((d.x >> 20) & 1) ? bet : v;
                             return zero ? 0.0 : v;
                         };
-                        if (p.pair_writer == 2) {
-                            // split writer (A/B): the record's raw elements (header + row scalars: one LDS read each) and its beta elements
-                            // (six LDS reads each) in separate trips, so that no lane computes a beta_of it does not store and no beta lane
-                            // reads a descriptor
-                            const int NRAW = HDR + R * RS, NBETA = R * JT;
-                            for (int q = lane; q < NRAW; q += 64) {
-                                int e = q;
-                                if (q >= HDR) { const int qq = q - HDR, r = qq / RS; e = HDR + r * RWD + (qq - r * RS); }
-                                const int2 d = desc[e];
-                                const int jj = d.y & 0xffff, r = d.y >> 16;
-                                const int jcl = min(jt * JT + jj, J - 1);
-                                const int k = rb * R + r, kcl = min(k, K - 1);
-                                const int msel = (d.x >> 16) & 7;
-                                const int add = msel == 0 ? cJ + jcl : msel == 1 ? cK + kcl : msel == 2 ? cT : msel == 3 ? cR : cS;
-                                const bool zero = ((d.x >> 22) & 1) | (((d.x >> 21) & 1) & (k >= K));
-                                const double raw = lds[zero ? 0 : (d.x & 0xffff) + add];
-                                const double v = ((d.x >> 19) & 1) ? raw * psc : raw;
-                                st_(zero ? 0.0 : v, &o[e]);
-                            }
-                            for (int q = lane; q < NBETA; q += 64) {
-                                const int r = q / JT, jj = q - r * JT;
-                                const int k = rb * R + r;
-                                const double bet = beta_of(c, min(jt * JT + jj, J - 1), min(k, K - 1));
-                                st_(k >= K ? 0.0 : bet, &o[HDR + r * RWD + RS + jj]);
-                            }
-                        } else if (one_trip) {
+                        if (one_trip) {
                             if (lane < REC / 2) {
                                 const double vx = element(int2{dd0.x, dd0.y}), vy = element(int2{dd0.z, dd0.w});
                                 st_(vx, &o[2 * lane]);
@@ -783,7 +758,7 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
     const int cb = prep_batch_cells(p.K);
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
-    {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1 | 2 | 3, read per launch so that one process can alternate
+    {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1 | 3, read per launch so that one process can alternate
         const char *e = getenv("IS3D_PREP_PAIR");
         p.pair_writer = e ? atoi(e) : kPrepWriterDefault;
         const char *k = getenv("IS3D_PREP_SKIP");
