@@ -20,7 +20,10 @@
 
 namespace is3d {
 
-constexpr int kFqCB = 4;           // cells per workgroup batch of the prep kernel
+constexpr int kFqCB = 4;           // cells per workgroup batch of the prep kernel with long rows (2+1D: 241 eta nodes) ...
+constexpr int kFqCB3 = 16;         // ... and with K <= 32 (3+1D): the serial per-cell phase 1 (a 3 x 3 inverse, the Jonah tables) runs on CB lanes of the
+                                   // workgroup, so 4-cell batches made it the kernel: 10.3 ms per 1e6 cells
+static int fq_batch_cells(int K) { return K > 32 ? kFqCB : kFqCB3; }
 constexpr int kFqThreads = 256;
 
 struct FqScal {
@@ -74,6 +77,7 @@ __device__ __forceinline__ double gt_J20(const double *root, const double *weigh
     return s;
 }
 
+template <int CB>
 __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
 {
     extern __shared__ double lds[];
@@ -84,15 +88,15 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     double *jx = sc + 3 * nT;                  // [5][nj]: x, lambda^2, z, c_lambda, c_z
     double *gl = jx + 5 * nj;                  // [4][ngl]
     FqScal *cs = (FqScal *)(gl + 4 * ngl);     // [CB]
-    double *lk = (double *)(cs + kFqCB);       // [6][CB][K]: A, alphaf, W, a'x, a'y, a'z
-    double *lj = lk + 6 * kFqCB * K;           // [5][CB][J]: B, gammaf, b'x, b'y, b'z
-    double *l_bm = lj + 5 * kFqCB * J;         // [CB][K][jtiles]: min over a phi tile of betaf_jk
+    double *lk = (double *)(cs + CB);       // [6][CB][K]: A, alphaf, W, a'x, a'y, a'z
+    double *lj = lk + 6 * CB * K;           // [5][CB][J]: B, gammaf, b'x, b'y, b'z
+    double *l_bm = lj + 5 * CB * J;         // [CB][K][jtiles]: min over a phi tile of betaf_jk
     // 3+1D: bounds of the main kernel's unit-level cull, per (cell, row block): min alphaf, max |A|, max |W|; per (cell, row block, phi
     // tile): min betaf; per (cell, phi tile): min gammaf, max |B|   (row blocks <= K, phi tiles <= J / 4)
-    double *l_ub = l_bm + (p.dim3 ? kFqCB * K * p.jtiles : 0);   // [CB][3 rblocks + rblocks jtiles + 2 jtiles]
+    double *l_ub = l_bm + (p.dim3 ? CB * K * p.jtiles : 0);   // [CB][3 rblocks + rblocks jtiles + 2 jtiles]
     // element descriptors of a unit record, one int2 per element, filled once per workgroup (as in cf_prep, cf_kernels.hip)
-    int2 *desc = (int2 *)(l_ub + (p.dim3 ? kFqCB * (3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles) : 0));
-    const int CK = kFqCB * K, CJ = kFqCB * J;
+    int2 *desc = (int2 *)(l_ub + (p.dim3 ? CB * (3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles) : 0));
+    const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_al = lk + CK, *l_W = lk + 2 * CK, *l_ax = lk + 3 * CK, *l_ay = lk + 4 * CK, *l_az = lk + 5 * CK;
     double *l_B = lj, *l_ga = lj + CJ, *l_bx = lj + 2 * CJ, *l_by = lj + 3 * CJ, *l_bz = lj + 4 * CJ;
 
@@ -149,10 +153,10 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     __syncthreads();
     const double two_pi2_hbarC3 = 2.0 * M_PI * M_PI * (kHbarC * kHbarC * kHbarC);   // iS3D.h:11
 
-    const int nbatch = (p.n_cells + kFqCB - 1) / kFqCB;
+    const int nbatch = (p.n_cells + CB - 1) / CB;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-        const int cbase = batch * kFqCB;
-        const int ncb = min(kFqCB, p.n_cells - cbase);
+        const int cbase = batch * CB;
+        const int ncb = min(CB, p.n_cells - cbase);
 
         // ---- phase 1: per-cell scalars (smooth_kernels.cpp:486-735) ----
         if (tid < ncb) {
@@ -475,17 +479,20 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
 
 size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles /* 0 in 2+1D: no beta-min table */, int rec)
 {
-    const size_t bounds = jtiles ? (size_t)kFqCB * (3 * (size_t)K + (size_t)K * jtiles + 2 * (size_t)jtiles) : 0;   // row blocks <= K
-    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)kFqCB * (6 * K + 5 * J + K * jtiles) + bounds + (size_t)rec) + sizeof(FqScal) * kFqCB;   // + one int2 per record element
+    const int cb = fq_batch_cells(K);
+    const size_t bounds = jtiles ? (size_t)cb * (3 * (size_t)K + (size_t)K * jtiles + 2 * (size_t)jtiles) : 0;   // row blocks <= K
+    return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)cb * (6 * K + 5 * J + K * jtiles) + bounds + (size_t)rec) + sizeof(FqScal) * cb;   // + one int2 per record element
 }
 
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
 {
     if (p.n_cells <= 0) return hipSuccess;
-    const int nbatch = (p.n_cells + kFqCB - 1) / kFqCB;
+    const int cb = fq_batch_cells(p.K);
+    const int nbatch = (p.n_cells + cb - 1) / cb;
     const int grid = nbatch < 4096 ? nbatch : 4096;
     const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K, p.dim3 ? p.jtiles : 0, 4 * p.JT + p.R * (4 + p.JT));
-    hipLaunchKernelGGL(cf_prep_feqmod, dim3(grid), dim3(kFqThreads), lds, st, p);
+    if (cb == kFqCB3) hipLaunchKernelGGL(cf_prep_feqmod<kFqCB3>, dim3(grid), dim3(kFqThreads), lds, st, p);
+    else hipLaunchKernelGGL(cf_prep_feqmod<kFqCB>, dim3(grid), dim3(kFqThreads), lds, st, p);
     return hipGetLastError();
 }
 

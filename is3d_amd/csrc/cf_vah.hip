@@ -55,7 +55,9 @@ struct VahPrepParams {
     unsigned long long *status;         // [7] min cell whose E_a/Lambda can exceed 1e9
 };
 
-constexpr int kVahCB = 4;
+constexpr int kVahCB = 4;      // cells per workgroup batch of the prep kernel with long rows (2+1D eta table) ...
+constexpr int kVahCB3 = 16;    // ... and with K <= 32 (3+1D): the serial per-cell phase runs on CB lanes of the workgroup (cf_prep, cf_prep_feqmod alike)
+static inline int vah_batch_cells(int K) { return K > 32 ? kVahCB : kVahCB3; }
 constexpr int kVahThreads = 256;
 
 struct VahScal {
@@ -64,25 +66,26 @@ struct VahScal {
     double Wt, Wx, Wy, tWn, invL2, xi, Pi, c0, c1, c2, c3, c4, invL;
 };
 
+template <int CB>
 __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
 {
     extern __shared__ double lds[];
     const int J = p.J, K = p.K;
     VahScal *cs = (VahScal *)lds;                     // [CB]
-    double *lk = (double *)(cs + kVahCB);             // [9][CB][K]: A, ax, ad, W, ch, sh, C, Z, V1
-    double *lj = lk + 9 * kVahCB * K;                 // [7][CB][J]: B, gx, gd, D, V2, E, F
-    double *l_dmx = lj + 7 * kVahCB * J;              // [CB][jtiles] F records: max_j d_j of a phi tile
-    const int CK = kVahCB * K, CJ = kVahCB * J;
+    double *lk = (double *)(cs + CB);             // [9][CB][K]: A, ax, ad, W, ch, sh, C, Z, V1
+    double *lj = lk + 9 * CB * K;                 // [7][CB][J]: B, gx, gd, D, V2, E, F
+    double *l_dmx = lj + 7 * CB * J;              // [CB][jtiles] F records: max_j d_j of a phi tile
+    const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_ax = lk + CK, *l_ad = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK;
     double *l_C = lk + 6 * CK, *l_Z = lk + 7 * CK, *l_V1 = lk + 8 * CK;
     double *l_B = lj, *l_gx = lj + CJ, *l_gd = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_V2 = lj + 4 * CJ, *l_E = lj + 5 * CJ, *l_F = lj + 6 * CJ;
     // F records: the slots of ax_k, W_k (= 1 in 3+1D) and gx_j carry the factored exponent's c_k = C_k / Lambda, e_k = xi Z_k^2 / Lambda^2, d_j = D_j / Lambda
     double *l_ck = l_ax, *l_ek = l_W, *l_dj = l_gx;
     const int tid = threadIdx.x;
-    const int nbatch = (p.n_cells + kVahCB - 1) / kVahCB;
+    const int nbatch = (p.n_cells + CB - 1) / CB;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-        const int cbase = batch * kVahCB;
-        const int ncb = min(kVahCB, p.n_cells - cbase);
+        const int cbase = batch * CB;
+        const int ncb = min(CB, p.n_cells - cbase);
         if (tid < ncb) {                                                          // :2208-2256
             const int64_t gi = cbase + tid;
             VahScal s;
@@ -822,7 +825,7 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     P->jtiles = (J + P->JT - 1) / P->JT; P->rblocks = (K + P->R - 1) / P->R;
     P->ktiles = three_d ? P->rblocks : 1; P->upc = three_d ? 1 : P->rblocks;
     P->REC = P->fact ? 4 * P->JT + P->R * (4 + P->JT) : 4 * P->JT + P->R * (4 + 2 * P->JT);
-    P->lds_prep = sizeof(is3d::VahScal) * is3d::kVahCB + sizeof(double) * (size_t)is3d::kVahCB * (9 * K + 8 * J);   // + [CB][jtiles <= J] tile maxima of the F records
+    P->lds_prep = sizeof(is3d::VahScal) * is3d::vah_batch_cells(K) + sizeof(double) * (size_t)is3d::vah_batch_cells(K) * (9 * K + 8 * J);   // + [CB][jtiles <= J] tile maxima of the F records
     if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
@@ -928,8 +931,10 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         pp.cosphi = P->d_cos.as<double>(); pp.sinphi = P->d_sin.as<double>(); pp.kgrid = P->d_kg.as<double>(); pp.kweight = P->d_kw.as<double>();
         pp.JT = P->JT; pp.R = P->R; pp.jtiles = P->jtiles; pp.rblocks = P->rblocks; pp.TS = P->d_TS.as<double>();
         pp.fact = P->fact; pp.cell0 = c0; pp.mTmax = P->mTmax; pp.pTmax = P->pTmax; pp.status = d_st;
-        const int nbatch = (nc + is3d::kVahCB - 1) / is3d::kVahCB;
-        hipLaunchKernelGGL(is3d::cf_prep_vah, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), P->lds_prep, st, pp);
+        const int cb = is3d::vah_batch_cells(P->K);
+        const int nbatch = (nc + cb - 1) / cb;
+        if (cb == is3d::kVahCB3) hipLaunchKernelGGL(is3d::cf_prep_vah<is3d::kVahCB3>, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), P->lds_prep, st, pp);
+        else hipLaunchKernelGGL(is3d::cf_prep_vah<is3d::kVahCB>, dim3(std::min(nbatch, 4096)), dim3(is3d::kVahThreads), P->lds_prep, st, pp);
         VAH_TRY(hipGetLastError());
         if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 1], st));
         is3d::MainGeom g{};
