@@ -735,8 +735,8 @@ __global__ void __launch_bounds__(kPrepThreads) cf_prep(PrepParams p)
 static int prep_batch_cells(int K)
 {
     if (K > 32) return kPrepCB;
-    // dev switch (A/B only): IS3D_PREP_CB3 = 4 | 8 | 16 cells per workgroup batch in 3+1D
-    static const int env = [] { const char *e = getenv("IS3D_PREP_CB3"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16) ? v : 0; }();
+    // dev switch (A/B only): IS3D_PREP_CB3 = 4 | 16 cells per workgroup batch in 3+1D (8 measured between the two)
+    static const int env = [] { const char *e = getenv("IS3D_PREP_CB3"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16) ? v : 0; }();
     return env ? env : kPrepCB3;
 }
 
@@ -771,11 +771,9 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
     const bool nt = (p.dev_skip & 16) != 0;     // dev A/B (IS3D_PREP_SKIP bit 4): record stores non-temporal; default plain, see cf_prep
     if (nt) {
         if (cb == 16) hipLaunchKernelGGL((cf_prep<16, true>), dim3(grid), dim3(kPrepThreads), lds, stream, p);
-        else if (cb == 8) hipLaunchKernelGGL((cf_prep<8, true>), dim3(grid), dim3(kPrepThreads), lds, stream, p);
         else hipLaunchKernelGGL((cf_prep<kPrepCB, true>), dim3(grid), dim3(kPrepThreads), lds, stream, p);
     } else {
         if (cb == 16) hipLaunchKernelGGL((cf_prep<16, false>), dim3(grid), dim3(kPrepThreads), lds, stream, p);
-        else if (cb == 8) hipLaunchKernelGGL((cf_prep<8, false>), dim3(grid), dim3(kPrepThreads), lds, stream, p);
         else hipLaunchKernelGGL((cf_prep<kPrepCB, false>), dim3(grid), dim3(kPrepThreads), lds, stream, p);
     }
     return hipGetLastError();
