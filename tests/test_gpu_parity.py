@@ -339,6 +339,10 @@ def test_surface_relative_cull_is_bounded_not_bitwise(fx):
     few, sf = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=3, cell_chunks=4))
     few0, sf0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0, cell_chunks=4))
     assert np.array_equal(few, few0) and sf["n_wave_rows_culled"] == sf0["n_wave_rows_culled"]
+    # several workspace passes: the floors of a later pass come from partial sums that already hold the earlier passes (still a lower bound)
+    mp, smp = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=3, workspace_bytes=1 << 27))
+    assert smp["n_passes"] > 1      # (another summation order than `full`: compared to rounding, not one-sidedly)
+    assert (np.abs(mp - full) / np.maximum(np.abs(full), 1e-300)).max() < 1e-12
     a, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=3, outflow=0))
     b, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=2, outflow=0))
     assert np.array_equal(a, b)
