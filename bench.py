@@ -27,6 +27,7 @@ One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   value_incl_transfers, ms_per_step_incl_transfers   the same steps with the H->D upload of the cell arrays and the D->H
                               download of the spectrum inside the timed region (SURVEY.md 8d's t_kernel), N = 1 only
   kernel_ms.main_no_cull      the dominant kernel with all culling off (zero_skip = 2): the data-independent floor
+  kernel_ms.surface_cull      config 3 only: the dominant kernel with the opt-in surface-relative cull (zero_skip = 3), and how far its spectrum is from the default's
   ranks           N > 1: one entry per rank -- device, cells, kernel_ms, allreduce_ms (device time of the collective on that rank,
                   the wait for the slowest rank included), the rank / size its library communicator reports (is3d_comm_rank)
 N > 1: the all-reduce is the library's own RCCL call (is3d_plan_execute_allreduce over an is3d_comm); torch.distributed
@@ -392,7 +393,7 @@ def main():
         del hpin, hout
     # untimed: the row / unit culling skips only work that cannot change a bit of the spectrum -- check it here against the same
     # kernels with culling off (zero_skip = 2) on the same resident surface
-    cull_identical, ms_no_cull = None, None
+    cull_identical, ms_no_cull, surf_cull = None, None, None
     if world == 1 and not a.no_cull_check:
         plan2 = make_plan(dict(opts, zero_skip=2))
         plan2.set_timing(True)
@@ -402,6 +403,16 @@ def main():
         ms_no_cull = plan2.timings()["ms_main"]   # untimed w.r.t. the metric: the data-independent floor of the dominant kernel
         cull_identical = bool(torch.equal(out, out2))
         plan2.close()
+        if not vah and wl["dimension"] == 3 and wl["df_mode"] in (1, 2) and a.zero_skip == 0:
+            # untimed w.r.t. the metric: the opt-in surface-relative cull (zero_skip = 3; bounded, not bitwise) on the same surface
+            plan3 = make_plan(dict(opts, zero_skip=3))
+            plan3.set_timing(True)
+            for _ in range(2):
+                plan3.execute(n_loc, ptrs, out2.data_ptr(), stream, want_status=False)
+            torch.cuda.synchronize()
+            d = (out2 - out).abs() / out.abs().clamp_min(1e-300)
+            surf_cull = dict(main_ms=plan3.timings()["ms_main"], max_rel_diff=float(d.max().item()), bins_that_differ=int((out2 != out).sum().item()))
+            plan3.close()
         del out2
     # untimed: the shader clock the main kernel runs at (idle probe waves on a private stream while one more step executes)
     clock_ghz = None
@@ -483,7 +494,7 @@ def main():
                                    world, "one surface (BASELINE config 4 at 8)" if a.scaling == "strong" else "a surface that grows with N")) if world > 1 else "1 GPU",
                                workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok,
                                culled_rows_change_no_bit=cull_identical),
-                   kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"])), main_no_cull=ms_no_cull),
+                   kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"])), main_no_cull=ms_no_cull, surface_cull=surf_cull),
                    roofline=roofline, roofline_valu=rv)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, fq=fq)
