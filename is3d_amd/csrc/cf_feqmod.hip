@@ -537,12 +537,16 @@ cf_feqmod_renorm(const double *__restrict__ CR, const double *__restrict__ gl, i
             double s_neq = 0.0, s_n10 = 0.0, s_j20 = 0.0, s_mod = 0.0;
             for (int k = 0; k < ngl; k++) {
                 const double c1 = l_c1[k];
-                const double e = exp(sqrt(l_p1[k] + mb2) - chem), q = e + sign;
-                s_neq += c1 / q;
-                if (baryon != 0.0) s_n10 += c1 * e / (q * q);
-                s_mod += c1 / (exp(sqrt(l_p1[k] + mm2) - chem_mod) + sign);
-                const double E2 = sqrt(l_p2[k] + mb2), e2 = exp(E2 - chem), q2 = e2 + sign;
-                s_j20 += l_c2[k] * (E2 * e2 / (q2 * q2));
+                // (exp_full / sqrt_nr of cf_math.h instead of libm: 1e-15 relative, arguments of order 1..1e3, inf beyond 709 like exp();
+                // the node constants above stay libm, once per workgroup)
+                // The quotients are reciprocals by v_rcp_f64 + two Newton steps (1e-16); an exponential that overflowed is held at 1e300
+                // so that 1/q stays a number: such a node adds < 1e-300 of its weight instead of exactly 0.
+                const double e = __builtin_fmin(exp_full(sqrt_nr(l_p1[k] + mb2) - chem), 1.0e300), r = rcp_nr(e + sign);
+                s_neq = __builtin_fma(c1, r, s_neq);
+                if (baryon != 0.0) s_n10 = __builtin_fma(c1, (e * r) * r, s_n10);
+                s_mod = __builtin_fma(c1, rcp_nr(__builtin_fmin(exp_full(sqrt_nr(l_p1[k] + mm2) - chem_mod), 1.0e300) + sign), s_mod);
+                const double E2 = sqrt_nr(l_p2[k] + mb2), e2 = __builtin_fmin(exp_full(E2 - chem), 1.0e300), r2 = rcp_nr(e2 + sign);
+                s_j20 = __builtin_fma(l_c2[k], E2 * ((e2 * r2) * r2), s_j20);
             }
             const double neq = neq_fact * s_neq;
             const double N10 = (baryon != 0.0) ? baryon * neq_fact * s_n10 : 0.0;     // N10_fact = neq_fact, :717
