@@ -10,6 +10,11 @@ from conftest import ROOT
 
 def test_isa_counts_are_read_from_the_isa_and_sane():
     d = json.load(open(os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")))
+    audit = d.pop("_audit")
+    # no pointer of any kernel lost its address space: a flat_load waits on vmcnt, which on gfx9 also counts the stores in flight
+    # (cf_prep's descriptor table once did: every trip of its record writer then waited for all of the wave's outstanding stores)
+    assert set(audit["flat_instructions"]) >= {"cf_kernels.hip", "cf_feqmod.hip", "cf_vah.hip", "cf_yield.hip", "cf_sampler.hip", "cf_multi.hip"}
+    assert all(n == 0 for n in audit["flat_instructions"].values()), audit["flat_instructions"]
     assert len(d) >= 100
     names = set()
     for key, v in d.items():

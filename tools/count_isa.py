@@ -28,6 +28,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRCS = [os.path.join(ROOT, "is3d_amd", "csrc", f) for f in ("cf_kernels.hip", "cf_feqmod.hip", "cf_vah.hip")]
+AUDIT_ONLY = [os.path.join(ROOT, "is3d_amd", "csrc", f) for f in ("cf_yield.hip", "cf_sampler.hip", "cf_multi.hip")]
 OUT = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
 
 F64_OPS = ["v_fma_f64", "v_fmac_f64", "v_mul_f64", "v_add_f64", "v_max_f64", "v_min_f64", "v_rcp_f64", "v_ldexp_f64",
@@ -120,12 +121,23 @@ def count_evaluations(ins):
 
 def main():
     text = []
+    flat_main = {}
     with tempfile.TemporaryDirectory() as td:
         for src in SRCS:
             s_path = os.path.join(td, "k.s")
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                                    "-I", os.path.dirname(src), src, "-o", s_path], stderr=subprocess.DEVNULL)
-            text += open(s_path).read().split("\n")
+            asm = open(s_path).read()
+            text += asm.split("\n")
+            flat_main[os.path.basename(src)] = len(re.findall(r"^\s+flat_(?:load|store|atomic)", asm, re.M))
+        # address-space audit over EVERY kernel source: a flat_* instruction means a pointer lost its address space (an LDS pointer rounded
+        # through uintptr_t did, in cf_prep: its reads became flat_load + s_waitcnt vmcnt(0), which on gfx9 also waits for every store in flight)
+        flat = dict(flat_main)
+        for src in AUDIT_ONLY:
+            s_path = os.path.join(td, "a.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                   "-I", os.path.dirname(src), "-I", os.path.join(ROOT, "include"), src, "-o", s_path], stderr=subprocess.DEVNULL)
+            flat[os.path.basename(src)] = len(re.findall(r"^\s+flat_(?:load|store|atomic)", open(s_path).read(), re.M))
     kernels = {}
     cur, blocks = None, None
     for ln in text:
@@ -207,13 +219,16 @@ def main():
         out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), m0_writes=m0_set, global_load_lds=glds, m0_other_users=m0_other, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
                         histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
+    out["_audit"] = dict(flat_instructions=flat)
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
     if "-v" in sys.argv:
         for k, v in sorted(out.items()):
+            if k.startswith("_"):
+                continue
             print(k, v["flop_per_eval"], v["valu_f64_instr_per_eval"], v["issue_cycles_per_eval"])
-    print("wrote", OUT, len(out), "kernels")
+    print("wrote", OUT, len(out) - 1, "kernels")
 
 
 if __name__ == "__main__":
