@@ -569,7 +569,9 @@ int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t inclu
 
 /* FO_data_reader::read_surf_switch (src/cpp/readindata.cpp:133-144) for the viscous-hydro surface formats the
  * smooth path accepts: mode 0 read_surf_VH_old (:148-318), 1 read_surf_VH (:320-468), 4 read_surf_VH_MUSIC (:552-668),
- * 6 read_surf_VH_MUSIC_New (:671-810), 7 read_surf_VH_hiceventgen (:1059-1196).  Same calling pattern and array order
+ * 5 read_surf_VH_Vorticity (:470-551: the mode-1 columns, V^tau inside the diffusion block, six thermal-vorticity columns that the
+ * viscous-hydro kernels calculate_spectra runs on such a surface do not read; unlike the reference's reader this one also returns the
+ * surface averages), 6 read_surf_VH_MUSIC_New (:671-810), 7 read_surf_VH_hiceventgen (:1059-1196).  Same calling pattern and array order
  * as is3d_surface_read_vh; every format is converted to the kernel's conventions the way the reference does (tau
  * Jacobians, hbar*c, p = T s - e, u = gamma v); muB is stored whenever the array is given (modes 4, 6, 7 always
  * carry it), nB and V^mu are zero in modes 4, 6, 7.  Other modes: IS3D_EINVAL. */

@@ -760,7 +760,7 @@ def surface_read_vh(path, include_baryon=0, include_baryondiff_deltaf=0, dimensi
 
 
 def surface_read(path, mode, include_baryon=0, include_baryondiff_deltaf=0, dimension=3):
-    """is3d_surface_read: modes 0, 1, 4, 6, 7 -> (dict of the 23 arrays, averages)."""
+    """is3d_surface_read: modes 0, 1, 4, 5, 6, 7 -> (dict of the 23 arrays, averages)."""
     L = load()
     n = C.c_int64(0)
     _check(L.is3d_surface_read(path.encode(), mode, include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), None, None))

@@ -334,8 +334,8 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
                                  int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
 {
     if (mode == 1) return is3d_surface_read_vh(path, include_baryon, include_baryondiff_deltaf, dimension, n_cells, A, avg5);
-    if (mode != 0 && mode != 4 && mode != 6 && mode != 7)
-        return io_fail(IS3D_EINVAL, "surface mode %d is not a viscous-hydro format of the smooth path (0, 1, 4, 6, 7)", mode);
+    if (mode != 0 && mode != 4 && mode != 5 && mode != 6 && mode != 7)
+        return io_fail(IS3D_EINVAL, "surface mode %d is not a viscous-hydro format of the smooth path (0, 1, 4, 5, 6, 7)", mode);
     if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
     std::string text;
     if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
@@ -391,6 +391,23 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
                 (void)next();  // Vt
                 Vx = next(); Vy = next(); Vn = next();
             }
+        } else if (mode == 5) {
+            // read_surf_VH_Vorticity (readindata.cpp:470-551): the mode-1 columns -- with V^tau inside the baryon-diffusion block, as in
+            // mode 0 -- then the six components of the thermal vorticity.  calculate_spectra runs the viscous-hydro kernels on such a
+            // surface (emissionfunction.cpp:1503, :1643; its calculate_spin_polzn branch at :1675 is unreachable), which do not read them.
+            dat = next(); dax = next(); day = next(); dan = next();
+            ux = next(); uy = next(); un = next();
+            E = next() * kHbarC; T = next() * kHbarC; P = next() * kHbarC;
+            pixx = next() * kHbarC; pixy = next() * kHbarC; pixn = next() * kHbarC;
+            piyy = next() * kHbarC; piyn = next() * kHbarC;
+            bulkPi = next() * kHbarC;
+            if (include_baryon) muB = next() * kHbarC;
+            if (include_baryondiff_deltaf) {
+                nB = next();
+                (void)next();  // Vt
+                Vx = next(); Vy = next(); Vn = next();
+            }
+            for (int k = 0; k < 6; k++) (void)next();   // wtx wty wtn wxy wxn wyn
         } else if (mode == 4 || mode == 6) {
             eta = 0.0;
             dat = next() * tau; dax = next() * tau; day = next() * tau;

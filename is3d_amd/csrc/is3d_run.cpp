@@ -16,7 +16,7 @@
 // reference allocates the per-cell c0..c4 (emissionfunction.cpp:1397-1418) and the CUDA tree loads the VAH tables
 // (src/cuda/deltafReader.cu:74-81) -- reads input/surface.dat with read_surf_VAH_PLMatch and deltaf_coefficients/vah/c{0..4}_vah1.dat,
 // runs what the commented-out call site would (emissionfunction.cpp:1650-1654) and writes the same three result files.
-// Scope: operation in {1, 2}, mode in {0, 1, 4, 6, 7}, df_mode in {1, 2, 3} with include_baryon in {0, 1}, df_mode 4
+// Scope: operation in {1, 2}, mode in {0, 1, 4, 5, 6, 7}, df_mode in {1, 2, 3} with include_baryon in {0, 1}, df_mode 4
 // (modified equilibrium; also reads tables/gla_roots_weights_32_points.txt, deta_min, mass_pion0 and the surface
 // averages it has just written, as the reference does) with include_baryon = 0.  Anything else is refused
 // with a message instead of silently doing something different from the reference.
@@ -169,8 +169,8 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (operation != 1) DIE("mode = 2 (anisotropic hydro): only operation = 1; the reference's VAH sampler is an empty stub (emissionfunction_sampling_kernels.cpp:1231-1239)");
         if (df_mode != 4) DIE("mode = 2 (anisotropic hydro) needs df_mode = 4: the per-cell 14-moment coefficients c0..c4 exist for that combination only (emissionfunction.cpp:1410-1418)");
     }
-    if (!mem && !vah && mode != 0 && mode != 1 && mode != 4 && mode != 6 && mode != 7)
-        DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 6, 7 and the anisotropic-hydro format 2 (3 = VAH P_L, P_T matching and 5 = vorticity are other paths)", mode);
+    if (!mem && !vah && mode != 0 && mode != 1 && mode != 4 && mode != 5 && mode != 6 && mode != 7)
+        DIE("mode = %d: the smooth path reads the viscous-hydro surface formats 0, 1, 4, 5, 6, 7 and the anisotropic-hydro format 2 (3 = VAH P_L, P_T matching has no kernel in the reference: emissionfunction.cpp:1328-1681)", mode);
     if (df_mode < 1 || df_mode > 4) DIE("df_mode = %d: 1 (14-moment), 2 (Chapman-Enskog), 3 (modified equilibrium, Mike), 4 (Jonah)", df_mode);
     const bool feqmod = !vah && (df_mode == 3 || df_mode == 4);
     if (df_mode == 4 && include_baryon && !vah)   // deltafReader.cpp:470-474

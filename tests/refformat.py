@@ -149,6 +149,14 @@ def write_surface_mode(path, s, mode, include_baryon=0, include_baryondiff=0):
             cols.append(muB / h)
         if include_baryondiff:
             cols += [s["nB"], junk, s["Vx"], s["Vy"], s["Vn"]]
+    elif mode == 5:      # gpu-vh + thermal vorticity (readindata.cpp:470-551): mode-1 columns, V^tau in the diffusion block, six w^{mu nu}
+        cols = [tau, s["x"], s["y"], s["eta"], s["dat"], s["dax"], s["day"], s["dan"], s["ux"], s["uy"], s["un"],
+                s["E"] / h, s["T"] / h, s["P"] / h, s["pixx"] / h, s["pixy"] / h, s["pixn"] / h, s["piyy"] / h, s["piyn"] / h, s["bulkPi"] / h]
+        if include_baryon:
+            cols.append(muB / h)
+        if include_baryondiff:
+            cols += [s["nB"], junk, s["Vx"], s["Vy"], s["Vn"]]
+        cols += [junk * k for k in (1, 2, 3, 4, 5, 6)]
     elif mode in (4, 6):
         ent = (s["E"] + s["P"]) / s["T"]                       # entropy density, fm^-3: p = T s - e
         cols = [tau, s["x"], s["y"], junk, s["dat"] / tau, s["dax"] / tau, s["day"] / tau, s["dan"] / tau, ut, s["ux"], s["uy"],

@@ -98,11 +98,12 @@ def test_cli_feqmod_with_baryon(tmp_path, fx):
     assert relerr(allsp[:, 3], want, floor=1e-250) < 2e-8
 
 
-@pytest.mark.parametrize("mode", [0, 4, 6, 7])
+@pytest.mark.parametrize("mode", [0, 4, 5, 6, 7])
 def test_cli_other_surface_formats(tmp_path, fx, mode):
     """The other viscous-hydro surface formats end to end: 2+1D boost-invariant MUSIC /
-    hic-eventgen files and the old 26-column gpu-vh file."""
-    dim = 3 if mode == 0 else 2
+    hic-eventgen files, the old 26-column gpu-vh file and the gpu-vh file with thermal-vorticity columns (mode 5: the reference runs the
+    viscous-hydro kernels on it, emissionfunction.cpp:1503-1643)."""
+    dim = 3 if mode in (0, 5) else 2
     ids = [211, 321, 2212]
     cells = synth.synth_surface(11, dim, seed=70 + mode)
     root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(dimension=dim, df_mode=2, mode=mode))
@@ -122,7 +123,7 @@ def test_cli_other_surface_formats(tmp_path, fx, mode):
 
 def test_cli_refuses_what_it_does_not_implement(tmp_path):
     cells = synth.synth_surface(3, 3, seed=1)
-    for bad in (dict(operation=3), dict(operation=2, include_baryon=1, df_mode=4), dict(mode=2), dict(mode=5), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
+    for bad in (dict(operation=3), dict(operation=2, include_baryon=1, df_mode=4), dict(mode=2), dict(mode=3), dict(df_mode=5), dict(df_mode=4, include_baryon=1)):
         root = refformat.make_run_dir(str(tmp_path / ("r%d" % len(os.listdir(tmp_path)))), cells, [211], bad)
         r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "iS3D-amd:" in r.stderr

@@ -151,8 +151,18 @@ def test_surface_reader_other_formats(tmp_path):
     for k in keys:
         assert np.allclose(got[k], c2[k], rtol=4e-15, atol=1e-18), k
     assert not got["eta"].any() and not got["dan"].any() and not got["un"].any()
+    # mode 5 (gpu-vh + thermal vorticity, readindata.cpp:470-551): the viscous-hydro kernels run on it, the six vorticity columns are not theirs
+    for ib, idf in ((1, 1), (1, 0), (0, 0)):
+        refformat.write_surface_mode(path, c3, 5, include_baryon=ib, include_baryondiff=idf)
+        got5, avg5 = api.surface_read(path, 5, ib, idf, 3)
+        for k in synth.CELL_FIELDS + (synth.BARYON_FIELDS if idf else []):
+            assert np.allclose(got5[k], c3[k], rtol=5e-16, atol=0), (k, ib, idf)
+        assert (np.allclose(got5["muB"], c3["muB"], rtol=5e-16) if ib else not got5["muB"].any())
+    synth.write_surface_dat(path, {k: v for k, v in c3.items() if k not in ("muB", "nB", "Vx", "Vy", "Vn")})   # the 20-column mode-1 file
+    m1, avg1 = api.surface_read(path, 1, 0, 0, 3)
+    assert all(np.array_equal(m1[k], got5[k]) for k in synth.CELL_FIELDS) and np.allclose(avg1, avg5, rtol=1e-14)
     with pytest.raises(api.Is3dError) as e:
-        api.surface_read(path, 5, 0, 0, 3)
+        api.surface_read(path, 3, 0, 0, 3)
     assert e.value.code == api.IS3D_EINVAL
     # mode 1 through the switch == the dedicated entry
     synth.write_surface_dat(path, c3)
