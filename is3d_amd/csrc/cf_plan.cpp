@@ -475,13 +475,15 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves
-        // Chunk count.  Two floors: enough tasks for ~24 rounds of the chip (load balance: lane-wave groups cull differently), and chunks of at
+        static const int64_t kChunkRounds = [] { const char *e = getenv("IS3D_CHUNK_ROUNDS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 12); }();   // dev A/B
+        // Chunk count.  Two floors: enough tasks for ~12 rounds of the chip (load balance: lane-wave groups cull differently; 24 until the end of
+        // round 3 -- on a 125 000-cell shard 144 instead of 288 chunks run the same 43.1 ms and reduce 0.3 ms less), and chunks of at
         // most ~1152 cells -- the streams of one (phi tile, chunk) pair are then ~5 MB, the readers' drift along them stays about the size of an
         // XCD's 4 MB L2, and the fabric / HBM-side traffic of the main kernel drops 3x (config 3: FETCH_SIZE 1.82e8 -> 5.99e7 KiB per launch)
         // at an unchanged step time (the main kernel gains what the 1.3 ms of extra partial-slab reduction cost; 1.0 point less culling because
         // every chunk warms its thresholds up anew).  profiles/r03_chunks.log
         int64_t nch = o->cell_chunks > 0 ? o->cell_chunks
-                                         : std::max<int64_t>((24 * capacity + tasks_per_chunk - 1) / tasks_per_chunk, (pc + 1151) / 1152);
+                                         : std::max<int64_t>((kChunkRounds * capacity + tasks_per_chunk - 1) / tasks_per_chunk, (pc + 1151) / 1152);
         int64_t by_cells = std::max<int64_t>(1, pc / 64);
         nch = std::min(nch, by_cells);
         int64_t part_bytes_per_chunk = (int64_t)P->J * P->Kacc * P->Lpad * (int64_t)sizeof(double);
