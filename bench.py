@@ -20,16 +20,19 @@ surface with its 14-moment coefficients interpolated on the device from the delt
 One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   roofline        the contract's object for the dominant kernel, HBM view: algorithmic bytes / kernel time
   roofline_valu   the roofline that actually binds this kernel: fp64 VALU
-  cpu_baseline    the CPU oracle (a port of the reference loop) timed on this host, bounded sample
+  cpu_baseline    the CPU oracle (a port of the reference loop) timed on this host's cores (all of them: `cores`, `cores_available`, `cpu_model`),
+                  bounded sample, in the same run for EVERY N (rank 0, after the timed region, the other ranks parked at the closing barrier)
   executed_evals_per_s        `value` counts evals as the reference would execute them (every species, every row); the kernel
                               evaluates one representative per distinct (mass, sign) class (75 of 305) and skips rows that
                               cannot change a bit of the result -- this is the rate of integrands actually executed
-  value_incl_transfers, ms_per_step_incl_transfers   the same steps with the H->D upload of the cell arrays and the D->H
-                              download of the spectrum inside the timed region (SURVEY.md 8d's t_kernel), N = 1 only
+  value_incl_transfers, ms_per_step_incl_transfers   the same steps with the H->D upload of the cell arrays (every rank its shard) and the
+                              D->H download of the spectrum inside the timed region (SURVEY.md 8d's t_kernel; `value` itself follows the bench
+                              contract: inputs resident in HBM when the timed region starts), any N
   kernel_ms.main_no_cull      the dominant kernel with all culling off (zero_skip = 2): the data-independent floor
   kernel_ms.surface_cull      config 3 only: the dominant kernel with the opt-in surface-relative cull (zero_skip = 3), and how far its spectrum is from the default's
   ranks           N > 1: one entry per rank -- device, cells, kernel_ms, allreduce_ms (device time of the collective on that rank,
-                  the wait for the slowest rank included), the rank / size its library communicator reports (is3d_comm_rank)
+                  the wait for the slowest rank included), the rank / size its library communicator reports (is3d_comm_rank), and the
+                  rank's own roofline_valu (its culled fraction, its kernel time)
 N > 1: the all-reduce is the library's own RCCL call (is3d_plan_execute_allreduce over an is3d_comm); torch.distributed
 only launches the ranks, ships the ncclUniqueId and provides the barrier.
 """
@@ -88,6 +91,47 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     return d.get(key)
 
 
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def host_cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_mem_available():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return 1024.0 * float(ln.split()[1])
+    except OSError:
+        pass
+    return 16e9
+
+
+def pmc_traffic(workload_name, n_cells):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE need their
+    own passes and cannot be collected inside this run): newest profiles/rNN_pmc_traffic.json that holds this workload at this shard
+    size -- `shards` maps a cell count (a rank's shard at N = 1, 2, 4, 8) to its counter set."""
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tp = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tp):
+            continue
+        tj = json.load(open(tp)).get(workload_name)
+        if not tj:
+            continue
+        hit = tj if tj.get("cells") == n_cells else (tj.get("shards") or {}).get(str(n_cells))
+        if hit and hit.get("hbm_bytes_per_launch"):
+            return hit["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc passes of this command at %d cells, not measured in this run)" % (tname, n_cells)
+    return None, None
+
+
 def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     """The oracle (variant B, a scratch-free port of smooth_kernels.cpp:106-349; OpenMP over cells) on the first
     cells of the same surface, all host cores.  Also the reference-shaped variant A (chunk + scratch + reduce)."""
@@ -97,9 +141,11 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     per_cell = nbins * len(sp["mass"])
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"])
     vah_tab = df if wl["name"] == "config5" else None   # config5: `df` is the VAH (Lambda, alpha_L) table set
-    # a 1-GPU box owns a 16-core share of the host (and the oracle keeps one 39 MB partial spectrum per thread)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = oracle.set_num_threads(min(16, avail))
+    # every host core this process may run on ("all host cores, count and model stated"); the oracle keeps one
+    # partial spectrum per thread (39 MB for config 3), so the count is bounded by a quarter of the free host memory, nothing else
+    avail = host_cores()
+    per_thread = 8.0 * per_cell + 1e6
+    threads = oracle.set_num_threads(max(1, min(avail, int(0.25 * host_mem_available() / per_thread))))
     make = synth.synth_surface
     if vah_tab is not None:
         make = synth.synth_vah_surface
@@ -116,13 +162,13 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     t0 = time.time()
     run(probe)
     t_probe = max(time.time() - t0, 1e-3)
-    n = int(max(2 * threads, min(8192, 2 * threads * (0.5 * seconds_budget / t_probe))))
+    n = int(max(2 * threads, min(65536, 2 * threads * (0.5 * seconds_budget / t_probe))))
     n -= n % threads
     cells = make(n, wl["dimension"])
     t0 = time.time()
     run(cells)
     tb = time.time() - t0
-    res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, kind="port",
+    res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, cores_available=avail, cpu_model=host_cpu_model(), kind="port",
                sample="first %d cells of the workload surface x all %d species x %d bins, oracle %s, %.1f s" % (
                    n, len(sp["mass"]), nbins, "VAH restatement (coefficients + kernel)" if vah_tab is not None else
                    "feqmod restatement" if fq is not None else "variant B (no scratch)", tb))
@@ -190,6 +236,7 @@ def main():
                     help="N > 1: strong (default) = BASELINE config 4, ONE surface in N shards; weak = every rank its own surface")
     ap.add_argument("--cell-chunks", type=int, default=0, help="dev: override the number of cell chunks of the main kernel's grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0, help="budget of CPU work for the cpu_baseline sample (variant B; variant A takes about as long again)")
     ap.add_argument("--no-clock-probe", action="store_true")
     ap.add_argument("--no-cull-check", action="store_true", help="skip the untimed bitwise comparison with culling off")
     ap.add_argument("--rehearse-comm", action="store_true",
@@ -350,35 +397,81 @@ def main():
     culled = (st["n_wave_rows_culled"] / st["n_wave_rows"]) if st.get("n_wave_rows") else 0.0
     unique_evals = float(n_loc) * nbins * st["n_classes"] * (len(grid["eta"]) if wl["dimension"] == 2 else 1)
     executed_evals = unique_evals * (1.0 - culled)   # rows the kernel proved unable to change a bit for a whole wave are not executed
+    ms_main = float(np.mean(ms["main"]))
+    # ---- the binding roofline, per rank: fp64 VALU (flops and instructions per integrand from the emitted ISA, this rank's own culled fraction and kernel time)
+    ic = isa_counts(plan.main_kernel_name, wl, plan.tile_shape, st["kernel_variant"])
+
+    def valu_roofline(clock_ghz=None):
+        if not ic:
+            return None
+        tf = executed_evals * ic["flop_per_eval"] / (ms_main * 1e-3) / 1e12
+        return dict(bound="fp64_valu", achieved=tf, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_VALU_PEAK_TF,
+                    executed_flop_per_eval=ic["flop_per_eval"], fp64_valu_instr_per_eval=ic["valu_f64_instr_per_eval"],
+                    issue_cycles_per_eval=ic["issue_cycles_per_eval"],
+                    issue_bound_frac_at_2p4GHz=executed_evals / 64.0 * ic["issue_cycles_per_eval"] / (1024 * 2.4e9 * ms_main * 1e-3),
+                    shader_clock_ghz=clock_ghz,
+                    frac_at_shader_clock=(tf / (FP64_VALU_PEAK_TF * clock_ghz / 2.4)) if clock_ghz else None,
+                    integrands_per_launch=unique_evals, integrands_executed=executed_evals, wave_rows_culled_frac=culled,
+                    kernel=plan.main_kernel_name, kernel_ms=ms_main,
+                    note="flops and issue cycles count executed integrands only: rows whose exp(-p.u/T) is exactly +0 for a "
+                         "whole wave are skipped (bitwise-identical result)")
+
+    # untimed: the shader clock the main kernel runs at (idle probe waves on a private stream while one more step executes); rank 0, any N
+    clock_ghz, clock_err = None, None
+    if rank == 0 and not a.no_clock_probe:
+        import threading
+        box = {}
+
+        def probe():
+            try:
+                time.sleep(float(np.mean(ms["prep"])) * 1e-3 + 0.002)   # let cf_prep pass: the probe should see cf_main only
+                box["ghz"] = api.probe_shader_clock(min(0.25, 0.6 * np.mean(ms["main"]) * 1e-3), local)
+            except Exception as e:   # diagnostic only
+                box["err"] = str(e)
+
+        th = threading.Thread(target=probe)
+        plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)   # enqueue, returns before the kernels finish
+        th.start()
+        th.join()
+        torch.cuda.synchronize()
+        clock_ghz, clock_err = box.get("ghz") or None, box.get("err")
+    rv = valu_roofline(clock_ghz)
     ranks = None
     if multi:
         mine = dict(rank=rank, device=local, cells=n_loc, first_cell=lo,
-                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=float(np.mean(ms["main"])), finalize=float(np.mean(ms["finalize"]))),
+                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"]))),
                     allreduce_ms=float(np.mean(ms["allreduce"])) if ms["allreduce"] else None,
                     comm_rank_seen=list(comm.rank_seen()) if comm is not None else None,
-                    wave_rows_culled_frac=culled, integrands_executed=executed_evals)
+                    wave_rows_culled_frac=culled, integrands_executed=executed_evals, roofline_valu=rv)
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
-    # SURVEY.md 8d's t_kernel: the same steps with the upload of the cell arrays and the download of the spectrum inside the timed
-    # region (pinned host buffers, as a host that cares would hold them); N = 1 only
-    incl = None
-    if world == 1:
-        used = [k for k in cell_fields if k in ptrs and (k != "eta" or wl["dimension"] == 3)]
-        hpin = {k: torch.from_numpy(cells[k]).pin_memory() for k in used}
-        hout = torch.empty(plan.output_size, dtype=torch.float64).pin_memory()
+    # SURVEY.md 8d's t_kernel: the same steps with the upload of the cell arrays (every rank its shard) and the download of the (summed)
+    # spectrum inside the timed region -- pinned host buffers, as a host that cares would hold them; barrier + MAX over ranks as for `value`
+    used = [k for k in cell_fields if k in ptrs and (k != "eta" or wl["dimension"] == 3)]
+    hpin = {k: torch.from_numpy(cells[k]).pin_memory() for k in used}
+    hout = torch.empty(plan.output_size, dtype=torch.float64).pin_memory()
 
-        def step_incl():
-            for k in used:
-                tens[k].copy_(hpin[k], non_blocking=True)
-            plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)
-            hout.copy_(out, non_blocking=True)
-            torch.cuda.synchronize()   # the spectrum is resident on the host
+    def step_incl():
+        for k in used:
+            tens[k].copy_(hpin[k], non_blocking=True)
+        step(False)
+        hout.copy_(out, non_blocking=True)
+        torch.cuda.synchronize()   # the spectrum is resident on the host
 
+    step_incl()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
         step_incl()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            step_incl()
-        incl = (time.perf_counter() - t1) / a.steps
+    fence()
+    incl = (time.perf_counter() - t1) / a.steps
+    if multi:
+        tt = torch.tensor([incl], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        incl = float(tt.item())
+    del hpin, hout
+    host_entry = None
+    if world == 1:
         # and the one-shot host entry a maintainer would call from calculate_dN_pTdpTdphidy: pageable host arrays, plan creation and
         # workspace allocation included
         t1 = time.perf_counter()
@@ -390,7 +483,6 @@ def main():
                           ms_kernels=st_host["ms_prep"] + st_host["ms_main"] + st_host["ms_finalize"],
                           note="%s, one call: plan creation + workspace hipMalloc + pageable H->D + kernels + D->H" % (
                               "is3d_smooth_spectra_vah_df" if vah else "is3d_smooth_spectra"))
-        del hpin, hout
     # untimed: the row / unit culling skips only work that cannot change a bit of the spectrum -- check it here against the same
     # kernels with culling off (zero_skip = 2) on the same resident surface
     cull_identical, ms_no_cull, surf_cull = None, None, None
@@ -414,76 +506,37 @@ def main():
             surf_cull = dict(main_ms=plan3.timings()["ms_main"], max_rel_diff=float(d.max().item()), bins_that_differ=int((out2 != out).sum().item()))
             plan3.close()
         del out2
-    # untimed: the shader clock the main kernel runs at (idle probe waves on a private stream while one more step executes)
-    clock_ghz = None
-    if rank == 0 and not a.no_clock_probe:
-        import threading
-        box = {}
-
-        def probe():
-            try:
-                time.sleep(float(np.mean(ms["prep"])) * 1e-3 + 0.002)   # let cf_prep pass: the probe should see cf_main only
-                box["ghz"] = api.probe_shader_clock(min(0.25, 0.6 * np.mean(ms["main"]) * 1e-3), local)
-            except Exception as e:   # diagnostic only
-                box["err"] = str(e)
-
-        th = threading.Thread(target=probe)
-        plan.execute(n_loc, ptrs, out.data_ptr(), stream, want_status=False)   # enqueue, returns before the kernels finish
-        th.start()
-        th.join()
-        torch.cuda.synchronize()
-        clock_ghz = box.get("ghz") or None
     spectrum_ok = bool(torch.isfinite(out).all().item())
 
     if rank == 0:
         nsp = len(sp["mass"])
         evals_step = float(n_total) * nbins * nsp
         value = evals_step * a.steps / elapsed
-        ms_main = float(np.mean(ms["main"]))
         # ---- roofline (contract form, HBM): algorithmic bytes of the launch = cell arrays read once + spectrum written once
         ncell_arrays = len(cell_fields) - (0 if wl["dimension"] == 3 else 1)   # 18 (17 in 2+1D: no eta); VAH: 24
         b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
-        traffic, traffic_source = None, None
-        for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC counters need their own rocprofv3 passes: not this run
-            tp = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tp):
-                tj = json.load(open(tp)).get(wl["name"])
-                if tj and tj.get("cells") == n_loc and tj.get("hbm_bytes_per_launch") and not a.df_mode and not a.variant:
-                    traffic = tj["hbm_bytes_per_launch"]
-                    traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, not measured in this run)" % tname
-                    break
+        traffic, traffic_source = (None, None) if (a.df_mode or a.variant) else pmc_traffic(wl["name"], n_loc)
         roofline = dict(bound="hbm", achieved=b_alg / (ms_main * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=b_alg / (ms_main * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, kernel=plan.main_kernel_name,
                         kernel_ms=ms_main, algorithmic_bytes=b_alg,
-                        note="not the binding roofline: 1e6 flop/byte; see roofline_valu and DESIGN.md section 5")
-        # ---- the binding roofline: fp64 VALU
-        jt_r = plan.tile_shape
-        ic = isa_counts(plan.main_kernel_name, wl, jt_r, st["kernel_variant"])
-        rv = None
-        if ic:
-            tf = executed_evals * ic["flop_per_eval"] / (ms_main * 1e-3) / 1e12
-            rv = dict(bound="fp64_valu", achieved=tf, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_VALU_PEAK_TF,
-                      executed_flop_per_eval=ic["flop_per_eval"], fp64_valu_instr_per_eval=ic["valu_f64_instr_per_eval"],
-                      issue_cycles_per_eval=ic["issue_cycles_per_eval"],
-                      issue_bound_frac_at_2p4GHz=executed_evals / 64.0 * ic["issue_cycles_per_eval"] / (1024 * 2.4e9 * ms_main * 1e-3),
-                      shader_clock_ghz=clock_ghz,
-                      frac_at_shader_clock=(tf / (FP64_VALU_PEAK_TF * clock_ghz / 2.4)) if clock_ghz else None,
-                      integrands_per_launch=unique_evals, integrands_executed=executed_evals, wave_rows_culled_frac=culled,
-                      note="flops and issue cycles count executed integrands only: rows whose exp(-p.u/T) is exactly +0 for a "
-                           "whole wave are skipped (bitwise-identical result)")
+                        note="rank 0's launch (its shard of %d cells); not the binding roofline: 1e6 flop/byte; see roofline_valu and DESIGN.md section 5" % n_loc)
         # integrands the kernels actually executed per second, summed over the ranks' own counters
         executed_all = sum(r["integrands_executed"] for r in ranks) if ranks else executed_evals
         executed_per_s = executed_all * a.steps / elapsed
+        inner = len(grid["eta"]) if wl["dimension"] == 2 else 1   # 2+1D: an eval is a sum over the eta table; integrands are its terms
         res = dict(metric="FO-cell x momentum-bin x species evals/sec", value=value, unit="evals/s", n_gpus=world, steps=a.steps,
                    warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling, vs_baseline=None,
                    dtype="f64", data="synthetic",
-                   value_note="reference-equivalent evals (cells x bins x all %d species, every row) per second; the kernel executes %d species "
-                              "classes and %.1f %% of their rows: executed_evals_per_s" % (nsp, st["n_classes"], 100.0 * (1.0 - culled)),
-                   executed_evals_per_s=executed_per_s, executed_fraction_of_value=executed_per_s / value,
+                   value_note="reference-equivalent evals (cells x bins x all %d species, every row) per second, cell arrays resident in HBM when the "
+                              "timed region starts (the bench contract); SURVEY.md 8d's t_kernel also contains the H->D upload of the cell arrays and the "
+                              "D->H download of the spectrum: value_incl_transfers / ms_per_step_incl_transfers.  The kernel executes %d species "
+                              "classes and %.1f %% of their rows: executed_evals_per_s (2+1D: integrands = evals x %d eta nodes)" % (
+                                  nsp, st["n_classes"], 100.0 * (1.0 - culled), inner),
+                   executed_evals_per_s=executed_per_s, executed_fraction_of_value=executed_per_s / (value * inner),
                    transfers_included=False,
-                   value_incl_transfers=(evals_step / incl) if incl else None,
-                   ms_per_step_incl_transfers=(incl * 1e3) if incl else None,
-                   host_entry=host_entry if incl else None,
+                   value_incl_transfers=evals_step / incl,
+                   ms_per_step_incl_transfers=incl * 1e3,
+                   host_entry=host_entry,
                    allreduce=allreduce_by,
                    allreduce_ms=(max(r["allreduce_ms"] for r in ranks) if ranks and all(r["allreduce_ms"] is not None for r in ranks) else None),
                    ranks_seen=(sorted(r["comm_rank_seen"][0] for r in ranks) if ranks and all(r["comm_rank_seen"] for r in ranks) else None),
@@ -496,10 +549,14 @@ def main():
                                culled_rows_change_no_bit=cull_identical),
                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"])), main_no_cull=ms_no_cull, surface_cull=surf_cull),
                    roofline=roofline, roofline_valu=rv)
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, fq=fq)
+        if clock_err:
+            res["clock_probe_error"] = clock_err
+        if not a.no_cpu_baseline:
+            # every N: the CPU path on this node's own host cores in the same run (north_star); rank 0 computes it after the timed region while
+            # the other ranks wait at the closing barrier
+            res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, seconds_budget=a.cpu_baseline_seconds, fq=fq)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
-            res["gpu_over_cpu_executed"] = executed_per_s / res["cpu_baseline"]["value"]   # the CPU port executes every eval
+            res["gpu_over_cpu_executed"] = executed_per_s / inner / res["cpu_baseline"]["value"]   # the CPU port executes every eval
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     plan.close()

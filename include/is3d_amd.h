@@ -256,6 +256,11 @@ int is3d_probe_shader_clock(int32_t device, double seconds, double *ghz);
  * (Cody-Waite, degree 10) | 1 exp_p9 (one-fma reduction, degree 9; |x| < 1.4e9) | 2 exp_p9_sat | 3 exp_full_sat (|x| up to ~1e45) | 4 sqrt_g1 (v_rsq_f64 +
  * one Goldschmidt step) | 5 sqrt_nr | 6 rcp_nr1 (v_rcp_f64 + one Newton step) | 7 rcp_nr (two steps). */
 int is3d_math_probe(int32_t which, int64_t n, const double *x, double *y, int32_t device);
+/* Diagnostic (no reference counterpart): process-wide counts of the plans this library has created (is3d_plan_create*, the per-shard plans of
+ * is3d_multi_plan_create and of the one-shot entries) and of the device allocations (hipMalloc) it has made, since the library was loaded.  What a
+ * persistent plan promises -- a second execute creates nothing and allocates nothing -- is checked with these, not with a wall clock.  Either
+ * pointer may be NULL. */
+int is3d_resource_counters(int64_t *plans_created, int64_t *device_allocations);
 /* Name of the dominant kernel as it appears in rocprofv3 traces, for the variant in use. */
 const char *is3d_plan_main_kernel_name(const is3d_plan *plan);
 /* tile of the main kernel: *JT phi's x *R rows (y's in 3+1D, eta nodes in 2+1D) */

@@ -105,7 +105,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
            "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
            "is3d_vah_plan_workspace_bytes", "is3d_vah_plan_execute", "is3d_vah_plan_set_timing", "is3d_vah_plan_timings",
-           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah", "is3d_vah_plan_main_kernel_name", "is3d_math_probe"]
+           "is3d_vah_plan_tile_shape", "is3d_vah_plan_destroy", "is3d_surface_read_vah", "is3d_vah_plan_main_kernel_name", "is3d_math_probe", "is3d_resource_counters"]
 
 REDUCE_ORDERED, REDUCE_RCCL = 0, 1
 IS3D_EPEER = -6
@@ -627,6 +627,15 @@ class Comm:
 
 
 MATH_FUNCS = dict(exp_full=0, exp_p9=1, exp_p9_sat=2, exp_full_sat=3, sqrt_g1=4, sqrt_nr=5, rcp_nr1=6, rcp_nr=7)
+
+
+def resource_counters():
+    """is3d_resource_counters: (plans created, device allocations made) by the library in this process so far."""
+    L = load()
+    a, b = C.c_int64(0), C.c_int64(0)
+    L.is3d_resource_counters.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    _check(L.is3d_resource_counters(C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def math_probe(which, x, device=-1):

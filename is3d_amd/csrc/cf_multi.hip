@@ -266,6 +266,7 @@ extern "C" int is3d_comm_create(is3d_comm **out, const uint8_t id[IS3D_COMM_ID_B
         delete c;
         return fail(IS3D_ENODEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, n_ranks, dev, rccl().GetErrorString(r));
     }
+    is3d::count_resource(1);
     const hipError_t e1 = hipMalloc((void **)&c->d_flag, 4 * sizeof(double));
     const hipError_t e2 = hipHostMalloc((void **)&c->h_flag, sizeof(double), hipHostMallocDefault);
     const hipError_t e3 = e1 == hipSuccess ? hipMemset(c->d_flag, 0, 4 * sizeof(double)) : e1;
@@ -495,6 +496,7 @@ int shard_create(Shard &s, const is3d_species *sp, const is3d_grid *grid, const 
     HIP_TRY(hipMalloc((void **)&s.d_cells, sizeof(double) * kCellArrays * (size_t)s.cap));
     HIP_TRY(hipMalloc((void **)&s.d_out, sizeof(double) * (size_t)nout));
     if (need_tmp) HIP_TRY(hipMalloc((void **)&s.d_tmp, sizeof(double) * (size_t)nout));
+    for (int k = 0; k < (need_tmp ? 3 : 2); k++) is3d::count_resource(1);
     HIP_TRY(hipEventCreate(&s.e0));
     HIP_TRY(hipEventCreate(&s.e1));
     HIP_TRY(hipEventCreateWithFlags(&s.e_sum, hipEventDisableTiming));

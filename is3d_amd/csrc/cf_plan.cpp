@@ -42,6 +42,7 @@ struct DevBuf {
         release();
         n = count;
         if (!count) return hipSuccess;
+        is3d::count_resource(1);
         return hipMalloc((void **)&p, count * sizeof(T));
     }
     hipError_t upload(const std::vector<T> &h)
@@ -174,6 +175,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if (is3d_device_count() < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
 
     std::unique_ptr<is3d_plan> P(new is3d_plan);
+    is3d::count_resource(0);
     P->opts = *o;
     if (o->device >= 0) HIP_TRY(hipSetDevice(o->device));
     HIP_TRY(hipGetDevice(&P->device));
@@ -551,6 +553,7 @@ extern "C" int is3d_probe_shader_clock(int32_t device, double seconds, double *g
     hipStream_t st;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     unsigned long long *d = nullptr, h[16] = {0};
+    is3d::count_resource(1);
     hipError_t e = hipMalloc(&d, sizeof h);
     if (e == hipSuccess) e = hipMemsetAsync(d, 0, sizeof h, st);
     if (e == hipSuccess) e = is3d::launch_clock_probe((unsigned long long)(seconds * khz * 1e3), d, st);

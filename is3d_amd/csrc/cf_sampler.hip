@@ -573,6 +573,7 @@ struct DevMem {
     {
         release();
         if (!bytes) return hipSuccess;
+        is3d::count_resource(1);
         return hipMalloc(&p, bytes);
     }
     template <class T>

@@ -655,7 +655,14 @@ namespace {
 struct DevMem {
     void *p = nullptr;
     size_t bytes = 0;
-    hipError_t alloc(size_t b) { release(); bytes = b; return b ? hipMalloc(&p, b) : hipSuccess; }
+    hipError_t alloc(size_t b)
+    {
+        release();
+        bytes = b;
+        if (!b) return hipSuccess;
+        is3d::count_resource(1);
+        return hipMalloc(&p, b);
+    }
     template <class T>
     hipError_t upload(const std::vector<T> &h)
     {
@@ -774,6 +781,7 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
     std::unique_ptr<is3d_vah_plan> P(new is3d_vah_plan);
+    is3d::count_resource(0);
     P->o = *o;
     if (o->device >= 0) VAH_TRY(hipSetDevice(o->device));
     VAH_TRY(hipGetDevice(&P->device));

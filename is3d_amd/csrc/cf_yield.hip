@@ -110,7 +110,13 @@ namespace {
 
 struct DevMem {
     void *p = nullptr;
-    hipError_t alloc(size_t bytes) { release(); return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+    hipError_t alloc(size_t bytes)
+    {
+        release();
+        if (!bytes) return hipSuccess;
+        is3d::count_resource(1);
+        return hipMalloc(&p, bytes);
+    }
     hipError_t upload(const void *h, size_t bytes)
     {
         hipError_t e = alloc(bytes);

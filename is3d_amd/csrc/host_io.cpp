@@ -12,6 +12,7 @@
 #include <fstream>
 #include <iomanip>
 #include <sstream>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -64,8 +65,17 @@ int set_error(int code, const char *fmt, ...)
     g_last_error = buf;
     return code;
 }
+static std::atomic<int64_t> g_resource[2];
+void count_resource(int what) { if (what >= 0 && what < 2) g_resource[what].fetch_add(1, std::memory_order_relaxed); }
 }  // namespace is3d
 #define io_fail is3d::set_error
+
+extern "C" int is3d_resource_counters(int64_t *plans_created, int64_t *device_allocations)
+{
+    if (plans_created) *plans_created = is3d::g_resource[0].load(std::memory_order_relaxed);
+    if (device_allocations) *device_allocations = is3d::g_resource[1].load(std::memory_order_relaxed);
+    return IS3D_OK;
+}
 
 extern "C" const char *is3d_last_error(void) { return is3d::g_last_error.c_str(); }
 

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_line(workload, kernel, extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--cells", "6000", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-clock-probe"] + extra, env=env, capture_output=True, text=True, timeout=600)
+                        "--cpu-baseline-seconds", "1", "--no-clock-probe"] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -33,3 +33,8 @@ def test_bench_line(workload, kernel, extra):
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert rv is not None and rv["bound"] == "fp64_valu" and 20 <= rv["executed_flop_per_eval"] <= 70 and 0 < rv["frac"] < 1
     assert d["kernel_ms"]["main"] > 0 and d["kernel_ms"]["prep"] > 0
+    # executed integrands against reference-equivalent integrands, like with like (2+1D: both count the eta nodes)
+    assert 0 < d["executed_fraction_of_value"] <= 1, d["executed_fraction_of_value"]
+    assert d["transfers_included"] is False and 0 < d["value_incl_transfers"] <= d["value"] * 1.05 and d["ms_per_step_incl_transfers"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and 1 <= cb["cores"] <= cb["cores_available"] and cb["cpu_model"] and cb["unit"] == "evals/s"

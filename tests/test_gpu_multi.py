@@ -138,8 +138,10 @@ def test_sampler_over_several_shards_gives_the_single_device_list(fx):
 
 
 def test_persistent_multi_plan_is_bitwise_the_one_shot_and_cheaper_per_execute(fx):
-    """is3d_multi_plan_*: plans, workspaces, streams, pinned staging created once.  Two shards on one GPU through the persistent
-    plan == is3d_smooth_spectra_multi bitwise; a second execute no longer pays plan creation + workspace hipMalloc."""
+    """is3d_multi_plan_*: plans, workspaces, streams created once.  Two shards on one GPU through the persistent plan ==
+    is3d_smooth_spectra_multi bitwise, and -- the structural fact behind "cheaper per execute" -- a second execute creates no plan and makes
+    no device allocation (is3d_resource_counters), whereas every one-shot call creates its two plans and allocates their workspaces anew.
+    The wall-clock times of both are printed for the log, not asserted (a shared box's jitter is not a defect)."""
     import time
     N = 125000                                   # one shard of BASELINE config 4
     cells = synth.synth_surface(N, 3)
@@ -147,22 +149,25 @@ def test_persistent_multi_plan_is_bitwise_the_one_shot_and_cheaper_per_execute(f
     api.smooth_spectra_multi(cells, fx["urqmd"], fx["grid"], fx["df"], o, devices=[0, 0])    # warm (contexts, code objects)
     t_one_shot = 1e9
     for _ in range(3):      # per call: two plans, two workspace hipMallocs, streams, events -- and the work
+        p0, a0 = api.resource_counters()
         t0 = time.perf_counter()
         one_shot, _, _ = api.smooth_spectra_multi(cells, fx["urqmd"], fx["grid"], fx["df"], o, devices=[0, 0])
         t_one_shot = min(t_one_shot, time.perf_counter() - t0)
+        p1, a1 = api.resource_counters()
+        assert p1 - p0 == 2 and a1 - a0 >= 2 * 3, (p1 - p0, a1 - a0)   # two shard plans; per shard at least workspace + cells + spectrum
     mp = api.MultiPlan(fx["urqmd"], fx["grid"], fx["df"], o, devices=[0, 0], max_cells=N)
     first, st, sh = mp.execute(cells)
     assert np.array_equal(first, one_shot) and mp.n_shards == 2 and len(sh) == 2 and st["code"] == 0
     t_second = 1e9
     for _ in range(3):
+        p0, a0 = api.resource_counters()
         t0 = time.perf_counter()
         second, st2, _ = mp.execute(cells)
         t_second = min(t_second, time.perf_counter() - t0)
+        assert api.resource_counters() == (p0, a0)                   # nothing created, nothing allocated
         assert np.array_equal(second, one_shot)
     print("multi plan, 2 x 62 500 cells on one GPU (best of 3): one-shot entry %.1f ms, persistent execute %.1f ms (h2d %.1f, d2h + sum %.1f ms)" % (
         t_one_shot * 1e3, t_second * 1e3, st2["ms_h2d"], st2["ms_d2h"]))
-    # measured 5-12 ms at this size (20 ms at 2 x 500 000 cells: the workspace hipMalloc grows with the shard); asserted with margin
-    assert t_second + 3e-3 < t_one_shot
     cells = {k: v[:20000] for k, v in cells.items()}
     # fewer cells than max_cells, an odd count, an empty surface: the same plan
     for n in (7777, 1, 0):
@@ -259,6 +264,21 @@ def test_allreduce_error_word_and_refusals(fx):
     comm.close()
 
 
+def _check_multi_rank_line(d):
+    """What an N > 1 line must carry to be self-sufficient (north_star: the CPU path timed on the node's own cores in the same run, beside
+    the GPU numbers): cpu_baseline with the cores and the CPU model, the contract's roofline, every rank's own fp64-VALU roofline, and the
+    transfer-inclusive step -- present and sane; the magnitudes belong to the full-size runs under profiles/."""
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and 1 <= cb["cores"] <= cb["cores_available"] and cb["cpu_model"] and cb["kind"] == "port"
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline_valu"]["frac"] > 0
+    for x in d["ranks"]:
+        rv = x["roofline_valu"]
+        assert rv["bound"] == "fp64_valu" and 0 < rv["frac"] < 1 and rv["kernel_ms"] == x["kernel_ms"]["main"]
+        assert 0 <= rv["wave_rows_culled_frac"] < 1 and rv["integrands_executed"] == x["integrands_executed"]
+    assert d["roofline_valu"]["shader_clock_ghz"] is None or 1.0 < d["roofline_valu"]["shader_clock_ghz"] < 3.0   # rank 0's probe runs for any N
+    assert 0 < d["executed_fraction_of_value"] <= 1 and d["value_incl_transfers"] > 0 and d["ms_per_step_incl_transfers"] > 0
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts the two rank processes itself (before it
     imports torch), they share the one GPU through --backend gloo, and exactly one JSON line comes back -- strong scaling of ONE
@@ -268,7 +288,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cells", "2000", "--steps", "1",
-                        "--warmup", "0", "--no-cpu-baseline", "--no-clock-probe"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "0", "--cpu-baseline-seconds", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -276,6 +296,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["cells_total"] == 2000 and d["config"]["cells_per_gpu"] == 1000
     assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["cells"] for x in d["ranks"]] == [1000, 1000]
     assert d["value"] > 0 and d["config"]["spectrum_finite"]
+    _check_multi_rank_line(d)
 
 
 def test_persistent_multi_plan_other_modes(fx):
@@ -344,7 +365,8 @@ def test_two_ranks_through_a_stub_communicator(tmp_path):
         assert r["s4_check"] == 0 and r["s4_relerr"] < 1e-13                # 4: the communicator survived
     assert r0["s2_exec"] == 0 and r1["s2_exec"] == api.IS3D_EINVAL
     assert r0["s3_exec"] == api.IS3D_EDOMAIN and r0["s3_text_has_cell"] and r1["s3_exec"] == api.IS3D_EPEER   # 3
-    assert r0["s5_exec"] == api.IS3D_ENODEVICE and "abort" in r0["s5_text"] and r0["s5_seconds"] < 30        # 5: fails, does not hang
+    assert r0["s5_exec"] == api.IS3D_ENODEVICE and "abort" in r0["s5_text"]        # 5: fails (behaviour of the test double; see the docstring)
+    print("s5: rank 0's collective failed %.2f s after rank 1's abort" % r0["s5_seconds"])
 
 
 def test_bench_two_ranks_through_the_library_communicator(tmp_path):
@@ -360,7 +382,7 @@ def test_bench_two_ranks_through_the_library_communicator(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["IS3D_RCCL_LIBRARY"] = so
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cells", "3000", "--steps", "2",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-clock-probe"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--cpu-baseline-seconds", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -368,3 +390,4 @@ def test_bench_two_ranks_through_the_library_communicator(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["allreduce"].startswith("is3d_plan_execute_allreduce")
     assert d["ranks_seen"] == [0, 1] and [x["comm_rank_seen"] for x in d["ranks"]] == [[0, 2], [1, 2]]
     assert all(x["allreduce_ms"] is not None and x["allreduce_ms"] >= 0 for x in d["ranks"]) and d["config"]["spectrum_finite"]
+    _check_multi_rank_line(d)
