@@ -44,7 +44,12 @@ import subprocess
 import sys
 import time
 
-import numpy as np
+# the cpu_baseline leg runs an OpenMP team on every core the process may use; where the affinity mask is wider than the CPU share (a container),
+# idle team members must sleep, not spin the share away (read by libgomp when it is first loaded: before numpy / torch)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -77,7 +82,8 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     d = json.load(open(p))
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
     if kernel_name == "cf_main_feqmod":
-        key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1])
+        rows = (0 if variant == 5 else 2 if variant == 6 else 1) if d3 else 0   # how the kernel walks a unit's rows (cf_feqmod.hip)
+        key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d,ROWS=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1], rows)
     elif kernel_name == "cf_main_vah":
         key = "cf_main_vah:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_vah3":
@@ -92,7 +98,25 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
 
 
 def host_cores():
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """Cores this process may actually use: its affinity mask, capped by the cgroup CPU quota (a 1-GPU box of the pool sees all 256 hardware
+    threads in its mask but owns a 16-core share: 256 OpenMP threads on that share ran the oracle 7x SLOWER than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                                 # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n
 
 
 def host_cpu_model():
@@ -145,7 +169,7 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     # partial spectrum per thread (39 MB for config 3), so the count is bounded by a quarter of the free host memory, nothing else
     avail = host_cores()
     per_thread = 8.0 * per_cell + 1e6
-    threads = oracle.set_num_threads(max(1, min(avail, int(0.25 * host_mem_available() / per_thread))))
+    tmax = max(1, min(avail, int(0.25 * host_mem_available() / per_thread)))
     make = synth.synth_surface
     if vah_tab is not None:
         make = synth.synth_vah_surface
@@ -158,6 +182,24 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
         run = lambda c, **kw: oracle.dN_pTdpTdphidy_feqmod(c, sp, grid, df, fq, opts)
     else:
         run = lambda c, **kw: oracle.dN_pTdpTdphidy(c, sp, grid, df, opts, **kw)
+    # How many threads: the affinity mask can be wider than what the process may use (a 1-GPU box of the pool shows 256 hardware threads and
+    # owns a 16-core share that no cgroup file here reveals), and an oversubscribed OpenMP team ran this oracle 7x slower than one that fits.
+    # So the usable parallelism is MEASURED first: a cheap run (3 species instead of the workload's list) on all tmax threads, CPU time of the
+    # process over wall time = the cores it was really given; the team is that many threads (all of them when the ratio is within 20 % of tmax).
+    import resource
+    from is3d_amd import inputs as _inputs
+    sp_probe = _inputs.species("pikp")
+    oracle.set_num_threads(tmax)
+    pc = synth.synth_surface(64 * tmax, wl["dimension"])
+    po = dict(dimension=wl["dimension"], df_mode=2 if wl["dimension"] == 3 else 1)
+    pdf = _inputs.df_tables()
+    oracle.dN_pTdpTdphidy({k: v[:tmax] for k, v in pc.items()}, sp_probe, grid, pdf, po)   # starts the team
+    r0, w0 = resource.getrusage(resource.RUSAGE_SELF), time.time()
+    oracle.dN_pTdpTdphidy(pc, sp_probe, grid, pdf, po)
+    r1, w1 = resource.getrusage(resource.RUSAGE_SELF), time.time()
+    eff = ((r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime)) / max(w1 - w0, 1e-6)
+    threads = tmax if eff > 0.8 * tmax else max(1, min(tmax, int(round(eff))))
+    threads = oracle.set_num_threads(threads)
     probe = make(2 * threads, wl["dimension"])
     t0 = time.time()
     run(probe)
@@ -168,7 +210,8 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     t0 = time.time()
     run(cells)
     tb = time.time() - t0
-    res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, cores_available=avail, cpu_model=host_cpu_model(), kind="port",
+    res = dict(value=n * per_cell / tb, unit="evals/s", cores=threads, cores_available=avail, cores_effective_measured=eff,
+               cpu_model=host_cpu_model(), kind="port",
                sample="first %d cells of the workload surface x all %d species x %d bins, oracle %s, %.1f s" % (
                    n, len(sp["mass"]), nbins, "VAH restatement (coefficients + kernel)" if vah_tab is not None else
                    "feqmod restatement" if fq is not None else "variant B (no scratch)", tb))
@@ -370,6 +413,8 @@ def main():
                 ms["allreduce"].append(comm.allreduce_ms())   # HIP events on `stream` around the library's RCCL group
 
     def fence():
+        if comm is not None:
+            comm.synchronize(stream)   # hipStreamSynchronize with a deadline: a rank whose peer died raises (exits non-zero) instead of hanging the node
         torch.cuda.synchronize()
         if multi:
             dist.barrier()

@@ -314,23 +314,36 @@ void is3d_comm_destroy(is3d_comm *comm);
 /* is3d_plan_execute on this rank's shard of the cells, then the sum of dN_out over the ranks on the same stream (ncclAllReduce):
  * every rank ends with the spectrum of the whole surface.  comm == NULL: plain is3d_plan_execute.  The plan must have been created
  * with opts.accumulate = 0 (the old contents would be summed n_ranks times): IS3D_EINVAL otherwise.
- * No rank is ever left waiting in the collective.  A one-double error word is summed next to the spectrum (same RCCL group):
+ * Failures.  A one-double error word is summed next to the spectrum (same RCCL group):
  *   - a rank whose execute fails in a way that leaves its stream usable (IS3D_EDOMAIN; IS3D_EINVAL for a bad shard or plan option)
  *     still joins -- after a domain error with the cells it could evaluate, after an argument error with zeros -- with its error word
  *     set, and returns its own error code;
  *   - the other ranks learn of it: with status != NULL (the call synchronises anyway) they return IS3D_EPEER; with status == NULL
  *     (fully asynchronous) at the next is3d_comm_check;
- *   - a rank that cannot join (dN_out or plan NULL, a HIP error) calls ncclCommAbort on its communicator before it returns, so that
- *     the peers' collective fails instead of blocking; the communicator is unusable afterwards (every call returns IS3D_ENODEVICE). */
+ *   - a rank that cannot join (dN_out or plan NULL, a HIP error) calls ncclCommAbort on its OWN communicator before it returns
+ *     (unusable afterwards: every call returns IS3D_ENODEVICE) and its host should exit non-zero so that the launcher ends the job.
+ *     Its abort is local: RCCL enqueues an all-reduce and returns at once, and nothing tells the peers' kernels that a rank will never
+ *     arrive.  What protects the PEERS is their own deadline: every host-side wait the library makes behind a collective
+ *     (the status read-back of this call, is3d_comm_check, is3d_comm_timings, is3d_comm_synchronize) polls the stream together with
+ *     ncclCommGetAsyncError and, on an asynchronous RCCL error or after the communicator's timeout (is3d_comm_set_timeout; default 300 s,
+ *     or IS3D_COMM_TIMEOUT_S at is3d_comm_create), aborts this rank's communicator and returns IS3D_ENODEVICE instead of blocking for ever.
+ *     A host that synchronises the stream itself (hipStreamSynchronize) has no such deadline: use is3d_comm_synchronize. */
 int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *shard, double *dN_out, is3d_comm *comm, void *hip_stream,
                                 is3d_status *status);
-/* Error words of the collectives since the last check (synchronises hip_stream): IS3D_OK, or IS3D_EPEER with *n_failed (may be NULL)
- * = how many rank-executes had failed before their all-reduce -- this rank's own failures included. */
+/* Error words of the collectives since the last check (waits for hip_stream, with the communicator's deadline): IS3D_OK, or IS3D_EPEER with
+ * *n_failed (may be NULL) = how many rank-executes had failed before their all-reduce -- this rank's own failures included; IS3D_ENODEVICE
+ * when the wait hit an asynchronous RCCL error or the deadline (the communicator is aborted then). */
 int is3d_comm_check(is3d_comm *comm, void *hip_stream, int32_t *n_failed);
-/* ncclCommAbort: for a host that has to leave a job whose other ranks may be inside a collective. */
+/* ncclCommAbort on this rank's communicator: for a host that has to leave a job.  Local -- the other ranks find out through their own
+ * deadline (see is3d_plan_execute_allreduce), not through this call. */
 int is3d_comm_abort(is3d_comm *comm);
+/* Deadline, in seconds, of the host-side waits behind this communicator's collectives (default 300). */
+int is3d_comm_set_timeout(is3d_comm *comm, double seconds);
+/* hipStreamSynchronize(hip_stream) with that deadline and with ncclCommGetAsyncError polled beside it: IS3D_OK when everything enqueued on
+ * the stream has finished, IS3D_ENODEVICE (communicator aborted) on an asynchronous RCCL error or when the deadline passes. */
+int is3d_comm_synchronize(is3d_comm *comm, void *hip_stream);
 /* Device time of the last collective on this rank (HIP events on its stream around the RCCL group; it includes the wait for the
- * slowest rank).  Synchronises the closing event. */
+ * slowest rank).  Waits for the closing event (with the communicator's deadline). */
 int is3d_comm_timings(is3d_comm *comm, double *ms_allreduce);
 
 /* Persistent form of is3d_smooth_spectra_multi: one plan, one workspace, one stream, the device blocks for cells and spectrum and
@@ -582,6 +595,26 @@ int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t inclu
  * carry it), nB and V^mu are zero in modes 4, 6, 7.  Other modes: IS3D_EINVAL. */
 int is3d_surface_read(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf,
                       int32_t dimension, int64_t *n_cells, double *const *cell_arrays23, double *avg5);
+
+/* The same readers (modes 0, 1, 4, 5, 6, 7 and the anisotropic-hydro mode 2) behind ONE read and ONE parse of the text, the arrays owned by
+ * the library, and a binary sidecar next to the text so that a second run on the same surface skips the parse (no reference counterpart: the
+ * reference re-parses `input/surface.dat` with operator>> on every run, readindata.cpp:320-468; the drop-in keeps its result, not its cost).
+ *   cache = 0: parse the text, touch nothing else | 1: use `<path>.is3dcache` when it matches the text file as it is now -- size, mtime (ns), a
+ *   hash of sampled blocks of its contents, the parse parameters (mode, include_baryon, include_baryondiff_deltaf, dimension) and the sidecar's
+ *   own length -- else parse the text and (re)write it (temp file + rename, on a thread of the library's while the caller computes; a directory
+ *   that cannot be written to is not an error) | 2: as 1 with a hash of the WHOLE text (reads the text: slower, for the wary).
+ *   IS3D_NO_CACHE=1 in the environment forces 0.  The cached arrays and averages are bit for bit what the text parse produced.
+ * is3d_surface_arrays: modes 0-7 except 2: n_arrays = 25 -- cell_arrays23 order (T P E tau eta ux uy un dat dax day dan pixx pixy pixn piyy
+ * piyn bulkPi muB nB Vx Vy Vn; NULL for the ones the flags leave out) then the positions x, y (columns 2, 3: the sampler's) -- and avg5 as
+ * is3d_surface_read; mode 2: n_arrays = 32, the arrays32 of is3d_surface_read_vah, avg5 untouched.  Pointers stay valid until is3d_surface_close.
+ * is3d_surface_source: 0 the text was parsed, no sidecar written | 1 parsed, sidecar written (waits for the writer) | 2 loaded from the sidecar. */
+typedef struct is3d_surface is3d_surface;
+int is3d_surface_open(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf, int32_t dimension,
+                      int32_t cache, is3d_surface **surface);
+int64_t is3d_surface_cells(const is3d_surface *surface);
+int32_t is3d_surface_source(is3d_surface *surface);
+int is3d_surface_arrays(const is3d_surface *surface, const double **arrays, int32_t n_arrays, double avg5[5]);
+void is3d_surface_close(is3d_surface *surface);
 
 /* PDG_Data::read_resonances_conventional (src/cpp/readindata.cpp:1440-1568), reduced to what the
  * smooth path uses.  Two-call pattern (mc_id == NULL -> only *n).  Arrays of capacity entries. */

@@ -11,8 +11,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libis3d_amd.so")
-CLI_PATH = os.path.join(_HERE, "bin", "iS3D_amd")
+# IS3D_USE_DEV_LIB=1: the developer build (`make -C is3d_amd/csrc DEV=1`: A/B switches and cycle-accounting kernels, csrc/errors.h) for tools/
+DEV_LIB = os.environ.get("IS3D_USE_DEV_LIB", "") == "1"
+LIB_PATH = os.path.join(_HERE, "lib_dev" if DEV_LIB else "lib", "libis3d_amd.so")
+CLI_PATH = os.path.join(_HERE, "bin_dev" if DEV_LIB else "bin", "iS3D_amd")
 
 IS3D_OK, IS3D_EINVAL, IS3D_ENODEVICE, IS3D_EDOMAIN, IS3D_ENOMEM, IS3D_EIO = 0, -1, -2, -3, -4, -5
 
@@ -101,7 +103,8 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
            "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi",
-           "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_multi_plan_create", "is3d_multi_plan_execute",
+           "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_comm_set_timeout", "is3d_comm_synchronize", "is3d_surface_open", "is3d_surface_cells", "is3d_surface_source",
+           "is3d_surface_arrays", "is3d_surface_close", "is3d_multi_plan_create", "is3d_multi_plan_execute",
            "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
            "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
            "is3d_vah_plan_workspace_bytes", "is3d_vah_plan_execute", "is3d_vah_plan_set_timing", "is3d_vah_plan_timings",
@@ -608,6 +611,17 @@ class Comm:
     def abort(self):
         _check(load().is3d_comm_abort(self._h))
 
+    def set_timeout(self, seconds):
+        """Deadline of the library's host-side waits behind this communicator's collectives (is3d_comm_set_timeout)."""
+        L = load()
+        L.is3d_comm_set_timeout.argtypes = [C.c_void_p, C.c_double]
+        _check(L.is3d_comm_set_timeout(self._h, float(seconds)))
+
+    def synchronize(self, stream=0):
+        """hipStreamSynchronize with that deadline (is3d_comm_synchronize): raises Is3dError(IS3D_ENODEVICE) instead of blocking for ever
+        behind a collective a peer never joined."""
+        _check(load().is3d_comm_synchronize(self._h, C.c_void_p(int(stream or 0))))
+
     def allreduce_ms(self):
         """Device time of the last collective on this rank (is3d_comm_timings)."""
         ms = C.c_double(0.0)
@@ -779,6 +793,36 @@ def surface_read(path, mode, include_baryon=0, include_baryondiff_deltaf=0, dime
     if n.value > 0:
         _check(L.is3d_surface_read(path.encode(), mode, include_baryon, include_baryondiff_deltaf, dimension, C.byref(n), ptrs, _p(avg)))
     return arrs, avg
+
+
+def surface_open(path, mode=1, include_baryon=0, include_baryondiff_deltaf=0, dimension=3, cache=1):
+    """is3d_surface_open / _arrays / _source / _close: one read and one parse of the text, or the binary sidecar `<path>.is3dcache` when it
+    matches -> (dict of arrays [copies], averages or None, source) with source 0 text parsed | 1 text parsed + sidecar written | 2 sidecar.
+    Modes 0, 1, 4, 5, 6, 7: the 23 arrays of SURFACE_READ_ORDER (absent ones None) + x, y; mode 2: the 32 arrays of VAH_SURFACE_ORDER."""
+    L = load()
+    L.is3d_surface_open.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.is3d_surface_cells.argtypes = [C.c_void_p]
+    L.is3d_surface_cells.restype = C.c_int64
+    L.is3d_surface_source.argtypes = [C.c_void_p]
+    L.is3d_surface_arrays.argtypes = [C.c_void_p, C.POINTER(_dp), C.c_int32, _dp]
+    L.is3d_surface_close.argtypes = [C.c_void_p]
+    L.is3d_surface_close.restype = None
+    h = C.c_void_p()
+    _check(L.is3d_surface_open(path.encode(), int(mode), int(include_baryon), int(include_baryondiff_deltaf), int(dimension), int(cache), C.byref(h)))
+    try:
+        n = L.is3d_surface_cells(h)
+        names = list(VAH_SURFACE_ORDER) if mode == 2 else list(SURFACE_READ_ORDER) + ["x", "y"]
+        ptrs = (_dp * len(names))()
+        avg = np.zeros(5)
+        _check(L.is3d_surface_arrays(h, ptrs, len(names), _p(avg)))
+        if n > 0:
+            arrs = {f: (np.ctypeslib.as_array(ptrs[i], shape=(n,)).copy() if ptrs[i] else None) for i, f in enumerate(names)}
+        else:
+            arrs = {f: np.zeros(0) for f in names}
+        source = L.is3d_surface_source(h)
+    finally:
+        L.is3d_surface_close(h)
+    return arrs, (None if mode == 2 else avg), source
 
 
 def pdg_read(path):

@@ -11,7 +11,9 @@
 //   alphaf_k = (1 + |A^-1 a_k|^2)/T_mod^2,  betaf_jk = 2 (A^-1 a_k).(A^-1 b_j)/T_mod^2,  gammaf_j = (|A^-1 b_j|^2 - 1)/T_mod^2
 // (m^2 = mT^2 - pT^2 folded in), and f = |renorm| / (exp(E_mod/T_mod) + sign).  cf_prep_feqmod writes these coefficients
 // into the same tiled unit-record stream the delta-f kernel uses (cf_device.h) with the slots reused:
-//   header jj : {B_j, gammaf_j, 0, 0}          row r : {A_k, alphaf_k, W_k, min_j betaf_jk (3+1D), betaf_{j0..j0+JT-1,k}}
+//   header jj : {B_j, gammaf_j, 0, 0}          row r, 2+1D : {A_k, alphaf_k, W_k, 0, betaf_{j0..j0+JT-1,k}}
+//                                              row r, 3+1D : {alphaf_k, min_j betaf_jk, A_k, W_k, betaf_{j0..j0+JT-1,k}} -- the two operands of a row's
+//                                              liveness test in ONE 16-byte LDS read (fq_row_slots)
 //   (include_baryon: header slot 2 of jj = 0 carries alpha_B,mod = alpha_B + Pi G / beta_Pi, :637; the lane's baryon number
 //   times it is added to the exponent, :742, :927; A_ij ignores the baryon diffusion, ":660 leave for future work")
 //   p.dsigma = rn (mT A_k + W_k pT B_j),  A_k = w_k ch dat + sh dan/tau  (the reference keeps dsigma_eta outside the eta
@@ -25,6 +27,10 @@
 #include <hip/hip_runtime_api.h>
 
 namespace is3d {
+
+// slots of a row's four scalars within the record (the phi entries follow from slot 4)
+struct FqRowSlots { int A, AL, W, BM; };
+constexpr FqRowSlots fq_row_slots(bool dim3) { return dim3 ? FqRowSlots{2, 0, 3, 1} : FqRowSlots{0, 1, 2, 3}; }
 
 constexpr int kFbRec = 36;   // doubles per fallback record (cf_feqmod.hip::FbRec)
 constexpr int kCrRec = 8;    // doubles per cell record of the df_mode 3 renormalisation kernel

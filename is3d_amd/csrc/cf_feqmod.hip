@@ -14,9 +14,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+
 #include "cf_feqmod.h"
 #include "cf_launch.h"
 #include "cf_math.h"
+#include "errors.h"
 
 namespace is3d {
 
@@ -141,10 +144,12 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             } else {
                 const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                 y = r << 16;
-                if (f == 0) x = o_A | (1 << 16) | PADZ;        // padding rows: p.dsigma = 0, the quadratic form of row K-1
-                else if (f == 1) x = o_al | (1 << 16);
-                else if (f == 2) x = o_W | (1 << 16) | PADZ;
-                else if (f == 3) x = p.dim3 ? (o_bm | (6 << 16)) : ZERO;
+                // row scalars in the slot order of fq_row_slots (cf_feqmod.h): 3+1D {alphaf, min_j betaf, A, W}, 2+1D {A, alphaf, W, 0}
+                const FqRowSlots sl = fq_row_slots(p.dim3 != 0);
+                if (f == sl.A) x = o_A | (1 << 16) | PADZ;     // padding rows: p.dsigma = 0, the quadratic form of row K-1
+                else if (f == sl.AL) x = o_al | (1 << 16);
+                else if (f == sl.W) x = o_W | (1 << 16) | PADZ;
+                else if (f == sl.BM) x = p.dim3 ? (o_bm | (6 << 16)) : ZERO;
                 else { x = BETA; y |= f - 4; }
             }
             desc[e] = int2{x, y};
@@ -582,7 +587,21 @@ hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, con
 // tile except the row and column products.  Rows whose X exceeds 745.2 for every lane and phi of the tile (z = +0
 // exactly) are culled as in cf_main_tile.
 // ------------------------------------------------------------------------------------------------
-template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R, bool BARYON = false>
+// dev: cycle accounting of the PROF instantiation (-DIS3D_DEV builds, IS3D_DEV_PROF=1; tools/gpu_ab.py): sums over waves of s_memtime intervals
+//   [0] waves  [1] wave lifetime  [2] staging issue  [3] vmcnt + barrier waits  [4] dead units  [5] live units  [6] their bounds + row tests
+//   [7] dead units (count)  [8] live units (count)  [9] first-wave share of [3]  [10] threshold refresh  [11] vmcnt part of [3]  [12] prologue
+//   [13] live rows evaluated (count)  [14] cycles inside the evaluated rows
+__device__ unsigned long long g_prof_fq[16];
+
+// ROWS: how the R rows of a 3+1D unit are walked.
+//   0  software pipeline (row r+1's twelve operands fetched before row r's evaluations), every row forms its own threshold and lower bound:
+//      the round-1 form, kept for 2+1D (61-row units) and as the A/B reference (kernel_variant 5)
+//   1  (default, 3+1D) liveness of all rows first, from ONE LDS round trip at the head of the unit that also brings the unit-level bounds: a
+//      row's test is {alphaf_k, min_j betaf_jk} (one 16-byte read) against the UNIT's threshold -- 4 instructions and no further read for a dead
+//      row instead of 6 reads and ~17 instructions; rows that pass are tested again against their own (tighter) threshold when their operands
+//      are there, so the set of culled rows is exactly that of ROWS = 0 (same status counters, bitwise the same spectrum)
+//   2  as 1 without the second, row-level test (kernel_variant 6; A/B)
+template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R, bool BARYON = false, int ROWS = 0, bool PROF = false>
 __global__ void __launch_bounds__(512)
 cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
                const double *__restrict__ lane_sign, const double *__restrict__ RN, const int32_t *__restrict__ lane_cls,
@@ -597,6 +616,8 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     constexpr int NLD = (BUF2 + 127) / 128;
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
     static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples (JT even)");
+    static_assert(ROWS == 0 || (DIM3 && JT >= 4), "the row mask needs the unit-level bounds of the 3+1D records");
+    constexpr FqRowSlots SL = fq_row_slots(DIM3);
     constexpr int BUFP = ((BUF2 * 16 + 1023) / 1024) * 64;   // the batch as whole 1-KiB staging pieces (64 double2 each)
     __shared__ double2 lbuf[2][BUFP + RW / 2 + 1];
     (void)NLD;
@@ -641,69 +662,98 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     for (int i = 0; i < NACC; i++) acc[i] = 0.0;
 
     int n_rows = 0, n_dead = 0;
+    unsigned long long pf_stage = 0, pf_wait = 0, pf_dead = 0, pf_live = 0, pf_hdr = 0, pf_nd = 0, pf_nl = 0, pf_thr = 0, pf_t0 = 0, pf_u0 = 0, pf_vm = 0, pf_pro = 0,
+                       pf_nr = 0, pf_rows = 0;
+    if constexpr (PROF) pf_t0 = clock64();
     // Accumulator-relative row cull (with the outflow clamp, g.zskip == 2), as in cf_main_tile: every term of a row is
     // pds w with 0 <= pds <= pmax = |mT A_k| + max_j |pT B_j| |W_k| and w = z/(1 + sign z) <= 2 z for z <= 1/2,
     // z = e^(cm - X) <= e^(cm - sqrt(x2lb)); the accumulators only grow and fma(pds, w, acc) == acc when pds w < ulp(acc)/2.
     // With pmax < 2^ep and min(acc) >= 2^(acc_e - 1): X > cm + (ep - acc_e + 58) ln 2 leaves every accumulator unchanged.
     constexpr bool RELCULL = OUTFLOW;
     int acc_e = -100000;   // frexp exponent of a (stale) minimum over the lane's accumulators; refreshed once per batch
-    auto process_unit = [&](const double *U, double rn) {
+    auto process_unit = [&](const double *U, double rn) -> bool {
         double pTB[JT], pT2g[JT];
         const double rpT = MODE3 ? rn * pT : pT, rmT = MODE3 ? rn * mT : mT;
         const double cm = BARYON ? bq * U[2] : 0.0;   // chem_mod = baryon * alpha_B,mod (:742): f = |renorm| / (exp(E_mod/T_mod - chem_mod) + sign)
         // exact-zero culling: exp(cm - X) == +0 needs X > 745.25 + cm
         const double xcut = BARYON ? 745.25 + __builtin_fmax(cm, 0.0) : 745.25;
         const double x2cut = BARYON ? xcut * xcut : 555400.0;
+        // threshold on X^2 from an upper bound pmax of the row's (or the unit's) p.dsigma: see RELCULL above
+        auto x2_threshold = [&](double pmax) {
+            const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
+            const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
+            const double xcp = __builtin_fmax(xc, 0.0);
+            return __builtin_fmin(x2cut, xcp * xcp);
+        };
+        double x2c_u = x2cut;
+        double ral[ROWS ? R : 1], rbm[ROWS ? R : 1];
+        double gmin_u = 0.0;
         if constexpr (DIM3 && JT >= 4) {
             // Unit-level cull (3+1D; bounds from cf_prep_feqmod in free header slots): X^2 >= mT^2 min_k alphaf + mT pT min_jk betaf + pT^2
             // min_j gammaf for every evaluation of the unit, and the threshold of every row is at most the one formed with max_k |A_k|,
             // max_k |W_k| and max_j |B_j| (all roundings monotone): a unit that fails here would have every row culled below, so its
             // header work and its R row fetches are skipped -- bitwise the same spectrum
-            if (g.zskip) {
-                double x2c_u = x2cut;
-                if (RELCULL && g.zskip == 2) {
-                    const double pmax = __builtin_fma(__builtin_fabs(rpT * U[14]), U[11], __builtin_fabs(rmT * U[10]));
-                    const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
-                    const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
-                    const double xcp = __builtin_fmax(xc, 0.0);
-                    x2c_u = __builtin_fmin(x2cut, xcp * xcp);
+            if constexpr (ROWS != 0) {
+                // ... and with them, in the same LDS round trip, the operands of the R row tests
+                const double u_al = U[3], u_be = U[6], u_ga = U[7], u_A = U[10], u_W = U[11], u_B = U[14];
+#pragma unroll
+                for (int r = 0; r < R; r++) { ral[r] = U[HDR + r * RW + SL.AL]; rbm[r] = U[HDR + r * RW + SL.BM]; }
+                __builtin_amdgcn_sched_barrier(0);
+                gmin_u = pT2 * u_ga;                   // == min_j pT^2 gammaf_j (pT^2 >= 0, monotone rounding)
+                if (g.zskip) {
+                    if (RELCULL && g.zskip == 2) x2c_u = x2_threshold(__builtin_fma(__builtin_fabs(rpT * u_B), u_W, __builtin_fabs(rmT * u_A)));
+                    const double x2lb_u = __builtin_fma(mTpT, u_be, mT2 * u_al + gmin_u);
+                    if (__all(x2lb_u > x2c_u)) { n_rows += R; n_dead += R; return false; }
                 }
+            } else if (g.zskip) {
+                if (RELCULL && g.zskip == 2) x2c_u = x2_threshold(__builtin_fma(__builtin_fabs(rpT * U[14]), U[11], __builtin_fabs(rmT * U[10])));
                 const double x2lb_u = __builtin_fma(mTpT, U[6], mT2 * U[3] + pT2 * U[7]);
-                if (__all(x2lb_u > x2c_u)) { n_rows += R; n_dead += R; return; }
+                if (__all(x2lb_u > x2c_u)) { n_rows += R; n_dead += R; return false; }
             }
+        }
+        unsigned live = (1u << (ROWS ? R : 1)) - 1u;
+        if constexpr (ROWS != 0) {
+            if (g.zskip) {
+                live = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double x2lb = __builtin_fma(mTpT, rbm[r], mT2 * ral[r] + gmin_u);
+                    live |= __all(x2lb > x2c_u) ? 0u : (1u << r);
+                }
+            }
+            n_rows += R;
+            n_dead += R - __builtin_popcount(live);
+            if constexpr (PROF) pf_hdr += clock64() - pf_u0;
         }
         double g_min = 1.0e300, pb_max = 0.0;
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
             pTB[jj] = rpT * U[4 * jj + 0];
             pT2g[jj] = pT2 * U[4 * jj + 1];
-            if (DIM3) g_min = __builtin_fmin(g_min, pT2g[jj]);
-            if (RELCULL) pb_max = __builtin_fmax(pb_max, __builtin_fabs(pTB[jj]));
+            if (DIM3 && ROWS == 0) g_min = __builtin_fmin(g_min, pT2g[jj]);
+            if (RELCULL && ROWS != 2) pb_max = __builtin_fmax(pb_max, __builtin_fabs(pTB[jj]));
         }
+        if (ROWS != 0) g_min = gmin_u;
         struct Row { double v[RW]; };
         auto fetch = [&](Row &rw, const double *row) {
 #pragma unroll
             for (int i = 0; i < RW; i++) rw.v[i] = row[i];
         };
         auto evals = [&](const Row &rw, int r) {
-            const double mTA = rmT * rw.v[0];
-            const double a = mT2 * rw.v[1];
-            const double W = rw.v[2];
-            n_rows += 1;
+            const double mTA = rmT * rw.v[SL.A];
+            const double a = mT2 * rw.v[SL.AL];
+            const double W = rw.v[SL.W];
+            if (ROWS == 0) n_rows += 1;
             double X2[JT];
             double x2c = x2cut;                                                     // X > 745.25 (+ cm): exp(cm - X) == +0
-            if (RELCULL && g.zskip == 2) {
-                const double pmax = __builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA));
-                const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
-                const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
-                const double xcp = __builtin_fmax(xc, 0.0);
-                x2c = __builtin_fmin(x2cut, xcp * xcp);
-            }
+            if (RELCULL && ROWS != 2 && g.zskip == 2) x2c = x2_threshold(__builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA)));
             if constexpr (DIM3) {
                 // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + pT^2 min_j gammaf_j (mT pT >= 0; the row carries min_j betaf_jk):
                 // two instructions per row instead of a minimum per evaluation, and a culled row forms no X^2 at all
-                const double x2lb = __builtin_fma(mTpT, rw.v[3], a + g_min);
-                if (g.zskip && __all(x2lb > x2c)) { n_dead += 1; return; }
+                if constexpr (ROWS != 2) {
+                    const double x2lb = __builtin_fma(mTpT, rw.v[SL.BM], a + g_min);
+                    if (g.zskip && __all(x2lb > x2c)) { n_dead += 1; return; }
+                }
 #pragma unroll
                 for (int jj = 0; jj < JT; jj++) X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
             } else {
@@ -716,6 +766,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 }
                 if (g.zskip && __all(x2min > x2c)) { n_dead += 1; return; }
             }
+            if constexpr (PROF) pf_nr++;
             // the reciprocals of RB evaluations share one v_rcp_f64 (rcp_batch, cf_math.h): d = 1 + sign z lies in (1e-3, 2]
 #pragma unroll
             for (int j0 = 0; j0 < JT; j0 += RB) {
@@ -739,9 +790,21 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             }
         };
         const double *rows = U + HDR;
-        Row cur, nxt;
-        fetch(cur, rows);
-        if (DIM3) {
+        if constexpr (ROWS != 0) {
+            unsigned long long pr = 0;
+            if constexpr (PROF) pr = clock64();
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (live & (1u << r)) {
+                    Row rw;
+                    fetch(rw, rows + r * RW);
+                    evals(rw, r);
+                }
+            }
+            if constexpr (PROF) pf_rows += clock64() - pr;
+        } else if (DIM3) {
+            Row cur, nxt;
+            fetch(cur, rows);
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
@@ -750,6 +813,8 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             }
         } else {
             // rolled, two rows per trip (see cf_main_tile); for even R the last fetch reads the head of the next unit or the pad
+            Row cur, nxt;
+            fetch(cur, rows);
 #pragma clang loop unroll(disable)
             for (int r = 0; r + 1 < R; r += 2) {
                 fetch(nxt, rows + (r + 1) * RW);
@@ -759,6 +824,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             }
             if (R & 1) evals(cur, 0);
         }
+        return true;
     };
 
     // staging: the next batch by direct-to-LDS loads (stage_pieces, cf_math.h), issued before the current batch is consumed
@@ -779,8 +845,12 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (MODE3) asm volatile("" :: "v"(rn), "v"(rn1));   // a use: the compiler's own wait for the two loads goes here
         __syncthreads();
+        if constexpr (PROF) pf_pro = clock64() - pf_t0;
         for (int ib = 0; ib < nb; ib++) {
+            unsigned long long pa = 0;
+            if constexpr (PROF) pa = clock64();
             if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
+            if constexpr (PROF) pf_stage += clock64() - pa;
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
                 const double *base = (const double *)lbuf[ib & 1] + sub_off;
@@ -788,26 +858,53 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 for (int u = 0; u < nu; u += S) {      // nu is a multiple of S (plan)
                     double rn_next = rn1;
                     if (MODE3 && u > 0) rn_next = rn_at(u0 + u + S);
-                    process_unit(base + u * REC, rn);
+                    if constexpr (PROF) pf_u0 = clock64();
+                    const bool lv = process_unit(base + u * REC, rn);
+                    if constexpr (PROF) {
+                        const unsigned long long d = clock64() - pf_u0;
+                        if (lv) { pf_live += d; pf_nl++; } else { pf_dead += d; pf_nd++; }
+                    }
                     rn = rn_next;
                 }
                 if (MODE3) rn1 = rn_at(u0 + nu + S);
+                if constexpr (PROF) pa = clock64();
                 if (RELCULL && g.zskip == 2 && (((ib + 1) & ib) == 0 || (ib & 31) == 31)) {   // as in cf_main_tile: log2(acc) moves slowly
                     double m = acc[0];
 #pragma unroll
                     for (int i = 1; i < NACC; i++) m = __builtin_fmin(m, acc[i]);
                     acc_e = (m > 1.0e-290) ? __builtin_amdgcn_frexp_exp(m) : -100000;
                 }
+                if constexpr (PROF) pf_thr += clock64() - pa;
             }
+            if constexpr (PROF) pa = clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PROF) pf_vm += clock64() - pa;
             if (MODE3) asm volatile("" :: "v"(rn), "v"(rn1));
             __syncthreads();
+            if constexpr (PROF) pf_wait += clock64() - pa;
         }
     }
     if (!wave_active) return;
     if ((tid & 63) == 0) {
         atomicAdd(&stats[2], (unsigned long long)n_rows);
         atomicAdd(&stats[3], (unsigned long long)n_dead);
+        if constexpr (PROF) {
+            atomicAdd(&g_prof_fq[0], 1ull);
+            atomicAdd(&g_prof_fq[1], clock64() - pf_t0);
+            atomicAdd(&g_prof_fq[2], pf_stage);
+            atomicAdd(&g_prof_fq[3], pf_wait);
+            atomicAdd(&g_prof_fq[4], pf_dead);
+            atomicAdd(&g_prof_fq[5], pf_live);
+            atomicAdd(&g_prof_fq[6], pf_hdr);
+            atomicAdd(&g_prof_fq[7], pf_nd);
+            atomicAdd(&g_prof_fq[8], pf_nl);
+            if ((tid >> 6) == 0) atomicAdd(&g_prof_fq[9], pf_wait);
+            atomicAdd(&g_prof_fq[10], pf_thr);
+            atomicAdd(&g_prof_fq[11], pf_vm);
+            atomicAdd(&g_prof_fq[12], pf_pro);
+            atomicAdd(&g_prof_fq[13], pf_nr);
+            atomicAdd(&g_prof_fq[14], pf_rows);
+        }
     }
 
     const int64_t JKacc = (int64_t)J * g.Kacc;
@@ -833,29 +930,60 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     }
 }
 
-template <bool DIM3, bool OF, bool M3, int JT, int R>
+template <bool DIM3, bool OF, bool M3, int JT, int R, int ROWS = 0>
 static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
 {
     const int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
     if constexpr (M3) {
         if (a.lane_b) {   // include_baryon (df_mode 3 only)
-            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, true>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT,
+            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, true, ROWS>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT,
                                a.lane_pT, a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
             return;
         }
     }
-    hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
+#ifdef IS3D_DEV
+    if constexpr (DIM3 && OF && !M3 && JT == 8) {
+        // dev: the cycle-accounting instantiation (df_mode 4, 8 x 7), synchronous, counters to stderr
+        if (dev_env("IS3D_DEV_PROF")) {
+            unsigned long long h[16] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_fq), h, sizeof h);
+            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, false, ROWS, true>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
+                               a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof_fq), sizeof h);
+            const double T = (double)h[1];
+            fprintf(stderr, "[prof_fq rows=%d zskip=%d] waves %llu  cycles/wave %.3e  stage %.4f  wait %.4f (first wave of the workgroup %.4f)  dead units %.4f  live units %.4f "
+                            "(bounds + row tests %.4f, evaluated rows %.4f)  thr %.4f  vmcnt part of wait %.4f  prologue %.4f | dead units %llu (%.0f cycles each)  "
+                            "live units %llu (%.0f cycles each)  rows evaluated %llu (%.0f cycles each)\n",
+                    ROWS, a.g.zskip, h[0], T / (double)h[0], h[2] / T, h[3] / T, h[9] / T, h[4] / T, h[5] / T, h[6] / T, h[14] / T, h[10] / T, h[11] / T, h[12] / T,
+                    h[7], h[7] ? (double)h[4] / h[7] : 0.0, h[8], h[8] ? (double)h[5] / h[8] : 0.0, h[13], h[13] ? (double)h[14] / h[13] : 0.0);
+            return;
+        }
+    }
+#endif
+    hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, false, ROWS>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
                        a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
 }
 
 template <bool DIM3, bool OF, bool M3>
 static void launch_fq_variant(int variant, const FqMainArgs &a, hipStream_t st)
 {
-    // tile shapes of main_tile_shape (cf_kernels.hip): variants 2, 3, 4
-    switch (variant) {
-    case 3: launch_fq_t<DIM3, OF, M3, (DIM3 ? 8 : 12), (DIM3 ? 7 : 61)>(a, st); break;
-    case 4: launch_fq_t<DIM3, OF, M3, 4, (DIM3 ? 7 : 61)>(a, st); break;
-    default: launch_fq_t<DIM3, OF, M3, (DIM3 ? 6 : 8), (DIM3 ? 7 : 61)>(a, st); break;
+    // tile shapes of main_tile_shape (cf_kernels.hip): variants 2, 3, 4; in 3+1D variants 5 and 6 are the 8 x 7 tile of variant 3 with the
+    // rows walked as ROWS = 0 (the pipelined round-1 form) resp. ROWS = 2 (row mask from the unit threshold only) for A/B
+    if constexpr (DIM3) {
+        switch (variant) {
+        case 3: launch_fq_t<DIM3, OF, M3, 8, 7, 1>(a, st); break;
+        case 5: launch_fq_t<DIM3, OF, M3, 8, 7, 0>(a, st); break;
+        case 6: launch_fq_t<DIM3, OF, M3, 8, 7, 2>(a, st); break;
+        case 4: launch_fq_t<DIM3, OF, M3, 4, 7, 1>(a, st); break;
+        default: launch_fq_t<DIM3, OF, M3, 6, 7, 1>(a, st); break;
+        }
+    } else {
+        switch (variant) {
+        case 3: launch_fq_t<DIM3, OF, M3, 12, 61>(a, st); break;
+        case 4: launch_fq_t<DIM3, OF, M3, 4, 61>(a, st); break;
+        default: launch_fq_t<DIM3, OF, M3, 8, 61>(a, st); break;
+        }
     }
 }
 

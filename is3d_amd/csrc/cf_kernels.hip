@@ -32,6 +32,7 @@
 
 #include "cf_launch.h"
 #include "cf_math.h"
+#include "errors.h"
 
 namespace is3d {
 
@@ -736,7 +737,7 @@ static int prep_batch_cells(int K)
 {
     if (K > 32) return kPrepCB;
     // dev switch (A/B only): IS3D_PREP_CB3 = 4 | 16 cells per workgroup batch in 3+1D (8 measured between the two)
-    static const int env = [] { const char *e = getenv("IS3D_PREP_CB3"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16) ? v : 0; }();
+    static const int env = [] { const char *e = dev_env("IS3D_PREP_CB3"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16) ? v : 0; }();
     return env ? env : kPrepCB3;
 }
 
@@ -758,12 +759,13 @@ hipError_t launch_prep(const PrepParams &p_in, hipStream_t stream)
     const int cb = prep_batch_cells(p.K);
     int nbatch = (p.n_cells + cb - 1) / cb;
     int grid = nbatch < 4096 ? nbatch : 4096;
-    {   // dev switch (A/B only): IS3D_PREP_PAIR = 0 | 1 | 3, read per launch so that one process can alternate
-        const char *e = getenv("IS3D_PREP_PAIR");
+    {   // dev switches (-DIS3D_DEV builds only, errors.h): IS3D_PREP_PAIR = 0 | 1 | 3, read per launch so that one process can alternate
+        const char *e = dev_env("IS3D_PREP_PAIR");
         p.pair_writer = e ? atoi(e) : kPrepWriterDefault;
-        const char *k = getenv("IS3D_PREP_SKIP");
+        if (p.pair_writer != 0 && p.pair_writer != 1 && p.pair_writer != 3) p.pair_writer = kPrepWriterDefault;
+        const char *k = dev_env("IS3D_PREP_SKIP");
         p.dev_skip = k ? atoi(k) : 0;
-        const char *w = getenv("IS3D_PREP_W0");          // wave 0's share of the units while it runs the next batch's phase 1, in %
+        const char *w = dev_env("IS3D_PREP_W0");          // wave 0's share of the units while it runs the next batch's phase 1, in %
         p.w0_share = w ? atoi(w) : 0;
         if (p.w0_share < 1 || p.w0_share > 100) p.w0_share = p.dim3 ? kPrepW0Share3 : kPrepW0Share2;
     }
@@ -1776,7 +1778,7 @@ static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
     const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0);
     if constexpr (CE && OF && RG && MODE >= 1 && !BARYON) {
         // dev: the cycle-accounting instantiation, synchronous, counters to stderr
-        static const bool prof = std::getenv("IS3D_DEV_PROF") != nullptr;
+        static const bool prof = dev_env("IS3D_DEV_PROF") != nullptr;
         if (prof) {
             unsigned long long h[16] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof3e), h, sizeof h);

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -49,6 +50,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;   // optional: polled by the waits behind a collective
 };
 
 Rccl &rccl()
@@ -98,6 +100,7 @@ Rccl &rccl()
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (ok) r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(r.handle, "ncclCommGetAsyncError");
         if (!ok) { dlclose(r.handle); r.handle = nullptr; }
     });
     return r;
@@ -153,6 +156,7 @@ struct is3d_comm {
     bool flag_in_flight = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last collective (is3d_comm_timings)
     bool timed = false, aborted = false;
+    double timeout_s = 300.0;         // deadline of every host-side wait behind a collective (is3d_comm_set_timeout; IS3D_COMM_TIMEOUT_S at creation)
 };
 
 namespace is3d {
@@ -203,7 +207,8 @@ void comm_abort(is3d_comm *c)
 {
     if (c->comm && rccl().handle && rccl().CommAbort) {
         (void)hipSetDevice(c->device);
-        (void)rccl().CommAbort(c->comm);   // frees the communicator; peers blocked in a collective with this rank get an error instead of waiting
+        (void)rccl().CommAbort(c->comm);   // frees the communicator and makes THIS rank's collective kernels exit; the peers are not told:
+                                           // each finds out through its own comm_wait (asynchronous error or deadline)
     }
     c->comm = nullptr;
     c->aborted = true;
@@ -233,7 +238,47 @@ int comm_allreduce_flagged(is3d_comm *c, double *dN_dev, int64_t n, bool local_e
     return IS3D_OK;
 }
 
-// running total of the error words since the last read; synchronises the stream
+// Host-side wait for work that sits behind a collective -- the stream (ev == nullptr) or one event -- WITH A DEADLINE.  RCCL enqueues an
+// all-reduce and returns at once; if a peer never joins (it crashed, or it aborted its own communicator: a local ncclCommAbort does not
+// unblock the other ranks' kernels), the collective's kernel spins on the device and hipStreamSynchronize would block this process for
+// ever.  So the wait polls hipStreamQuery / hipEventQuery together with ncclCommGetAsyncError and, on an asynchronous RCCL error or after
+// timeout_s, aborts THIS rank's communicator (which makes its own collective kernel exit) and returns IS3D_ENODEVICE -- the caller is
+// expected to exit non-zero so that the launcher tears the job down.
+int comm_wait(is3d_comm *c, hipStream_t st, hipEvent_t ev, const char *what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    for (;;) {
+        const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+        if (q == hipSuccess) return IS3D_OK;
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            comm_abort(c);
+            return fail(IS3D_ENODEVICE, "%s: %s while waiting behind a collective on rank %d of %d; the communicator was aborted", what, hipGetErrorString(q),
+                        c->rank, c->n_ranks);
+        }
+        (void)hipGetLastError();   // hipErrorNotReady is sticky in hipGetLastError otherwise
+        if (c->comm && rccl().CommGetAsyncError) {
+            ncclResult_t ar = ncclSuccess;
+            if (rccl().CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                const std::string w = rccl().GetErrorString(ar);
+                comm_abort(c);
+                return fail(IS3D_ENODEVICE, "%s: RCCL reported an asynchronous error on rank %d of %d (%s); the communicator was aborted", what, c->rank,
+                            c->n_ranks, w.c_str());
+            }
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > c->timeout_s) {
+            comm_abort(c);
+            return fail(IS3D_ENODEVICE, "%s: rank %d of %d waited %.0f s behind a collective (a peer that never joined?); the communicator was aborted -- "
+                        "this rank should exit so that the launcher ends the job", what, c->rank, c->n_ranks, waited);
+        }
+        if (++spins < 2000) std::this_thread::yield();                              // the usual case: a few hundred microseconds
+        else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 50 : 500));
+    }
+}
+
+// running total of the error words since the last read; waits for the stream (with the communicator's deadline)
 int comm_read_errors(is3d_comm *c, hipStream_t st, double *total)
 {
     *total = 0.0;
@@ -241,7 +286,7 @@ int comm_read_errors(is3d_comm *c, hipStream_t st, double *total)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_flag + 3, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemsetAsync(c->d_flag + 3, 0, sizeof(double), st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = comm_wait(c, st, nullptr, "is3d_comm_check")) return rc;
     *total = c->h_flag[0];
     c->flag_in_flight = false;
     return IS3D_OK;
@@ -275,8 +320,29 @@ extern "C" int is3d_comm_create(is3d_comm **out, const uint8_t id[IS3D_COMM_ID_B
         is3d_comm_destroy(c);
         return fail(IS3D_ENODEVICE, "is3d_comm_create: cannot allocate the communicator's error word / events");
     }
+    if (const char *t = getenv("IS3D_COMM_TIMEOUT_S")) {
+        const double v = atof(t);
+        if (v > 0.0) c->timeout_s = v;
+    }
     *out = c;
     return IS3D_OK;
+}
+
+extern "C" int is3d_comm_set_timeout(is3d_comm *c, double seconds)
+{
+    if (!c || !(seconds > 0.0)) return fail(IS3D_EINVAL, "is3d_comm_set_timeout: null communicator or seconds <= 0");
+    c->timeout_s = seconds;
+    return IS3D_OK;
+}
+
+// wait for everything enqueued on hip_stream (kernels, collectives) with the communicator's deadline: what a host calls instead of
+// hipStreamSynchronize behind an is3d_plan_execute_allreduce whose peers may have died
+extern "C" int is3d_comm_synchronize(is3d_comm *c, void *hip_stream)
+{
+    if (!c) return fail(IS3D_EINVAL, "null communicator");
+    if (c->aborted) return fail(IS3D_ENODEVICE, "the communicator was aborted");
+    HIP_TRY(hipSetDevice(c->device));
+    return comm_wait(c, (hipStream_t)hip_stream, nullptr, "is3d_comm_synchronize");
 }
 
 extern "C" int is3d_comm_rank(const is3d_comm *c, int32_t *rank, int32_t *n_ranks)
@@ -328,7 +394,7 @@ extern "C" int is3d_comm_timings(is3d_comm *c, double *ms_allreduce)
     *ms_allreduce = 0.0;
     if (!c->timed || c->aborted) return IS3D_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev1));
+    if (int rc = comm_wait(c, nullptr, c->ev1, "is3d_comm_timings")) return rc;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *ms_allreduce = ms;
@@ -353,9 +419,11 @@ extern "C" int is3d_plan_execute_allreduce(is3d_plan *plan, const is3d_cells *sh
     if (!comm) return is3d_plan_execute(plan, shard, dN_out, hip_stream, status);
     if (comm->aborted) return fail(IS3D_ENODEVICE, "is3d_plan_execute_allreduce: the communicator was aborted");
     hipStream_t st = (hipStream_t)hip_stream;
-    // A rank must never leave its peers waiting in ncclAllReduce.  Whatever happens locally, it either joins the collective -- with its
-    // error word set, so that EVERY rank learns the sum is incomplete -- or, when it cannot (no buffer to reduce, a HIP error: the stream
-    // may be dead), aborts the communicator, which makes the peers' collective fail instead of hang.
+    // A rank should never leave its peers waiting in ncclAllReduce.  Whatever happens locally, it joins the collective if it can -- with its
+    // error word set, so that EVERY rank learns the sum is incomplete.  When it cannot (no buffer to reduce, a HIP error: the stream may be
+    // dead) it aborts its own communicator and returns an error; its host is expected to exit non-zero so that the launcher ends the job.
+    // The PEERS are protected by their own deadline, not by this rank's abort: every host-side wait behind a collective (comm_wait) polls
+    // the stream together with ncclCommGetAsyncError and gives up after the communicator's timeout.
     if (!plan || !dN_out) {
         comm_abort(comm);
         return fail(IS3D_EINVAL, "is3d_plan_execute_allreduce: null plan or spectrum; the communicator was aborted so that the other ranks do not wait");

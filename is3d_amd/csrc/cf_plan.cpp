@@ -155,7 +155,7 @@ static int validate(const is3d_species *sp, const is3d_grid *g, const is3d_df_ta
     return IS3D_OK;
 }
 
-extern "C" const char *is3d_version(void) { return "is3d_amd 0.1 (gfx950)"; }
+extern "C" const char *is3d_version(void) { return is3d::kDevBuild ? "is3d_amd 0.1 (gfx950) DEV BUILD" : "is3d_amd 0.1 (gfx950)"; }
 extern "C" int is3d_device_count(void)
 {
     int n = 0;
@@ -216,8 +216,11 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if ((P->variant == 7 || P->variant == 8) && (o->dimension == 3 || fq)) P->variant = default_variant;
     if (P->variant == 8 && o->include_baryon) P->variant = 7;   // variant 8 = variant 7 with the register-staged copy (A/B), without baryon slots only   // unit-strided lanes: the 2+1D delta-f tile kernel
     const bool e2ok = o->dimension == 3 && !fq && g->n_pT <= is3d::kE2Stride;   // the E2 table stream exists for the 3+1D delta-f kernels
-    if ((P->variant == 5 || P->variant == 6) && !e2ok) P->variant = (fq || !plain3) ? default_variant : 3;
-    P->e2tab = P->variant == 5 || P->variant == 6;
+    // (modified equilibrium in 3+1D: variants 5 and 6 are A/B forms of its 8 x 7 kernel -- rows pipelined as in round 1 / row mask from the unit
+    // threshold only, cf_feqmod.hip -- without baryon slots)
+    const bool fq56 = fq && plain3;
+    if ((P->variant == 5 || P->variant == 6) && !e2ok && !fq56) P->variant = (fq || !plain3) ? default_variant : 3;
+    P->e2tab = (P->variant == 5 || P->variant == 6) && e2ok;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
@@ -477,7 +480,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves
-        static const int64_t kChunkRounds = [] { const char *e = getenv("IS3D_CHUNK_ROUNDS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 12); }();   // dev A/B
+        static const int64_t kChunkRounds = [] { const char *e = is3d::dev_env("IS3D_CHUNK_ROUNDS"); const int v = e ? atoi(e) : 0; return (int64_t)(v > 0 ? v : 12); }();   // dev A/B
         // Chunk count.  Two floors: enough tasks for ~12 rounds of the chip (load balance: lane-wave groups cull differently; 24 until the end of
         // round 3 -- on a 125 000-cell shard 144 instead of 288 chunks run the same 43.1 ms and reduce 0.3 ms less), and chunks of at
         // most ~1152 cells -- the streams of one (phi tile, chunk) pair are then ~5 MB, the readers' drift along them stays about the size of an
@@ -778,7 +781,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             // zero_skip 3, surface-relative cull (cf_main_tile3e with outflow && regulate_deltaf; include/is3d_amd.h): an eighth of the chunks
             // runs first with the accumulator-relative rule; their partial spectrum is a lower bound of the final one (all terms >= 0) and
             // floors the row-cull thresholds of the other chunks, which would otherwise each start from an empty accumulator
-            static const int surf_den = [] { const char *e = getenv("IS3D_SURFCULL_DEN"); const int v = e ? atoi(e) : 0; return v >= 2 ? v : 8; }();
+            static const int surf_den = [] { const char *e = is3d::dev_env("IS3D_SURFCULL_DEN"); const int v = e ? atoi(e) : 0; return v >= 2 ? v : 8; }();
             const bool surf = o.zero_skip == 3 && P->e2tab && o.outflow != 0 && o.regulate_deltaf != 0 && nch_used >= 2 * surf_den;
             if (surf) {
                 const int nA = nch_used / surf_den;

@@ -2,7 +2,12 @@
 //
 // Each function states the reference routine whose observable behaviour it reproduces
 // (paths relative to /root/reference).  Nothing here calls exit(): errors become IS3D_E* codes.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <memory>
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <complex>
 #include <cstdarg>
@@ -247,12 +252,10 @@ extern "C" int is3d_table_read(const char *path, int64_t *n_rows, int32_t *n_col
 //   cell_arrays23 order: T P E tau eta ux uy un dat dax day dan pixx pixy pixn piyy piyn bulkPi muB nB Vx Vy Vn
 //   (argument order of calculate_dN_pTdpTdphidy after the species arrays, emissionfunction.h:179).
 // ---------------------------------------------------------------------------------------------
-extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t include_baryondiff_deltaf,
-                                    int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
+// (text: the file's bytes; XY: optional {x, y} arrays for the cell positions, columns 2 and 3 -- the sampler wants them)
+static int surface_read_vh_text(const std::string &text, const char *path, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                                int32_t dimension, int64_t *n_cells, double *const *A, double *avg5, double *const *XY)
 {
-    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
-    std::string text;
-    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
     int64_t rows;
     int32_t cols;
     std::vector<double> tab;
@@ -285,8 +288,8 @@ extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, in
     double Tavg = 0, Eavg = 0, Pavg = 0, muBavg = 0, nBavg = 0, vol = 0;
     for (int64_t i = 0; i < rows; i++) {
         double tau = next();
-        (void)next();  // x
-        (void)next();  // y
+        const double xpos = next(), ypos = next();
+        if (XY) { XY[0][i] = xpos; XY[1][i] = ypos; }
         double eta = next();
         double dat = next(), dax = next(), day = next(), dan = next();
         double ux = next(), uy = next(), un = next();
@@ -324,6 +327,15 @@ extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, in
     return IS3D_OK;
 }
 
+extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                                    int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
+{
+    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    return surface_read_vh_text(text, path, include_baryon, include_baryondiff_deltaf, dimension, n_cells, A, avg5, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // FO_data_reader::read_surf_switch (src/cpp/readindata.cpp:133-144) for the viscous-hydro formats the smooth
 // path accepts (emissionfunction.cpp:1503: MODE 0, 1, 4, 6, 7; 5 = vorticity/polarisation and 2, 3 = VAH are
@@ -340,15 +352,12 @@ extern "C" int is3d_surface_read_vh(const char *path, int32_t include_baryon, in
 // hbar*c multiplies E, T, P, pi**, bulkPi, muB in modes 0, 1, 4, 6.  u^tau and the pi^{tau mu}, pi^{eta eta} columns are
 // read and dropped: the kernel reconstructs them (smooth_kernels.cpp:133, :166-170).
 // ---------------------------------------------------------------------------------------------
-extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf,
-                                 int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
+static int surface_read_text(const std::string &text, const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                             int32_t dimension, int64_t *n_cells, double *const *A, double *avg5, double *const *XY)
 {
-    if (mode == 1) return is3d_surface_read_vh(path, include_baryon, include_baryondiff_deltaf, dimension, n_cells, A, avg5);
+    if (mode == 1) return surface_read_vh_text(text, path, include_baryon, include_baryondiff_deltaf, dimension, n_cells, A, avg5, XY);
     if (mode != 0 && mode != 4 && mode != 5 && mode != 6 && mode != 7)
         return io_fail(IS3D_EINVAL, "surface mode %d is not a viscous-hydro format of the smooth path (0, 1, 4, 5, 6, 7)", mode);
-    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
-    std::string text;
-    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
     int64_t rows;
     int32_t cols;
     std::vector<double> tab;
@@ -378,8 +387,8 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
     double Tavg = 0, Eavg = 0, Pavg = 0, muBavg = 0, nBavg = 0, vol = 0;
     for (int64_t i = 0; i < rows; i++) {
         double tau = next();
-        (void)next();  // x
-        (void)next();  // y
+        const double xpos = next(), ypos = next();
+        if (XY) { XY[0][i] = xpos; XY[1][i] = ypos; }
         double eta = next();
         double dat, dax, day, dan, ux, uy, un, E, T, P, pixx, pixy, pixn, piyy, piyn, bulkPi, muB = 0.0, nB = 0.0;
         double Vx = 0.0, Vy = 0.0, Vn = 0.0;
@@ -475,6 +484,17 @@ extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include
     return IS3D_OK;
 }
 
+extern "C" int is3d_surface_read(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf,
+                                 int32_t dimension, int64_t *n_cells, double *const *A, double *avg5)
+{
+    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
+    if (mode != 0 && mode != 1 && mode != 4 && mode != 5 && mode != 6 && mode != 7)
+        return io_fail(IS3D_EINVAL, "surface mode %d is not a viscous-hydro format of the smooth path (0, 1, 4, 5, 6, 7)", mode);
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    return surface_read_text(text, path, mode, include_baryon, include_baryondiff_deltaf, dimension, n_cells, A, avg5, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // FO_data_reader::read_surf_VAH_PLMatch (mode 2; src/cpp/readindata.cpp:813-928) with aL_fit and R200
 // (src/cpp/arsenal.cpp:999-1065): 31 numbers per cell, hbar*c on E, T, P, PL, pi^{mu nu}, W^mu, bulkPi, and the anisotropic
@@ -509,11 +529,8 @@ double R200(double aL, bool *ok)
 }
 }  // namespace
 
-extern "C" int is3d_surface_read_vah(const char *path, int32_t dimension, int64_t *n_cells, double *const *A)
+static int surface_read_vah_text(const std::string &text, const char *path, int32_t dimension, int64_t *n_cells, double *const *A)
 {
-    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
-    std::string text;
-    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
     int64_t rows;
     int32_t cols;
     std::vector<double> tab;
@@ -577,6 +594,257 @@ extern "C" int is3d_surface_read_vah(const char *path, int32_t dimension, int64_
     }
     return IS3D_OK;
 }
+
+extern "C" int is3d_surface_read_vah(const char *path, int32_t dimension, int64_t *n_cells, double *const *A)
+{
+    if (!path || !n_cells) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    return surface_read_vah_text(text, path, dimension, n_cells, A);
+}
+
+// ---------------------------------------------------------------------------------------------
+// is3d_surface: a parsed surface owned by the library -- ONE read and ONE parse of the text (the two-call readers above parse it twice
+// and the sampler's position columns a third time), and a binary sidecar `<path>.is3dcache` so that the next run on the same file skips
+// the parse altogether (0.9 s of a 2 s run at 1e6 cells; 8 GPUs shrink everything else).  No reference counterpart: the reference parses
+// the text with operator>> on every run (readindata.cpp:320-468); what is kept is its result -- the cache holds exactly the arrays and
+// the averages the text parse produced, bit for bit.
+//   sidecar = 128-byte header + the stored arrays as raw fp64, in array order.  It is used only if ALL of these match the text file as it
+//   is now: size, mtime (ns), a hash of sampled blocks of its contents (first / last 64 KiB + 256 evenly spaced 4 KiB blocks; the whole
+//   file with cache = 2), and the parse parameters (mode, include_baryon, include_baryondiff_deltaf, dimension) -- and if its own size is
+//   what the header says.  Anything else: ignored, the text is parsed, the sidecar rewritten (temp file + rename; a directory that
+//   cannot be written to is not an error).  IS3D_NO_CACHE=1 (or cache = 0) neither reads nor writes one.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kSurfArraysVH = 25;    // cell_arrays23 + x, y
+constexpr int kSurfArraysVAH = 32;   // arrays32 of is3d_surface_read_vah
+
+struct CacheHeader {
+    char magic[8];
+    uint32_t version, header_bytes;
+    uint64_t text_size;
+    int64_t text_mtime_ns;
+    uint64_t sample_hash, full_hash;       // full_hash 0: not computed when the cache was written
+    int32_t mode, include_baryon, include_diff, dimension;
+    int64_t n_cells;
+    uint64_t array_mask;
+    double avg[5];
+    uint8_t pad[8];
+};
+static_assert(sizeof(CacheHeader) == 128, "cache header is 128 bytes");
+const char kCacheMagic[8] = {'I', 'S', '3', 'D', 'S', 'R', 'F', '1'};
+
+inline uint64_t mix64(uint64_t h, uint64_t w)
+{
+    h ^= w;
+    h *= 0x9E3779B97F4A7C15ULL;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ULL;
+    h ^= h >> 32;
+    return h;
+}
+uint64_t hash_bytes(uint64_t h, const char *p, size_t n)
+{
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = mix64(h, w);
+    }
+    uint64_t w = 0;
+    if (i < n) memcpy(&w, p + i, n - i);
+    return mix64(h, w ^ ((uint64_t)n << 56));
+}
+// sampled-content hash of an open file of `size` bytes (pread; no dependence on the file position)
+bool sample_hash_fd(int fd, uint64_t size, uint64_t *out)
+{
+    uint64_t h = mix64(0x1553D5AF0C0FFEEULL, size);
+    std::vector<char> buf(65536);
+    auto block = [&](uint64_t off, size_t len) {
+        if (off >= size) return true;
+        len = (size_t)std::min<uint64_t>(len, size - off);
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t r = pread(fd, buf.data() + got, len - got, (off_t)(off + got));
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        h = hash_bytes(mix64(h, off), buf.data(), len);
+        return true;
+    };
+    if (!block(0, 65536)) return false;
+    if (size > 65536 && !block(size - std::min<uint64_t>(size, 65536), 65536)) return false;
+    if (size > 2 * 65536)
+        for (int k = 1; k <= 256; k++)
+            if (!block((size / 257) * (uint64_t)k, 4096)) return false;
+    *out = h;
+    return true;
+}
+
+}  // namespace
+
+struct is3d_surface {
+    int64_t n = 0;
+    int32_t mode = 1, include_baryon = 0, include_diff = 0, dimension = 3;
+    std::vector<std::vector<double>> a;   // kSurfArraysVH or kSurfArraysVAH arrays; empty = not present
+    double avg[5] = {0, 0, 0, 0, 0};
+    int32_t source = 0;                   // 0 text parsed (no cache written) | 1 text parsed, cache written | 2 loaded from the cache
+    std::thread writer;                   // the sidecar is written while the caller computes
+    std::atomic<int> written{0};
+    ~is3d_surface() { if (writer.joinable()) writer.join(); }
+};
+
+namespace {
+
+bool cache_write(const std::string &cpath, const CacheHeader &hd, const is3d_surface *s)
+{
+    char tmp[4096];
+    snprintf(tmp, sizeof tmp, "%s.tmp.%ld", cpath.c_str(), (long)getpid());
+    FILE *f = fopen(tmp, "wb");
+    if (!f) return false;
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+    for (size_t k = 0; ok && k < s->a.size(); k++)
+        if ((hd.array_mask >> k) & 1ULL) ok = s->a[k].empty() || fwrite(s->a[k].data(), sizeof(double), s->a[k].size(), f) == s->a[k].size();
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp, cpath.c_str()) == 0;
+    if (!ok) (void)remove(tmp);
+    return ok;
+}
+
+}  // namespace
+
+extern "C" int is3d_surface_open(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf, int32_t dimension,
+                                 int32_t cache, is3d_surface **out)
+{
+    if (!path || !out) return io_fail(IS3D_EINVAL, "null argument");
+    *out = nullptr;
+    const bool vah = mode == 2;
+    if (!vah && mode != 0 && mode != 1 && mode != 4 && mode != 5 && mode != 6 && mode != 7)
+        return io_fail(IS3D_EINVAL, "surface mode %d: the smooth path reads the formats 0, 1, 2, 4, 5, 6, 7", mode);
+    if (cache < 0 || cache > 2) return io_fail(IS3D_EINVAL, "is3d_surface_open: cache = 0 (off) | 1 (use / write the sidecar) | 2 (as 1, whole-file hash)");
+    if (const char *e = getenv("IS3D_NO_CACHE"))
+        if (*e && strcmp(e, "0")) cache = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    struct stat stt;
+    if (fstat(fd, &stt) != 0) { close(fd); return io_fail(IS3D_EIO, "%s: cannot stat", path); }
+    const uint64_t tsize = (uint64_t)stt.st_size;
+    const int64_t tmtime = (int64_t)stt.st_mtim.tv_sec * 1000000000LL + (int64_t)stt.st_mtim.tv_nsec;
+    std::unique_ptr<is3d_surface> S(new is3d_surface);
+    S->mode = mode; S->include_baryon = include_baryon != 0; S->include_diff = include_baryondiff_deltaf != 0; S->dimension = dimension;
+    const int narr = vah ? kSurfArraysVAH : kSurfArraysVH;
+    S->a.resize((size_t)narr);
+    uint64_t mask = 0;
+    for (int k = 0; k < narr; k++) {
+        bool used = true;
+        if (!vah) used = k < 18 || (k == 18 && S->include_baryon) || (k > 18 && k < 23 && S->include_diff) || k >= 23;
+        if (used) mask |= 1ULL << k;
+    }
+    const std::string cpath = std::string(path) + ".is3dcache";
+    uint64_t shash = 0, fhash = 0;
+    std::string text;
+    if (cache) {
+        if (!sample_hash_fd(fd, tsize, &shash)) { close(fd); return io_fail(IS3D_EIO, "%s: read error", path); }
+        if (cache == 2) {
+            if (!slurp(path, text)) { close(fd); return io_fail(IS3D_EIO, "the data file %s cannot be opened", path); }
+            fhash = hash_bytes(0x1553D, text.data(), text.size());
+            if (!fhash) fhash = 1;
+        }
+        // ---- try the sidecar ----
+        FILE *cf = fopen(cpath.c_str(), "rb");
+        if (cf) {
+            CacheHeader hd;
+            bool ok = fread(&hd, sizeof hd, 1, cf) == 1 && !memcmp(hd.magic, kCacheMagic, 8) && hd.version == 1 && hd.header_bytes == sizeof hd &&
+                      hd.text_size == tsize && hd.text_mtime_ns == tmtime && hd.sample_hash == shash && hd.mode == mode &&
+                      hd.include_baryon == S->include_baryon && hd.include_diff == S->include_diff && hd.dimension == dimension &&
+                      hd.array_mask == mask && hd.n_cells >= 0 && (cache != 2 || hd.full_hash == fhash);
+            if (ok) {
+                struct stat cst;
+                const uint64_t want = sizeof hd + (uint64_t)__builtin_popcountll(mask) * (uint64_t)hd.n_cells * sizeof(double);
+                ok = fstat(fileno(cf), &cst) == 0 && (uint64_t)cst.st_size == want;
+            }
+            if (ok) {
+                for (int k = 0; ok && k < narr; k++)
+                    if ((mask >> k) & 1ULL) {
+                        S->a[(size_t)k].resize((size_t)hd.n_cells);
+                        ok = hd.n_cells == 0 || fread(S->a[(size_t)k].data(), sizeof(double), (size_t)hd.n_cells, cf) == (size_t)hd.n_cells;
+                    }
+                if (ok) {
+                    S->n = hd.n_cells;
+                    memcpy(S->avg, hd.avg, sizeof S->avg);
+                    S->source = 2;
+                }
+            }
+            fclose(cf);
+            if (ok) {
+                close(fd);
+                *out = S.release();
+                return IS3D_OK;
+            }
+            for (auto &v : S->a) v.clear();
+        }
+    }
+    close(fd);
+    // ---- parse the text: one read, one parse ----
+    if (text.empty() && !slurp(path, text)) return io_fail(IS3D_EIO, "the data file %s cannot be opened", path);
+    int64_t rows = 0;
+    for (const char *p = text.data(), *end = p + text.size(); p < end;) {   // a row is a '\n'-terminated line (Table / readBlockData)
+        const char *q = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!q) break;
+        rows++;
+        p = q + 1;
+    }
+    std::vector<double *> ptr((size_t)narr, nullptr);
+    for (int k = 0; k < narr; k++)
+        if ((mask >> k) & 1ULL) { S->a[(size_t)k].assign((size_t)std::max<int64_t>(rows, 1), 0.0); ptr[(size_t)k] = S->a[(size_t)k].data(); }
+    int64_t n = rows;
+    int rc;
+    if (vah) rc = surface_read_vah_text(text, path, dimension, &n, ptr.data());
+    else rc = surface_read_text(text, path, mode, include_baryon, include_baryondiff_deltaf, dimension, &n, ptr.data(), S->avg, ptr.data() + 23);
+    if (rc) return rc;
+    S->n = n;
+    if (n == 0)
+        for (auto &v : S->a) v.clear();
+    { std::string().swap(text); }
+    if (cache) {
+        CacheHeader hd;
+        memset(&hd, 0, sizeof hd);
+        memcpy(hd.magic, kCacheMagic, 8);
+        hd.version = 1; hd.header_bytes = sizeof hd;
+        hd.text_size = tsize; hd.text_mtime_ns = tmtime; hd.sample_hash = shash; hd.full_hash = fhash;
+        hd.mode = mode; hd.include_baryon = S->include_baryon; hd.include_diff = S->include_diff; hd.dimension = dimension;
+        hd.n_cells = n; hd.array_mask = mask;
+        memcpy(hd.avg, S->avg, sizeof hd.avg);
+        is3d_surface *raw = S.get();
+        S->source = 1;   // provisional; is3d_surface_source joins the writer and reports what happened
+        S->writer = std::thread([raw, cpath, hd] { raw->written.store(cache_write(cpath, hd, raw) ? 1 : -1); });
+    }
+    *out = S.release();
+    return IS3D_OK;
+}
+
+extern "C" int64_t is3d_surface_cells(const is3d_surface *s) { return s ? s->n : -1; }
+
+extern "C" int32_t is3d_surface_source(is3d_surface *s)
+{
+    if (!s) return -1;
+    if (s->writer.joinable()) s->writer.join();
+    if (s->source == 1 && s->written.load() != 1) s->source = 0;   // the sidecar could not be written (read-only directory): not an error
+    return s->source;
+}
+
+extern "C" int is3d_surface_arrays(const is3d_surface *s, const double **arrays, int32_t n_arrays, double avg5[5])
+{
+    if (!s || !arrays) return io_fail(IS3D_EINVAL, "null argument");
+    if (n_arrays != (int32_t)s->a.size())
+        return io_fail(IS3D_EINVAL, "is3d_surface_arrays: this surface (mode %d) has %zu arrays, %d asked for", s->mode, s->a.size(), n_arrays);
+    for (size_t k = 0; k < s->a.size(); k++) arrays[k] = s->a[k].empty() ? nullptr : s->a[k].data();
+    if (avg5) memcpy(avg5, s->avg, sizeof s->avg);
+    return IS3D_OK;
+}
+
+extern "C" void is3d_surface_close(is3d_surface *s) { delete s; }
 
 // ---------------------------------------------------------------------------------------------
 // The anisotropic-hydro branch of load_df_coefficient_data in the CUDA tree (src/cuda/deltafReader.cu): file names :74-81,
@@ -810,30 +1078,63 @@ extern "C" int is3d_write_results(const char *dir, int32_t dimension, int32_t np
     };
     auto yval = [&](int iy) { return (dimension == 2) ? 0.0 : y[iy]; };
     const std::string base(dir);
-    auto block = [&](std::ostream &f, int ipart) {
+    // The text of a species' block goes to two files; producing it is the whole cost of this function -- 0.6 GB for the 305-species list.
+    // Three of a row's four numbers (y, phip, pT) are the same for every species: their text "y\tphip\tpT\t" is formatted ONCE per (y, phi, pT)
+    // with the reference's own iostream manipulators (scientific, setprecision(8); setw(5) never pads a 14-character number), and a row is
+    // that prefix + the value by std::to_chars(scientific, 8) -- the shortest-path Ryu printf, digit for digit what operator<< prints for a
+    // finite double ("inf" / "nan" as well: the value carries no setw) -- + '\n'.  Blocks are formatted by up to 16 threads, 64 species at a
+    // time; a worker also writes its species' own file, while the concatenated file takes the finished group on a thread of its own.
+    std::vector<std::string> prefix((size_t)y_pts * nphi * npT);
+    for (int iy = 0; iy < y_pts; iy++)
+        for (int iphip = 0; iphip < nphi; iphip++)
+            for (int ipT = 0; ipT < npT; ipT++) {
+                std::ostringstream f;
+                f << std::scientific << std::setw(5) << std::setprecision(8) << yval(iy) << "\t" << phi[iphip] << "\t" << pT[ipT] << "\t";
+                prefix[((size_t)iy * nphi + iphip) * npT + ipT] = f.str();
+            }
+    size_t block_bytes = 0;
+    for (const std::string &q : prefix) block_bytes += q.size() + 24;
+    block_bytes += (size_t)y_pts * nphi;
+    auto block = [&](std::string &out, int ipart) {
+        out.clear();
+        out.reserve(block_bytes);
+        char num[40];
         for (int iy = 0; iy < y_pts; iy++)
             for (int iphip = 0; iphip < nphi; iphip++) {
-                for (int ipT = 0; ipT < npT; ipT++)
-                    f << std::scientific << std::setw(5) << std::setprecision(8) << yval(iy) << "\t" << phi[iphip] << "\t" << pT[ipT]
-                      << "\t" << dN[idx(ipart, ipT, iphip, iy)] << "\n";
-                f << "\n";
+                for (int ipT = 0; ipT < npT; ipT++) {
+                    out += prefix[((size_t)iy * nphi + iphip) * npT + ipT];
+                    const auto r = std::to_chars(num, num + sizeof num, dN[idx(ipart, ipT, iphip, iy)], std::chars_format::scientific, 8);
+                    out.append(num, (size_t)(r.ptr - num));
+                    out.push_back('\n');
+                }
+                out.push_back('\n');
             }
     };
-    // The text of a species' block goes to two files; formatting it (iostream, as the reference) is the whole cost of this
-    // function -- 0.6 GB for the 305-species list -- so the blocks are formatted by up to 16 threads, 64 species at a time.
     {
-        std::ofstream all(base + "/dN_pTdpTdphidy.dat", std::ios_base::app);
+        FILE *all = fopen((base + "/dN_pTdpTdphidy.dat").c_str(), "ab");
         if (!all) return io_fail(IS3D_EIO, "cannot open %s/dN_pTdpTdphidy.dat (the results directory must exist)", dir);
         const int group = 64;
-        for (int g0 = 0; g0 < npart; g0 += group) {
+        std::vector<std::string> text[2];
+        std::thread all_writer;
+        std::atomic<int> failed{0};          // 1: a species file could not be opened / written, 2: the concatenated file
+        std::atomic<int> failed_part{-1};
+        for (int g0 = 0, gi = 0; g0 < npart; g0 += group, gi++) {
             const int g1 = std::min(npart, g0 + group);
-            std::vector<std::string> text((size_t)(g1 - g0));
+            std::vector<std::string> &txt = text[gi & 1];
+            txt.resize((size_t)(g1 - g0));
             const int nthreads = (int)std::min<unsigned>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), (unsigned)(g1 - g0));
             auto work = [&](int t) {
                 for (int ipart = g0 + t; ipart < g1; ipart += nthreads) {
-                    std::ostringstream f;
-                    block(f, ipart);
-                    text[(size_t)(ipart - g0)] = f.str();
+                    std::string &blk = txt[(size_t)(ipart - g0)];
+                    block(blk, ipart);
+                    char name[64];
+                    snprintf(name, sizeof name, "/dN_pTdpTdphidy_%d.dat", (int)mc_id[ipart]);
+                    FILE *f = fopen((base + name).c_str(), "ab");
+                    static const char hdr[] = "y\tphip\tpT\tdN_pTdpTdphidy\n";
+                    bool ok = f != nullptr;
+                    if (ok) ok = fwrite(hdr, 1, sizeof hdr - 1, f) == sizeof hdr - 1 && fwrite(blk.data(), 1, blk.size(), f) == blk.size();
+                    if (f && fclose(f) != 0) ok = false;
+                    if (!ok) { failed.store(1); failed_part.store(ipart); }
                 }
             };
             if (nthreads == 1) work(0);
@@ -842,17 +1143,16 @@ extern "C" int is3d_write_results(const char *dir, int32_t dimension, int32_t np
                 for (int t = 0; t < nthreads; t++) th.emplace_back(work, t);
                 for (auto &x : th) x.join();
             }
-            for (int ipart = g0; ipart < g1; ipart++) {
-                const std::string &blk = text[(size_t)(ipart - g0)];
-                all.write(blk.data(), (std::streamsize)blk.size());
-                char name[64];
-                snprintf(name, sizeof name, "/dN_pTdpTdphidy_%d.dat", (int)mc_id[ipart]);
-                std::ofstream f(base + name, std::ios_base::app);
-                if (!f) return io_fail(IS3D_EIO, "cannot open %s%s", dir, name);
-                f << "y" << "\t" << "phip" << "\t" << "pT" << "\t" << "dN_pTdpTdphidy" << "\n";
-                f.write(blk.data(), (std::streamsize)blk.size());
-            }
+            if (all_writer.joinable()) all_writer.join();          // the previous group is out: order kept, its buffer free for the next
+            all_writer = std::thread([&txt, all, &failed] {
+                for (const std::string &blk : txt)
+                    if (fwrite(blk.data(), 1, blk.size(), all) != blk.size()) failed.store(2);
+            });
         }
+        if (all_writer.joinable()) all_writer.join();
+        if (fclose(all) != 0) failed.store(2);
+        if (failed.load() == 1) return io_fail(IS3D_EIO, "cannot write %s/dN_pTdpTdphidy_%d.dat", dir, (int)mc_id[std::max(failed_part.load(), 0)]);
+        if (failed.load() == 2) return io_fail(IS3D_EIO, "cannot write %s/dN_pTdpTdphidy.dat", dir);
     }
     if (phi_w) {  // vn_continuous
         const std::complex<double> I(0.0, 1.0);

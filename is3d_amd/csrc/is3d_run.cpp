@@ -188,15 +188,17 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
     // ---- surface (iS3D.cpp:90-98) ----
     int64_t n_cells = 0;
-    std::vector<std::vector<double>> arr(23);
-    double *ptr[23];
+    double *ptr[23] = {nullptr};
     double avg[5] = {0, 0, 0, 0, 0};
-    std::vector<std::vector<double>> varr(32);   // mode 2: the arrays of is3d_surface_read_vah
+    // the text surface: one read + one parse, or the binary sidecar input/surface.dat.is3dcache of an earlier run on the same file
+    // (is3d_surface_open; IS3D_NO_CACHE=1 disables); the arrays are the library's until the end of this function
+    is3d_surface *surf = nullptr;
+    struct SurfCloser { is3d_surface *&s; ~SurfCloser() { if (s) is3d_surface_close(s); } } surf_closer{surf};
+    const double *sa[32] = {nullptr};     // modes 0-7 except 2: cell_arrays23 + x, y; mode 2: arrays32
     if (vah) {
-        if (is3d_surface_read_vah("input/surface.dat", dimension, &n_cells, nullptr)) DIE("%s", is3d_last_error());
-        double *vp[32];
-        for (int a = 0; a < 32; a++) { varr[a].assign((size_t)n_cells, 0.0); vp[a] = varr[a].data(); }
-        if (n_cells > 0 && is3d_surface_read_vah("input/surface.dat", dimension, &n_cells, vp)) DIE("%s", is3d_last_error());
+        if (is3d_surface_open("input/surface.dat", 2, 0, 0, dimension, 1, &surf)) DIE("%s", is3d_last_error());
+        n_cells = is3d_surface_cells(surf);
+        if (is3d_surface_arrays(surf, sa, 32, nullptr)) DIE("%s", is3d_last_error());
     } else if (mem) {
         // iS3D.cpp:100-134: the surface comes from the caller's vectors, already in GeV / fm units (no hbar*c conversion)
         printf("Reading in freezeout surface from memory \n");
@@ -208,13 +210,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
             if (!ptr[a] && !(a == 4 && dimension == 2)) DIE("in-memory surface: a required array is NULL");
         if (n_cells > 0) surface_averages(mem, avg);
     } else {
-        if (is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, nullptr, nullptr)) DIE("%s", is3d_last_error());
-        for (int a = 0; a < 23; a++) {
-            const bool used = a < 18 || (a == 18 && include_baryon) || (a > 18 && include_diff);
-            arr[a].assign(used ? (size_t)n_cells : 0, 0.0);
-            ptr[a] = used ? arr[a].data() : nullptr;
-        }
-        if (n_cells > 0 && is3d_surface_read("input/surface.dat", mode, include_baryon, include_diff, dimension, &n_cells, ptr, avg)) DIE("%s", is3d_last_error());
+        if (is3d_surface_open("input/surface.dat", mode, include_baryon, include_diff, dimension, 1, &surf)) DIE("%s", is3d_last_error());
+        n_cells = is3d_surface_cells(surf);
+        if (is3d_surface_arrays(surf, sa, 25, avg)) DIE("%s", is3d_last_error());
+        for (int a = 0; a < 23; a++) ptr[a] = const_cast<double *>(sa[a]);   // read-only from here on
     }
     if (!vah) {   // read_surf_VAH_PLMatch accumulates no averages (readindata.cpp:813-928)
         std::ofstream f("average_thermodynamic_quantities.dat", std::ios_base::out);
@@ -316,14 +315,9 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (mem) {
             if (mem_x) xs.assign(mem_x, mem_x + n_cells);
             if (mem_y) ys.assign(mem_y, mem_y + n_cells);
-        } else {
-            int64_t rows = 0;
-            int32_t cols = 0;
-            if (is3d_table_read("input/surface.dat", &rows, &cols, nullptr, 0)) DIE("%s", is3d_last_error());
-            if (rows != n_cells || cols < 3) DIE("input/surface.dat: %lld rows x %d columns, expected %lld cells", (long long)rows, cols, (long long)n_cells);
-            std::vector<double> tab((size_t)rows * cols);
-            if (is3d_table_read("input/surface.dat", &rows, &cols, tab.data(), (int64_t)tab.size())) DIE("%s", is3d_last_error());
-            for (int64_t r = 0; r < rows; r++) { xs[r] = tab[(size_t)r * cols + 1]; ys[r] = tab[(size_t)r * cols + 2]; }
+        } else if (n_cells > 0) {   // they came with the surface (is3d_surface_arrays: arrays 23, 24)
+            xs.assign(sa[23], sa[23] + n_cells);
+            ys.assign(sa[24], sa[24] + n_cells);
         }
         int32_t n_alpha = 0, n_pts = 0;
         const char *gla_path = "tables/gla_roots_weights_32_points.txt";
@@ -448,7 +442,7 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         vc.n_cells = n_cells;
         const double **vf[25] = {&vc.tau, &vc.eta, &vc.ux, &vc.uy, &vc.un, &vc.dat, &vc.dax, &vc.day, &vc.dan, &vc.T, &vc.pitt, &vc.pitx, &vc.pity,
                                  &vc.pitn, &vc.pixx, &vc.pixy, &vc.pixn, &vc.piyy, &vc.piyn, &vc.pinn, &vc.bulkPi, &vc.Wx, &vc.Wy, &vc.Lambda, &vc.aL};
-        for (int a = 0; a < 25; a++) *vf[a] = varr[a].data();
+        for (int a = 0; a < 25; a++) *vf[a] = sa[a];
         rc = is3d_smooth_spectra_vah_df(&vc, &sp, &grid, &vt, &opts, dN.data(), &st);
     } else if (feqmod) {
         printf("computing thermal spectra from vhydro with feqmod...\n");
@@ -498,7 +492,11 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     printf("species classes evaluated: %d of %d; cells skipped (u.dsigma <= 0): %lld\n", st.n_classes, sp.n, (long long)st.n_cells_skipped);
     printf("device time: prep %.3f ms, main %.3f ms (kernel variant %d), finalize %.3f ms; h2d %.3f ms, d2h %.3f ms\n", st.ms_prep,
            st.ms_main, st.kernel_variant, st.ms_finalize, st.ms_h2d, st.ms_d2h);
+    const int src_kind = surf ? is3d_surface_source(surf) : -1;
     printf("wall: read %.3f s, spectra %.3f s, write %.3f s\n", t1 - t0, t2 - t1, t3 - t2);
+    if (src_kind >= 0)
+        printf("surface: %s\n", src_kind == 2 ? "binary sidecar input/surface.dat.is3dcache (matches the text file; IS3D_NO_CACHE=1 to ignore)"
+                                 : src_kind == 1 ? "text parsed, sidecar input/surface.dat.is3dcache written for the next run" : "text parsed");
     if (res) {
         res->operation = 1; res->n_species = sp.n; res->n_spectrum = (int64_t)dN.size();
         res->spectrum = (double *)malloc(sizeof(double) * dN.size());

@@ -7,7 +7,9 @@
 // The nine entry points cf_multi.hip binds.  A communicator is a POSIX shared-memory segment named after the unique id: a generation-counting
 // barrier, an abort flag, and one slot of doubles per rank.  ncclAllReduce(sum, double) synchronises the stream, copies the device buffer into
 // the rank's slot, meets the other ranks, sums the slots in rank order, copies the sum back and meets again; a rank that finds the abort flag
-// while waiting returns ncclSystemError -- which is how a real communicator answers a peer's ncclCommAbort.
+// while waiting returns ncclSystemError.  THAT IS A PROPERTY OF THIS DOUBLE, NOT OF RCCL: a real ncclAllReduce is enqueued and returns
+// ncclSuccess at once, and a peer's local ncclCommAbort does not unblock it -- the library's protection against a rank that never joins is
+// the deadline of its own host-side waits (cf_multi.hip::comm_wait), which this double cannot exercise because its all-reduce is host-synchronous.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 

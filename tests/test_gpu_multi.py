@@ -279,6 +279,51 @@ def _check_multi_rank_line(d):
     assert 0 < d["executed_fraction_of_value"] <= 1 and d["value_incl_transfers"] > 0 and d["ms_per_step_incl_transfers"] > 0
 
 
+def test_waits_behind_a_collective_have_a_deadline(fx):
+    """RCCL enqueues an all-reduce and returns; a rank whose peer never joins would block for ever in hipStreamSynchronize.  The library's
+    own host-side waits (is3d_comm_check, is3d_comm_synchronize, is3d_comm_timings, the status read-back of is3d_plan_execute_allreduce) poll
+    the stream against the communicator's deadline instead and abort THIS rank's communicator when it passes.  One real RCCL rank here, so
+    nothing can actually hang: the deadline is set far below the time the enqueued kernels need (a 40 000-cell urqmd surface: tens of ms),
+    which takes the same code path as a peer that never arrives."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 40000
+    cells = synth.synth_surface(n, 3, seed=8)
+    o = dict(dimension=3, df_mode=2)
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = api.Plan(fx["urqmd"], fx["grid"], fx["df"], o, max_cells=n)
+    out = torch.zeros(plan.output_size, dtype=torch.float64, device=dev)
+    comm = api.Comm(api.Comm.unique_id(), 1, 0, 0)
+    plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    comm.synchronize(stream)                                            # default deadline (300 s): finishes
+    ref = out.cpu().numpy().copy()
+    comm.set_timeout(1e-4)
+    plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    with pytest.raises(api.Is3dError) as e:
+        comm.synchronize(stream)
+    assert e.value.code == api.IS3D_ENODEVICE and "waited" in str(e.value) and "aborted" in str(e.value)
+    torch.cuda.synchronize()                                            # the kernels themselves were fine
+    assert np.array_equal(out.cpu().numpy(), ref)
+    with pytest.raises(api.Is3dError) as e:                             # the communicator is gone, as after any abort
+        plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    assert e.value.code == api.IS3D_ENODEVICE
+    with pytest.raises(api.Is3dError):
+        comm.set_timeout(0.0)
+    comm.close()
+    # the same deadline inside is3d_comm_check
+    comm = api.Comm(api.Comm.unique_id(), 1, 0, 0)
+    comm.set_timeout(1e-4)
+    plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    with pytest.raises(api.Is3dError) as e:
+        comm.check(stream)
+    assert e.value.code == api.IS3D_ENODEVICE and "is3d_comm_check" in str(e.value)
+    torch.cuda.synchronize()
+    comm.close()
+    plan.close()
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts the two rank processes itself (before it
     imports torch), they share the one GPU through --backend gloo, and exactly one JSON line comes back -- strong scaling of ONE
@@ -338,7 +383,9 @@ def test_two_ranks_through_a_stub_communicator(tmp_path):
     communicator is pointed (IS3D_RCCL_LIBRARY) at a process-level test double of the nine RCCL entry points it binds
     (tests/cpp/fake_rccl.cpp: shared-memory slots, a barrier, an abort flag).  What this exercises for real is the library's own
     multi-rank logic: the sum over ranks, the error word (a failed rank joins with zeros, every rank learns), IS3D_EPEER on the
-    synchronous path, survival of the communicator, and ncclCommAbort making a peer's collective fail instead of hang.  It is not a
+    synchronous path, survival of the communicator.  Step 5 (rank 1 aborts, rank 0's collective fails) shows BEHAVIOUR OF THE TEST DOUBLE
+    ONLY: its host-synchronous all-reduce sees a shared abort flag; a real RCCL all-reduce returns at once and a peer's local abort does not
+    unblock it -- there the library's deadline (test_waits_behind_a_collective_have_a_deadline) is what ends the wait.  It is not a
     test of RCCL; the first run with more than one real RCCL rank is the driver's SCALE run."""
     import json
     import sys

@@ -332,6 +332,40 @@ def test_writers_format(tmp_path):
         api.write_results(str(tmp_path / "missing_dir"), 2, [211], g["pT"], g["pT_w"], g["phi"], g["phi_w"], g["y"], dN[:npT * nphi])
 
 
+def test_writer_is_byte_for_byte_the_iostream_text(tmp_path):
+    """The spectra writer formats y / phi / pT once per row position and the value with std::to_chars(scientific, 8): every byte must be what
+    the reference's `f << scientific << setprecision(8) << y << "\\t" << ...` prints (= printf "%.8e"), for ordinary values, zeros of both
+    signs, subnormals, 9-digit rounding carries and non-finite values, over more species than one 64-species group of the writer's threads."""
+    g = inputs.grid()
+    npart, npT, nphi, ny = 70, 5, 3, 4
+    rng = np.random.default_rng(7)
+    n = npart * npT * nphi * ny
+    dN = rng.random(n) * 10.0 ** rng.integers(-320, 300, n) * rng.choice([1.0, -1.0], n)
+    dN[:12] = [0.0, -0.0, 5e-324, 2.2250738585072014e-308, 9.999999995e5, 9.9999999949e5, 1.0, 1.7976931348623157e308, np.inf, -np.inf, np.nan, 1.234567885e-7]
+    os.makedirs(tmp_path / "results" / "vn_continuous")
+    res = str(tmp_path / "results")
+    ids = [100 + i for i in range(npart)]
+    pT, phi, y = g["pT"][:npT], g["phi"][:nphi], g["y"][:ny]
+    api.write_results(res, 3, ids, pT, g["pT_w"][:npT], phi, g["phi_w"][:nphi], y, dN)
+    d4 = dN.reshape(ny, nphi, npT, npart)
+
+    def fmt(v):
+        return "%.8e" % v
+
+    want_all = []
+    for ip in range(npart):
+        blk = []
+        for iy in range(ny):
+            for j in range(nphi):
+                for i in range(npT):
+                    blk.append("%s\t%s\t%s\t%s\n" % (fmt(y[iy]), fmt(phi[j]), fmt(pT[i]), fmt(d4[iy, j, i, ip])))
+                blk.append("\n")
+        blk = "".join(blk)
+        want_all.append(blk)
+        assert open(os.path.join(res, "dN_pTdpTdphidy_%d.dat" % ids[ip])).read() == "y\tphip\tpT\tdN_pTdpTdphidy\n" + blk, ip
+    assert open(os.path.join(res, "dN_pTdpTdphidy.dat")).read() == "".join(want_all)
+
+
 @pytest.mark.reference
 def test_readers_on_the_reference_files():
     """The shipped data files parse to the fixture the GPU box uses (is3d_amd/data/inputs_urqmd.json)."""
@@ -429,3 +463,136 @@ def test_vah_tables_of_the_reference_parse_to_the_fixture():
     tab = inputs.vah_df_tables()
     for k in ("L", "aL", "c0", "c1", "c2", "c3", "c4"):
         assert np.array_equal(got[k], tab[k]), k
+
+
+def test_surface_open_is_the_two_call_readers_in_one_pass(tmp_path):
+    """is3d_surface_open (one read, one parse, arrays owned by the library) gives bit for bit what is3d_surface_read / _read_vah give, for
+    every format of the smooth path, plus the position columns x, y the sampler wants; cache = 0 touches nothing next to the file."""
+    path = str(tmp_path / "surface.dat")
+    c3 = synth.synth_surface(41, 3, seed=31, baryon=True)
+    for mode, ib, idf in [(0, 1, 1), (1, 0, 0), (1, 1, 1), (4, 0, 0), (5, 1, 1), (6, 0, 0), (7, 0, 0)]:
+        if mode == 1:
+            synth.write_surface_dat(path, c3 if ib else {k: v for k, v in c3.items() if k not in synth.BARYON_FIELDS})
+        else:
+            refformat.write_surface_mode(path, c3, mode, include_baryon=ib, include_baryondiff=idf)
+        ref, avg_ref = api.surface_read(path, mode, ib, idf, 3)
+        got, avg, source = api.surface_open(path, mode, ib, idf, 3, cache=0)
+        assert source == 0 and not os.path.exists(path + ".is3dcache")
+        for k in api.SURFACE_READ_ORDER:
+            present = k in synth.CELL_FIELDS or (k == "muB" and ib) or (k in ("nB", "Vx", "Vy", "Vn") and idf)
+            if present:
+                assert np.array_equal(got[k], ref[k]), (mode, k)
+            else:
+                assert got[k] is None, (mode, k)
+        assert np.array_equal(avg, avg_ref)
+        cols = np.loadtxt(path, ndmin=2)
+        assert np.array_equal(got["x"], cols[:, 1]) and np.array_equal(got["y"], cols[:, 2])
+    vc = synth.synth_vah_surface(23, 3, seed=32)
+    synth.write_surface_vah_dat(path, vc)
+    ref = api.surface_read_vah(path, 3)
+    got, avg, source = api.surface_open(path, 2, dimension=3, cache=0)
+    assert avg is None and source == 0
+    for k in api.VAH_SURFACE_ORDER:
+        assert np.array_equal(got[k], ref[k]), k
+    # an unterminated single line is zero cells, a missing file IS3D_EIO, a format the path does not read IS3D_EINVAL
+    (tmp_path / "one.dat").write_text("0.5 0 0 0 1000.0 0 0 0 0 0 0 1.839  0.786  0.270 0 0 0 0 0 0")
+    got, _, _ = api.surface_open(str(tmp_path / "one.dat"), 1, cache=0)
+    assert len(got["tau"]) == 0
+    with pytest.raises(api.Is3dError) as e:
+        api.surface_open(str(tmp_path / "nope.dat"), 1)
+    assert e.value.code == api.IS3D_EIO
+    with pytest.raises(api.Is3dError) as e:
+        api.surface_open(path, 3)
+    assert e.value.code == api.IS3D_EINVAL
+
+
+def test_surface_sidecar_cache_and_its_invalidation_rules(tmp_path, monkeypatch):
+    """The binary sidecar `<path>.is3dcache` ("offer a binary cache"): written after the first parse, used -- bit for bit the
+    parsed arrays and averages -- when size, mtime, sampled-content hash and parse parameters match the text file as it is now, ignored and
+    rewritten otherwise; IS3D_NO_CACHE=1 neither reads nor writes one; cache = 2 hashes the whole text."""
+    monkeypatch.delenv("IS3D_NO_CACHE", raising=False)
+    path = str(tmp_path / "surface.dat")
+    side = path + ".is3dcache"
+    cells = synth.synth_surface(6000, 3, seed=33, baryon=True)       # ~ 3 MB of text: larger than the sampled head and tail
+    synth.write_surface_dat(path, cells)
+    first, avg1, s1 = api.surface_open(path, 1, 1, 1, 3)
+    assert s1 == 1 and os.path.exists(side)
+    n_arrays = 25
+    assert os.path.getsize(side) == 128 + n_arrays * 6000 * 8
+    again, avg2, s2 = api.surface_open(path, 1, 1, 1, 3)
+    assert s2 == 2 and np.array_equal(avg1, avg2)
+    for k in first:
+        assert np.array_equal(first[k], again[k]), k
+    ref, avg_ref = api.surface_read(path, 1, 1, 1, 3)
+    for k in api.SURFACE_READ_ORDER:
+        assert np.array_equal(again[k], ref[k]), k
+    assert np.array_equal(avg2, avg_ref)
+    # (a) other parse parameters: the sidecar of (include_baryon, diffusion) = (1, 1) is not the one of (0, 0) -- reparse, rewrite
+    _, _, s = api.surface_open(path, 1, 1, 0, 3)
+    assert s == 1 and os.path.getsize(side) == 128 + 21 * 6000 * 8
+    _, _, s = api.surface_open(path, 1, 1, 0, 3)
+    assert s == 2
+    _, _, s = api.surface_open(path, 1, 1, 0, 2)            # dimension is a parse parameter too (mode 0 / 4 treat dsigma_eta by it)
+    assert s == 1
+    # (b) mtime moved (same bytes): reparse
+    st = os.stat(path)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns + 1000))
+    _, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 1
+    _, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 2
+    # (c) content changed, size and mtime kept: a change inside a sampled block is seen by cache = 1 ...
+    st = os.stat(path)
+    text = bytearray(open(path, "rb").read())
+    size = len(text)
+    i = text.index(b"e", 100)                               # a digit of the first rows' mantissa -> 9 (head block)
+    text[i - 1:i] = b"9" if text[i - 1:i] != b"9" else b"8"
+    open(path, "wb").write(text)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
+    got, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 1
+    ref, _ = api.surface_read(path, 1, 1, 0, 2)
+    assert all(np.array_equal(got[k], ref[k]) for k in synth.CELL_FIELDS)
+    # ... one outside every sampled block (first / last 64 KiB, 256 blocks of 4 KiB at multiples of size // 257) only by cache = 2
+    st = os.stat(path)
+    kblk = 65536 // (size // 257) + 2                       # first sampled 4-KiB block that starts beyond the head
+    off = (size // 257) * kblk + 4096 + 700
+    assert 65536 < off < (size // 257) * (kblk + 1) - 64 and off < size - 65536
+    j = text.index(b"e", off)
+    text[j - 1:j] = b"7" if text[j - 1:j] != b"7" else b"6"
+    open(path, "wb").write(text)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
+    _, _, s = api.surface_open(path, 1, 1, 0, 2, cache=1)
+    assert s == 2                                           # the documented limit of the sampled hash
+    got, _, s = api.surface_open(path, 1, 1, 0, 2, cache=2)
+    assert s == 1                                           # the whole-file hash is not fooled
+    ref, _ = api.surface_read(path, 1, 1, 0, 2)
+    assert all(np.array_equal(got[k], ref[k]) for k in synth.CELL_FIELDS)
+    _, _, s = api.surface_open(path, 1, 1, 0, 2, cache=2)
+    assert s == 2
+    # (d) a truncated or foreign sidecar is ignored and replaced
+    blob = open(side, "rb").read()
+    open(side, "wb").write(blob[:-8])
+    _, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 1 and os.path.getsize(side) == len(blob)
+    open(side, "wb").write(b"not a cache")
+    _, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 1
+    # (e) size changed (a row appended)
+    with open(path, "ab") as f:
+        f.write(open(path, "rb").readline())
+    got, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 1 and len(got["tau"]) == 6001
+    # (f) IS3D_NO_CACHE=1: no read, no write
+    os.remove(side)
+    monkeypatch.setenv("IS3D_NO_CACHE", "1")
+    _, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 0 and not os.path.exists(side)
+    monkeypatch.delenv("IS3D_NO_CACHE")
+    # mode 2 (anisotropic hydro) has its own 32-array sidecar
+    vc = synth.synth_vah_surface(50, 3, seed=34)
+    vpath = str(tmp_path / "vah.dat")
+    synth.write_surface_vah_dat(vpath, vc)
+    a, _, s = api.surface_open(vpath, 2)
+    b, _, s2 = api.surface_open(vpath, 2)
+    assert (s, s2) == (1, 2) and all(np.array_equal(a[k], b[k]) for k in api.VAH_SURFACE_ORDER)

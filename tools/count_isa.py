@@ -47,7 +47,7 @@ def demangle_params(sym):
     elif name == "cf_main_tile3e":
         keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON"]
     elif name == "cf_main_feqmod":
-        keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON"]
+        keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON", "ROWS", "PROF"]
     elif name == "cf_main_vah":
         keys = ["DIM3", "REG", "JT", "R"]
     elif name == "cf_main_vah3":
