@@ -82,7 +82,7 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     d = json.load(open(p))
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
     if kernel_name == "cf_main_feqmod":
-        rows = (0 if variant == 5 else 2 if variant == 6 else 1) if d3 else 0   # how the kernel walks a unit's rows (cf_feqmod.hip)
+        rows = (0 if variant == 5 else 1 if variant == 6 else 2) if d3 else 0   # how the kernel walks a unit's rows (cf_feqmod.hip)
         key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d,ROWS=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1], rows)
     elif kernel_name == "cf_main_vah":
         key = "cf_main_vah:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
@@ -269,7 +269,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5", "config5-sampler"])
+    ap.add_argument("--events", type=int, default=20, help="--workload config5-sampler: events sampled per step")
     ap.add_argument("--df-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
     ap.add_argument("--cells", type=int, default=0, help="override the surface size: total cells (strong scaling) / cells per GPU (weak)")
@@ -349,6 +350,15 @@ def main():
             comm = None
             allreduce_by = "torch.distributed.all_reduce (%s)" % a.backend
 
+    if a.workload == "config5-sampler":
+        if comm is not None:
+            comm.close()   # the sampler shards need no collective: the streams are keyed by the global cell index
+        bench_sampler(a, rank, world, local, dev, multi, json_fd)
+        if multi:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     wl = workload(a.workload)
     if a.df_mode:
         wl["text"] += " -- df_mode overridden to %d" % a.df_mode
@@ -610,6 +620,164 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sampler_cpu_baseline(cells, sp, df, gla, opts, n_events, seed, seconds_budget):
+    """The serial CPU restatement of sample_dN_pTdpTdphidy (the reference IS serial over cells, emissionfunction_sampling_kernels.cpp:878: five
+    std:: engines consumed in cell order) on a bounded slice of the same surface, one core."""
+    from oracle import oracle  # checker doubling as the reported CPU baseline
+    n_all = len(cells["tau"])
+    nc = min(2000, n_all)
+    sub = {k: v[:nc] for k, v in cells.items()}
+    t0 = time.time()
+    oracle.sample_particles(sub, sp, df, gla, opts, n_events=n_events, seed=seed)
+    t_probe = max(time.time() - t0, 1e-3)
+    nc = int(max(nc, min(n_all, nc * 0.8 * seconds_budget / t_probe)))
+    sub = {k: v[:nc] for k, v in cells.items()}
+    t0 = time.time()
+    ref, rst = oracle.sample_particles(sub, sp, df, gla, opts, n_events=n_events, seed=seed)
+    dt = time.time() - t0
+    return dict(value=nc * n_events / dt, unit="cell-events/s", cores=1, cores_available=host_cores(), cpu_model=host_cpu_model(), kind="port",
+                particles_per_s=rst["n_kept"] / dt,
+                sample="first %d cells of the workload surface x %d events, oracle sampler (serial over cells like the reference), %.1f s" % (nc, n_events, dt)), ref, nc
+
+
+def bench_sampler(a, rank, world, local, dev, multi, json_fd):
+    """--workload config5-sampler: the Monte Carlo particle-sampler leg of BASELINE config 5 (sample_dN_pTdpTdphidy,
+    /root/reference/src/cpp/emissionfunction_sampling_kernels.cpp:833-1225) on the 1e6-cell surface: a step = `--events` events over the rank's
+    shard through the device-resident is3d_sampler_plan (cell arrays and the particle buffer in HBM; densities + cell records, Poisson pass +
+    compaction, count pass + scan, fill pass).  The shards need no collective (streams keyed by the global cell index)."""
+    import torch
+    from is3d_amd import api, inputs, synth
+    from is3d_amd import dist as idist
+    if multi:
+        import torch.distributed as dist
+    df_mode = a.df_mode or 2
+    n_total = (a.cells or 1000000) * (world if a.scaling == "weak" else 1)
+    lo, hi = idist.shard_bounds(n_total, rank, world)
+    n_loc = hi - lo
+    sp = inputs.species("urqmd")
+    df = inputs.df_tables()
+    cells = synth.synth_surface(n_loc, 3, first_cell=lo)
+    T_avg = idist.surface_average_T_global(cells) if df_mode in (3, 4) else 0.15
+    gla = inputs.feqmod_tables(T_avg)
+    opts = dict(dimension=3, df_mode=df_mode, device=local)
+    seed = 20260002
+    fq = gla if df_mode in (3, 4) else None
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}     # resident in HBM before timing
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    plan = api.SamplerPlan(sp, df, gla, opts, max_cells=max(n_loc, 1), fq=fq)
+    count, st0 = plan.execute(n_loc, ptrs, a.events, seed, first_cell=lo)          # count-only: sizes the particle buffer (and the workspaces)
+    buf = torch.zeros(max(count, 1) * api.PARTICLE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    keys = ("ms_prep", "ms_density", "ms_count", "ms_poisson", "ms_fill")
+    ms = {k: [] for k in keys}
+    last = {}
+
+    def step(record):
+        n, st = plan.execute(n_loc, ptrs, a.events, seed, particles_ptr=buf.data_ptr(), capacity=count, first_cell=lo)
+        assert n == count
+        if record:
+            for k in keys:
+                ms[k].append(st[k])
+            last.update(st)
+
+    def fence():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    p0, a0 = api.resource_counters()
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    allocs_in_steps = api.resource_counters()[1] - a0
+    if multi:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # the one-shot host entry (pageable arrays in, particle list out, plan + workspaces created inside): what operation = 2 of the driver calls
+    host_entry = None
+    if world == 1:
+        t1 = time.perf_counter()
+        plist, sth = api.sample_particles(cells, sp, df, gla, opts, n_events=a.events, seed=seed, fq=fq)
+        host_entry = dict(ms=(time.perf_counter() - t1) * 1e3, ms_h2d=sth["ms_h2d"], ms_device=sth["ms_prep"] + sth["ms_count"] + sth["ms_fill"],
+                          particles=int(sth["n_particles"]),
+                          note="is3d_sample_particles twice (count-only, then fill): plan + workspaces + pageable H->D + kernels + D->H of the list")
+        got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=api.PARTICLE_DTYPE)[:count]
+        same_as_host_entry = bool(len(plist) == count and all(np.array_equal(got[f], plist[f]) for f in got.dtype.names))
+    mine = dict(rank=rank, device=local, cells=n_loc, first_cell=lo, particles=count, hadrons_drawn=int(last.get("n_hadrons_drawn", 0)),
+                kernel_ms={k[3:]: float(np.mean(v)) for k, v in ms.items()})
+    ranks = None
+    if multi:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    if rank != 0:
+        plan.close()
+        return
+    particles_all = sum(r["particles"] for r in ranks) if ranks else count
+    dev_ms = float(np.mean(ms["ms_prep"]) + np.mean(ms["ms_count"]) + np.mean(ms["ms_fill"]))
+    kms = {k[3:]: float(np.mean(v)) for k, v in ms.items()}
+    kms["cells_records"] = kms["prep"] - kms["density"]
+    kms["count_and_scan"] = kms["count"] - kms["poisson"]
+    value = float(n_total) * a.events * a.steps / elapsed
+    n_used_arrays = 18
+    b_alg = 8.0 * n_used_arrays * n_loc + 96.0 * count
+    # fp64-VALU view of the Gauss-Laguerre density kernel (flops per node from the emitted ISA, tools/count_isa.py)
+    rv = None
+    icp = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
+    ic = json.load(open(icp)).get("cf_sampler_density") if os.path.exists(icp) else None
+    if ic and kms["density"] > 0:
+        nodes = float(n_loc) * last["n_classes"] * len(gla["root1"])
+        tf = nodes * ic["flop_per_node"] / (kms["density"] * 1e-3) / 1e12
+        rv = dict(bound="fp64_valu", kernel="cf_sampler_density", kernel_ms=kms["density"], achieved=tf, peak=FP64_VALU_PEAK_TF, unit="TFLOP/s",
+                  frac=tf / FP64_VALU_PEAK_TF, quadrature_nodes_per_launch=nodes, flop_per_node=ic["flop_per_node"],
+                  fp64_valu_instr_per_node=ic["valu_f64_instr_per_node"])
+    div = None
+    pp = os.path.join(ROOT, "profiles", "r04_pmc_sampler.json")
+    if os.path.exists(pp):
+        div = json.load(open(pp))
+    res = dict(metric="FO-cell x event samples/sec (Monte Carlo particle sampler, the second leg of BASELINE config 5)", value=value, unit="cell-events/s",
+               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling, vs_baseline=None,
+               dtype="f64", data="synthetic",
+               particles_per_s=float(particles_all) * a.steps / elapsed, particles_per_step=particles_all,
+               hadrons_drawn_per_step=int(last["n_hadrons_drawn"]) if not ranks else sum(r["hadrons_drawn"] for r in ranks),
+               momentum_sampling_efficiency=last["n_acceptances"] / max(last["n_momentum_samples"], 1),
+               device_ms_per_step=dev_ms, device_allocations_during_timed_steps=allocs_in_steps,
+               value_note="(cell, event) pairs sampled per second, wall clock of the steps; cell arrays and the particle buffer resident in HBM; a step also "
+                          "reads back two counters per event batch (the number of emitting pairs, the batch's particle count), nothing else crosses PCIe",
+               host_entry=host_entry, same_list_as_host_entry=(same_as_host_entry if world == 1 else None), ranks=ranks,
+               config=dict(workload="BASELINE config 5, sampler leg: 1e6-cell synthetic 3+1D surface (seed 20260002), %s, 305-species pdg-urqmd_v3.3+ list, "
+                                    "%d events per step, regular (not fast) mode; the reference's VAH sampler is an empty stub "
+                                    "(emissionfunction_sampling_kernels.cpp:1231-1239), so the viscous-hydro sampler is what exists to be measured" % (
+                                        {1: "14-moment delta-f", 2: "Chapman-Enskog delta-f", 3: "modified equilibrium (Mike)", 4: "modified equilibrium (Jonah)"}[df_mode], a.events),
+                           cells_total=n_total, cells_per_gpu=n_loc, species=len(sp["mass"]), species_classes_evaluated=last["n_classes"], events=a.events,
+                           df_mode=df_mode, parallelism=("cell-axis shards x%d, no collective" % world) if world > 1 else "1 GPU"),
+               kernel_ms=kms,
+               roofline=dict(bound="hbm", achieved=b_alg / (dev_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b_alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             traffic=(div or {}).get("hbm_bytes_per_step"), traffic_source=(div or {}).get("source"),
+                             kernel="the sampler's kernels of one step (density, cell records, Poisson, compaction, count, scan, fill)", kernel_ms=dev_ms,
+                             algorithmic_bytes=b_alg,
+                             note="algorithmic bytes = 18 cell arrays read once + 96 B per kept particle written; not the binding bound: the time goes to "
+                                  "fp64 quadrature (density), Philox + rejection loops (count / fill, divergent) -- roofline_valu, divergence"),
+               roofline_valu=rv, divergence=div)
+    if not a.no_cpu_baseline:
+        cb, ref, nc = sampler_cpu_baseline(cells, sp, df, gla, dict(dimension=3, df_mode=df_mode), a.events, seed, a.cpu_baseline_seconds)
+        res["cpu_baseline"] = cb
+        res["gpu_over_cpu"] = value / cb["value"]
+        if world == 1:   # and the checker's list on that slice is the device's list (same hadrons, same order)
+            got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=api.PARTICLE_DTYPE)[:count]
+            sel = got["cell"] < nc
+            res["cpu_baseline"]["same_list_on_the_slice"] = bool(int(sel.sum()) == len(ref["E"]) and np.array_equal(got["species"][sel], ref["species"]))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(res) + "\n").encode())
+    plan.close()
+
 
 
 if __name__ == "__main__":

@@ -487,6 +487,8 @@ typedef struct {
     int32_t n_classes, reserved;
     int64_t n_cells_breakdown;          /* df_mode 3: cells sampled with the linear delta-f instead (:1038) */
     double ms_h2d, ms_prep, ms_count, ms_fill;   /* device time: upload, densities + cell records, count pass + scan, fill pass */
+    double ms_density;                  /* part of ms_prep: cf_sampler_density (the Gauss-Laguerre density integrals per (cell, class)) */
+    double ms_poisson;                  /* part of ms_count: cf_sampler_poisson + the compaction of the emitting (event, cell) pairs */
 } is3d_sampler_stats;
 
 /* All pointers HOST memory; opts: dimension, df_mode (1-4), include_bulk_deltaf, include_shear_deltaf, device.  Particles
@@ -495,6 +497,20 @@ typedef struct {
 int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
                           const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
                           int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats);
+/* Device-resident, persistent form (what bench.py --workload config5-sampler times; is3d_sample_particles is create + upload + execute +
+ * download + destroy, so the two give the same list bit for bit): the species classes, splines / bilinear grids, Jonah tables and fast-mode
+ * densities are set up once from (species, df, in, opts) -- `in` as for is3d_sample_particles; its n_events, seed, first_cell, x, y and
+ * batch_events are execute-time arguments here -- and the workspaces (8 B x classes + 360 B per cell, 25 B per (event, cell) of a batch) are
+ * allocated at the first execute of a shape and kept.  execute: cells->* and x, y are DEVICE arrays on the plan's device (x, y may be NULL),
+ * particles a DEVICE buffer of `capacity` entries (NULL: count only); runs on the null stream and returns when the list is complete.
+ * stats->ms_h2d is 0 (nothing is uploaded).  Return codes as is3d_sample_particles; cells->n_cells > max_cells: IS3D_EINVAL. */
+typedef struct is3d_sampler_plan is3d_sampler_plan;
+int is3d_sampler_plan_create(is3d_sampler_plan **plan, const is3d_species *species, const is3d_df_tables *df, const is3d_sampler_inputs *in,
+                             const is3d_options *opts, int64_t max_cells);
+int is3d_sampler_plan_execute(is3d_sampler_plan *plan, const is3d_cells *cells_dev, const double *x_dev, const double *y_dev, int32_t n_events,
+                              uint64_t seed, int64_t first_cell, int32_t batch_events, is3d_particle *particles_dev, int64_t capacity,
+                              int64_t *n_particles, is3d_sampler_stats *stats);
+void is3d_sampler_plan_destroy(is3d_sampler_plan *plan);
 /* is3d_sample_particles over several devices: the same contiguous cell shards, shard s on devices[s] with first_cell advanced to
  * the shard's first cell -- the counter-based streams are keyed by the GLOBAL cell index, so the hadrons are exactly those one device
  * samples; the shard lists are merged into the single-device order (event, cell, draw).  No collective at all.  Same calling

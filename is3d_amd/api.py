@@ -70,7 +70,7 @@ class SamplerStats(C.Structure):
     _fields_ = [("n_cells_skipped", C.c_int64), ("n_hadrons_drawn", C.c_int64), ("n_momentum_samples", C.c_int64),
                 ("n_acceptances", C.c_int64), ("n_classes", C.c_int32), ("reserved", C.c_int32), ("n_cells_breakdown", C.c_int64),
                 ("ms_h2d", C.c_double),
-                ("ms_prep", C.c_double), ("ms_count", C.c_double), ("ms_fill", C.c_double)]
+                ("ms_prep", C.c_double), ("ms_count", C.c_double), ("ms_fill", C.c_double), ("ms_density", C.c_double), ("ms_poisson", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -104,7 +104,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
            "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi",
            "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_comm_set_timeout", "is3d_comm_synchronize", "is3d_surface_open", "is3d_surface_cells", "is3d_surface_source",
-           "is3d_surface_arrays", "is3d_surface_close", "is3d_multi_plan_create", "is3d_multi_plan_execute",
+           "is3d_surface_arrays", "is3d_surface_close", "is3d_sampler_plan_create", "is3d_sampler_plan_execute", "is3d_sampler_plan_destroy", "is3d_multi_plan_create", "is3d_multi_plan_execute",
            "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
            "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
            "is3d_vah_plan_workspace_bytes", "is3d_vah_plan_execute", "is3d_vah_plan_set_timing", "is3d_vah_plan_timings",
@@ -904,6 +904,53 @@ def sample_particles(cells, species, df, gla, opts=None, n_events=1, seed=1, y_c
     d = st.as_dict()
     d["n_particles"] = int(cnt.value)
     return out[:min(int(cnt.value), int(capacity))], d
+
+
+class SamplerPlan:
+    """is3d_sampler_plan_*: the device-resident, persistent form of is3d_sample_particles.  Tables, species classes and (after the first
+    execute of a shape) the workspaces live on the device; execute takes DEVICE pointers for the cell arrays (dict field -> int), an optional
+    DEVICE particle buffer (PARTICLE_DTYPE entries) and returns (n_particles, stats).  The list is the one is3d_sample_particles gives."""
+
+    def __init__(self, species, df, gla, opts=None, max_cells=1, fq=None, fast=0, T_avg=0.0, T_avg_switch=0.0, muB_avg=0.0, y_cut=0.5):
+        L = load()
+        grid_dummy = dict(pT=[1.0], phi=[0.0], y=[0.0], eta=[0.0], eta_w=[1.0])
+        sps, _, ds, os_, _, self._keep = _pack_common(species, grid_dummy, df, opts)
+        r1, w1 = _f64(gla["root1"]), _f64(gla["weight1"])
+        fqs = _pack_feqmod(fq, self._keep) if fq is not None else None
+        si = SamplerInputs(1, len(r1), 0, float(y_cut), 0, None, None, _p(r1), _p(w1), C.pointer(fqs) if fqs is not None else None, int(fast), 0,
+                           float(T_avg), float(T_avg_switch), float(muB_avg))
+        L.is3d_sampler_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Species), C.POINTER(DfTables), C.POINTER(SamplerInputs), C.POINTER(Options), C.c_int64]
+        L.is3d_sampler_plan_execute.argtypes = [C.c_void_p, C.POINTER(Cells), C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p,
+                                                C.c_int64, C.POINTER(C.c_int64), C.POINTER(SamplerStats)]
+        L.is3d_sampler_plan_destroy.argtypes = [C.c_void_p]
+        L.is3d_sampler_plan_destroy.restype = None
+        self._h = C.c_void_p()
+        _check(L.is3d_sampler_plan_create(C.byref(self._h), C.byref(sps), C.byref(ds), C.byref(si), C.byref(os_), int(max_cells)))
+
+    def execute(self, n_cells, dev_ptrs, n_events, seed, particles_ptr=0, capacity=0, x_ptr=0, y_ptr=0, first_cell=0, batch_events=0):
+        cs = Cells()
+        cs.n_cells = int(n_cells)
+        for f in CELL_FIELDS:
+            if dev_ptrs.get(f):
+                setattr(cs, f, int(dev_ptrs[f]))
+        cnt, st = C.c_int64(0), SamplerStats()
+        rc = load().is3d_sampler_plan_execute(self._h, C.byref(cs), C.c_void_p(int(x_ptr) or None), C.c_void_p(int(y_ptr) or None), int(n_events), int(seed),
+                                              int(first_cell), int(batch_events), C.c_void_p(int(particles_ptr) or None), int(capacity), C.byref(cnt), C.byref(st))
+        _check(rc)
+        d = st.as_dict()
+        d["n_particles"] = int(cnt.value)
+        return int(cnt.value), d
+
+    def close(self):
+        if self._h:
+            load().is3d_sampler_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class YieldInputs(C.Structure):

@@ -596,12 +596,17 @@ __device__ unsigned long long g_prof_fq[16];
 // ROWS: how the R rows of a 3+1D unit are walked.
 //   0  software pipeline (row r+1's twelve operands fetched before row r's evaluations), every row forms its own threshold and lower bound:
 //      the round-1 form, kept for 2+1D (61-row units) and as the A/B reference (kernel_variant 5)
-//   1  (default, 3+1D) liveness of all rows first, from ONE LDS round trip at the head of the unit that also brings the unit-level bounds: a
-//      row's test is {alphaf_k, min_j betaf_jk} (one 16-byte read) against the UNIT's threshold -- 4 instructions and no further read for a dead
-//      row instead of 6 reads and ~17 instructions; rows that pass are tested again against their own (tighter) threshold when their operands
-//      are there, so the set of culled rows is exactly that of ROWS = 0 (same status counters, bitwise the same spectrum)
-//   2  as 1 without the second, row-level test (kernel_variant 6; A/B)
-template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R, bool BARYON = false, int ROWS = 0, bool PROF = false>
+//   1  (kernel_variant 6; A/B) liveness of all rows first, from ONE LDS round trip at the head of the unit that also brings the unit-level
+//      bounds: a row's test is {alphaf_k, min_j betaf_jk} (one 16-byte read) against the UNIT's threshold -- 4 instructions and no further read
+//      for a dead row instead of 6 reads and ~17 instructions; rows that pass are tested again against their own (tighter) threshold when their
+//      operands are there, so the set of culled rows is exactly that of ROWS = 0 (same status counters, bitwise the same spectrum as ROWS = 0)
+//   2  (default, 3+1D) as 1 without the second, row-level test: 0.4 points fewer rows culled (60.0 against 60.4 % on the config-3 surface), ten
+//      instructions fewer per evaluated row -- 499 against 541 (ROWS = 1) and 558 ms (ROWS = 0).  zero_skip on / off stay bitwise identical.
+// LDSD: doubles of unit records per LDS buffer (two buffers per workgroup).  1536 (13 units of the 8 x 7 tile: 24 KB per workgroup) for the
+// two-wave workgroups that share a stream; 1100 (9 units, 18 KB) for ONE-wave workgroups (g.wpb == 1), eight of which must fit a CU's 160 KB:
+// a wave that stages its own stream has no barrier partner to wait for -- on the config-3 surface 9.7 % of all wave cycles were spent at the
+// per-batch barrier (the two lane-waves of a workgroup cull differently and drift apart), against 0.8 % issuing the staging loads that double.
+template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R, bool BARYON = false, int ROWS = 0, bool PROF = false, int LDSD = 1536>
 __global__ void __launch_bounds__(512)
 cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
                const double *__restrict__ lane_sign, const double *__restrict__ RN, const int32_t *__restrict__ lane_cls,
@@ -611,7 +616,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     constexpr int HDR = 4 * JT;
     constexpr int RW = 4 + JT;
     constexpr int REC = HDR + R * RW;
-    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
+    constexpr int UB = (LDSD / REC) > 0 ? (LDSD / REC) : 1;
     constexpr int BUF2 = UB * REC / 2;
     constexpr int NLD = (BUF2 + 127) / 128;
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
@@ -930,13 +935,13 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     }
 }
 
-template <bool DIM3, bool OF, bool M3, int JT, int R, int ROWS = 0>
-static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
+template <bool DIM3, bool OF, bool M3, int JT, int R, int ROWS, int LDSD>
+static void launch_fq_l(const FqMainArgs &a, hipStream_t st)
 {
     const int grid = ((a.g.NT + 7) / 8) * 8 * a.g.G;
     if constexpr (M3) {
         if (a.lane_b) {   // include_baryon (df_mode 3 only)
-            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, true, ROWS>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT,
+            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, true, ROWS, false, LDSD>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT,
                                a.lane_pT, a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
             return;
         }
@@ -947,36 +952,48 @@ static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
         if (dev_env("IS3D_DEV_PROF")) {
             unsigned long long h[16] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_fq), h, sizeof h);
-            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, false, ROWS, true>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
+            hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, false, ROWS, true, LDSD>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
                                a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof_fq), sizeof h);
             const double T = (double)h[1];
-            fprintf(stderr, "[prof_fq rows=%d zskip=%d] waves %llu  cycles/wave %.3e  stage %.4f  wait %.4f (first wave of the workgroup %.4f)  dead units %.4f  live units %.4f "
-                            "(bounds + row tests %.4f, evaluated rows %.4f)  thr %.4f  vmcnt part of wait %.4f  prologue %.4f | dead units %llu (%.0f cycles each)  "
+            fprintf(stderr, "[prof_fq rows=%d waves/workgroup=%d culling=%s] waves %llu  cycles/wave %.3e  stage %.4f  wait %.4f (first wave of the workgroup %.4f)  dead units %.4f  "
+                            "live units %.4f (bounds + row tests %.4f, evaluated rows %.4f)  thr %.4f  vmcnt part of wait %.4f  prologue %.4f | dead units %llu (%.0f cycles each)  "
                             "live units %llu (%.0f cycles each)  rows evaluated %llu (%.0f cycles each)\n",
-                    ROWS, a.g.zskip, h[0], T / (double)h[0], h[2] / T, h[3] / T, h[9] / T, h[4] / T, h[5] / T, h[6] / T, h[14] / T, h[10] / T, h[11] / T, h[12] / T,
-                    h[7], h[7] ? (double)h[4] / h[7] : 0.0, h[8], h[8] ? (double)h[5] / h[8] : 0.0, h[13], h[13] ? (double)h[14] / h[13] : 0.0);
+                    ROWS, a.g.wpb, a.g.zskip == 2 ? "on" : a.g.zskip == 1 ? "exact zeros" : "off", h[0], T / (double)h[0], h[2] / T, h[3] / T, h[9] / T, h[4] / T, h[5] / T,
+                    h[6] / T, h[14] / T, h[10] / T, h[11] / T, h[12] / T, h[7], h[7] ? (double)h[4] / h[7] : 0.0, h[8], h[8] ? (double)h[5] / h[8] : 0.0, h[13],
+                    h[13] ? (double)h[14] / h[13] : 0.0);
             return;
         }
     }
 #endif
-    hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, false, ROWS>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
+    hipLaunchKernelGGL((cf_main_feqmod<DIM3, OF, M3, JT, R, false, ROWS, false, LDSD>), dim3(grid), dim3(a.g.wpb * 64), 0, st, a.TS, a.lane_mT, a.lane_pT,
                        a.lane_sign, a.RN, a.lane_cls, a.ncls, a.partial, a.stats, a.g, a.lane_b, a.lane_sub);
+}
+
+template <bool DIM3, bool OF, bool M3, int JT, int R, int ROWS = 0>
+static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
+{
+    if constexpr (DIM3 && JT == 8 && ROWS != 0) {
+        // one-wave workgroups (3+1D, 8 x 7, no baryon slots): 9-unit LDS batches so that eight workgroups fit a CU, no barrier partner
+        if (a.g.wpb == 1 && !a.lane_b) { launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1100>(a, st); return; }
+    }
+    launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1536>(a, st);
 }
 
 template <bool DIM3, bool OF, bool M3>
 static void launch_fq_variant(int variant, const FqMainArgs &a, hipStream_t st)
 {
-    // tile shapes of main_tile_shape (cf_kernels.hip): variants 2, 3, 4; in 3+1D variants 5 and 6 are the 8 x 7 tile of variant 3 with the
-    // rows walked as ROWS = 0 (the pipelined round-1 form) resp. ROWS = 2 (row mask from the unit threshold only) for A/B
+    // tile shapes of main_tile_shape (cf_kernels.hip): variants 2, 3, 4 (3+1D: rows walked by the row mask from the unit threshold, ROWS = 2:
+    // 499 against 558 ms on the config-3 surface, profiles/r04_ab_feqmod.log); variants 5 and 6 are the 8 x 7 tile of variant 3 with ROWS = 0 (the
+    // pipelined round-1 form) resp. ROWS = 1 (row mask + the exact per-row thresholds: the culled set of ROWS = 0, 541 ms) for A/B
     if constexpr (DIM3) {
         switch (variant) {
-        case 3: launch_fq_t<DIM3, OF, M3, 8, 7, 1>(a, st); break;
+        case 3: launch_fq_t<DIM3, OF, M3, 8, 7, 2>(a, st); break;
         case 5: launch_fq_t<DIM3, OF, M3, 8, 7, 0>(a, st); break;
-        case 6: launch_fq_t<DIM3, OF, M3, 8, 7, 2>(a, st); break;
-        case 4: launch_fq_t<DIM3, OF, M3, 4, 7, 1>(a, st); break;
-        default: launch_fq_t<DIM3, OF, M3, 6, 7, 1>(a, st); break;
+        case 6: launch_fq_t<DIM3, OF, M3, 8, 7, 1>(a, st); break;
+        case 4: launch_fq_t<DIM3, OF, M3, 4, 7, 2>(a, st); break;
+        default: launch_fq_t<DIM3, OF, M3, 6, 7, 2>(a, st); break;
         }
     } else {
         switch (variant) {

@@ -216,8 +216,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if ((P->variant == 7 || P->variant == 8) && (o->dimension == 3 || fq)) P->variant = default_variant;
     if (P->variant == 8 && o->include_baryon) P->variant = 7;   // variant 8 = variant 7 with the register-staged copy (A/B), without baryon slots only   // unit-strided lanes: the 2+1D delta-f tile kernel
     const bool e2ok = o->dimension == 3 && !fq && g->n_pT <= is3d::kE2Stride;   // the E2 table stream exists for the 3+1D delta-f kernels
-    // (modified equilibrium in 3+1D: variants 5 and 6 are A/B forms of its 8 x 7 kernel -- rows pipelined as in round 1 / row mask from the unit
-    // threshold only, cf_feqmod.hip -- without baryon slots)
+    // (modified equilibrium in 3+1D: variants 5 and 6 are A/B forms of its 8 x 7 kernel -- rows pipelined as in round 1 / row mask with the exact
+    // per-row thresholds, cf_feqmod.hip -- without baryon slots)
     const bool fq56 = fq && plain3;
     if ((P->variant == 5 || P->variant == 6) && !e2ok && !fq56) P->variant = (fq || !plain3) ? default_variant : 3;
     P->e2tab = (P->variant == 5 || P->variant == 6) && e2ok;
@@ -477,6 +477,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             }
             if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
             if (o->waves_per_group == 1 && P->e2tab) P->wpb = 1;   // cf_main_tile3e: one-wave workgroups (no barrier partner)
+            // cf_main_feqmod, 3+1D 8 x 7 without baryon slots: one-wave workgroups (cf_feqmod.hip, LDSD); the pipelined A/B form (variant 5) keeps two
+            if (P->feqmod && P->dim3 && !P->baryon && (P->variant == 3 || P->variant == 6) && o->waves_per_group == 1) P->wpb = 1;
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves

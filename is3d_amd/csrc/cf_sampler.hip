@@ -32,6 +32,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "../../include/is3d_amd.h"
@@ -164,21 +166,46 @@ __device__ __forceinline__ double gt_J20(const double *root, const double *weigh
 
 // GT[cell][class] = the n_eq integral; GT2 (df_mode 3, regular mode) = the J20 integral of n_linear, GT3 (with include_baryon) its
 // J10 integral; muB_fo != NULL (include_baryon && include_baryondiff_deltaf): chem = baryon mu_B / T
+// The integrands are those of gt_neq / gt_J20 / gt_J10 above with the node-only factors taken out and tabulated once per workgroup
+// (c1 = w p e^p for the alpha = 1 nodes, c2 = w e^p for the alpha = 2 nodes: one exponential per node and integral instead of two), and with
+// exp_full / sqrt_nr / rcp_nr of cf_math.h (1e-15 relative; arguments of order 1 .. 1e3) in place of libm's exp, sqrt and the division -- as
+// cf_feqmod_renorm does since round 3: 3.3 -> ~1 ms per 1e6 cells x 75 classes.  An exponential that overflowed is held at 1e300 so that its
+// node adds < 1e-300 of its weight instead of a division by inf.
+constexpr int kSmpGlMax = 256;   // n_gla <= 256 (is3d_sampler_plan_create checks)
 __global__ void __launch_bounds__(256)
 cf_sampler_density(const double *__restrict__ T_fo, const double *__restrict__ muB_fo, int64_t n_cells, SamplerSpecies sp,
                    const double *__restrict__ gl, int ngl, double *__restrict__ GT, double *__restrict__ GT2, double *__restrict__ GT3)
 {
+    __shared__ double l_p1[kSmpGlMax], l_c1[kSmpGlMax], l_p2[kSmpGlMax], l_c2[kSmpGlMax];
+    for (int k = threadIdx.x; k < ngl; k += blockDim.x) {
+        const double p1 = gl[k];
+        l_p1[k] = p1 * p1; l_c1[k] = gl[ngl + k] * (p1 * exp(p1));
+        if (GT2) { const double p2 = gl[2 * ngl + k]; l_p2[k] = p2 * p2; l_c2[k] = gl[3 * ngl + k] * exp(p2); }
+    }
+    __syncthreads();
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_cells * sp.ncls) return;
     const int64_t cell = idx / sp.ncls;
     const int c = (int)(idx - cell * sp.ncls);
     const double T = T_fo[cell];
-    const double mbar = sp.cls_mass[c] / T;
+    const double mbar = sp.cls_mass[c] / T, mb2 = mbar * mbar, sign = sp.cls_sign[c];
     const double alphaB = muB_fo ? muB_fo[cell] / T : 0.0;
     const double chem = sp.cls_baryon ? sp.cls_baryon[c] * alphaB : 0.0;
-    GT[idx] = gt_neq(gl, gl + ngl, ngl, mbar, sp.cls_sign[c], chem);
-    if (GT2) GT2[idx] = gt_J20(gl + 2 * ngl, gl + 3 * ngl, ngl, mbar, sp.cls_sign[c], chem);
-    if (GT3) GT3[idx] = gt_J10(gl, gl + ngl, ngl, mbar, sp.cls_sign[c], chem);
+    double s_neq = 0.0, s_j10 = 0.0, s_j20 = 0.0;
+    for (int k = 0; k < ngl; k++) {
+        const double e = __builtin_fmin(exp_full(sqrt_nr(l_p1[k] + mb2) - chem), 1.0e300), r = rcp_nr(e + sign);
+        s_neq = __builtin_fma(l_c1[k], r, s_neq);
+        if (GT3) s_j10 = __builtin_fma(l_c1[k], (e * r) * r, s_j10);
+    }
+    GT[idx] = s_neq;
+    if (GT3) GT3[idx] = s_j10;
+    if (GT2) {
+        for (int k = 0; k < ngl; k++) {
+            const double E2 = sqrt_nr(l_p2[k] + mb2), e2 = __builtin_fmin(exp_full(E2 - chem), 1.0e300), r2 = rcp_nr(e2 + sign);
+            s_j20 = __builtin_fma(l_c2[k], E2 * ((e2 * r2) * r2), s_j20);
+        }
+        GT2[idx] = s_j20;
+    }
 }
 
 // mean-number weight of species ip in a cell: fast_max_particle_number (:239-280) / max_particle_number (:282-359)
@@ -594,14 +621,31 @@ struct DevMem {
 
 }  // namespace
 
-extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
-                                     const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
-                                     int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats)
+struct is3d_sampler_plan {
+    int device = 0;
+    int64_t max_cells = 0;
+    is3d_options o{};
+    bool three_d = true;
+    int ngla = 0, ncls = 0;
+    is3d::SamplerParams p{};
+    is3d::SamplerSpecies sp{};
+    DevMem d_mass, d_sign, d_deg, d_cls, d_cmass, d_csign, d_gl, d_splx, d_sply[3], d_splc[3];
+    DevMem d_bar, d_cbar, d_bilT, d_bilB, d_biltab[5];
+    DevMem d_jonah, d_eqd, d_bkd;
+    DevMem d_status, d_GT, d_GT2, d_GT3, d_rec, d_counts, d_offsets, d_scan_tmp;
+    DevMem d_drawn, d_emits, d_active, d_nactive;
+    int64_t cap_cells = 0, cap_bt = 0;      // what the workspaces above were sized for
+    size_t tmp_bytes = 0;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" int is3d_sampler_plan_create(is3d_sampler_plan **out, const is3d_species *species, const is3d_df_tables *df,
+                                        const is3d_sampler_inputs *in, const is3d_options *opts, int64_t max_cells)
 {
     using is3d::set_error;
-    if (!cells || !species || !df || !in || !opts || !n_particles) return set_error(IS3D_EINVAL, "null argument");
-    *n_particles = 0;
-    if (stats) memset(stats, 0, sizeof *stats);
+    if (!out || !species || !df || !in || !opts) return set_error(IS3D_EINVAL, "null argument");
+    *out = nullptr;
+    if (max_cells < 1) max_cells = 1;
     if (opts->dimension != 2 && opts->dimension != 3) return set_error(IS3D_EINVAL, "dimension must be 2 or 3 (got %d)", opts->dimension);
     if (opts->df_mode < 1 || opts->df_mode > 4) return set_error(IS3D_EINVAL, "the sampler takes df_mode 1, 2, 3 or 4 (got %d)", opts->df_mode);
     const is3d_feqmod_tables *fq = in->feqmod;
@@ -626,31 +670,30 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     if (species->n < 1 || !species->mass || !species->sign || !species->degeneracy) return set_error(IS3D_EINVAL, "empty species list");
     for (int s = 0; s < species->n; s++)
         if (!(species->mass[s] > 0.0)) return set_error(IS3D_EINVAL, "species %d has mass 0: photons cannot be sampled with this method (reference: exit, sampling_kernels.cpp:478-482)", s);
-    if (in->n_events < 1) return set_error(IS3D_EINVAL, "n_events must be >= 1");
-    if (in->n_gla < 1 || !in->root1 || !in->weight1) return set_error(IS3D_EINVAL, "the sampler needs the Gauss-Laguerre roots and weights for alpha = 1");
+    if (in->n_gla < 1 || in->n_gla > is3d::kSmpGlMax || !in->root1 || !in->weight1)
+        return set_error(IS3D_EINVAL, "the sampler needs the Gauss-Laguerre roots and weights for alpha = 1 (1 to %d nodes)", is3d::kSmpGlMax);
     if (df->n_T < 3 || !df->T) return set_error(IS3D_EINVAL, "coefficient table needs >= 3 temperatures");
     if (opts->df_mode == 1 && (!df->c0 || !df->c2)) return set_error(IS3D_EINVAL, "df_mode 1 needs c0 and c2 tables");
     if ((opts->df_mode == 2 || opts->df_mode == 3) && (!df->F || !df->betabulk || !df->betapi))
         return set_error(IS3D_EINVAL, "df_mode 2 / 3 need F, betabulk, betapi tables");
     if (opts->df_mode == 4 && !df->betapi) return set_error(IS3D_EINVAL, "df_mode 4 needs the betapi table");
-    if (particles == nullptr) capacity = 0;
-    const int64_t n = cells->n_cells;
-    if (n < 0 || n + in->first_cell > 0xffffffffLL) return set_error(IS3D_EINVAL, "cell indices must fit 32 bits for the counter-based streams");
-    const bool three_d = opts->dimension == 3;
-    if (n > 0) {
-        if (!cells->tau || !cells->dat || !cells->dax || !cells->day || !cells->dan || !cells->ux || !cells->uy || !cells->un ||
-            !cells->T || !cells->P || !cells->E || (three_d && !cells->eta))
-            return set_error(IS3D_EINVAL, "a required cell array is NULL");
-        if (opts->include_shear_deltaf && (!cells->pixx || !cells->pixy || !cells->pixn || !cells->piyy || !cells->piyn))
-            return set_error(IS3D_EINVAL, "include_shear_deltaf needs pixx, pixy, pixn, piyy, piyn");
-        if (opts->include_bulk_deltaf && !cells->bulkPi) return set_error(IS3D_EINVAL, "include_bulk_deltaf needs bulkPi");
-        if (baryondiff && (!cells->muB || !cells->nB || !cells->Vx || !cells->Vy || !cells->Vn))
-            return set_error(IS3D_EINVAL, "include_baryon && include_baryondiff_deltaf need muB, nB, Vx, Vy, Vn");
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
+    std::unique_ptr<is3d_sampler_plan> P(new is3d_sampler_plan);
+    is3d::count_resource(0);
     if (opts->device >= 0) SMP_TRY(hipSetDevice(opts->device));
-    if (n == 0) return IS3D_OK;
+    SMP_TRY(hipGetDevice(&P->device));
+    P->max_cells = max_cells;
+    P->o = *opts;
+    P->three_d = opts->dimension == 3;
+    P->ngla = in->n_gla;
+    const bool three_d = P->three_d;
+    auto &d_mass = P->d_mass; auto &d_sign = P->d_sign; auto &d_deg = P->d_deg; auto &d_cls = P->d_cls; auto &d_cmass = P->d_cmass; auto &d_csign = P->d_csign;
+    auto &d_gl = P->d_gl; auto &d_splx = P->d_splx; auto &d_sply = P->d_sply; auto &d_splc = P->d_splc;
+    auto &d_bar = P->d_bar; auto &d_cbar = P->d_cbar; auto &d_bilT = P->d_bilT; auto &d_bilB = P->d_bilB; auto &d_biltab = P->d_biltab;
+    auto &d_jonah = P->d_jonah; auto &d_eqd = P->d_eqd; auto &d_bkd = P->d_bkd;
+    is3d::SamplerParams &p = P->p;
+    is3d::SamplerSpecies &sp = P->sp;
 
     // ---- species classes (mass, sign[, baryon number]): the density integral is per class ----
     const int npart = species->n;
@@ -665,8 +708,6 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         cls[s] = found;
     }
     const int ncls = (int)cmass.size();
-    DevMem d_mass, d_sign, d_deg, d_cls, d_cmass, d_csign, d_gl, d_splx, d_sply[3], d_splc[3], d_cell[23], d_x, d_y;
-    DevMem d_bar, d_cbar, d_bilT, d_bilB, d_biltab[5];
     SMP_TRY(d_mass.upload(std::vector<double>(species->mass, species->mass + npart)));
     SMP_TRY(d_sign.upload(std::vector<double>(species->sign, species->sign + npart)));
     SMP_TRY(d_deg.upload(std::vector<double>(species->degeneracy, species->degeneracy + npart)));
@@ -683,10 +724,10 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         SMP_TRY(d_bar.upload(std::vector<double>(species->baryon, species->baryon + npart)));
         SMP_TRY(d_cbar.upload(cbar));
     }
-    is3d::SamplerSpecies sp{d_mass.as<double>(), d_sign.as<double>(), d_deg.as<double>(), d_cls.as<int32_t>(),
-                            d_cmass.as<double>(), d_csign.as<double>(), npart, ncls, d_bar.as<double>(), d_cbar.as<double>()};
+    sp = is3d::SamplerSpecies{d_mass.as<double>(), d_sign.as<double>(), d_deg.as<double>(), d_cls.as<int32_t>(),
+                              d_cmass.as<double>(), d_csign.as<double>(), npart, ncls, d_bar.as<double>(), d_cbar.as<double>()};
+    P->ncls = ncls;
     // ---- splines (deltafReader.cpp:300-322) ----
-    is3d::SamplerParams p{};
     std::vector<double> xs(df->T, df->T + df->n_T);
     for (int i = 1; i < df->n_T; i++)
         if (!(xs[i] > xs[i - 1])) return set_error(IS3D_EINVAL, "coefficient table temperatures must ascend");
@@ -720,35 +761,10 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         }
     }
     p.baryon = baryon; p.baryondiff = baryondiff;
-    // ---- cell arrays ----
-    const double *src[23] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
-                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
-                             cells->muB, cells->nB, cells->Vx, cells->Vy, cells->Vn};
-    const double *dptr[23];
-    hipEvent_t ev[6];
-    for (auto &e : ev) SMP_TRY(hipEventCreate(&e));
-    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 6; i++) (void)hipEventDestroy(e[i]); } } evg{ev};
-    SMP_TRY(hipEventRecord(ev[0], nullptr));
-    for (int a = 0; a < 23; a++) {
-        dptr[a] = nullptr;
-        const bool need = a < 12 ? (a != 1 || three_d) : (a < 17 ? opts->include_shear_deltaf != 0 : (a == 17 ? opts->include_bulk_deltaf != 0 : baryondiff));
-        if (src[a] && need) {
-            SMP_TRY(d_cell[a].alloc((size_t)n * sizeof(double)));
-            SMP_TRY(hipMemcpyAsync(d_cell[a].p, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
-            dptr[a] = d_cell[a].as<double>();
-        }
-    }
-    if (in->x) { SMP_TRY(d_x.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_x.p, in->x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
-    if (in->y) { SMP_TRY(d_y.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_y.p, in->y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
-    p.cells = {dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], dptr[9], dptr[10], dptr[11],
-               dptr[12], dptr[13], dptr[14], dptr[15], dptr[16], dptr[17], dptr[18], dptr[19], dptr[20], dptr[21], dptr[22]};
-    p.x = d_x.as<double>(); p.y = d_y.as<double>();
-    p.n_cells = n; p.first_cell = in->first_cell;
     p.dim3 = three_d; p.df_mode = opts->df_mode;
     p.include_bulk = opts->include_bulk_deltaf != 0; p.include_shear = opts->include_shear_deltaf != 0;
     p.ngl = in->n_gla; p.gl = d_gl.as<double>();
     // ---- df_mode 4: lambda(Pi/P), z(Pi/P) tables (deltafReader.cpp:222-297) ----
-    DevMem d_jonah, d_eqd, d_bkd;
     if (opts->df_mode == 4) {
         std::vector<double> bp, l2, zz, cl, cz, jon;
         is3d::jonah_tables(fq, bp, l2, zz, p.bp_max);
@@ -832,49 +848,130 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         } else if (opts->df_mode == 3) { p.F_avg = spline_at(0, Tsw) * Tsw; p.betabulk_avg = spline_at(1, Tsw) * Tsw * Tsw * Tsw * Tsw; }
     }
     p.y_max = three_d ? 0.5 : in->y_cut;                                              // :837-838
-    p.seed = in->seed;
-    DevMem d_status, d_GT, d_GT2, d_GT3, d_rec, d_counts, d_offsets, d_scan_tmp, d_particles;
-    SMP_TRY(d_status.alloc(8 * sizeof(unsigned long long)));
+    SMP_TRY(P->d_status.alloc(8 * sizeof(unsigned long long)));
+    p.status = P->d_status.as<unsigned long long>();
+    for (auto &e : P->ev) SMP_TRY(hipEventCreate(&e));
+    *out = P.release();
+    return IS3D_OK;
+}
+
+namespace {
+// cell-array checks shared by the host and the device entry (pointers are only tested for NULL here)
+int check_cells(const is3d_cells *cells, const is3d_options *o, int64_t first_cell)
+{
+    using is3d::set_error;
+    const int64_t n = cells->n_cells;
+    if (n < 0 || n + first_cell > 0xffffffffLL) return set_error(IS3D_EINVAL, "cell indices must fit 32 bits for the counter-based streams");
+    const bool three_d = o->dimension == 3;
+    const bool baryondiff = o->include_baryon != 0 && o->include_baryondiff_deltaf != 0;
+    if (n > 0) {
+        if (!cells->tau || !cells->dat || !cells->dax || !cells->day || !cells->dan || !cells->ux || !cells->uy || !cells->un ||
+            !cells->T || !cells->P || !cells->E || (three_d && !cells->eta))
+            return set_error(IS3D_EINVAL, "a required cell array is NULL");
+        if (o->include_shear_deltaf && (!cells->pixx || !cells->pixy || !cells->pixn || !cells->piyy || !cells->piyn))
+            return set_error(IS3D_EINVAL, "include_shear_deltaf needs pixx, pixy, pixn, piyy, piyn");
+        if (o->include_bulk_deltaf && !cells->bulkPi) return set_error(IS3D_EINVAL, "include_bulk_deltaf needs bulkPi");
+        if (baryondiff && (!cells->muB || !cells->nB || !cells->Vx || !cells->Vy || !cells->Vn))
+            return set_error(IS3D_EINVAL, "include_baryon && include_baryondiff_deltaf need muB, nB, Vx, Vy, Vn");
+    }
+    return IS3D_OK;
+}
+// which of the 23 cell arrays (CellPtrs order) the kernels read under these options
+bool cell_array_needed(int a, const is3d_options *o)
+{
+    const bool three_d = o->dimension == 3;
+    const bool baryondiff = o->include_baryon != 0 && o->include_baryondiff_deltaf != 0;
+    return a < 12 ? (a != 1 || three_d) : (a < 17 ? o->include_shear_deltaf != 0 : (a == 17 ? o->include_bulk_deltaf != 0 : baryondiff));
+}
+}  // namespace
+
+extern "C" void is3d_sampler_plan_destroy(is3d_sampler_plan *P)
+{
+    if (!P) return;
+    (void)hipSetDevice(P->device);
+    for (auto &e : P->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete P;
+}
+
+// cells_dev: DEVICE arrays; x_dev, y_dev: DEVICE arrays or NULL; particles_dev: DEVICE buffer of `capacity` entries or NULL (count only)
+extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells *cells, const double *x_dev, const double *y_dev, int32_t n_events,
+                                         uint64_t seed, int64_t first_cell, int32_t batch_events, is3d_particle *particles_dev, int64_t capacity,
+                                         int64_t *n_particles, is3d_sampler_stats *stats)
+{
+    using is3d::set_error;
+    if (!P || !cells || !n_particles) return set_error(IS3D_EINVAL, "null argument");
+    *n_particles = 0;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (n_events < 1) return set_error(IS3D_EINVAL, "n_events must be >= 1");
+    if (particles_dev == nullptr) capacity = 0;
+    if (int rc = check_cells(cells, &P->o, first_cell)) return rc;
+    const int64_t n = cells->n_cells;
+    if (n > P->max_cells) return set_error(IS3D_EINVAL, "%lld cells, the sampler plan was created for %lld", (long long)n, (long long)P->max_cells);
+    SMP_TRY(hipSetDevice(P->device));
+    if (n == 0) return IS3D_OK;
+    const int ncls = P->ncls;
+    is3d::SamplerParams &p = P->p;
+    const is3d::SamplerSpecies &sp = P->sp;
+    const double *src[23] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
+                             cells->muB, cells->nB, cells->Vx, cells->Vy, cells->Vn};
+    const double *dptr[23];
+    for (int a = 0; a < 23; a++) dptr[a] = (src[a] && cell_array_needed(a, &P->o)) ? src[a] : nullptr;
+    p.cells = {dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], dptr[9], dptr[10], dptr[11],
+               dptr[12], dptr[13], dptr[14], dptr[15], dptr[16], dptr[17], dptr[18], dptr[19], dptr[20], dptr[21], dptr[22]};
+    p.x = x_dev; p.y = y_dev;
+    p.n_cells = n; p.first_cell = first_cell;
+    p.seed = seed;
+    hipEvent_t *ev = P->ev;
     unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0, 0};
-    SMP_TRY(hipMemcpyAsync(d_status.p, init, sizeof init, hipMemcpyHostToDevice, nullptr));
-    p.status = d_status.as<unsigned long long>();
-    SMP_TRY(d_GT.alloc((size_t)n * ncls * sizeof(double)));
-    if (opts->df_mode == 3 && !p.fast) SMP_TRY(d_GT2.alloc((size_t)n * ncls * sizeof(double)));
-    if (opts->df_mode == 3 && baryon) SMP_TRY(d_GT3.alloc((size_t)n * ncls * sizeof(double)));
-    SMP_TRY(d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
+    SMP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, nullptr));
+    // ---- workspaces: sized by the largest (cells, event batch) seen so far; a second execute of the same shape allocates nothing ----
+    const int64_t max_threads = (int64_t)1 << 25;
+    int eb = (int)std::max<int64_t>(1, std::min<int64_t>(n_events, max_threads / n));
+    if (batch_events > 0) eb = std::min(eb, batch_events);
+    const int64_t bt = (int64_t)eb * n;
+    if (n > P->cap_cells) {
+        SMP_TRY(P->d_GT.alloc((size_t)n * ncls * sizeof(double)));
+        if (P->o.df_mode == 3 && !p.fast) SMP_TRY(P->d_GT2.alloc((size_t)n * ncls * sizeof(double)));
+        if (P->o.df_mode == 3 && p.baryon) SMP_TRY(P->d_GT3.alloc((size_t)n * ncls * sizeof(double)));
+        SMP_TRY(P->d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
+        P->cap_cells = n;
+    }
+    if (bt > P->cap_bt) {
+        SMP_TRY(P->d_drawn.alloc((size_t)bt * sizeof(int32_t)));
+        SMP_TRY(P->d_emits.alloc((size_t)bt));
+        SMP_TRY(P->d_active.alloc((size_t)bt * sizeof(int32_t)));
+        SMP_TRY(P->d_nactive.alloc(sizeof(int32_t)));
+        SMP_TRY(P->d_counts.alloc((size_t)(bt + 1) * sizeof(int64_t)));
+        SMP_TRY(P->d_offsets.alloc((size_t)(bt + 1) * sizeof(int64_t)));
+        size_t tb = 0, tmp2 = 0;
+        SMP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, P->d_counts.as<int64_t>(), P->d_offsets.as<int64_t>(), (int)(bt + 1), nullptr));
+        SMP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp2, hipcub::CountingInputIterator<int32_t>(0), P->d_emits.as<uint8_t>(), P->d_active.as<int32_t>(),
+                                              P->d_nactive.as<int32_t>(), (int)bt, nullptr));
+        P->tmp_bytes = std::max(tb, tmp2);
+        SMP_TRY(P->d_scan_tmp.alloc(P->tmp_bytes));
+        P->cap_bt = bt;
+    }
+    DevMem &d_GT = P->d_GT, &d_GT2 = P->d_GT2, &d_GT3 = P->d_GT3, &d_rec = P->d_rec, &d_counts = P->d_counts, &d_offsets = P->d_offsets, &d_scan_tmp = P->d_scan_tmp;
+    DevMem &d_drawn = P->d_drawn, &d_emits = P->d_emits, &d_active = P->d_active, &d_nactive = P->d_nactive;
+    size_t tmp_bytes = P->tmp_bytes;
     SMP_TRY(hipEventRecord(ev[1], nullptr));
     {
         const int64_t tot = n * ncls;
         hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], dptr[18], n, sp,
-                           d_gl.as<double>(), in->n_gla, d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>());
+                           P->d_gl.as<double>(), P->ngla, d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>());
+        SMP_TRY(hipEventRecord(ev[6], nullptr));
         hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, p, sp, d_GT.as<double>(),
                            d_GT2.as<double>(), d_GT3.as<double>(), d_rec.as<is3d::SamplerCell>());
         SMP_TRY(hipGetLastError());
     }
     SMP_TRY(hipEventRecord(ev[2], nullptr));
     // ---- events in batches of <= 2^25 (event, cell) threads: count, scan, fill ----
-    const int64_t max_threads = (int64_t)1 << 25;
-    int eb = (int)std::max<int64_t>(1, std::min<int64_t>(in->n_events, max_threads / n));
-    if (in->batch_events > 0) eb = std::min(eb, in->batch_events);
-    const int64_t bt = (int64_t)eb * n;
-    DevMem d_drawn, d_emits, d_active, d_nactive;
-    SMP_TRY(d_drawn.alloc((size_t)bt * sizeof(int32_t)));
-    SMP_TRY(d_emits.alloc((size_t)bt));
-    SMP_TRY(d_active.alloc((size_t)bt * sizeof(int32_t)));
-    SMP_TRY(d_nactive.alloc(sizeof(int32_t)));
-    SMP_TRY(d_counts.alloc((size_t)(bt + 1) * sizeof(int64_t)));
-    SMP_TRY(d_offsets.alloc((size_t)(bt + 1) * sizeof(int64_t)));
-    size_t tmp_bytes = 0, tmp2 = 0;
-    SMP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_counts.as<int64_t>(), d_offsets.as<int64_t>(), (int)(bt + 1), nullptr));
-    SMP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp2, hipcub::CountingInputIterator<int32_t>(0), d_emits.as<uint8_t>(), d_active.as<int32_t>(),
-                                          d_nactive.as<int32_t>(), (int)bt, nullptr));
-    tmp_bytes = std::max(tmp_bytes, tmp2);
-    SMP_TRY(d_scan_tmp.alloc(tmp_bytes));
-    if (capacity > 0) SMP_TRY(d_particles.alloc((size_t)capacity * sizeof(is3d_particle)));
     int64_t base = 0;
-    double ms_count = 0.0, ms_fill = 0.0;
-    for (int e0 = 0; e0 < in->n_events; e0 += eb) {
-        const int ne = std::min(eb, in->n_events - e0);
+    double ms_count = 0.0, ms_fill = 0.0, ms_poisson = 0.0;
+    for (int e0 = 0; e0 < n_events; e0 += eb) {
+        const int ne = std::min(eb, n_events - e0);
         const int64_t nt = (int64_t)ne * n;
         SMP_TRY(hipEventRecord(ev[5], nullptr));
         // Poisson numbers of all pairs, then the ordered list of the pairs that emit
@@ -883,6 +980,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         SMP_TRY(hipGetLastError());
         SMP_TRY(hipcub::DeviceSelect::Flagged(d_scan_tmp.p, tmp_bytes, hipcub::CountingInputIterator<int32_t>(0), d_emits.as<uint8_t>(),
                                               d_active.as<int32_t>(), d_nactive.as<int32_t>(), (int)nt, nullptr));
+        SMP_TRY(hipEventRecord(ev[7], nullptr));
         int32_t n_active = 0;
         SMP_TRY(hipMemcpy(&n_active, d_nactive.p, sizeof(int32_t), hipMemcpyDeviceToHost));
         int64_t batch_total = 0;
@@ -900,7 +998,7 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
             if (capacity > 0 && base < capacity && batch_total > 0) {
                 hipLaunchKernelGGL((is3d::cf_sampler_run<true>), dim3(grid), dim3(128), 0, nullptr, p, sp, d_rec.as<is3d::SamplerCell>(),
                                    d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>(), e0, d_active.as<int32_t>(), (int64_t)n_active,
-                                   d_drawn.as<int32_t>(), (int64_t *)nullptr, d_offsets.as<int64_t>(), base, d_particles.as<is3d_particle>(), capacity);
+                                   d_drawn.as<int32_t>(), (int64_t *)nullptr, d_offsets.as<int64_t>(), base, particles_dev, capacity);
                 SMP_TRY(hipGetLastError());
             }
         } else {
@@ -908,21 +1006,24 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
         }
         SMP_TRY(hipEventRecord(ev[4], nullptr));
         SMP_TRY(hipEventSynchronize(ev[4]));
-        float a = 0, b = 0;
+        float a = 0, b = 0, c = 0;
         SMP_TRY(hipEventElapsedTime(&a, ev[5], ev[3]));
         SMP_TRY(hipEventElapsedTime(&b, ev[3], ev[4]));
-        ms_count += a; ms_fill += b;
+        SMP_TRY(hipEventElapsedTime(&c, ev[5], ev[7]));
+        ms_count += a; ms_fill += b; ms_poisson += c;
         base += batch_total;
     }
     unsigned long long h[8];
-    SMP_TRY(hipMemcpy(h, d_status.p, sizeof h, hipMemcpyDeviceToHost));
+    SMP_TRY(hipMemcpy(h, P->d_status.p, sizeof h, hipMemcpyDeviceToHost));
     *n_particles = base;
     if (stats) {
-        float a = 0, b = 0;
-        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+        float b = 0, dn = 0;
         (void)hipEventElapsedTime(&b, ev[1], ev[2]);
-        stats->ms_h2d = a;
+        (void)hipEventElapsedTime(&dn, ev[1], ev[6]);
+        stats->ms_h2d = 0.0;
         stats->ms_prep = b;
+        stats->ms_density = dn;
+        stats->ms_poisson = ms_poisson;
         stats->n_cells_skipped = (int64_t)h[1];
         stats->n_momentum_samples = (int64_t)h[2];
         stats->n_acceptances = (int64_t)h[3];
@@ -933,11 +1034,77 @@ extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species
     }
     if (h[0] != ~0ULL)
         return set_error(IS3D_EDOMAIN, "cell %lld: T%s outside the coefficient table (the reference aborts in gsl_spline_eval here)", (long long)h[0],
-                         opts->df_mode == 4 ? " (or bulkPi/P)" : (baryon ? " or (T, muB)" : ""));
-    const int64_t ncopy = std::min<int64_t>(base, capacity);
-    if (ncopy > 0) SMP_TRY(hipMemcpy(particles, d_particles.p, (size_t)ncopy * sizeof(is3d_particle), hipMemcpyDeviceToHost));
-    if (particles && base > capacity)
+                         P->o.df_mode == 4 ? " (or bulkPi/P)" : (p.baryon ? " or (T, muB)" : ""));
+    if (particles_dev && base > capacity)
         return set_error(IS3D_ENOMEM, "%lld particles sampled but the caller's buffer holds %lld (call with particles = NULL for the count)",
                          (long long)base, (long long)capacity);
+    return IS3D_OK;
+}
+
+// the host-pointer entry: plan + upload + execute + download (the particle list is the plan's, bit for bit)
+extern "C" int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, const is3d_df_tables *df,
+                                     const is3d_sampler_inputs *in, const is3d_options *opts, is3d_particle *particles,
+                                     int64_t capacity, int64_t *n_particles, is3d_sampler_stats *stats)
+{
+    using is3d::set_error;
+    if (!cells || !species || !df || !in || !opts || !n_particles) return set_error(IS3D_EINVAL, "null argument");
+    *n_particles = 0;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (in->n_events < 1) {
+        // (argument checks of the plan first, so that a bad option is reported before a bad event count -- as the one-shot entry always did)
+        is3d_sampler_plan *chk = nullptr;
+        const int rc0 = is3d_sampler_plan_create(&chk, species, df, in, opts, 1);
+        is3d_sampler_plan_destroy(chk);
+        if (rc0 && rc0 != IS3D_ENODEVICE) return rc0;
+        return set_error(IS3D_EINVAL, "n_events must be >= 1");
+    }
+    if (particles == nullptr) capacity = 0;
+    is3d_sampler_plan *P = nullptr;
+    if (int rc = is3d_sampler_plan_create(&P, species, df, in, opts, std::max<int64_t>(cells->n_cells, 1))) return rc;
+    struct Guard { is3d_sampler_plan *p; ~Guard() { is3d_sampler_plan_destroy(p); } } guard{P};
+    if (int rc = check_cells(cells, opts, in->first_cell)) return rc;
+    const int64_t n = cells->n_cells;
+    if (n == 0) return IS3D_OK;
+    const double *src[23] = {cells->tau, cells->eta, cells->dat, cells->dax, cells->day, cells->dan, cells->ux, cells->uy, cells->un,
+                             cells->T, cells->P, cells->E, cells->pixx, cells->pixy, cells->pixn, cells->piyy, cells->piyn, cells->bulkPi,
+                             cells->muB, cells->nB, cells->Vx, cells->Vy, cells->Vn};
+    DevMem d_cell[23], d_x, d_y, d_particles;
+    const double *dptr[23];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SMP_TRY(hipEventCreate(&e0));
+    SMP_TRY(hipEventCreate(&e1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
+    SMP_TRY(hipEventRecord(e0, nullptr));
+    for (int a = 0; a < 23; a++) {
+        dptr[a] = nullptr;
+        if (src[a] && cell_array_needed(a, opts)) {
+            SMP_TRY(d_cell[a].alloc((size_t)n * sizeof(double)));
+            SMP_TRY(hipMemcpyAsync(d_cell[a].p, src[a], (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+            dptr[a] = d_cell[a].as<double>();
+        }
+    }
+    if (in->x) { SMP_TRY(d_x.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_x.p, in->x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
+    if (in->y) { SMP_TRY(d_y.alloc((size_t)n * sizeof(double))); SMP_TRY(hipMemcpyAsync(d_y.p, in->y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, nullptr)); }
+    SMP_TRY(hipEventRecord(e1, nullptr));
+    is3d_cells dc{};
+    dc.n_cells = n;
+    dc.tau = dptr[0]; dc.eta = dptr[1]; dc.dat = dptr[2]; dc.dax = dptr[3]; dc.day = dptr[4]; dc.dan = dptr[5]; dc.ux = dptr[6]; dc.uy = dptr[7]; dc.un = dptr[8];
+    dc.T = dptr[9]; dc.P = dptr[10]; dc.E = dptr[11]; dc.pixx = dptr[12]; dc.pixy = dptr[13]; dc.pixn = dptr[14]; dc.piyy = dptr[15]; dc.piyn = dptr[16];
+    dc.bulkPi = dptr[17]; dc.muB = dptr[18]; dc.nB = dptr[19]; dc.Vx = dptr[20]; dc.Vy = dptr[21]; dc.Vn = dptr[22];
+    if (capacity > 0) SMP_TRY(d_particles.alloc((size_t)capacity * sizeof(is3d_particle)));
+    int64_t total = 0;
+    const int rc = is3d_sampler_plan_execute(P, &dc, d_x.as<double>(), d_y.as<double>(), in->n_events, in->seed, in->first_cell, in->batch_events,
+                                             d_particles.as<is3d_particle>(), capacity, &total, stats);
+    *n_particles = total;
+    if (stats) {
+        float a = 0;
+        (void)hipEventElapsedTime(&a, e0, e1);
+        stats->ms_h2d = a;
+    }
+    if (rc && rc != IS3D_ENOMEM) return rc;
+    const std::string kept = rc ? is3d_last_error() : "";
+    const int64_t ncopy = std::min<int64_t>(total, capacity);
+    if (ncopy > 0) SMP_TRY(hipMemcpy(particles, d_particles.p, (size_t)ncopy * sizeof(is3d_particle), hipMemcpyDeviceToHost));
+    if (rc) return set_error(rc, "%s", kept.c_str());
     return IS3D_OK;
 }

@@ -16,6 +16,10 @@ def test_isa_counts_are_read_from_the_isa_and_sane():
     assert set(audit["flat_instructions"]) >= {"cf_kernels.hip", "cf_feqmod.hip", "cf_vah.hip", "cf_yield.hip", "cf_sampler.hip", "cf_multi.hip"}
     assert all(n == 0 for n in audit["flat_instructions"].values()), audit["flat_instructions"]
     assert len(d) >= 100
+    # the sampler's Gauss-Laguerre density kernel is counted per quadrature node (one v_rcp_f64 and one v_rsq_f64 each)
+    dens = d.pop("cf_sampler_density")
+    assert dens["histogram"]["v_rcp_f64"] == dens["nodes_in_loop"] == dens["histogram"]["v_rsq_f64"]
+    assert 25.0 <= dens["valu_f64_instr_per_node"] <= 50.0 and 40.0 <= dens["flop_per_node"] <= 90.0
     names = set()
     for key, v in d.items():
         assert key.startswith("cf_main_"), key
@@ -31,6 +35,9 @@ def test_isa_counts_are_read_from_the_isa_and_sane():
     # M0 audit: the direct-to-LDS helper (cf_math.h::glds16a) sets M0 inside an asm statement; no other instruction of a kernel that stages
     # this way may read M0 (a compiler-generated user would have been handed the helper's value or have had its own overwritten)
     staged = [k for k, v in d.items() if v["global_load_lds"] > 0]
+    # the modified-equilibrium kernel's row walk (cf_feqmod.hip): the row mask with the unit threshold only (ROWS = 2) issues fewest instructions
+    fq = {r: d["cf_main_feqmod:DIM3=1,OUTFLOW=1,MODE3=0,JT=8,R=7,ROWS=%d" % r]["valu_f64_instr_per_eval"] for r in (0, 1, 2)}
+    assert fq[2] < fq[0] and fq[2] < fq[1]
     assert len(staged) > 50 and "cf_main_tile3e:CE=1,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1" in staged
     for k in staged:
         assert d[k]["m0_other_users"] == [] and d[k]["m0_writes"] >= 1, (k, d[k]["m0_other_users"])

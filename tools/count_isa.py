@@ -219,13 +219,57 @@ def main():
         out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), m0_writes=m0_set, global_load_lds=glds, m0_other_users=m0_other, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
                         histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
+    # ---- the sampler's Gauss-Laguerre density kernel (cf_sampler.hip): fp64 instructions and flops per quadrature node, from its innermost loops
+    # (one v_rcp_f64 per node; the compiler versions the loop for the optional J10 / J20 integrals -- the leanest version is the plain n_eq integral
+    # that df_mode 1, 2, 4 run)
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(ROOT, "is3d_amd", "csrc", "cf_sampler.hip")
+        s_path = os.path.join(td, "s.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-I", os.path.dirname(src), "-I", os.path.join(ROOT, "include"), src, "-o", s_path], stderr=subprocess.DEVNULL)
+        loops, cur_loop, inside = [], None, False
+        for ln in open(s_path).read().split("\n"):
+            if re.match(r"^_ZN4is3d18cf_sampler_density", ln):
+                inside = True
+                continue
+            if not inside:
+                continue
+            if ln.startswith(".Lfunc_end"):
+                break
+            m = re.match(r"^\.LBB\d+_\d+:(.*)", ln)
+            if m:
+                d = re.search(r"Depth=(\d+)", m.group(1))
+                if d and int(d.group(1)) >= 1:
+                    if cur_loop is None or "Parent Loop" not in m.group(1) and "in Loop: Header" in m.group(1):
+                        cur_loop = collections.Counter()
+                        loops.append(cur_loop)
+                else:
+                    cur_loop = None
+                continue
+            m = re.match(r"^\s+(v_[a-z0-9_]+)\s", ln)
+            if m and cur_loop is not None:
+                cur_loop[m.group(1).replace("_e32", "").replace("_e64", "")] += 1
+        best = None
+        for lp in loops:
+            nodes = lp.get("v_rcp_f64", 0)
+            if not nodes:
+                continue
+            f64 = {k: v for k, v in lp.items() if k.endswith("_f64")}
+            fma = lp.get("v_fma_f64", 0) + lp.get("v_fmac_f64", 0)
+            per = dict(nodes_in_loop=nodes, valu_f64_instr_per_node=round(sum(f64.values()) / nodes, 3),
+                       flop_per_node=round((2 * fma + sum(v for k, v in f64.items() if k not in ("v_fma_f64", "v_fmac_f64"))) / nodes, 3),
+                       histogram={k: v for k, v in sorted(lp.items()) if k.endswith("_f64")})
+            if best is None or per["valu_f64_instr_per_node"] < best["valu_f64_instr_per_node"]:
+                best = per
+        if best:
+            out["cf_sampler_density"] = best
     out["_audit"] = dict(flat_instructions=flat)
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
     if "-v" in sys.argv:
         for k, v in sorted(out.items()):
-            if k.startswith("_"):
+            if k.startswith("_") or "flop_per_eval" not in v:
                 continue
             print(k, v["flop_per_eval"], v["valu_f64_instr_per_eval"], v["issue_cycles_per_eval"])
     print("wrote", OUT, len(out) - 1, "kernels")
