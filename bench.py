@@ -87,7 +87,7 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     elif kernel_name == "cf_main_vah":
         key = "cf_main_vah:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_vah3":
-        key = "cf_main_vah3:REG=1,JT=%d,R=%d" % (JT_R[0], JT_R[1])
+        key = "cf_main_vah3:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_tile3e":
         key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,MODE=%d" % (ce, JT_R[0], JT_R[1], 0 if variant == 5 else 1)
     elif kernel_name == "cf_main_tile":
@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5", "config5-sampler"])
+    ap.add_argument("--dimension", type=int, default=0, choices=[0, 2, 3],
+                    help="--workload config5 only: 2 = the 2+1D anisotropic-hydro kernel on a 1e5-cell boost-invariant surface, pi/K/p (config 2's shape)")
     ap.add_argument("--events", type=int, default=20, help="--workload config5-sampler: events sampled per step")
     ap.add_argument("--df-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
@@ -360,6 +362,13 @@ def main():
             dist.destroy_process_group()
         return
     wl = workload(a.workload)
+    if a.dimension and a.workload != "config5":
+        raise SystemExit("--dimension applies to --workload config5 only")
+    if a.workload == "config5" and a.dimension == 2:
+        wl.update(dimension=2, species="pikp", cells=100000,
+                  text="anisotropic-hydro (VAH, P_L matching) kernel in 2+1D: 1e5-cell synthetic boost-invariant surface (seed 20260001), 14-moment delta-f with "
+                       "c0..c4 interpolated on the device from the deltaf_coefficients/vah tables, pi/K/p, 32x24 (pT,phi) bins x 241-point eta quadrature "
+                       "(config 2's shape on config 5's kernel; not a BASELINE configuration)")
     if a.df_mode:
         wl["text"] += " -- df_mode overridden to %d" % a.df_mode
         wl["df_mode"] = a.df_mode
@@ -377,10 +386,10 @@ def main():
         # anisotropic hydro: 24 cell arrays (no T, no c0..c4: the coefficients are interpolated on the device from the tables)
         if a.df_mode:
             raise SystemExit("--df-mode does not apply to --workload config5")
-        cells = synth.synth_vah_surface(n_loc, 3, first_cell=lo)
+        cells = synth.synth_vah_surface(n_loc, wl["dimension"], first_cell=lo)
         cell_fields = [f for f in api.VAH_FIELDS[:25] if f != "T"]
         df = inputs.vah_df_tables()
-        opts = dict(dimension=3, device=local, zero_skip=a.zero_skip, cell_chunks=a.cell_chunks)
+        opts = dict(dimension=wl["dimension"], device=local, zero_skip=a.zero_skip, cell_chunks=a.cell_chunks, kernel_variant=a.variant)
         tens = {k: torch.from_numpy(cells[k]).to(dev) for k in cell_fields}   # resident in HBM before timing
         make_plan = lambda o: api.VahPlan(sp, grid, o, tab=df, max_cells=max(n_loc, 1))
     else:
@@ -664,17 +673,18 @@ def bench_sampler(a, rank, world, local, dev, multi, json_fd):
     opts = dict(dimension=3, df_mode=df_mode, device=local)
     seed = 20260002
     fq = gla if df_mode in (3, 4) else None
-    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in synth.CELL_FIELDS}     # resident in HBM before timing
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in list(synth.CELL_FIELDS) + ["x", "y"]}     # resident in HBM before timing
     ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    xy = dict(x_ptr=ptrs["x"], y_ptr=ptrs["y"])
     plan = api.SamplerPlan(sp, df, gla, opts, max_cells=max(n_loc, 1), fq=fq)
-    count, st0 = plan.execute(n_loc, ptrs, a.events, seed, first_cell=lo)          # count-only: sizes the particle buffer (and the workspaces)
+    count, st0 = plan.execute(n_loc, ptrs, a.events, seed, first_cell=lo, **xy)    # count-only: sizes the particle buffer (and the workspaces)
     buf = torch.zeros(max(count, 1) * api.PARTICLE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     keys = ("ms_prep", "ms_density", "ms_count", "ms_poisson", "ms_fill")
     ms = {k: [] for k in keys}
     last = {}
 
     def step(record):
-        n, st = plan.execute(n_loc, ptrs, a.events, seed, particles_ptr=buf.data_ptr(), capacity=count, first_cell=lo)
+        n, st = plan.execute(n_loc, ptrs, a.events, seed, particles_ptr=buf.data_ptr(), capacity=count, first_cell=lo, **xy)
         assert n == count
         if record:
             for k in keys:

@@ -478,7 +478,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
             if (o->waves_per_group == 1 && P->e2tab) P->wpb = 1;   // cf_main_tile3e: one-wave workgroups (no barrier partner)
             // cf_main_feqmod, 3+1D 8 x 7 without baryon slots: one-wave workgroups (cf_feqmod.hip, LDSD); the pipelined A/B form (variant 5) keeps two
-            if (P->feqmod && P->dim3 && !P->baryon && (P->variant == 3 || P->variant == 6) && o->waves_per_group == 1) P->wpb = 1;
+            // -- the default there since round 4 (486 against 501 ms on the config-3 surface, profiles/r04_ab_feqmod.log); waves_per_group = 2 keeps the pair
+            if (P->feqmod && P->dim3 && !P->baryon && (P->variant == 3 || P->variant == 6) && (o->waves_per_group == 1 || o->waves_per_group == 0)) P->wpb = 1;
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves

@@ -72,15 +72,16 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
     extern __shared__ double lds[];
     const int J = p.J, K = p.K;
     VahScal *cs = (VahScal *)lds;                     // [CB]
-    double *lk = (double *)(cs + CB);             // [9][CB][K]: A, ax, ad, W, ch, sh, C, Z, V1
-    double *lj = lk + 9 * CB * K;                 // [7][CB][J]: B, gx, gd, D, V2, E, F
+    double *lk = (double *)(cs + CB);             // [10][CB][K]: A, ax, ad, W, ch, sh, C, Z, V1, e (F records in 2+1D)
+    double *lj = lk + 10 * CB * K;                // [7][CB][J]: B, gx, gd, D, V2, E, F
     double *l_dmx = lj + 7 * CB * J;              // [CB][jtiles] F records: max_j d_j of a phi tile
     const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_ax = lk + CK, *l_ad = lk + 2 * CK, *l_W = lk + 3 * CK, *l_ch = lk + 4 * CK, *l_sh = lk + 5 * CK;
     double *l_C = lk + 6 * CK, *l_Z = lk + 7 * CK, *l_V1 = lk + 8 * CK;
     double *l_B = lj, *l_gx = lj + CJ, *l_gd = lj + 2 * CJ, *l_D = lj + 3 * CJ, *l_V2 = lj + 4 * CJ, *l_E = lj + 5 * CJ, *l_F = lj + 6 * CJ;
-    // F records: the slots of ax_k, W_k (= 1 in 3+1D) and gx_j carry the factored exponent's c_k = C_k / Lambda, e_k = xi Z_k^2 / Lambda^2, d_j = D_j / Lambda
-    double *l_ck = l_ax, *l_ek = l_W, *l_dj = l_gx;
+    // F records: the slots of ax_k and gx_j carry the factored exponent's c_k = C_k / Lambda and d_j = D_j / Lambda; e_k = xi Z_k^2 / Lambda^2 has its
+    // own array (2+1D rows keep their eta weight W_k beside it; in 3+1D W_k = 1 is not stored)
+    double *l_ck = l_ax, *l_ek = lk + 9 * CK, *l_dj = l_gx;
     const int tid = threadIdx.x;
     const int nbatch = (p.n_cells + CB - 1) / CB;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             if (p.fact) {
                 l_ck[idx] = C * s.invL;
                 l_ek[idx] = s.xi * Z * Z * s.invL2;
+                l_W[idx] = w;
             } else {
                 l_W[idx] = w;
                 l_ax[idx] = (C * C + s.xi * Z * Z) * s.invL2;
@@ -172,7 +174,9 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
                 l_dmx[idx] = v;
             }
             __syncthreads();
-            const int HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
+            // row scalars: 3+1D {A_k, c_k, ad_k, e_k}; 2+1D {A_k, c_k, ad_k, e_k, W_k, 0} (the eta weight; rows stay 16-byte multiples)
+            const int RS = p.dim3 ? 4 : 6;
+            const int HDR = 4 * JT, RWD = RS + JT, REC = HDR + R * RWD;
             const int units_per_cell = p.jtiles * p.rblocks, per_cell = units_per_cell * REC;
             for (int idx = tid; idx < ncb * per_cell; idx += kVahThreads) {
                 const int c = idx / per_cell;
@@ -197,14 +201,17 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
                     else if (f == 1) v = l_ck[c * K + kc];
                     else if (f == 2) v = l_ad[c * K + kc];
                     else if (f == 3) v = l_ek[c * K + kc];
+                    else if (f < RS) v = (f == 4 && k < K) ? l_W[c * K + kc] : 0.0;
                     else {
-                        const int j = min(jt * JT + (f - 4), J - 1);
+                        const int j = min(jt * JT + (f - RS), J - 1);
                         const double X = l_E[c * J + j] * l_ch[c * K + kc] + l_F[c * J + j] * l_sh[c * K + kc];
                         v = s.c4 * X - s.c3 * l_Z[c * K + kc] * l_V2[c * J + j] - 2.0 * s.Pi * s.c2 * l_C[c * K + kc] * l_D[c * J + j];
                     }
                 }
                 const int64_t cell = cbase + c;
-                const int64_t unit = (int64_t)ut * p.n_cells + cell;
+                int64_t unit;
+                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;
+                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
                 __builtin_nontemporal_store(v, &p.TS[unit * REC + e]);
             }
         } else {
@@ -433,18 +440,25 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
 //     exact-zero rule of the round-1 kernel (E_a/Lambda > 745.25: f_a == +0): bitwise the same spectrum with zero_skip on or off.
 //   * exp_p9 (cf_math.h): one fma for the range reduction, degree 9 -- two instructions fewer per evaluation, 7e-14 relative.
 //     cf_prep_vah refuses cells whose E_a/Lambda could exceed 1e9 (status[7]) so that the shift-trick conversion is in its domain.
+//   * 2+1D (round 4; DIM3 = false): the same factored records with the eta weight kept in the row -- {A_k, c_k, ad_k, e_k, W_k, 0, bd_jk...}, 14
+//     doubles per row of the 8-wide tile against 20 for the round-1 layout -- on the 8 x 31 tile of config 2 with unit-strided lanes (g.split = S
+//     lane slots per momentum bin, slot s takes the units u = s (mod S) of the stream; cf_finalize adds a bin's slots in slot order): pi / K / p
+//     are 96 bins = 1.5 waves, 384 slots are six full ones.  Eight evaluations share a v_rcp_f64 (the 8 accumulators of a 2+1D lane leave
+//     the registers for it).  The row and unit tests are the same lower bounds; with strided lanes a vote spans lanes on different units.
 // ------------------------------------------------------------------------------------------------
-template <bool REG, int JT, int R>
+template <bool DIM3, bool REG, int JT, int R>
 __global__ void __launch_bounds__(512)
 cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
-             const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g)
+             const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g,
+             const int32_t *__restrict__ lane_sub)
 {
     constexpr int HDR = 4 * JT;
-    constexpr int RW = 4 + JT;
+    constexpr int RS = DIM3 ? 4 : 6;
+    constexpr int RW = RS + JT;
     constexpr int REC = HDR + R * RW;
-    constexpr int UB = (1536 / REC) > 0 ? (1536 / REC) : 1;
+    constexpr int UB = DIM3 ? ((1536 / REC) > 0 ? (1536 / REC) : 1) : 4;   // 2+1D: four units per LDS buffer (S in {1, 2, 4} divides it)
     constexpr int BUF2 = UB * REC / 2;
-    constexpr int RB = JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2);
+    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);
     static_assert(REC % 2 == 0 && JT % RB == 0 && JT >= 3, "unit records must be 16-byte multiples; the cull bounds sit in header slots jj = 0, 1, 2");
     constexpr int BUFP = ((BUF2 * 16 + 1023) / 1024) * 64;   // the batch as whole 1-KiB staging pieces (64 double2 each)
     __shared__ double2 lbuf[2][BUFP + RW / 2 + 1];
@@ -469,16 +483,19 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     const double mT2 = mT * mT;
     const double hs = REG ? 0.5 : 1.0;   // u = (1 + fbar df) * hs, clamped to [0, 1] by the VOP3 clamp modifier when REG
     const double mT2s = hs * mT2, mTpTs = hs * (mT * pT), pT2s = hs * (pT * pT);
+    const int S = (!DIM3 && g.split > 1) ? g.split : 1;
+    const int sub_off = (!DIM3 && g.split > 1 && lane_sub) ? lane_sub[l] * REC : 0;
     const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
     const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
-    const int n_units = c1 - c0;
-    const int s_tile = jt * g.ktiles + kt;
-    const double2 *src = (const double2 *)(TS + ((int64_t)s_tile * g.n_cells + c0) * REC);
+    const int n_units = (c1 - c0) * g.upc;
+    const int s_tile = DIM3 ? (jt * g.ktiles + kt) : jt;
+    const double2 *src = (const double2 *)(TS + (((int64_t)s_tile * g.n_cells + c0) * g.upc) * REC);
     const int nb = (n_units + UB - 1) / UB;
 
-    double acc[JT * R];
+    constexpr int NACC = DIM3 ? JT * R : JT;
+    double acc[NACC];
 #pragma unroll
-    for (int i = 0; i < JT * R; i++) acc[i] = 0.0;
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
     int n_rows = 0, n_dead = 0;
     constexpr double X2CUT = 555400.0;   // E_a/Lambda > 745.25: exp(-E_a/Lambda) == +0
 
@@ -523,29 +540,42 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
                 for (int i = 0; i < RB; i++) {
                     const int jj = j0 + i;
                     const double rr = inv[i];
-                    const double br = __builtin_fma(mTpTs, rw.v[4 + jj], ad + gd[jj]);         // hs * df/(f_a fbar_a)
+                    const double br = __builtin_fma(mTpTs, rw.v[RS + jj], ad + gd[jj]);        // hs * df/(f_a fbar_a)
                     const double u = REG ? fma_clamp01_half(rr, br) : __builtin_fma(rr, br, 1.0);
-                    const double pds = pTB[jj] + mTA;                                          // W_k = 1 in 3+1D
+                    const double pds = DIM3 ? pTB[jj] + mTA : __builtin_fma(pTB[jj], rw.v[4], mTA);   // W_k = 1 in 3+1D
                     const double w = (zz[i] * rr) * u;
-                    acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                    if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                    else acc[jj] = __builtin_fma(pds, w, acc[jj]);
                 }
             }
         };
         const double *rows = U + HDR;
         Row cur, nxt;
         fetch(cur, rows);
+        if (DIM3) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
-            evals(cur, r);
-            if (r + 1 < R) cur = nxt;
+            for (int r = 0; r < R; r++) {
+                if (r + 1 < R) fetch(nxt, rows + (r + 1) * RW);
+                evals(cur, r);
+                if (r + 1 < R) cur = nxt;
+            }
+        } else {
+            // rolled, two rows per trip (see cf_main_tile); for even R the last fetch reads the head of the next unit or the pad
+#pragma clang loop unroll(disable)
+            for (int r = 0; r + 1 < R; r += 2) {
+                fetch(nxt, rows + (r + 1) * RW);
+                evals(cur, 0);
+                fetch(cur, rows + (r + 2) * RW);
+                evals(nxt, 0);
+            }
+            if (R & 1) evals(cur, 0);
         }
     };
 
     // staging: the next batch by direct-to-LDS loads (stage_pieces, cf_math.h), issued before the current batch is consumed
     auto stage = [&](int ib, int buf) { stage_pieces<BUFP / 64>((const char *)(src + (int64_t)ib * BUF2), lbuf[buf], tid, nthr); };
     // the lane constants must have ARRIVED before the batch loop (see cf_main_vah)
-    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2s), "v"(mTpTs), "v"(pT2s), "v"(mT2) : "memory");
+    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2s), "v"(mTpTs), "v"(pT2s), "v"(mT2), "v"(sub_off) : "memory");
     if (nb > 0) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -554,8 +584,8 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
             if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
             if (wave_active) {
                 const int nu = min(UB, n_units - ib * UB);
-                const double *base = (const double *)lbuf[ib & 1];
-                for (int u = 0; u < nu; u++) process_unit(base + u * REC);
+                const double *base = (const double *)lbuf[ib & 1] + sub_off;
+                for (int u = 0; u < nu; u += S) process_unit(base + u * REC);   // nu is a multiple of S (the plan: S divides the units per cell and UB)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -572,10 +602,14 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     for (int jj = 0; jj < JT; jj++) {
         const int j = jt * JT + jj;
         if (j < J) {
+            if (DIM3) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int k = kt * R + r;
-                if (k < K) pp[((int64_t)j * g.Kacc + k) * g.Lpad + l] = unscale * acc[jj * R + r];
+                for (int r = 0; r < R; r++) {
+                    const int k = kt * R + r;
+                    if (k < K) pp[((int64_t)j * g.Kacc + k) * g.Lpad + l] = unscale * acc[jj * R + r];
+                }
+            } else {
+                pp[(int64_t)j * g.Lpad + l] = unscale * acc[jj];
             }
         }
     }
@@ -683,13 +717,16 @@ struct DevMem {
 
 constexpr int kJT3 = 6, kR3 = 7, kJT2 = 8, kR2 = 61;   // the round-1 kernel's tile shapes (kernel variant 2; 2+1D always)
 constexpr int kJT3F = 8, kR3F = 7;                       // cf_main_vah3 (3+1D default, kernel variant 3)
+constexpr int kJT2F = 8, kR2F = 31;                      // cf_main_vah3 in 2+1D (default since round 4): config 2's tile, four units per LDS buffer
 
+template <bool DIM3>
 void launch_vah3(bool reg, const double *TS, const double *mT, const double *pT, const double *sg, double *partial, unsigned long long *stats,
-                 const is3d::MainGeom &g, hipStream_t st)
+                 const is3d::MainGeom &g, const int32_t *lane_sub, hipStream_t st)
 {
     const int grid = ((g.NT + 7) / 8) * 8 * g.G;
-    if (reg) hipLaunchKernelGGL((is3d::cf_main_vah3<true, kJT3F, kR3F>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g);
-    else hipLaunchKernelGGL((is3d::cf_main_vah3<false, kJT3F, kR3F>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g);
+    constexpr int JT = DIM3 ? kJT3F : kJT2F, R = DIM3 ? kR3F : kR2F;
+    if (reg) hipLaunchKernelGGL((is3d::cf_main_vah3<DIM3, true, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g, lane_sub);
+    else hipLaunchKernelGGL((is3d::cf_main_vah3<DIM3, false, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g, lane_sub);
 }
 
 template <bool DIM3>
@@ -746,10 +783,11 @@ struct is3d_vah_plan {
     bool fact = false;            // F records + cf_main_vah3 (3+1D, kernel variant 0 / 3)
     double mTmax = 0.0, pTmax = 0.0;
     int npart = 0, npT = 0, J = 0, K = 0, Kacc = 1, ncls = 0, Lpad = 0;
+    int Lbins = 0, split = 1;      // momentum bins (classes x pT); lane slots per bin (unit-strided lanes, 2+1D F records)
     int JT = 0, R = 0, jtiles = 0, rblocks = 0, ktiles = 0, upc = 0, REC = 0, wpb = 4, nch = 1;
     int64_t nout = 0, max_cells = 0, pass_cells = 0;
     size_t lds_prep = 0;
-    DevMem d_mT, d_pT, d_sg, d_lane, d_deg, d_cos, d_sin, d_kg, d_kw, d_TS, d_partial, d_coef, d_status;
+    DevMem d_mT, d_pT, d_sg, d_lane, d_deg, d_cos, d_sin, d_kg, d_kw, d_TS, d_partial, d_coef, d_status, d_lane_sub;
     TabDev tab;
     std::vector<hipEvent_t> ev;   // [pass][0..2]: start, after coefficients + prep, after main; last: after finalize
     int last_passes = 0;
@@ -802,16 +840,45 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
         if (found < 0) { found = (int)cmass.size(); cmass.push_back(sp->mass[s]); csign.push_back(sp->sign[s]); }
         cls[s] = found;
     }
-    const int ncls = (int)cmass.size(), L = ncls * npT, Lpad = ((L + 63) / 64) * 64;
+    if (o->kernel_variant != 0 && o->kernel_variant != 2 && o->kernel_variant != 3)
+        return set_error(IS3D_EINVAL, "VAH kernel_variant %d: 0 (default), 2 (round-1 kernel: 6 x 7 tile in 3+1D, 8 x 61 in 2+1D) or 3 (factored exponent: "
+                         "8 x 7 tile in 3+1D, 8 x 31 with unit-strided lanes in 2+1D)", o->kernel_variant);
+    P->fact = o->kernel_variant != 2;
+    P->JT = three_d ? (P->fact ? kJT3F : kJT3) : (P->fact ? kJT2F : kJT2); P->R = three_d ? (P->fact ? kR3F : kR3) : (P->fact ? kR2F : kR2);
+    P->jtiles = (J + P->JT - 1) / P->JT; P->rblocks = (K + P->R - 1) / P->R;
+    const int ncls = (int)cmass.size(), Lbins = ncls * npT;
+    // unit-strided lanes (2+1D F records, as cf_plan.cpp's variant 7): S lane slots per momentum bin when that fills the waves better -- S in
+    // {1, 2, 4} must divide the units per cell (the eta table's row blocks) and the four units of an LDS buffer
+    int split = 1;
+    if (!three_d && P->fact) {
+        double best = 1.0 - (double)Lbins / (double)(((Lbins + 63) / 64) * 64);
+        for (int S : {2, 4}) {
+            if (P->rblocks % S) continue;
+            const int tot = Lbins * S, pad = ((tot + 127) / 128) * 128;   // whole 2-wave workgroups
+            const double waste = 1.0 - (double)tot / (double)pad;
+            if (waste < best - 0.05) { best = waste; split = S; }
+        }
+    }
+    P->Lbins = Lbins; P->split = split;
+    const int L = Lbins * split, Lpad = ((L + 63) / 64) * 64;
     P->ncls = ncls; P->Lpad = Lpad;
-    std::vector<double> mT(Lpad, 1.0), pT(Lpad, 0.0), sg(Lpad, 1.0), mT_nat(L);
-    std::vector<int> order(L), slot_of(L), lane_sp((size_t)npart * npT);
+    std::vector<double> mT(Lpad, 1.0), pT(Lpad, 0.0), sg(Lpad, 1.0), mT_nat(Lbins);
+    std::vector<int32_t> lsub(Lpad, 0);
+    std::vector<int> order(Lbins), slot_of(Lbins), lane_sp((size_t)npart * npT);
     for (int c = 0; c < ncls; c++)
         for (int i = 0; i < npT; i++) { mT_nat[c * npT + i] = std::sqrt(cmass[c] * cmass[c] + gr->pT[i] * gr->pT[i]); order[c * npT + i] = c * npT + i; }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mT_nat[a] < mT_nat[b]; });
-    for (int s = 0; s < L; s++) { const int nat = order[s]; slot_of[nat] = s; mT[s] = mT_nat[nat]; pT[s] = gr->pT[nat % npT]; sg[s] = csign[nat / npT]; }
+    for (int s = 0; s < Lbins; s++) {
+        const int nat = order[s];
+        slot_of[nat] = s;
+        for (int sl = 0; sl < split; sl++) {   // slot (bin s, sub sl) = sl * Lbins + s (cf_finalize adds a bin's slots in this order)
+            const int t = sl * Lbins + s;
+            mT[t] = mT_nat[nat]; pT[t] = gr->pT[nat % npT]; sg[t] = csign[nat / npT]; lsub[t] = sl;
+        }
+    }
     for (int s = 0; s < npart; s++)
         for (int i = 0; i < npT; i++) lane_sp[(size_t)s * npT + i] = slot_of[cls[s] * npT + i];
+    VAH_TRY(P->d_lane_sub.upload(lsub));
     std::vector<double> cosphi(J), sinphi(J), kgrid(K), kweight(K, 1.0), deg(sp->degeneracy, sp->degeneracy + npart);
     for (int j = 0; j < J; j++) { cosphi[j] = std::cos(gr->phi[j]); sinphi[j] = std::sin(gr->phi[j]); }
     for (int k = 0; k < K; k++) {
@@ -825,15 +892,10 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
         P->tables = true;
         VAH_TRY(P->d_coef.alloc(sizeof(double) * 5 * (size_t)max_cells));
     }
-    if (o->kernel_variant != 0 && o->kernel_variant != 2 && o->kernel_variant != 3)
-        return set_error(IS3D_EINVAL, "VAH kernel_variant %d: 0 (default), 2 (round-1 kernel, 6 x 7 tile) or 3 (factored exponent, 8 x 7 tile; 3+1D)", o->kernel_variant);
-    P->fact = three_d && o->kernel_variant != 2;
     for (int s2 = 0; s2 < L; s2++) { P->mTmax = std::max(P->mTmax, mT[s2]); P->pTmax = std::max(P->pTmax, pT[s2]); }
-    P->JT = three_d ? (P->fact ? kJT3F : kJT3) : kJT2; P->R = three_d ? (P->fact ? kR3F : kR3) : kR2;
-    P->jtiles = (J + P->JT - 1) / P->JT; P->rblocks = (K + P->R - 1) / P->R;
     P->ktiles = three_d ? P->rblocks : 1; P->upc = three_d ? 1 : P->rblocks;
-    P->REC = P->fact ? 4 * P->JT + P->R * (4 + P->JT) : 4 * P->JT + P->R * (4 + 2 * P->JT);
-    P->lds_prep = sizeof(is3d::VahScal) * is3d::vah_batch_cells(K) + sizeof(double) * (size_t)is3d::vah_batch_cells(K) * (9 * K + 8 * J);   // + [CB][jtiles <= J] tile maxima of the F records
+    P->REC = P->fact ? 4 * P->JT + P->R * ((three_d ? 4 : 6) + P->JT) : 4 * P->JT + P->R * (4 + 2 * P->JT);
+    P->lds_prep = sizeof(is3d::VahScal) * is3d::vah_batch_cells(K) + sizeof(double) * (size_t)is3d::vah_batch_cells(K) * (10 * K + 8 * J);   // + [CB][jtiles <= J] tile maxima of the F records
     if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
@@ -948,8 +1010,9 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         is3d::MainGeom g{};
         g.n_cells = nc; g.J = P->J; g.K = P->K; g.Lpad = P->Lpad; g.wpb = P->wpb; g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
         g.jtiles = P->jtiles; g.ktiles = P->ktiles; g.nch = nch; g.NT = P->jtiles * P->ktiles * nch; g.Kacc = P->Kacc;
-        g.first_pass = 1; g.upc = P->upc; g.zskip = (o.zero_skip != 2); g.baryon = 0;
-        if (P->fact) launch_vah3(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
+        g.first_pass = 1; g.upc = P->upc; g.zskip = (o.zero_skip != 2); g.baryon = 0; g.split = P->split;
+        if (P->fact && P->three_d) launch_vah3<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, nullptr, st);
+        else if (P->fact) launch_vah3<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, P->d_lane_sub.as<int32_t>(), st);
         else if (P->three_d) launch_vah<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
         else launch_vah<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
         VAH_TRY(hipGetLastError());
@@ -957,7 +1020,7 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         // each pass finalises into the output (accumulating after the first): the partial slots are rewritten per pass
         const double prefactor = 1.0 / (8.0 * (M_PI * M_PI * M_PI)) / is3d::kHbarC / is3d::kHbarC / is3d::kHbarC;   // :2147
         VAH_TRY(is3d::launch_finalize(P->d_partial.as<double>(), P->d_lane.as<int>(), P->d_deg.as<double>(), dN_out, P->nout, P->npart, P->npT, P->J,
-                                      P->Kacc, P->Lpad, nch, prefactor, (pass > 0 || o.accumulate) ? 1 : 0, nullptr, st));
+                                      P->Kacc, P->Lpad, nch, prefactor, (pass > 0 || o.accumulate) ? 1 : 0, nullptr, st, P->split, P->Lbins));
     }
     if (P->timing && npasses) VAH_TRY(hipEventRecord(P->ev[npasses * 3], st));
     if (status) {

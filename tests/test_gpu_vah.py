@@ -19,10 +19,10 @@ def test_vah_parity(fx, dim, flags):
     sp = inputs.species([211, 321, 2212, -2212, 3122, 333]) if dim == 3 else fx["pikp"]
     o = dict(dimension=dim, **flags)
     ref = oracle.dN_pTdpTdphidy_vah(cells, sp, fx["grid"], o)
-    for variant in (0, 2, 3):                    # 3 (= the 3+1D default): cf_main_vah3, factored exponent on the 8 x 7 tile; 2: the round-1 kernel
+    for variant in (0, 2, 3):                    # 3 (= the default): cf_main_vah3, factored exponent -- 8 x 7 tile in 3+1D, 8 x 31 with unit-strided lanes in 2+1D; 2: the round-1 kernel
         got, st = api.smooth_spectra_vah(cells, sp, fx["grid"], dict(o, kernel_variant=variant))
         assert relerr(got, ref, floor=1e-270) < TOL, (variant, relerr(got, ref, floor=1e-270))
-        assert st["kernel_variant"] == (2 if (dim == 2 or variant == 2) else 3)
+        assert st["kernel_variant"] == (2 if variant == 2 else 3)
         off, _ = api.smooth_spectra_vah(cells, sp, fx["grid"], dict(o, kernel_variant=variant, zero_skip=2))
         assert np.array_equal(off, got), variant         # the row / unit culls skip exact zeros only
     assert (ref < 0).any() or dim == 2
@@ -238,6 +238,32 @@ def test_vah_odd_grids(fx):
         assert relerr(got, ref, floor=1e-270) < TOL, neta
 
 
+def test_vah_2d_factored_kernel_against_the_round1_kernel(fx):
+    """2+1D: cf_main_vah3<DIM3 = false> (factored exponent, 8 x 31 tile, unit-strided lanes: pi / K / p are 96 bins, four lane slots each) against
+    the round-1 cf_main_vah (8 x 61, expanded quadratic form) on 700 cells: the same sums in another order and with another polynomial for the
+    exponential -- <= 2e-13 on every bin that is not cancellation noise; cell counts that do not fill the LDS batches; a species list whose bin
+    count gives no split; several passes."""
+    cells = synth.synth_vah_surface(700, 2, seed=77)
+    tab = inputs.vah_df_tables()
+    o = dict(dimension=2)
+    old, st_old = api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], dict(o, kernel_variant=2), tab=tab)
+    new, st_new = api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], o, tab=tab)
+    assert st_old["kernel_variant"] == 2 and st_new["kernel_variant"] == 3
+    scale = np.abs(old).max()
+    assert float(np.max(np.abs(new - old) / np.maximum(np.abs(old), 1e-12 * scale))) < 2e-13
+    for n in (1, 3, 65):
+        sub = {k: v[:n] for k, v in cells.items()}
+        a, _ = api.smooth_spectra_vah(sub, fx["pikp"], fx["grid"], dict(o, kernel_variant=2), tab=tab)
+        b, _ = api.smooth_spectra_vah(sub, fx["pikp"], fx["grid"], o, tab=tab)
+        assert float(np.max(np.abs(b - a) / np.maximum(np.abs(a), 1e-12 * np.abs(a).max()))) < 2e-13, n
+    many = inputs.species([211, 321, 2212, -2212, 3122, 333, 111, 221])      # 8 classes x 32 pT = 256 bins: whole waves, no split
+    a, _ = api.smooth_spectra_vah(cells, many, fx["grid"], dict(o, kernel_variant=2), tab=tab)
+    b, _ = api.smooth_spectra_vah(cells, many, fx["grid"], o, tab=tab)
+    assert float(np.max(np.abs(b - a) / np.maximum(np.abs(a), 1e-12 * np.abs(a).max()))) < 2e-13
+    c, st = api.smooth_spectra_vah(cells, fx["pikp"], fx["grid"], dict(o, workspace_bytes=1 << 22), tab=tab)   # passes
+    assert st["n_passes"] > 1 and float(np.max(np.abs(c - new) / np.maximum(np.abs(new), 1e-12 * scale))) < 1e-13
+
+
 def test_vah_golden_vectors_on_device():
     """The committed independent vectors (tests/golden/golden_vah.npz: scipy coefficients, numpy long-double spectra) against the device:
     coefficients to 2e-12, spectra -- with the coefficients interpolated on the device from the tables -- to the parity tolerance."""
@@ -253,7 +279,7 @@ def test_vah_golden_vectors_on_device():
         cells = {k[len("cells%d_" % dim):]: z[k] for k in z.files if k.startswith("cells%d_" % dim)}
         grid = {k[len("grid%d_" % dim):]: z[k] for k in z.files if k.startswith("grid%d_" % dim)}
         for reg in (1, 0):
-            for variant in ((0, 2) if dim == 3 else (0,)):
+            for variant in (0, 2):
                 got, _ = api.smooth_spectra_vah(cells, sp, grid, dict(dimension=dim, regulate_deltaf=reg, kernel_variant=variant), tab=tab)
                 assert relerr(got, z["dN%d_reg%d" % (dim, reg)], floor=1e-270) < TOL, (dim, reg, variant)
 

@@ -51,7 +51,7 @@ def demangle_params(sym):
     elif name == "cf_main_vah":
         keys = ["DIM3", "REG", "JT", "R"]
     elif name == "cf_main_vah3":
-        keys = ["REG", "JT", "R"]
+        keys = ["DIM3", "REG", "JT", "R"]
     else:
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
     return name, dict(zip(keys, vals))
