@@ -579,7 +579,8 @@ def main():
         # ---- roofline (contract form, HBM): algorithmic bytes of the launch = cell arrays read once + spectrum written once
         ncell_arrays = len(cell_fields) - (0 if wl["dimension"] == 3 else 1)   # 18 (17 in 2+1D: no eta); VAH: 24
         b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
-        traffic, traffic_source = (None, None) if (a.df_mode or a.variant) else pmc_traffic(wl["name"], n_loc)
+        tkey = wl["name"] + ("_feqmod%d" % a.df_mode if a.df_mode in (3, 4) else "") + ("_dim2" if (vah and wl["dimension"] == 2) else "")
+        traffic, traffic_source = (None, None) if (a.variant or a.df_mode in (1, 2)) else pmc_traffic(tkey, n_loc)
         roofline = dict(bound="hbm", achieved=b_alg / (ms_main * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=b_alg / (ms_main * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, kernel=plan.main_kernel_name,
                         kernel_ms=ms_main, algorithmic_bytes=b_alg,

@@ -140,7 +140,10 @@ typedef struct {
                                            round 1 (A/B only).  A variant that does not exist for the requested mode falls back to the
                                            default; status.kernel_variant says which one ran */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
-    int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass */
+    int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass; 0: max(16 GiB, 45 % of the device's TOTAL memory) --
+                                           the total, not what is free at the moment, so that the pass / chunk count (and with it the
+                                           summation order) of a large surface does not depend on the GPU's other tenants.  An
+                                           allocation that does not fit returns IS3D_ENOMEM naming the sizes */
     int32_t collapse_species;           /* 0 default(on) | 1 on | 2 off: evaluate one representative per
                                            distinct (mass, sign) and scale by degeneracy */
     int32_t zero_skip;                  /* wave-level culling of rows that cannot change the result (bitwise-identical spectra

@@ -446,14 +446,16 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if (P->feqmod)   // fallback record, flag, list entry; df_mode 3: cell record + |renorm| per class
         P->bytes_per_cell += sizeof(double) * is3d::kFbRec + 2 * sizeof(int32_t) +
                              (o->df_mode == 3 ? sizeof(double) * ((size_t)is3d::kCrRec + P->ncls) : 0);
-    // cap on the derived streams of one pass: the caller's, else 16 GiB or half of the device memory that is free right now, whichever
-    // is larger (288 GB of HBM: a 1e6-cell surface with baryon slots -- 20.6 KB per cell -- stays a single pass; only what max_cells
-    // needs is allocated)
+    // cap on the derived streams of one pass: the caller's, else 16 GiB or 45 % of the device's TOTAL memory, whichever is larger (288 GB of
+    // HBM: a 1e6-cell surface with baryon slots -- 20.6 KB per cell -- stays a single pass; only what max_cells needs is allocated).  The
+    // total, not what happens to be free: the pass count, the chunk count and with them the summation order of a surface that needs several
+    // passes must not depend on what else occupies the GPU at the moment (the partial slab below adds up to 12 GiB on top; an allocation that
+    // does not fit is reported as IS3D_ENOMEM with the sizes, and opts.workspace_bytes sets the cap explicitly)
     int64_t ws = o->workspace_bytes;
     if (ws <= 0) {
         ws = (int64_t)16 << 30;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)(free_b / 2));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
     }
     int64_t pc = ws / (int64_t)P->bytes_per_cell;
     if (pc < 1) pc = 1;
@@ -501,12 +503,26 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         nch = std::max<int64_t>(1, std::min(nch, by_mem));
         P->nch_max = (int)nch;
     }
+#define BIG_ALLOC(buf, count, what)                                                                                                  \
+    do {                                                                                                                              \
+        const size_t n_ = (count);                                                                                                    \
+        hipError_t e_ = (buf).alloc(n_);                                                                                              \
+        if (e_ == hipErrorOutOfMemory) {                                                                                              \
+            (void)hipGetLastError();                                                                                                  \
+            size_t fr_ = 0, to_ = 0;                                                                                                  \
+            (void)hipMemGetInfo(&fr_, &to_);                                                                                          \
+            return fail(IS3D_ENOMEM, "out of device memory allocating %s (%.2f GB; %.2f GB free of %.2f GB): %lld cells per pass x %zu B of streams, " \
+                        "%d partial slabs -- lower opts.workspace_bytes (more passes) or opts.cell_chunks", what, n_ * sizeof(*(buf).p) / 1e9, \
+                        fr_ / 1e9, to_ / 1e9, (long long)pc, P->bytes_per_cell, P->nch_max);                                          \
+        }                                                                                                                             \
+        if (e_ != hipSuccess) return fail(IS3D_ENODEVICE, "hipMalloc(%s) failed: %s", what, hipGetErrorString(e_));                  \
+    } while (0)
     if (tiled) {
         // unpredicated direct-to-LDS staging over-reads a short last batch (cf_main_tile3e, cf_main_tile variant 8)
         const size_t slack = (size_t)is3d::tile3e_stream_slack_doubles(P->JT, P->KT) + 16 * (size_t)is3d::unit_rec_doubles(P->JT, P->KT, 1);
-        HIP_TRY(P->d_TS.alloc((size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0) + slack));
+        BIG_ALLOC(P->d_TS, (size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0) + slack, "the unit-record stream");
         if (P->e2tab) {
-            HIP_TRY(P->d_TE.alloc((size_t)pc * P->jtiles * is3d::kE2Stride * P->JT + slack));
+            BIG_ALLOC(P->d_TE, (size_t)pc * P->jtiles * is3d::kE2Stride * P->JT + slack, "the E2 table stream");
             P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb, P->baryon ? 1 : 0);
             if (P->ub3e < 1) return fail(IS3D_EINVAL, "kernel_variant 5: a unit record plus its %d x %d E2 table does not fit the LDS budget", P->npT, P->JT);
         }
@@ -515,7 +531,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
         HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
     }
-    HIP_TRY(P->d_partial.alloc((size_t)P->nch_max * P->J * P->Kacc * P->Lpad));
+    BIG_ALLOC(P->d_partial, (size_t)P->nch_max * P->J * P->Kacc * P->Lpad, "the per-chunk partial spectra");
+#undef BIG_ALLOC
     if (P->e2tab) HIP_TRY(P->d_cull_floor.alloc((size_t)P->jtiles * P->ktiles * P->Lpad));
     HIP_TRY(P->d_status.alloc(8));
     HIP_TRY(P->d_sticky.upload(std::vector<unsigned long long>{~0ULL, ~0ULL}));

@@ -900,10 +900,10 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
     int64_t ws = o->workspace_bytes;
-    if (ws <= 0) {   // as cf_plan.cpp: 16 GiB or half of the free device memory
+    if (ws <= 0) {   // as cf_plan.cpp: 16 GiB or 45 % of the device's TOTAL memory (not of what is free now: the pass count must not depend on the GPU's other tenants)
         ws = (int64_t)16 << 30;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)(free_b / 2));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
     }
     P->pass_cells = std::max<int64_t>(1, std::min<int64_t>(max_cells, ws / (int64_t)bytes_per_cell));
     const int lane_waves = Lpad / 64;
@@ -915,8 +915,17 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     nch = std::min<int64_t>(nch, std::max<int64_t>(1, P->pass_cells / 64));
     nch = std::max<int64_t>(1, std::min<int64_t>(nch, ((int64_t)(o->cell_chunks > 0 ? 32 : 12) << 30) / ((int64_t)J * Kacc * Lpad * 8)));
     P->nch = (int)nch;
-    VAH_TRY(P->d_TS.alloc((size_t)P->pass_cells * bytes_per_cell + 64 * 1024));   // + slack: the staging pieces of the last batch over-read the stream
-    VAH_TRY(P->d_partial.alloc((size_t)nch * J * Kacc * Lpad * sizeof(double)));
+    for (int which = 0; which < 2; which++) {
+        const size_t bytes = which == 0 ? (size_t)P->pass_cells * bytes_per_cell + 64 * 1024   // + slack: the staging pieces of the last batch over-read the stream
+                                        : (size_t)nch * J * Kacc * Lpad * sizeof(double);
+        const hipError_t e = (which == 0 ? P->d_TS : P->d_partial).alloc(bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            return set_error(IS3D_ENOMEM, "out of device memory allocating %s (%.2f GB): lower opts.workspace_bytes (more passes) or opts.cell_chunks",
+                             which == 0 ? "the unit-record stream" : "the per-chunk partial spectra", bytes / 1e9);
+        }
+        if (e != hipSuccess) return set_error(IS3D_ENODEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
     VAH_TRY(P->d_status.alloc(8 * sizeof(unsigned long long)));
     *out = P.release();
     return IS3D_OK;

@@ -22,7 +22,38 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from is3d_amd import inputs, synth  # noqa: E402
 
 
+def unit_list_model():
+    """under zero_skip = 3 (static threshold floors) cf_cull_floor could also emit, per (chunk, phi tile, row block,
+    workgroup), the list of units that are live for at least one of the workgroup's lane-waves, and the main kernel could stage only those.
+    What that can return is bounded by the cycle accounting of the kernel as it is (profiles/r02_cycle_accounting.log, culling on): the phases
+    that scale with the number of units that pass through LDS.  Pure arithmetic on the committed counters -- build only if >= 6 % of the wave cycles."""
+    import re
+    log = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_cycle_accounting.log")).readline()
+    f = {}
+    for k, v in re.findall(r"(record part of stage|vmcnt part of wait|stage|wait|dead units|live units) (\d\.\d+)", log):
+        f.setdefault(k, float(v))
+    dead_n, live_n = [int(x) for x in re.findall(r"(?:dead|live) units (\d+) \(", log)]
+    dead_frac = dead_n / (dead_n + live_n)
+    # a unit can be left out of a workgroup's stream only if it is dead for BOTH of its lane-waves; neighbouring lane-waves (m_T-sorted) agree on
+    # most units -- take the per-wave dead fraction as the upper bound
+    save_dead = f["dead units"]                       # the dead units' own test: two LDS reads, three instructions, a vote
+    save_stage = f["stage"] * dead_frac               # staging scales with the units staged
+    # what the indirection costs: the records are 928 B, the staging pieces 1 KiB -- a gathered unit costs one whole piece for its record (today
+    # 0.906 pieces per unit on average) and an address per unit instead of per four pieces; the E2 table (2 KiB per unit) is piece-aligned
+    cost_gather = f["record part of stage"] * (1.0 - dead_frac) * (1.0 / 0.906 - 1.0) + f["stage"] * (1.0 - dead_frac) * 0.25
+    net = save_dead + save_stage - cost_gather
+    print("unit-list model (zero_skip = 3 only): staged units %.0f M, dead on arrival %.1f %%" % ((dead_n + live_n) / 1e6, 100 * dead_frac))
+    print("  upper bound of what is saved: dead-unit tests %.2f %% + staging of dead units %.2f %% of the wave cycles = %.2f %%" % (
+        100 * save_dead, 100 * save_stage, 100 * (save_dead + save_stage)))
+    print("  gathered staging costs back ~%.2f %% (whole pieces per record, one address per unit)" % (100 * cost_gather))
+    print("  net <= %.2f %% of the wave cycles; the barrier wait (%.1f %%) is the two waves' imbalance, not a per-unit cost" % (100 * net, 100 * f["wait"]))
+    print("  threshold for building it: 6 %% -> %s" % ("build" if net >= 0.06 else "not built"))
+
+
 def main():
+    if "--unit-list-model" in sys.argv:
+        unit_list_model()
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--cells", type=int, default=4525)
     ap.add_argument("--first", type=int, default=0)

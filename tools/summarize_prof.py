@@ -76,7 +76,8 @@ out = {workload: dict(cells=bench["config"]["cells_per_gpu"], kernel=bench["conf
                       SQ_ACTIVE_INST_VALU_quadcycles=per_launch("cf_main", "SQ_ACTIVE_INST_VALU"))}
 tp = os.path.join(dst, tag + "_pmc_traffic.json")
 old = json.load(open(tp)) if os.path.exists(tp) else {}
-old.update(out)
+for k_, v_ in out.items():   # keep what other tools put beside it (tools/summarize_shards.py: "shards")
+    old[k_] = dict({kk: vv for kk, vv in old.get(k_, {}).items() if kk in ("shards", "shards_note")}, **v_)
 json.dump(old, open(tp, "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
