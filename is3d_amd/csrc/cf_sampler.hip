@@ -230,10 +230,22 @@ __device__ __forceinline__ double species_dn(const SamplerParams &p, const Sampl
     return c.z * equilibrium_density;
 }
 
+// The cell's n_eq integrals (GT[cell][class], 600 B per cell for 75 classes) are summed over the SPECIES in list order (the order the reference
+// and the oracle add them in): 305 gathers per lane from rows 600 B apart were 3.0 of the kernel's 3.1 ms (64 cache lines per load
+// instruction).  The rows of a workgroup's consecutive cells are one contiguous block: staged through LDS with coalesced loads, read from
+// there (row stride 75 doubles: 2-way bank conflicts at worst).  Same values, same order of additions.
 __global__ void __launch_bounds__(128)
 cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ GT, const double *__restrict__ GT2,
                  const double *__restrict__ GT3, SamplerCell *__restrict__ out)
 {
+    extern __shared__ double l_gt[];               // [blockDim.x][ncls]
+    {
+        const int64_t c0 = (int64_t)blockIdx.x * blockDim.x;
+        const int64_t nrow = min((int64_t)blockDim.x, p.n_cells - c0);
+        const double *src = GT + c0 * sp.ncls;
+        for (int64_t i = threadIdx.x; i < nrow * sp.ncls; i += blockDim.x) l_gt[i] = src[i];
+        __syncthreads();
+    }
     const int64_t ic = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= p.n_cells) return;
     SamplerCell c;
@@ -357,7 +369,7 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
         const double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * Fb / Tb / Tb) / bbb;
         if (detA <= p.detA_min || (neq_pion0 + dn_pion0) < 0.0) { c.breakdown = 1.0; atomicAdd(&p.status[5], 1ULL); }
     }
-    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
+    const double *gt = l_gt + threadIdx.x * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
     double dn = 0.0;
     for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
     c.dn_sum = dn;
@@ -962,8 +974,11 @@ extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells 
         hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], dptr[18], n, sp,
                            P->d_gl.as<double>(), P->ngla, d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>());
         SMP_TRY(hipEventRecord(ev[6], nullptr));
-        hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, p, sp, d_GT.as<double>(),
-                           d_GT2.as<double>(), d_GT3.as<double>(), d_rec.as<is3d::SamplerCell>());
+        const int cb = ncls <= 64 ? 128 : 64;      // cells per workgroup: their n_eq rows sit in LDS (<= 64 KB: ncls <= 128; larger lists take 32)
+        const int cbk = (size_t)cb * ncls * sizeof(double) <= 64 * 1024 ? cb : 32;
+        if ((size_t)cbk * ncls * sizeof(double) > 64 * 1024) return set_error(IS3D_EINVAL, "%d species classes: more than the sampler's cell kernel stages through LDS (256)", ncls);
+        hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + cbk - 1) / cbk)), dim3(cbk), (size_t)cbk * ncls * sizeof(double), nullptr, p, sp,
+                           d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>(), d_rec.as<is3d::SamplerCell>());
         SMP_TRY(hipGetLastError());
     }
     SMP_TRY(hipEventRecord(ev[2], nullptr));
