@@ -165,54 +165,96 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
         }
         if (p.fact) {
             // ---- F records (cf_main_vah3): header jj {B_j, d_j, gd_j, x}, x of jj = 0, 1, 2 = min_k c_k, min_k e_k over the unit's rows and
-            // max_j d_j over its phi tile (the bounds of the unit- and row-level culls); row r {A_k, c_k, ad_k, e_k, bd_{j0..,k}}
+            // max_j d_j over its phi tile (the bounds of the unit- and row-level culls); row r {A_k, c_k, ad_k, e_k[, W_k, 0], bd_{j0..,k}}
+            // (3+1D: four row scalars; 2+1D: six -- the eta weight travels with the row, rows stay 16-byte multiples).
+            // The writer (round 4; it was a flat index decoded with four integer divisions and a dozen branches per element: 22 of the 85 ms of a
+            // 2+1D step): WHICH quantity an element of a record is does not depend on the unit, so it is decoded once per workgroup into a
+            // descriptor table; the tile / row-block minima are formed once per (cell, tile) / (cell, row block); then one unit per wave at a time,
+            // lanes <-> elements, units walked so that a wave's consecutive records are adjacent in the stream.
             const int JT = p.JT, R = p.R;
+            const int RS = p.dim3 ? 4 : 6;
+            const int HDR = 4 * JT, RWD = RS + JT, REC = HDR + R * RWD;
+            double *l_ckmin = l_dmx + CB * p.jtiles;          // [CB][rblocks]
+            double *l_ekmin = l_ckmin + CB * p.rblocks;       // [CB][rblocks]
+            int2 *desc = (int2 *)(l_ekmin + CB * p.rblocks);  // [REC]: x = kind, y = jj | r << 8
+            enum { kB = 0, kDj, kGd, kCkMin, kEkMin, kDmx, kZero, kA, kCk, kAd, kEk, kW, kBeta };
+            if (batch == (int)blockIdx.x) {                   // first batch of this workgroup: the table
+                for (int e = tid; e < REC; e += kVahThreads) {
+                    int kind, y;
+                    if (e < HDR) {
+                        const int jj = e >> 2, f = e & 3;
+                        y = jj;
+                        kind = f == 0 ? kB : f == 1 ? kDj : f == 2 ? kGd : jj == 0 ? kCkMin : jj == 1 ? kEkMin : jj == 2 ? kDmx : kZero;
+                    } else {
+                        const int q = e - HDR, r = q / RWD, f = q - r * RWD;
+                        y = r << 8;
+                        if (f == 0) kind = kA;
+                        else if (f == 1) kind = kCk;
+                        else if (f == 2) kind = kAd;
+                        else if (f == 3) kind = kEk;
+                        else if (f < RS) kind = f == 4 ? kW : kZero;
+                        else { kind = kBeta; y |= f - RS; }
+                    }
+                    desc[e] = int2{kind, y};
+                }
+            }
             for (int idx = tid; idx < ncb * p.jtiles; idx += kVahThreads) {
                 const int c = idx / p.jtiles, jt = idx - c * p.jtiles;
                 double v = -1.0e300;
                 for (int q2 = 0; q2 < JT; q2++) v = fmax(v, l_dj[c * J + min(jt * JT + q2, J - 1)]);
-                l_dmx[idx] = v;
+                l_dmx[c * p.jtiles + jt] = v;
+            }
+            for (int idx = tid; idx < ncb * p.rblocks; idx += kVahThreads) {
+                const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
+                double a = 1.0e300, b2 = 1.0e300;
+                for (int r = 0; r < R; r++) {
+                    const int kc = min(rb * R + r, K - 1);
+                    a = fmin(a, l_ck[c * K + kc]);
+                    b2 = fmin(b2, l_ek[c * K + kc]);
+                }
+                l_ckmin[c * p.rblocks + rb] = a;
+                l_ekmin[c * p.rblocks + rb] = b2;
             }
             __syncthreads();
-            // row scalars: 3+1D {A_k, c_k, ad_k, e_k}; 2+1D {A_k, c_k, ad_k, e_k, W_k, 0} (the eta weight; rows stay 16-byte multiples)
-            const int RS = p.dim3 ? 4 : 6;
-            const int HDR = 4 * JT, RWD = RS + JT, REC = HDR + R * RWD;
-            const int units_per_cell = p.jtiles * p.rblocks, per_cell = units_per_cell * REC;
-            for (int idx = tid; idx < ncb * per_cell; idx += kVahThreads) {
-                const int c = idx / per_cell;
-                const int rem = idx - c * per_cell;
-                const int ut = rem / REC, e = rem - ut * REC;
-                const int jt = ut / p.rblocks, rb = ut - jt * p.rblocks;
+            const int wave = tid >> 6, lane = tid & 63, nwaves = kVahThreads / 64;
+            const int n_units = ncb * p.jtiles * p.rblocks;
+            for (int u = wave; u < n_units; u += nwaves) {
+                int c, jt, rb;
+                if (p.dim3) { c = u % ncb; const int t = u / ncb; rb = t % p.rblocks; jt = t / p.rblocks; }      // cells innermost: adjacent records of one stream
+                else { rb = u % p.rblocks; const int t = u / p.rblocks; c = t % ncb; jt = t / ncb; }             // row blocks innermost
                 const VahScal &s = cs[c];
-                double v = 0.0;
-                if (e < HDR) {
-                    const int jj = e >> 2, f = e & 3;
-                    const int j = min(jt * JT + jj, J - 1);
-                    if (f == 0) v = l_B[c * J + j];
-                    else if (f == 1) v = l_dj[c * J + j];
-                    else if (f == 2) v = l_gd[c * J + j];
-                    else if (jj == 0) { v = 1.0e300; for (int r = 0; r < R; r++) v = fmin(v, l_ck[c * K + min(rb * R + r, K - 1)]); }
-                    else if (jj == 1) { v = 1.0e300; for (int r = 0; r < R; r++) v = fmin(v, l_ek[c * K + min(rb * R + r, K - 1)]); }
-                    else if (jj == 2) v = l_dmx[c * p.jtiles + jt];
-                } else {
-                    const int q = e - HDR, r = q / RWD, f = q - r * RWD;
-                    const int k = rb * R + r, kc = min(k, K - 1);     // padding rows: the forms of row K-1 with p.dsigma = 0
-                    if (f == 0) v = (k < K) ? l_A[c * K + kc] : 0.0;
-                    else if (f == 1) v = l_ck[c * K + kc];
-                    else if (f == 2) v = l_ad[c * K + kc];
-                    else if (f == 3) v = l_ek[c * K + kc];
-                    else if (f < RS) v = (f == 4 && k < K) ? l_W[c * K + kc] : 0.0;
-                    else {
-                        const int j = min(jt * JT + (f - RS), J - 1);
-                        const double X = l_E[c * J + j] * l_ch[c * K + kc] + l_F[c * J + j] * l_sh[c * K + kc];
-                        v = s.c4 * X - s.c3 * l_Z[c * K + kc] * l_V2[c * J + j] - 2.0 * s.Pi * s.c2 * l_C[c * K + kc] * l_D[c * J + j];
-                    }
-                }
                 const int64_t cell = cbase + c;
-                int64_t unit;
-                if (p.dim3) unit = (int64_t)ut * p.n_cells + cell;
-                else unit = ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
-                __builtin_nontemporal_store(v, &p.TS[unit * REC + e]);
+                const int64_t unit = p.dim3 ? (int64_t)(jt * p.rblocks + rb) * p.n_cells + cell : ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
+                double *o = p.TS + unit * REC;
+                const int cJ = c * J, cK = c * K;
+                for (int e = lane; e < REC; e += 64) {
+                    const int2 d = desc[e];
+                    const int jj = d.y & 0xff, r = d.y >> 8;
+                    const int j = cJ + min(jt * JT + jj, J - 1);
+                    const int k = rb * R + r, kc = cK + min(k, K - 1);
+                    const bool pad = k >= K;
+                    double v;
+                    switch (d.x) {
+                    case kB: v = l_B[j]; break;
+                    case kDj: v = l_dj[j]; break;
+                    case kGd: v = l_gd[j]; break;
+                    case kCkMin: v = l_ckmin[c * p.rblocks + rb]; break;
+                    case kEkMin: v = l_ekmin[c * p.rblocks + rb]; break;
+                    case kDmx: v = l_dmx[c * p.jtiles + jt]; break;
+                    case kA: v = pad ? 0.0 : l_A[kc]; break;          // padding rows: the forms of row K-1 with p.dsigma = 0
+                    case kCk: v = l_ck[kc]; break;
+                    case kAd: v = l_ad[kc]; break;
+                    case kEk: v = l_ek[kc]; break;
+                    case kW: v = pad ? 0.0 : l_W[kc]; break;
+                    case kBeta: {
+                        const double X = l_E[j] * l_ch[kc] + l_F[j] * l_sh[kc];
+                        v = s.c4 * X - s.c3 * l_Z[kc] * l_V2[j] - 2.0 * s.Pi * s.c2 * l_C[kc] * l_D[j];
+                        break;
+                    }
+                    default: v = 0.0; break;
+                    }
+                    o[e] = v;
+                }
             }
         } else {
             const int JT = p.JT, R = p.R;
@@ -895,7 +937,7 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     for (int s2 = 0; s2 < L; s2++) { P->mTmax = std::max(P->mTmax, mT[s2]); P->pTmax = std::max(P->pTmax, pT[s2]); }
     P->ktiles = three_d ? P->rblocks : 1; P->upc = three_d ? 1 : P->rblocks;
     P->REC = P->fact ? 4 * P->JT + P->R * ((three_d ? 4 : 6) + P->JT) : 4 * P->JT + P->R * (4 + 2 * P->JT);
-    P->lds_prep = sizeof(is3d::VahScal) * is3d::vah_batch_cells(K) + sizeof(double) * (size_t)is3d::vah_batch_cells(K) * (10 * K + 8 * J);   // + [CB][jtiles <= J] tile maxima of the F records
+    P->lds_prep = sizeof(is3d::VahScal) * is3d::vah_batch_cells(K) + sizeof(double) * ((size_t)is3d::vah_batch_cells(K) * (10 * K + 8 * J + 2 * P->rblocks) + (size_t)P->REC);   // + [CB][jtiles <= J] tile maxima, [CB][2 rblocks] row-block minima and the REC-entry descriptor table of the F records
     if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
