@@ -231,7 +231,7 @@ __device__ __forceinline__ double species_dn(const SamplerParams &p, const Sampl
 }
 
 // The cell's n_eq integrals (GT[cell][class], 600 B per cell for 75 classes) are summed over the SPECIES in list order (the order the reference
-// and the oracle add them in): 305 gathers per lane from rows 600 B apart were 3.0 of the kernel's 3.1 ms (64 cache lines per load
+// adds them in): 305 gathers per lane from rows 600 B apart were 3.0 of the kernel's 3.1 ms (64 cache lines per load
 // instruction).  The rows of a workgroup's consecutive cells are one contiguous block: staged through LDS with coalesced loads, read from
 // there (row stride 75 doubles: 2-way bank conflicts at worst).  Same values, same order of additions.
 __global__ void __launch_bounds__(128)
