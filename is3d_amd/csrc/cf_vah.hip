@@ -176,26 +176,32 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             const int HDR = 4 * JT, RWD = RS + JT, REC = HDR + R * RWD;
             double *l_ckmin = l_dmx + CB * p.jtiles;          // [CB][rblocks]
             double *l_ekmin = l_ckmin + CB * p.rblocks;       // [CB][rblocks]
-            int2 *desc = (int2 *)(l_ekmin + CB * p.rblocks);  // [REC]: x = kind, y = jj | r << 8
-            enum { kB = 0, kDj, kGd, kCkMin, kEkMin, kDmx, kZero, kA, kCk, kAd, kEk, kW, kBeta };
+            // descriptor of a record element: x = bits 0-19 offset of its source array in the LDS block | 20-22 index rule (0: + c J + j, 1: + c K + k,
+            // 2: + c rblocks + rb, 3: + c jtiles + jt) | 24 beta element | 25 zero in a padding row | 26 always zero;  y = jj | r << 8.
+            // Branch-free per element: ONE read of the selected source, the beta form evaluated beside it (six more reads) and selected by a flag -- a
+            // switch over the thirteen kinds ran seven exec-masked bodies with an LDS round trip each per trip (13.5 ms per 1e5 cells in 2+1D).
+            int2 *desc = (int2 *)(l_ekmin + CB * p.rblocks);  // [REC]
+            constexpr int BETA = 1 << 24, PADZ = 1 << 25, ZERO = 1 << 26;
             if (batch == (int)blockIdx.x) {                   // first batch of this workgroup: the table
+                const int o_B = (int)(l_B - lds), o_dj = (int)(l_dj - lds), o_gd = (int)(l_gd - lds), o_ckm = (int)(l_ckmin - lds), o_ekm = (int)(l_ekmin - lds);
+                const int o_dmx = (int)(l_dmx - lds), o_A = (int)(l_A - lds), o_ck = (int)(l_ck - lds), o_ad = (int)(l_ad - lds), o_ek = (int)(l_ek - lds), o_W = (int)(l_W - lds);
                 for (int e = tid; e < REC; e += kVahThreads) {
-                    int kind, y;
+                    int x, y;
                     if (e < HDR) {
                         const int jj = e >> 2, f = e & 3;
                         y = jj;
-                        kind = f == 0 ? kB : f == 1 ? kDj : f == 2 ? kGd : jj == 0 ? kCkMin : jj == 1 ? kEkMin : jj == 2 ? kDmx : kZero;
+                        x = f == 0 ? o_B : f == 1 ? o_dj : f == 2 ? o_gd : jj == 0 ? (o_ckm | (2 << 20)) : jj == 1 ? (o_ekm | (2 << 20)) : jj == 2 ? (o_dmx | (3 << 20)) : ZERO;
                     } else {
                         const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                         y = r << 8;
-                        if (f == 0) kind = kA;
-                        else if (f == 1) kind = kCk;
-                        else if (f == 2) kind = kAd;
-                        else if (f == 3) kind = kEk;
-                        else if (f < RS) kind = f == 4 ? kW : kZero;
-                        else { kind = kBeta; y |= f - RS; }
+                        if (f == 0) x = o_A | (1 << 20) | PADZ;
+                        else if (f == 1) x = o_ck | (1 << 20);
+                        else if (f == 2) x = o_ad | (1 << 20);
+                        else if (f == 3) x = o_ek | (1 << 20);
+                        else if (f < RS) x = f == 4 ? (o_W | (1 << 20) | PADZ) : ZERO;
+                        else { x = BETA; y |= f - RS; }
                     }
-                    desc[e] = int2{kind, y};
+                    desc[e] = int2{x, y};
                 }
             }
             for (int idx = tid; idx < ncb * p.jtiles; idx += kVahThreads) {
@@ -227,33 +233,20 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
                 const int64_t unit = p.dim3 ? (int64_t)(jt * p.rblocks + rb) * p.n_cells + cell : ((int64_t)jt * p.n_cells + cell) * p.rblocks + rb;
                 double *o = p.TS + unit * REC;
                 const int cJ = c * J, cK = c * K;
+                const double c4 = s.c4, c3 = s.c3, pc2 = 2.0 * s.Pi * s.c2;
                 for (int e = lane; e < REC; e += 64) {
                     const int2 d = desc[e];
                     const int jj = d.y & 0xff, r = d.y >> 8;
                     const int j = cJ + min(jt * JT + jj, J - 1);
                     const int k = rb * R + r, kc = cK + min(k, K - 1);
-                    const bool pad = k >= K;
-                    double v;
-                    switch (d.x) {
-                    case kB: v = l_B[j]; break;
-                    case kDj: v = l_dj[j]; break;
-                    case kGd: v = l_gd[j]; break;
-                    case kCkMin: v = l_ckmin[c * p.rblocks + rb]; break;
-                    case kEkMin: v = l_ekmin[c * p.rblocks + rb]; break;
-                    case kDmx: v = l_dmx[c * p.jtiles + jt]; break;
-                    case kA: v = pad ? 0.0 : l_A[kc]; break;          // padding rows: the forms of row K-1 with p.dsigma = 0
-                    case kCk: v = l_ck[kc]; break;
-                    case kAd: v = l_ad[kc]; break;
-                    case kEk: v = l_ek[kc]; break;
-                    case kW: v = pad ? 0.0 : l_W[kc]; break;
-                    case kBeta: {
-                        const double X = l_E[j] * l_ch[kc] + l_F[j] * l_sh[kc];
-                        v = s.c4 * X - s.c3 * l_Z[kc] * l_V2[j] - 2.0 * s.Pi * s.c2 * l_C[kc] * l_D[j];
-                        break;
-                    }
-                    default: v = 0.0; break;
-                    }
-                    o[e] = v;
+                    const int rule = (d.x >> 20) & 7;
+                    const int add = rule == 0 ? j : rule == 1 ? kc : rule == 2 ? c * p.rblocks + rb : c * p.jtiles + jt;
+                    const bool zero = ((d.x >> 26) & 1) | (((d.x >> 25) & 1) & (k >= K));   // padding rows: the forms of row K-1 with p.dsigma = 0
+                    const double raw = lds[zero ? 0 : (d.x & 0xfffff) + add];
+                    const double X = l_E[j] * l_ch[kc] + l_F[j] * l_sh[kc];
+                    const double bet = c4 * X - c3 * l_Z[kc] * l_V2[j] - pc2 * l_C[kc] * l_D[j];
+                    const double v = ((d.x >> 24) & 1) ? bet : raw;
+                    o[e] = zero ? 0.0 : v;
                 }
             }
         } else {

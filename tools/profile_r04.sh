@@ -28,6 +28,10 @@ if [ "$PART" = "a" ]; then
   run_pmc fqpmc_sq "$SQ1" --df-mode 4
   run_pmc fqpmc_misc "$SQ2" --df-mode 4
   echo "feqmod done"
+elif [ "$PART" = "c" ]; then   # only the kernel-trace stats of the anisotropic-hydro workloads (after a change to cf_prep_vah)
+  run_stats trace_c5 --workload config5
+  run_stats trace_v2 --workload config5 --dimension 2
+  run_pmc v2pmc_sq "$SQ1" --workload config5 --dimension 2
 else
   run_stats trace_c5 --workload config5
   run_pmc c5pmc_fetch FETCH_SIZE --workload config5
