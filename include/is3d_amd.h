@@ -503,7 +503,8 @@ int is3d_sample_particles(const is3d_cells *cells, const is3d_species *species, 
 /* Device-resident, persistent form (what bench.py --workload config5-sampler times; is3d_sample_particles is create + upload + execute +
  * download + destroy, so the two give the same list bit for bit): the species classes, splines / bilinear grids, Jonah tables and fast-mode
  * densities are set up once from (species, df, in, opts) -- `in` as for is3d_sample_particles; its n_events, seed, first_cell, x, y and
- * batch_events are execute-time arguments here -- and the workspaces (8 B x classes + 360 B per cell, 25 B per (event, cell) of a batch) are
+ * batch_events are execute-time arguments here -- and the workspaces (8 B x classes + 360 B per cell, + 8 B x species per cell for the running sums of the
+ * species weights unless df_mode = 3; 25 B per (event, cell) of a batch) are
  * allocated at the first execute of a shape and kept.  execute: cells->* and x, y are DEVICE arrays on the plan's device (x, y may be NULL),
  * particles a DEVICE buffer of `capacity` entries (NULL: count only); runs on the null stream and returns when the list is complete.
  * stats->ms_h2d is 0 (nothing is uploaded).  Return codes as is3d_sample_particles; cells->n_cells > max_cells: IS3D_EINVAL. */

@@ -85,6 +85,7 @@ struct SamplerParams {
     double y_max;
     uint64_t seed;
     unsigned long long *status; // [0] min bad cell, [1] skipped, [2] momentum samples, [3] acceptances, [4] hadrons drawn, [5] breakdown cells
+    double *cdf;                // [npart][n_cells] running sums of the species weights of a cell, as cf_sampler_cells adds them (NULL: df_mode 3)
 };
 
 // ---- Philox4x32-10 streams ----
@@ -370,8 +371,13 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
         if (detA <= p.detA_min || (neq_pion0 + dn_pion0) < 0.0) { c.breakdown = 1.0; atomicAdd(&p.status[5], 1ULL); }
     }
     const double *gt = l_gt + threadIdx.x * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
+    // the running sums are kept (species-major, so that the lanes of a wave -- consecutive cells -- store adjacent words): the sampling kernels
+    // then find a hadron's species by bisection of exactly these sums instead of re-adding up to 305 gathered weights per hadron
     double dn = 0.0;
-    for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
+    for (int ip = 0; ip < sp.npart; ip++) {
+        dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
+        if (p.cdf) p.cdf[(int64_t)ip * p.n_cells + ic] = dn;
+    }
     c.dn_sum = dn;
     c.dn_tot = dn * (2.0 * p.y_max * c.ds_max);
     c.live = (c.dn_tot > 0.0) ? 1.0 : 0.0;                                          // :1079
@@ -494,10 +500,22 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
     for (long ih = 0; ih < N_hadrons; ih++) {
         const double ut_ = g_type.uniform() * c.dn_sum;
         int chosen = sp.npart - 1;
-        double cum = 0.0;
-        for (int ip = 0; ip < sp.npart; ip++) {
-            cum += species_dn(p, sp, c, gt, gt2, gt3, ip);
-            if (ut_ < cum) { chosen = ip; break; }
+        if (p.cdf) {
+            // first species whose running sum exceeds ut_ (the last one if none does): bisection of the sums cf_sampler_cells stored -- the
+            // weights are >= 0 for df_mode 1, 2, 4, so the sums are non-decreasing and this IS the linear inversion below, in 9 reads
+            int lo = 0, hi = sp.npart - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ut_ < p.cdf[(int64_t)mid * p.n_cells + ic]) hi = mid;
+                else lo = mid + 1;
+            }
+            chosen = lo;
+        } else {
+            double cum = 0.0;
+            for (int ip = 0; ip < sp.npart; ip++) {
+                cum += species_dn(p, sp, c, gt, gt2, gt3, ip);
+                if (ut_ < cum) { chosen = ip; break; }
+            }
         }
         const double mass = sp.mass[chosen], mass_squared = mass * mass, sign = sp.sign[chosen];
         const double baryon = sp.baryon ? sp.baryon[chosen] : 0.0;
@@ -645,7 +663,7 @@ struct is3d_sampler_plan {
     DevMem d_bar, d_cbar, d_bilT, d_bilB, d_biltab[5];
     DevMem d_jonah, d_eqd, d_bkd;
     DevMem d_status, d_GT, d_GT2, d_GT3, d_rec, d_counts, d_offsets, d_scan_tmp;
-    DevMem d_drawn, d_emits, d_active, d_nactive;
+    DevMem d_drawn, d_emits, d_active, d_nactive, d_cdf;
     int64_t cap_cells = 0, cap_bt = 0;      // what the workspaces above were sized for
     size_t tmp_bytes = 0;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -935,6 +953,7 @@ extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells 
     p.x = x_dev; p.y = y_dev;
     p.n_cells = n; p.first_cell = first_cell;
     p.seed = seed;
+    p.cdf = nullptr;           // set below, once the workspaces exist
     hipEvent_t *ev = P->ev;
     unsigned long long init[8] = {~0ULL, 0, 0, 0, 0, 0, 0, 0};
     SMP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, nullptr));
@@ -948,6 +967,9 @@ extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells 
         if (P->o.df_mode == 3 && !p.fast) SMP_TRY(P->d_GT2.alloc((size_t)n * ncls * sizeof(double)));
         if (P->o.df_mode == 3 && p.baryon) SMP_TRY(P->d_GT3.alloc((size_t)n * ncls * sizeof(double)));
         SMP_TRY(P->d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
+        // running sums of the species weights per cell (2.4 KB per cell for 305 species): df_mode 3's weights may be negative (n_eq + Pi dn_bulk),
+        // its sums are not monotone and the species is found by the linear inversion there
+        if (P->o.df_mode != 3) SMP_TRY(P->d_cdf.alloc((size_t)n * sp.npart * sizeof(double)));
         P->cap_cells = n;
     }
     if (bt > P->cap_bt) {
@@ -965,6 +987,7 @@ extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells 
         SMP_TRY(P->d_scan_tmp.alloc(P->tmp_bytes));
         P->cap_bt = bt;
     }
+    p.cdf = P->d_cdf.as<double>();
     DevMem &d_GT = P->d_GT, &d_GT2 = P->d_GT2, &d_GT3 = P->d_GT3, &d_rec = P->d_rec, &d_counts = P->d_counts, &d_offsets = P->d_offsets, &d_scan_tmp = P->d_scan_tmp;
     DevMem &d_drawn = P->d_drawn, &d_emits = P->d_emits, &d_active = P->d_active, &d_nactive = P->d_nactive;
     size_t tmp_bytes = P->tmp_bytes;
