@@ -481,7 +481,7 @@ cf_main_vah(const double *__restrict__ TS, const double *__restrict__ lane_mT, c
 //     are 96 bins = 1.5 waves, 384 slots are six full ones.  Eight evaluations share a v_rcp_f64 (the 8 accumulators of a 2+1D lane leave
 //     the registers for it).  The row and unit tests are the same lower bounds; with strided lanes a vote spans lanes on different units.
 // ------------------------------------------------------------------------------------------------
-template <bool DIM3, bool REG, int JT, int R>
+template <bool DIM3, bool REG, int JT, int R, int LDSD = 1536>
 __global__ void __launch_bounds__(512)
 cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
              const double *__restrict__ lane_sign, double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g,
@@ -491,7 +491,9 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr int RS = DIM3 ? 4 : 6;
     constexpr int RW = RS + JT;
     constexpr int REC = HDR + R * RW;
-    constexpr int UB = DIM3 ? ((1536 / REC) > 0 ? (1536 / REC) : 1) : 4;   // 2+1D: four units per LDS buffer (S in {1, 2, 4} divides it)
+    // 3+1D: LDSD doubles of records per LDS buffer -- 1536 (13 units) for two-wave workgroups, 1100 (9 units, 18 KB per workgroup) for the one-wave
+    // workgroups of g.wpb == 1 (no barrier partner; cf_main_feqmod has the same); 2+1D: four units per buffer (S in {1, 2, 4} divides it)
+    constexpr int UB = DIM3 ? ((LDSD / REC) > 0 ? (LDSD / REC) : 1) : 4;
     constexpr int BUF2 = UB * REC / 2;
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);
     static_assert(REC % 2 == 0 && JT % RB == 0 && JT >= 3, "unit records must be 16-byte multiples; the cull bounds sit in header slots jj = 0, 1, 2");
@@ -760,6 +762,13 @@ void launch_vah3(bool reg, const double *TS, const double *mT, const double *pT,
 {
     const int grid = ((g.NT + 7) / 8) * 8 * g.G;
     constexpr int JT = DIM3 ? kJT3F : kJT2F, R = DIM3 ? kR3F : kR2F;
+    if constexpr (DIM3) {
+        if (g.wpb == 1) {   // one-wave workgroups: 9-unit LDS batches, eight workgroups per CU
+            if (reg) hipLaunchKernelGGL((is3d::cf_main_vah3<DIM3, true, JT, R, 1100>), dim3(grid), dim3(64), 0, st, TS, mT, pT, sg, partial, stats, g, lane_sub);
+            else hipLaunchKernelGGL((is3d::cf_main_vah3<DIM3, false, JT, R, 1100>), dim3(grid), dim3(64), 0, st, TS, mT, pT, sg, partial, stats, g, lane_sub);
+            return;
+        }
+    }
     if (reg) hipLaunchKernelGGL((is3d::cf_main_vah3<DIM3, true, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g, lane_sub);
     else hipLaunchKernelGGL((is3d::cf_main_vah3<DIM3, false, JT, R>), dim3(grid), dim3(g.wpb * 64), 0, st, TS, mT, pT, sg, partial, stats, g, lane_sub);
 }
@@ -944,6 +953,8 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     const int lane_waves = Lpad / 64;
     int best = 1 << 30;
     for (int w : {8, 4, 2}) { const int waste = ((lane_waves + w - 1) / w) * w - lane_waves; if (waste < best) { best = waste; P->wpb = w; } }
+    if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
+    if (o->waves_per_group == 1 && P->fact && three_d) P->wpb = 1;   // cf_main_vah3, 3+1D: one-wave workgroups (A/B: profiles/r04_ab_vah_wpb.log)
     // chunk count as in cf_plan.cpp: ~24 rounds of the chip, chunks of at most ~1152 cells (the streams of a chunk stay near the XCD's L2), partials <= 12 GiB
     const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
     int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : std::max<int64_t>((24LL * 4096 + tasks_per_chunk - 1) / tasks_per_chunk, (P->pass_cells + 1151) / 1152);

@@ -49,9 +49,9 @@ def demangle_params(sym):
     elif name == "cf_main_feqmod":
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON", "ROWS", "PROF"]
     elif name == "cf_main_vah":
-        keys = ["DIM3", "REG", "JT", "R"]
+        keys = ["DIM3", "REG", "JT", "R", "LDSD"]
     elif name == "cf_main_vah3":
-        keys = ["DIM3", "REG", "JT", "R"]
+        keys = ["DIM3", "REG", "JT", "R", "LDSD"]
     else:
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "KT"]
     return name, dict(zip(keys, vals))
@@ -168,6 +168,8 @@ def main():
             continue
         name, params = p
         if params.pop("PROF", 0):   # the cycle-accounting instantiation (dev) is not a product kernel
+            continue
+        if name == "cf_main_vah3" and params.pop("LDSD", 1536) != 1536:   # the one-wave-workgroup instantiation: same loop body
             continue
         if name == "cf_main_tile":
             params.pop("LAZY", None)

@@ -28,6 +28,12 @@ if [ "$PART" = "a" ]; then
   run_pmc fqpmc_sq "$SQ1" --df-mode 4
   run_pmc fqpmc_misc "$SQ2" --df-mode 4
   echo "feqmod done"
+elif [ "$PART" = "d" ]; then   # only the sampler leg (after a change to its kernels)
+  run_stats trace_smp --workload config5-sampler
+  run_pmc smppmc_fetch FETCH_SIZE --workload config5-sampler
+  run_pmc smppmc_write WRITE_SIZE --workload config5-sampler
+  run_pmc smppmc_sq "$SQ1" --workload config5-sampler
+  run_pmc smppmc_misc "$SQ2" --workload config5-sampler
 elif [ "$PART" = "c" ]; then   # only the kernel-trace stats of the anisotropic-hydro workloads (after a change to cf_prep_vah)
   run_stats trace_c5 --workload config5
   run_stats trace_v2 --workload config5 --dimension 2
