@@ -954,7 +954,9 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     int best = 1 << 30;
     for (int w : {8, 4, 2}) { const int waste = ((lane_waves + w - 1) / w) * w - lane_waves; if (waste < best) { best = waste; P->wpb = w; } }
     if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
-    if (o->waves_per_group == 1 && P->fact && three_d) P->wpb = 1;   // cf_main_vah3, 3+1D: one-wave workgroups (A/B: profiles/r04_ab_vah_wpb.log)
+    // cf_main_vah3, 3+1D: one-wave workgroups by default (no barrier partner; 962.2 against 974.6 ms on the config-5 surface, bitwise the same spectrum:
+    // profiles/r04_ab_vah_wpb.log); waves_per_group = 2 keeps the pair
+    if ((o->waves_per_group == 1 || o->waves_per_group == 0) && P->fact && three_d) P->wpb = 1;
     // chunk count as in cf_plan.cpp: ~24 rounds of the chip, chunks of at most ~1152 cells (the streams of a chunk stay near the XCD's L2), partials <= 12 GiB
     const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
     int64_t nch = o->cell_chunks > 0 ? o->cell_chunks : std::max<int64_t>((24LL * 4096 + tasks_per_chunk - 1) / tasks_per_chunk, (P->pass_cells + 1151) / 1152);
