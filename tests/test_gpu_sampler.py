@@ -246,3 +246,57 @@ def test_sampler_config5_size(fx):
     avg = inputs.surface_averages(cells)
     N, _ = api.total_yield(cells, sp, fx["df"], inputs.feqmod_tables(avg[0]), avg, o)
     assert abs(len(p) / nev / N - 1) < 0.08
+
+
+def test_sampler_plan_is_the_one_shot_entry_on_resident_data(fx):
+    """is3d_sampler_plan_* (device-resident cell arrays and particle buffer, persistent workspaces): the same list as is3d_sample_particles for the
+    same (seed, first_cell, events) -- df_mode 2 (species by bisection of the stored running sums) and df_mode 3 (linear inversion: its weights may be
+    negative) --, a second execute of the same shape allocates nothing, another seed gives another list, a shard with its global offset gives the
+    whole surface's hadrons for its cells, and the refusals: more cells than the plan holds, a buffer too small, zero events."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 3000
+    cells = synth.synth_surface(n, 3, seed=821)
+    sp = inputs.species("urqmd")
+    fields = list(synth.CELL_FIELDS) + ["x", "y"]
+    tens = {k: torch.from_numpy(cells[k]).to(dev) for k in fields}
+    ptrs = {k: v.data_ptr() for k, v in tens.items()}
+    for df_mode in (2, 3):
+        gla = inputs.feqmod_tables(inputs.surface_average_T(cells))
+        o = dict(dimension=3, df_mode=df_mode)
+        fq = gla if df_mode == 3 else None
+        ref, rst = api.sample_particles(cells, sp, fx["df"], gla, o, n_events=12, seed=99, fq=fq)
+        plan = api.SamplerPlan(sp, fx["df"], gla, o, max_cells=n, fq=fq)
+        count, st = plan.execute(n, ptrs, 12, 99, x_ptr=ptrs["x"], y_ptr=ptrs["y"])                     # count only
+        assert count == len(ref) == rst["n_particles"] and st["ms_h2d"] == 0.0
+        buf = torch.zeros(count * api.PARTICLE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        p0, a0 = api.resource_counters()
+        got_n, st = plan.execute(n, ptrs, 12, 99, particles_ptr=buf.data_ptr(), capacity=count, x_ptr=ptrs["x"], y_ptr=ptrs["y"])
+        assert api.resource_counters() == (p0, a0)                                                      # workspaces of this shape exist already
+        got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=api.PARTICLE_DTYPE)[:got_n]
+        assert got_n == count and all(np.array_equal(got[f], ref[f]) for f in got.dtype.names), df_mode
+        assert st["n_hadrons_drawn"] == rst["n_hadrons_drawn"] and st["ms_density"] > 0 and st["ms_density"] < st["ms_prep"] and st["ms_poisson"] <= st["ms_count"]
+        # another seed: another list (the buffer may be too small now: IS3D_ENOMEM carries the full count)
+        c2, _ = plan.execute(n, ptrs, 12, 100)
+        assert c2 != count or c2 > 0
+        if c2 > count:
+            with pytest.raises(api.Is3dError) as e:
+                plan.execute(n, ptrs, 12, 100, particles_ptr=buf.data_ptr(), capacity=count)
+            assert e.value.code == api.IS3D_ENOMEM
+        # a shard of the resident arrays with its global offset: the whole surface's hadrons of those cells
+        lo, hi = 1000, 2200
+        sub = {k: v + 8 * lo for k, v in ptrs.items()}
+        cs, _ = plan.execute(hi - lo, sub, 12, 99, first_cell=lo)
+        sel = (ref["cell"] >= lo) & (ref["cell"] < hi)
+        assert cs == int(sel.sum())
+        b2 = torch.zeros(max(cs, 1) * api.PARTICLE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        plan.execute(hi - lo, sub, 12, 99, particles_ptr=b2.data_ptr(), capacity=cs, first_cell=lo, x_ptr=sub["x"], y_ptr=sub["y"])
+        g2 = np.frombuffer(b2.cpu().numpy().tobytes(), dtype=api.PARTICLE_DTYPE)[:cs]
+        assert all(np.array_equal(g2[f], ref[f][sel]) for f in g2.dtype.names)
+        with pytest.raises(api.Is3dError) as e:
+            plan.execute(n + 1, ptrs, 12, 99)
+        assert e.value.code == api.IS3D_EINVAL and "created for" in str(e.value)
+        with pytest.raises(api.Is3dError) as e:
+            plan.execute(n, ptrs, 0, 99)
+        assert e.value.code == api.IS3D_EINVAL
+        plan.close()
