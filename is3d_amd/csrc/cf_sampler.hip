@@ -184,10 +184,12 @@ cf_sampler_density(const double *__restrict__ T_fo, const double *__restrict__ m
         if (GT2) { const double p2 = gl[2 * ngl + k]; l_p2[k] = p2 * p2; l_c2[k] = gl[3 * ngl + k] * exp(p2); }
     }
     __syncthreads();
+    // class-major, GT[class][cell]: the lanes of a wave are consecutive cells of ONE class -- T_fo and the stores coalesce, the class constants
+    // are wave-uniform -- and the readers (thread <-> cell) read a class's value of consecutive cells as one run
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_cells * sp.ncls) return;
-    const int64_t cell = idx / sp.ncls;
-    const int c = (int)(idx - cell * sp.ncls);
+    const int c = (int)(idx / n_cells);
+    const int64_t cell = idx - (int64_t)c * n_cells;
     const double T = T_fo[cell];
     const double mbar = sp.cls_mass[c] / T, mb2 = mbar * mbar, sign = sp.cls_sign[c];
     const double alphaB = muB_fo ? muB_fo[cell] / T : 0.0;
@@ -210,6 +212,7 @@ cf_sampler_density(const double *__restrict__ T_fo, const double *__restrict__ m
 }
 
 // mean-number weight of species ip in a cell: fast_max_particle_number (:239-280) / max_particle_number (:282-359)
+// gt, gt2, gt3: the cell's column of the class-major integral tables (GT + cell), element of class k at [k * p.n_cells]
 __device__ __forceinline__ double species_dn(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell &c, const double *gt,
                                              const double *gt2, const double *gt3, int ip)
 {
@@ -219,34 +222,27 @@ __device__ __forceinline__ double species_dn(const SamplerParams &p, const Sampl
         if (p.df_mode == 3) return p.eqd[ip] + c.bulkPi * p.bkd[ip];
         return c.z * p.eqd[ip];
     }
-    const double equilibrium_density = c.neq_fact * sp.degeneracy[ip] * gt[sp.cls[ip]];
+    const int64_t kk = (int64_t)sp.cls[ip] * p.n_cells;
+    const double equilibrium_density = c.neq_fact * sp.degeneracy[ip] * gt[kk];
     if (linear) return 2.0 * equilibrium_density;
     if (p.df_mode == 3) {
-        const double J20 = (c.T * c.neq_fact) * sp.degeneracy[ip] * gt2[sp.cls[ip]];
+        const double J20 = (c.T * c.neq_fact) * sp.degeneracy[ip] * gt2[kk];
         double bJ10G = 0.0;                                                             // baryon * J10 * G, :319-325
-        if (gt3) bJ10G = sp.baryon[ip] * (c.neq_fact * sp.degeneracy[ip] * gt3[sp.cls[ip]]) * c.G;
+        if (gt3) bJ10G = sp.baryon[ip] * (c.neq_fact * sp.degeneracy[ip] * gt3[kk]) * c.G;
         const double bulk_density = (equilibrium_density + bJ10G + (J20 * c.F / c.T / c.T)) / c.betabulk;
         return equilibrium_density + c.bulkPi * bulk_density;
     }
     return c.z * equilibrium_density;
 }
 
-// The cell's n_eq integrals (GT[cell][class], 600 B per cell for 75 classes) are summed over the SPECIES in list order (the order the reference
-// adds them in): 305 gathers per lane from rows 600 B apart were 3.0 of the kernel's 3.1 ms (64 cache lines per load
-// instruction).  The rows of a workgroup's consecutive cells are one contiguous block: staged through LDS with coalesced loads, read from
-// there (row stride 75 doubles: 2-way bank conflicts at worst).  Same values, same order of additions.
+// The cell's n_eq integrals are summed over the SPECIES in list order (the order the reference adds them in).  With GT[cell][class] that was 305
+// gathers per lane from rows 600 B apart -- 3.0 of the kernel's 3.1 ms (64 cache lines per load instruction); staged through LDS (38 KB per 64
+// cells: four waves per CU) 1.75 ms; with the class-major tables a lane's read of class k is word `cell` of row k: consecutive lanes, one run,
+// no LDS, full occupancy.  Same values, same order of additions.
 __global__ void __launch_bounds__(128)
 cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ GT, const double *__restrict__ GT2,
                  const double *__restrict__ GT3, SamplerCell *__restrict__ out)
 {
-    extern __shared__ double l_gt[];               // [blockDim.x][ncls]
-    {
-        const int64_t c0 = (int64_t)blockIdx.x * blockDim.x;
-        const int64_t nrow = min((int64_t)blockDim.x, p.n_cells - c0);
-        const double *src = GT + c0 * sp.ncls;
-        for (int64_t i = threadIdx.x; i < nrow * sp.ncls; i += blockDim.x) l_gt[i] = src[i];
-        __syncthreads();
-    }
     const int64_t ic = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= p.n_cells) return;
     SamplerCell c;
@@ -370,7 +366,7 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
         const double dn_pion0 = bulkPi * (neq_pion0 + J20_pion0 * Fb / Tb / Tb) / bbb;
         if (detA <= p.detA_min || (neq_pion0 + dn_pion0) < 0.0) { c.breakdown = 1.0; atomicAdd(&p.status[5], 1ULL); }
     }
-    const double *gt = l_gt + threadIdx.x * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
+    const double *gt = GT + ic, *gt2 = GT2 ? GT2 + ic : nullptr, *gt3 = GT3 ? GT3 + ic : nullptr;
     // the running sums are kept (species-major, so that the lanes of a wave -- consecutive cells -- store adjacent words): the sampling kernels
     // then find a hadron's species by bisection of exactly these sums instead of re-adding up to 305 gathered weights per hadron
     double dn = 0.0;
@@ -492,7 +488,7 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
     g_momentum.init(p.seed, 2, gcell, (uint32_t)ievent);
     g_keep.init(p.seed, 3, gcell, (uint32_t)ievent);
     g_rapidity.init(p.seed, 4, gcell, (uint32_t)ievent);
-    const double *gt = GT + ic * sp.ncls, *gt2 = GT2 ? GT2 + ic * sp.ncls : nullptr, *gt3 = GT3 ? GT3 + ic * sp.ncls : nullptr;
+    const double *gt = GT + ic, *gt2 = GT2 ? GT2 + ic : nullptr, *gt3 = GT3 ? GT3 + ic : nullptr;
     const bool linear = p.df_mode <= 2 || c.breakdown != 0.0;
     const double sinheta = sinh(c.eta), cosheta = sqrt(1.0 + sinheta * sinheta);   // :888-889
     long kept = 0, samples = 0, acceptances = 0;
@@ -997,11 +993,8 @@ extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells 
         hipLaunchKernelGGL(is3d::cf_sampler_density, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dptr[9], dptr[18], n, sp,
                            P->d_gl.as<double>(), P->ngla, d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>());
         SMP_TRY(hipEventRecord(ev[6], nullptr));
-        const int cb = ncls <= 64 ? 128 : 64;      // cells per workgroup: their n_eq rows sit in LDS (<= 64 KB: ncls <= 128; larger lists take 32)
-        const int cbk = (size_t)cb * ncls * sizeof(double) <= 64 * 1024 ? cb : 32;
-        if ((size_t)cbk * ncls * sizeof(double) > 64 * 1024) return set_error(IS3D_EINVAL, "%d species classes: more than the sampler's cell kernel stages through LDS (256)", ncls);
-        hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + cbk - 1) / cbk)), dim3(cbk), (size_t)cbk * ncls * sizeof(double), nullptr, p, sp,
-                           d_GT.as<double>(), d_GT2.as<double>(), d_GT3.as<double>(), d_rec.as<is3d::SamplerCell>());
+        hipLaunchKernelGGL(is3d::cf_sampler_cells, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, nullptr, p, sp, d_GT.as<double>(),
+                           d_GT2.as<double>(), d_GT3.as<double>(), d_rec.as<is3d::SamplerCell>());
         SMP_TRY(hipGetLastError());
     }
     SMP_TRY(hipEventRecord(ev[2], nullptr));
