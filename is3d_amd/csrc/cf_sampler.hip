@@ -370,9 +370,17 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
     // the running sums are kept (species-major, so that the lanes of a wave -- consecutive cells -- store adjacent words): the sampling kernels
     // then find a hadron's species by bisection of exactly these sums instead of re-adding up to 305 gathered weights per hadron
     double dn = 0.0;
-    for (int ip = 0; ip < sp.npart; ip++) {
-        dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
-        if (p.cdf) p.cdf[(int64_t)ip * p.n_cells + ic] = dn;
+    if (p.cdf) {
+        // (the stores never alias the tables read: said so, and the loop unrolled, so that four species' loads are in flight per trip)
+        double *__restrict__ cdf = p.cdf + ic;
+        const double *__restrict__ gtr = gt;
+#pragma unroll 4
+        for (int ip = 0; ip < sp.npart; ip++) {
+            dn += species_dn(p, sp, c, gtr, gt2, gt3, ip);
+            cdf[(int64_t)ip * p.n_cells] = dn;
+        }
+    } else {
+        for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
     }
     c.dn_sum = dn;
     c.dn_tot = dn * (2.0 * p.y_max * c.ds_max);
