@@ -455,7 +455,11 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     if (ws <= 0) {
         ws = (int64_t)16 << 30;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
+            // ... and never more than the device can hold beside the partial slab (<= 12 GiB) and the fixed buffers: streams + slab <= 90 % of the total
+            ws = std::min<int64_t>(ws, std::max<int64_t>((int64_t)1 << 30, (int64_t)((double)total_b * 0.9) - ((int64_t)12 << 30)));
+        }
     }
     int64_t pc = ws / (int64_t)P->bytes_per_cell;
     if (pc < 1) pc = 1;
