@@ -236,3 +236,45 @@ def test_feqmod_argument_errors(fx):
     with pytest.raises(api.Is3dError) as e:
         api.smooth_spectra(hot, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=4), fq=fq)
     assert e.value.code == -3 and "cell 2" in str(e.value)
+
+
+@pytest.mark.parametrize("df_mode", [4, 3])
+def test_feqmod_config3_size_stratified_oracle_sample_and_row_walks(fx, df_mode):
+    """The modified-equilibrium kernel at BASELINE config-3 size (df_mode 4 is the reference's shipped default): a 60 000-cell slice of the 1e6-cell
+    surface x 305 species through the default kernel (3+1D: row mask against the unit threshold, one-wave workgroups) against the oracle on a
+    stratified sample -- one species of every fifth (mass, sign) class x 4 pT x 4 phi x all 21 rapidities --, and against the two other row walks
+    (kernel_variant 5: rows pipelined with their own thresholds, the round-3 kernel; 6: row mask + exact row thresholds) and two-wave workgroups:
+    5 and 6 cull the same rows and agree bitwise with each other; the default culls slightly fewer rows and agrees with them to rounding (1e-12:
+    its row code forms mT^2 alphaf_k + pT^2 gammaf_j as one fused multiply-add where theirs rounds the product first -- X moves by an ulp, e^-X by
+    X ulps); culling off changes no bit of any of them."""
+    n = 60000
+    cells = synth.synth_surface(1000000, 3)
+    sl = {k: v[400000:400000 + n] for k, v in cells.items()}
+    sp = fx["urqmd"]
+    fq = fq_for(sl)
+    o = dict(dimension=3, df_mode=df_mode)
+    got, st = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], o, fq=fq)
+    assert st["n_classes"] == 75 and st["kernel_variant"] == 3 and st["n_wave_rows_culled"] > 0.4 * st["n_wave_rows"]
+    seen, reps = set(), []
+    for s, (m, sg) in enumerate(zip(sp["mass"], sp["sign"])):
+        if (m, sg) not in seen:
+            seen.add((m, sg))
+            reps.append(s)
+    reps = reps[::5]
+    ipT, iphi = [0, 9, 20, 31], [2, 7, 13, 22]
+    g = fx["grid"]
+    sub_grid = dict(g, pT=g["pT"][ipT], phi=g["phi"][iphi])
+    ref, _ = oracle.dN_pTdpTdphidy_feqmod(sl, inputs.species([int(sp["mc_id"][s]) for s in reps]), sub_grid, fx["df"], fq, o)
+    g5 = got.reshape(21, 24, 32, 305)
+    sub = g5[:, iphi][:, :, ipT][:, :, :, reps]
+    assert sub.size == 21 * 16 * len(reps) and relerr(sub, ref.reshape(21, 4, 4, len(reps))) < TOL
+    off, st_off = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, zero_skip=2), fq=fq)
+    assert np.array_equal(off, got) and st_off["n_wave_rows_culled"] == 0
+    pair, st_pair = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, waves_per_group=2), fq=fq)
+    assert np.array_equal(pair, got)                                     # the batch size moves the threshold refresh, not a bit of the result
+    v5, st5 = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5), fq=fq)
+    v6, st6 = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=6, waves_per_group=2), fq=fq)
+    assert np.array_equal(v5, v6) and st5["n_wave_rows_culled"] == st6["n_wave_rows_culled"] >= st_pair["n_wave_rows_culled"]
+    assert relerr(v5, got) < 1e-12
+    off5, _ = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5, zero_skip=2), fq=fq)
+    assert np.array_equal(off5, v5)                                      # every rule skips only rows that cannot change a bit
