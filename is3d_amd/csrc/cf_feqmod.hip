@@ -606,6 +606,9 @@ __device__ unsigned long long g_prof_fq[16];
 // two-wave workgroups that share a stream; 1100 (9 units, 18 KB) for ONE-wave workgroups (g.wpb == 1), eight of which must fit a CU's 160 KB:
 // a wave that stages its own stream has no barrier partner to wait for -- on the config-3 surface 9.7 % of all wave cycles were spent at the
 // per-batch barrier (the two lane-waves of a workgroup cull differently and drift apart), against 0.8 % issuing the staging loads that double.
+// (Measured and dropped, round 4: the 6 x 7 tile at 166 VGPRs with one-wave workgroups of 7-unit batches = THREE waves per SIMD -- 487.1 against
+// 488.0 ms for the 8 x 7 tile at two, with culling off 1114 against 1083: the third wave returns what the smaller tile's amortisation costs.
+// profiles/r04_ab_feqmod_3w.log)
 template <bool DIM3, bool OUTFLOW, bool MODE3, int JT, int R, bool BARYON = false, int ROWS = 0, bool PROF = false, int LDSD = 1536>
 __global__ void __launch_bounds__(512)
 cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT, const double *__restrict__ lane_pT,
@@ -978,6 +981,7 @@ static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
         // one-wave workgroups (3+1D, 8 x 7, no baryon slots): 9-unit LDS batches so that eight workgroups fit a CU, no barrier partner
         if (a.g.wpb == 1 && !a.lane_b) { launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1100>(a, st); return; }
     }
+
     launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1536>(a, st);
 }
 
