@@ -82,7 +82,7 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     d = json.load(open(p))
     ce, d3 = int(wl["df_mode"] == 2), int(wl["dimension"] == 3)
     if kernel_name == "cf_main_feqmod":
-        rows = (0 if variant == 5 else 1 if variant == 6 else 2) if d3 else 0   # how the kernel walks a unit's rows (cf_feqmod.hip)
+        rows = (0 if variant == 5 else 1 if variant == 6 else 2) if d3 else (3 if variant == 7 else 0)   # how the kernel walks a unit's rows (cf_feqmod.hip)
         key = "cf_main_feqmod:DIM3=%d,OUTFLOW=1,MODE3=%d,JT=%d,R=%d,ROWS=%d" % (d3, int(wl["df_mode"] == 3), JT_R[0], JT_R[1], rows)
     elif kernel_name == "cf_main_vah":
         key = "cf_main_vah:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])

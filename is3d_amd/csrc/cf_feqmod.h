@@ -11,7 +11,7 @@
 //   alphaf_k = (1 + |A^-1 a_k|^2)/T_mod^2,  betaf_jk = 2 (A^-1 a_k).(A^-1 b_j)/T_mod^2,  gammaf_j = (|A^-1 b_j|^2 - 1)/T_mod^2
 // (m^2 = mT^2 - pT^2 folded in), and f = |renorm| / (exp(E_mod/T_mod) + sign).  cf_prep_feqmod writes these coefficients
 // into the same tiled unit-record stream the delta-f kernel uses (cf_device.h) with the slots reused:
-//   header jj : {B_j, gammaf_j, 0, 0}          row r, 2+1D : {A_k, alphaf_k, W_k, 0, betaf_{j0..j0+JT-1,k}}
+//   header jj : {B_j, gammaf_j, 0, 0}          row r, 2+1D : {A_k, alphaf_k, W_k, min_j betaf_jk, betaf_{j0..j0+JT-1,k}}
 //                                              row r, 3+1D : {alphaf_k, min_j betaf_jk, A_k, W_k, betaf_{j0..j0+JT-1,k}} -- the two operands of a row's
 //                                              liveness test in ONE 16-byte LDS read (fq_row_slots)
 //   (include_baryon: header slot 2 of jj = 0 carries alpha_B,mod = alpha_B + Pi G / beta_Pi, :637; the lane's baryon number
@@ -83,7 +83,7 @@ struct FqLinearArgs {
     int32_t Lbins;                      // momentum bins: with unit-strided lanes only a bin's first slot (lanes < Lbins) takes the fallback cells
 };
 
-size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles, int rec);
+size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles, int rblocks, int rec);
 hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st);
 // RN[cell][cls] = |n_linear / n_mod| (/ detA in 3+1D), 0 where the reference skips the species (nan / inf) or the cell
 hipError_t launch_feqmod_renorm(const double *CR, const double *gl, int ngl, const double *cls_mass, const double *cls_sign,

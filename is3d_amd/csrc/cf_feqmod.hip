@@ -23,7 +23,8 @@
 
 namespace is3d {
 
-constexpr int kFqCB = 4;           // cells per workgroup batch of the prep kernel with long rows (2+1D: 241 eta nodes) ...
+constexpr int kFqCB = 3;           // cells per workgroup batch of the prep kernel with long rows (2+1D: 241 eta nodes; 3 since round 4: with the
+                                   // beta-minimum table two workgroups still share a CU's LDS -- 4 cells, one workgroup per CU: 7.9 against 4.3 ms) ...
 constexpr int kFqCB3 = 16;         // ... and with K <= 32 (3+1D): the serial per-cell phase 1 (a 3 x 3 inverse, the Jonah tables) runs on CB lanes of the
                                    // workgroup, so 4-cell batches made it the kernel: 10.3 ms per 1e6 cells
 static int fq_batch_cells(int K) { return K > 32 ? kFqCB : kFqCB3; }
@@ -80,6 +81,13 @@ __device__ __forceinline__ double gt_J20(const double *root, const double *weigh
     return s;
 }
 
+// betaf_jk = 2 (a'_k . b'_j) / T_mod^2 with the roundings written out: the record writer and the minima over a phi tile (the main kernel's
+// lower bound on a row's X^2) must hold the SAME doubles
+__device__ __forceinline__ double fq_beta(double ax, double ay, double az, double bx, double by, double bz, double invTm2)
+{
+    return (2.0 * __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx))) * invTm2;
+}
+
 template <int CB>
 __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
 {
@@ -94,11 +102,11 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     double *lk = (double *)(cs + CB);       // [6][CB][K]: A, alphaf, W, a'x, a'y, a'z
     double *lj = lk + 6 * CB * K;           // [5][CB][J]: B, gammaf, b'x, b'y, b'z
     double *l_bm = lj + 5 * CB * J;         // [CB][K][jtiles]: min over a phi tile of betaf_jk
-    // 3+1D: bounds of the main kernel's unit-level cull, per (cell, row block): min alphaf, max |A|, max |W|; per (cell, row block, phi
-    // tile): min betaf; per (cell, phi tile): min gammaf, max |B|   (row blocks <= K, phi tiles <= J / 4)
-    double *l_ub = l_bm + (p.dim3 ? CB * K * p.jtiles : 0);   // [CB][3 rblocks + rblocks jtiles + 2 jtiles]
+    // bounds of the main kernel's unit-level cull and unit threshold, per (cell, row block): min alphaf, max |A|, max |W|; per (cell, row
+    // block, phi tile): min betaf; per (cell, phi tile): min gammaf, max |B|
+    double *l_ub = l_bm + CB * K * p.jtiles;   // [CB][3 rblocks + rblocks jtiles + 2 jtiles]
     // element descriptors of a unit record, one int2 per element, filled once per workgroup (as in cf_prep, cf_kernels.hip)
-    int2 *desc = (int2 *)(l_ub + (p.dim3 ? CB * (3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles) : 0));
+    int2 *desc = (int2 *)(l_ub + CB * (3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles));
     const int CK = CB * K, CJ = CB * J;
     double *l_A = lk, *l_al = lk + CK, *l_W = lk + 2 * CK, *l_ax = lk + 3 * CK, *l_ay = lk + 4 * CK, *l_az = lk + 5 * CK;
     double *l_B = lj, *l_ga = lj + CJ, *l_bx = lj + 2 * CJ, *l_by = lj + 3 * CJ, *l_bz = lj + 4 * CJ;
@@ -117,7 +125,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     //   x: bits 0-15 offset of the source in the LDS block | 16-18 index rule (0: + c J + j, 1: + c K + k, 2: + c ubs + 3 rb, 3: + c ubs + rb
     //      jtiles + jt, 4: + c ubs + 2 jt, 5: + c sizeof(FqScal)/8, 6: + (c K + k) jtiles + jt) | 20 betaf | 21 zero in a padding row | 22 zero
     //   y: jj (header entry / beta column) | r << 16 (row)
-    const int ubs = p.dim3 ? 3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles : 0;   // doubles per cell in l_ub
+    const int ubs = 3 * p.rblocks + p.rblocks * p.jtiles + 2 * p.jtiles;   // doubles per cell in l_ub
     {
         const int JT = p.JT, R = p.R, HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
         const int o_A = (int)(l_A - lds), o_al = (int)(l_al - lds), o_W = (int)(l_W - lds), o_B = (int)(l_B - lds), o_ga = (int)(l_ga - lds);
@@ -131,9 +139,9 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                 if (f == 0) x = o_B;
                 else if (f == 1) x = o_ga;
                 else if (e == 2) x = o_aB | (5 << 16);
-                else if (p.dim3 && JT >= 4 && jj < 4) {
-                    // bounds of the main kernel's unit-level cull (phase 2d): min alphaf_k (e = 3), min_jk betaf_jk (6), max |A_k| (10),
-                    // max |W_k| (11) over the unit's rows; min gammaf_j (7), max |B_j| (14) over its phi's
+                else if (JT >= 4 && jj < 4) {
+                    // bounds of the main kernel's unit-level cull and unit threshold (phase 2d): min alphaf_k (e = 3), min_jk betaf_jk (6),
+                    // max |A_k| (10), max |W_k| (11) over the unit's rows; min gammaf_j (7), max |B_j| (14) over its phi's
                     if (e == 3) x = o_ub | (2 << 16);
                     else if (e == 10) x = (o_ub + 1) | (2 << 16);
                     else if (e == 11) x = (o_ub + 2) | (2 << 16);
@@ -144,12 +152,12 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             } else {
                 const int q = e - HDR, r = q / RWD, f = q - r * RWD;
                 y = r << 16;
-                // row scalars in the slot order of fq_row_slots (cf_feqmod.h): 3+1D {alphaf, min_j betaf, A, W}, 2+1D {A, alphaf, W, 0}
+                // row scalars in the slot order of fq_row_slots (cf_feqmod.h): 3+1D {alphaf, min_j betaf, A, W}, 2+1D {A, alphaf, W, min_j betaf}
                 const FqRowSlots sl = fq_row_slots(p.dim3 != 0);
                 if (f == sl.A) x = o_A | (1 << 16) | PADZ;     // padding rows: p.dsigma = 0, the quadratic form of row K-1
                 else if (f == sl.AL) x = o_al | (1 << 16);
                 else if (f == sl.W) x = o_W | (1 << 16) | PADZ;
-                else if (f == sl.BM) x = p.dim3 ? (o_bm | (6 << 16)) : ZERO;
+                else if (f == sl.BM) x = o_bm | (6 << 16);
                 else { x = BETA; y |= f - 4; }
             }
             desc[e] = int2{x, y};
@@ -363,7 +371,20 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
         }
         __syncthreads();
 
-        // ---- phase 2: (cell, k) quantities ----
+        // ---- phase 2b: (cell, j) quantities ----
+        for (int idx = tid; idx < ncb * J; idx += kFqThreads) {
+            const int c = idx / J, j = idx - c * J;
+            const FqScal &s = cs[c];
+            const double cp = p.cosphi[j], sp = p.sinphi[j];
+            const double b0 = s.Xx * cp + s.Xy * sp, b1 = s.Yx * cp + s.Yy * sp;
+            const double bx = s.Ai[0] * b0 + s.Ai[1] * b1, by = s.Ai[3] * b0 + s.Ai[4] * b1, bz = s.Ai[6] * b0 + s.Ai[7] * b1;
+            l_B[idx] = cp * s.dax + sp * s.day;
+            l_ga[idx] = ((bx * bx + by * by + bz * bz) - 1.0) * s.invTm2;
+            l_bx[idx] = bx; l_by[idx] = by; l_bz[idx] = bz;
+        }
+        __syncthreads();
+        // ---- phase 2: (cell, k) quantities, and with a'_k in registers min_j betaf_jk over every phi tile: the main kernel's lower bound on a
+        // row's X^2 (the SAME betaf_jk the writer stores: fq_beta) ----
         for (int idx = tid; idx < ncb * K; idx += kFqThreads) {
             const int c = idx / K, k = idx - c * K;
             const FqScal &s = cs[c];
@@ -379,34 +400,19 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             l_W[idx] = (v * s.rn) * w;
             l_al[idx] = (1.0 + (ax * ax + ay * ay + az * az)) * s.invTm2;
             l_ax[idx] = ax; l_ay[idx] = ay; l_az[idx] = az;
-        }
-        // ---- phase 2b: (cell, j) quantities ----
-        for (int idx = tid; idx < ncb * J; idx += kFqThreads) {
-            const int c = idx / J, j = idx - c * J;
-            const FqScal &s = cs[c];
-            const double cp = p.cosphi[j], sp = p.sinphi[j];
-            const double b0 = s.Xx * cp + s.Xy * sp, b1 = s.Yx * cp + s.Yy * sp;
-            const double bx = s.Ai[0] * b0 + s.Ai[1] * b1, by = s.Ai[3] * b0 + s.Ai[4] * b1, bz = s.Ai[6] * b0 + s.Ai[7] * b1;
-            l_B[idx] = cp * s.dax + sp * s.day;
-            l_ga[idx] = ((bx * bx + by * by + bz * bz) - 1.0) * s.invTm2;
-            l_bx[idx] = bx; l_by[idx] = by; l_bz[idx] = bz;
-        }
-        __syncthreads();
-
-        // ---- phase 2c: (cell, k, phi tile): min_j betaf_jk, the main kernel's lower bound on X^2 for the exact-zero cull ----
-        for (int idx = tid; p.dim3 && idx < ncb * K * p.jtiles; idx += kFqThreads) {   // 3+1D only (2+1D: minimum per evaluation, below)
-            const int c = idx / (K * p.jtiles), rem = idx - c * (K * p.jtiles), k = rem / p.jtiles, jt = rem - k * p.jtiles;
-            const double ax = l_ax[c * K + k], ay = l_ay[c * K + k], az = l_az[c * K + k], s2 = 2.0 * cs[c].invTm2;
-            double v = 1.0e300;
-            for (int q2 = 0; q2 < p.JT; q2++) {
-                const int j = min(jt * p.JT + q2, J - 1);
-                v = fmin(v, (ax * l_bx[c * J + j] + ay * l_by[c * J + j] + az * l_bz[c * J + j]) * s2);
+            const double *pbx = l_bx + c * J, *pby = l_by + c * J, *pbz = l_bz + c * J;
+            for (int jt = 0; jt < p.jtiles; jt++) {
+                double m = 1.0e300;
+                for (int q2 = 0; q2 < p.JT; q2++) {
+                    const int j = min(jt * p.JT + q2, J - 1);
+                    m = fmin(m, fq_beta(ax, ay, az, pbx[j], pby[j], pbz[j], s.invTm2));
+                }
+                l_bm[idx * p.jtiles + jt] = m;
             }
-            l_bm[idx] = v;
         }
         __syncthreads();
-        // ---- phase 2d (3+1D): the unit-level cull bounds ----
-        if (p.dim3) {
+        // ---- phase 2d: the unit-level bounds ----
+        {
             const int R = p.R, JT = p.JT;
             for (int idx = tid; idx < ncb * p.rblocks; idx += kFqThreads) {
                 const int c = idx / p.rblocks, rb = idx - c * p.rblocks;
@@ -468,8 +474,8 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                                           : (cK + kcl) * p.jtiles + jt;
                             const bool zero = ((d.x >> 22) & 1) | (((d.x >> 21) & 1) & (k >= K));
                             const double raw = lds[zero ? 0 : (d.x & 0xffff) + add];
-                            // betaf_jk, as the flat writer formed it: 2 (a'_k . b'_j) / T_mod^2
-                            const double bet = 2.0 * (l_ax[cK + kcl] * l_bx[cJ + jcl] + l_ay[cK + kcl] * l_by[cJ + jcl] + l_az[cK + kcl] * l_bz[cJ + jcl]) * cs[c].invTm2;
+                            // betaf_jk = 2 (a'_k . b'_j) / T_mod^2
+                            const double bet = fq_beta(l_ax[cK + kcl], l_ay[cK + kcl], l_az[cK + kcl], l_bx[cJ + jcl], l_by[cJ + jcl], l_bz[cJ + jcl], cs[c].invTm2);
                             const double v = ((d.x >> 20) & 1) ? bet : raw;
                             o[e] = zero ? 0.0 : v;
                         }
@@ -482,10 +488,10 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     }
 }
 
-size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles /* 0 in 2+1D: no beta-min table */, int rec)
+size_t prep_feqmod_lds_bytes(int nT, int nj, int ngl, int J, int K, int jtiles, int rblocks, int rec)
 {
     const int cb = fq_batch_cells(K);
-    const size_t bounds = jtiles ? (size_t)cb * (3 * (size_t)K + (size_t)K * jtiles + 2 * (size_t)jtiles) : 0;   // row blocks <= K
+    const size_t bounds = (size_t)cb * (3 * (size_t)rblocks + (size_t)rblocks * jtiles + 2 * (size_t)jtiles);
     return sizeof(double) * ((size_t)nT * 7 + (size_t)nj * 5 + (size_t)ngl * 4 + (size_t)cb * (6 * K + 5 * J + K * jtiles) + bounds + (size_t)rec) + sizeof(FqScal) * cb;   // + one int2 per record element
 }
 
@@ -495,7 +501,7 @@ hipError_t launch_prep_feqmod(const FqPrepParams &p, hipStream_t st)
     const int cb = fq_batch_cells(p.K);
     const int nbatch = (p.n_cells + cb - 1) / cb;
     const int grid = nbatch < 4096 ? nbatch : 4096;
-    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K, p.dim3 ? p.jtiles : 0, 4 * p.JT + p.R * (4 + p.JT));
+    const size_t lds = prep_feqmod_lds_bytes(p.spl.n, p.nj, p.ngl, p.J, p.K, p.jtiles, p.rblocks, 4 * p.JT + p.R * (4 + p.JT));
     if (cb == kFqCB3) hipLaunchKernelGGL(cf_prep_feqmod<kFqCB3>, dim3(grid), dim3(kFqThreads), lds, st, p);
     else hipLaunchKernelGGL(cf_prep_feqmod<kFqCB>, dim3(grid), dim3(kFqThreads), lds, st, p);
     return hipGetLastError();
@@ -602,6 +608,10 @@ __device__ unsigned long long g_prof_fq[16];
 //      operands are there, so the set of culled rows is exactly that of ROWS = 0 (same status counters, bitwise the same spectrum as ROWS = 0)
 //   2  (default, 3+1D) as 1 without the second, row-level test: 0.4 points fewer rows culled (60.0 against 60.4 % on the config-3 surface), ten
 //      instructions fewer per evaluated row -- 499 against 541 (ROWS = 1) and 558 ms (ROWS = 0).  zero_skip on / off stay bitwise identical.
+//   3  (default, 2+1D; kernel_variant 7) the rolled row loop of ROWS = 0 with the test of ROWS = 2: the UNIT's threshold (max |A_k|, max |W_k|,
+//      max |B_j| in free header slots) against fma(mT pT, min_j betaf_jk, mT^2 alphaf_k + min_j pT^2 gammaf_j) -- the row carries min_j betaf_jk
+//      in its fourth slot.  Two instructions and a vote per row; ROWS = 0 formed a threshold per row (~9 instructions) and the minimum over the
+//      row's JT X^2 (JT more): 3.4 of its 30.7 instructions per evaluation.
 // LDSD: doubles of unit records per LDS buffer (two buffers per workgroup).  1536 (13 units of the 8 x 7 tile: 24 KB per workgroup) for the
 // two-wave workgroups that share a stream; 1100 (9 units, 18 KB) for ONE-wave workgroups (g.wpb == 1), eight of which must fit a CU's 160 KB:
 // a wave that stages its own stream has no barrier partner to wait for -- on the config-3 surface 9.7 % of all wave cycles were spent at the
@@ -624,7 +634,8 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     constexpr int NLD = (BUF2 + 127) / 128;
     constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
     static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples (JT even)");
-    static_assert(ROWS == 0 || (DIM3 && JT >= 4), "the row mask needs the unit-level bounds of the 3+1D records");
+    static_assert(ROWS == 0 || (DIM3 && JT >= 4 && ROWS <= 2) || (!DIM3 && JT >= 4 && ROWS == 3), "the row tests against the unit threshold need the bounds in the header");
+    constexpr bool MASK = ROWS == 1 || ROWS == 2;     // 3+1D: liveness of all rows of a unit first
     constexpr FqRowSlots SL = fq_row_slots(DIM3);
     constexpr int BUFP = ((BUF2 * 16 + 1023) / 1024) * 64;   // the batch as whole 1-KiB staging pieces (64 double2 each)
     __shared__ double2 lbuf[2][BUFP + RW / 2 + 1];
@@ -694,14 +705,14 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             return __builtin_fmin(x2cut, xcp * xcp);
         };
         double x2c_u = x2cut;
-        double ral[ROWS ? R : 1], rbm[ROWS ? R : 1];
+        double ral[MASK ? R : 1], rbm[MASK ? R : 1];
         double gmin_u = 0.0;
         if constexpr (DIM3 && JT >= 4) {
             // Unit-level cull (3+1D; bounds from cf_prep_feqmod in free header slots): X^2 >= mT^2 min_k alphaf + mT pT min_jk betaf + pT^2
             // min_j gammaf for every evaluation of the unit, and the threshold of every row is at most the one formed with max_k |A_k|,
             // max_k |W_k| and max_j |B_j| (all roundings monotone): a unit that fails here would have every row culled below, so its
             // header work and its R row fetches are skipped -- bitwise the same spectrum
-            if constexpr (ROWS != 0) {
+            if constexpr (MASK) {
                 // ... and with them, in the same LDS round trip, the operands of the R row tests
                 const double u_al = U[3], u_be = U[6], u_ga = U[7], u_A = U[10], u_W = U[11], u_B = U[14];
 #pragma unroll
@@ -719,8 +730,15 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 if (__all(x2lb_u > x2c_u)) { n_rows += R; n_dead += R; return false; }
             }
         }
-        unsigned live = (1u << (ROWS ? R : 1)) - 1u;
-        if constexpr (ROWS != 0) {
+        if constexpr (ROWS == 3) {
+            // 2+1D: the unit's threshold and min_j pT^2 gammaf_j from the bounds cf_prep_feqmod left in the header; no unit-level cull (a unit is
+            // 31 of a cell's 241 eta rows: its row tests are 2 % of a live unit's work)
+            const double u_ga = U[7], u_A = U[10], u_W = U[11], u_B = U[14];
+            gmin_u = pT2 * u_ga;
+            if (RELCULL && g.zskip == 2) x2c_u = x2_threshold(__builtin_fma(__builtin_fabs(rpT * u_B), u_W, __builtin_fabs(rmT * u_A)));
+        }
+        unsigned live = (1u << (MASK ? R : 1)) - 1u;
+        if constexpr (MASK) {
             if (g.zskip) {
                 live = 0;
 #pragma unroll
@@ -739,9 +757,9 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             pTB[jj] = rpT * U[4 * jj + 0];
             pT2g[jj] = pT2 * U[4 * jj + 1];
             if (DIM3 && ROWS == 0) g_min = __builtin_fmin(g_min, pT2g[jj]);
-            if (RELCULL && ROWS != 2) pb_max = __builtin_fmax(pb_max, __builtin_fabs(pTB[jj]));
+            if (RELCULL && ROWS < 2) pb_max = __builtin_fmax(pb_max, __builtin_fabs(pTB[jj]));
         }
-        if (ROWS != 0) g_min = gmin_u;
+        if (MASK) g_min = gmin_u;
         struct Row { double v[RW]; };
         auto fetch = [&](Row &rw, const double *row) {
 #pragma unroll
@@ -751,10 +769,10 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             const double mTA = rmT * rw.v[SL.A];
             const double a = mT2 * rw.v[SL.AL];
             const double W = rw.v[SL.W];
-            if (ROWS == 0) n_rows += 1;
+            if (!MASK) n_rows += 1;
             double X2[JT];
             double x2c = x2cut;                                                     // X > 745.25 (+ cm): exp(cm - X) == +0
-            if (RELCULL && ROWS != 2 && g.zskip == 2) x2c = x2_threshold(__builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA)));
+            if (RELCULL && ROWS < 2 && g.zskip == 2) x2c = x2_threshold(__builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA)));
             if constexpr (DIM3) {
                 // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + pT^2 min_j gammaf_j (mT pT >= 0; the row carries min_j betaf_jk):
                 // two instructions per row instead of a minimum per evaluation, and a culled row forms no X^2 at all
@@ -764,8 +782,14 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
                 }
 #pragma unroll
                 for (int jj = 0; jj < JT; jj++) X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
+            } else if constexpr (ROWS == 3) {
+                // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + min_j pT^2 gammaf_j, against the unit's threshold (mT pT >= 0, monotone roundings)
+                const double x2lb = __builtin_fma(mTpT, rw.v[SL.BM], a + gmin_u);
+                if (g.zskip && __all(x2lb > x2c_u)) { n_dead += 1; return; }
+#pragma unroll
+                for (int jj = 0; jj < JT; jj++) X2[jj] = __builtin_fma(mTpT, rw.v[4 + jj], a + pT2g[jj]);
             } else {
-                // 2+1D: 241 eta rows per cell would need a 70 KB beta-min table in cf_prep_feqmod (its occupancy, +6 ms per 1e5 cells)
+                // 2+1D, the round-1 form (A/B): a threshold per row and the minimum over the row's X^2
                 double x2min = 1.0e300;
 #pragma unroll
                 for (int jj = 0; jj < JT; jj++) {
@@ -798,7 +822,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             }
         };
         const double *rows = U + HDR;
-        if constexpr (ROWS != 0) {
+        if constexpr (MASK) {
             unsigned long long pr = 0;
             if constexpr (PROF) pr = clock64();
 #pragma unroll
@@ -977,12 +1001,16 @@ static void launch_fq_l(const FqMainArgs &a, hipStream_t st)
 template <bool DIM3, bool OF, bool M3, int JT, int R, int ROWS = 0>
 static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
 {
-    if constexpr (DIM3 && JT == 8 && ROWS != 0) {
-        // one-wave workgroups (3+1D, 8 x 7, no baryon slots): 9-unit LDS batches so that eight workgroups fit a CU, no barrier partner
-        if (a.g.wpb == 1 && !a.lane_b) { launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1100>(a, st); return; }
+    if constexpr (!DIM3 && ROWS == 3) {
+        // 2+1D, 8 x 31: four units per LDS buffer (4 x 404 doubles), one per lane slot of a bin under unit-strided lanes
+        launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 4 * (4 * JT + R * (4 + JT))>(a, st);
+    } else {
+        if constexpr (DIM3 && JT == 8 && ROWS != 0) {
+            // one-wave workgroups (3+1D, 8 x 7, no baryon slots): 9-unit LDS batches so that eight workgroups fit a CU, no barrier partner
+            if (a.g.wpb == 1 && !a.lane_b) { launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1100>(a, st); return; }
+        }
+        launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1536>(a, st);
     }
-
-    launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1536>(a, st);
 }
 
 template <bool DIM3, bool OF, bool M3>
@@ -1001,6 +1029,7 @@ static void launch_fq_variant(int variant, const FqMainArgs &a, hipStream_t st)
         }
     } else {
         switch (variant) {
+        case 7: launch_fq_t<DIM3, OF, M3, 8, 31, 3>(a, st); break;
         case 3: launch_fq_t<DIM3, OF, M3, 12, 61>(a, st); break;
         case 4: launch_fq_t<DIM3, OF, M3, 4, 61>(a, st); break;
         default: launch_fq_t<DIM3, OF, M3, 8, 61>(a, st); break;

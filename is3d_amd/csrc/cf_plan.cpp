@@ -213,7 +213,11 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     int default_variant = plain3 ? 3 : 2;
     if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
     P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 8) ? o->kernel_variant : default_variant;
-    if ((P->variant == 7 || P->variant == 8) && (o->dimension == 3 || fq)) P->variant = default_variant;
+    // modified equilibrium in 2+1D: variant 7 (8 x 31 tile, unit-strided lanes, rows tested against the unit's threshold from the beta minimum
+    // they carry) is the default since round 4; variants 2-4 keep the round-1 row walk on the 61-row tiles for A/B
+    if (fq && o->dimension == 2 && !(o->kernel_variant >= 2 && o->kernel_variant <= 4)) P->variant = 7;
+    if ((P->variant == 7 || P->variant == 8) && o->dimension == 3) P->variant = default_variant;
+    if (P->variant == 8 && fq) P->variant = 7;
     if (P->variant == 8 && o->include_baryon) P->variant = 7;   // variant 8 = variant 7 with the register-staged copy (A/B), without baryon slots only   // unit-strided lanes: the 2+1D delta-f tile kernel
     const bool e2ok = o->dimension == 3 && !fq && g->n_pT <= is3d::kE2Stride;   // the E2 table stream exists for the 3+1D delta-f kernels
     // (modified equilibrium in 3+1D: variants 5 and 6 are A/B forms of its 8 x 7 kernel -- rows pipelined as in round 1 / row mask with the exact
@@ -245,8 +249,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     P->split = 1;
     if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8) && split_for(P->Lbins) > 1) P->variant = 7;   // default
     if (P->variant == 7 || P->variant == 8) P->split = split_for(P->Lbins);
-    if (fq && o->dimension == 2) {
-        // modified equilibrium, 2+1D: the same lane slots on the kernel's own tile -- S = 2 when it divides the units per cell and
+    if (fq && o->dimension == 2 && P->variant != 7) {
+        // modified equilibrium, 2+1D, the 61-row tiles (A/B): the same lane slots on the kernel's own tile -- S = 2 when it divides the units per cell and
         // the units per LDS batch (cf_main_feqmod stages 1536 / REC units) and fills the two-wave workgroups better
         int JTf = 0, Rf = 0;
         is3d::main_tile_shape(P->variant, 0, &JTf, &Rf);
@@ -425,8 +429,6 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_cls_mass.upload(cmass));
         HIP_TRY(P->d_cls_sign.upload(csign));
         if (P->baryon) HIP_TRY(P->d_cls_baryon.upload(cbar));
-        if (is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K, P->dim3 ? (P->J + 3) / 4 : 0, 1152) > 160 * 1024)   // jtiles <= J/4 (4-wide tiles); records <= 1152 doubles
-            return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     }
 
     // ---- tiling / workspace ----
@@ -438,6 +440,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     P->rblocks = tiled ? (P->K + P->KT - 1) / P->KT : 1;
     P->ktiles = P->dim3 ? (P->K + P->KT - 1) / P->KT : 1;   // k tiles are separate tasks only in 3+1D
     P->upc = (tiled && !P->dim3) ? P->rblocks : 1;            // 2+1D: eta blocks are consecutive units of one stream
+    if (fq && is3d::prep_feqmod_lds_bytes(df->n_T, P->nj, P->ngl, P->J, P->K, P->jtiles, P->rblocks, is3d::unit_rec_doubles(P->JT, P->KT, 0)) > 160 * 1024)
+        return fail(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     if (tiled)
         P->bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0);
     else

@@ -31,9 +31,10 @@ def test_feqmod_parity_matrix(fx, dim, df_mode, flags):
     fq = fq_for(cells)
     o = dict(dimension=dim, df_mode=df_mode, **flags)
     ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], fx["df"], fq, o)
-    for variant in (2, 3, 4):
+    for variant in (0, 2, 3, 4):   # 0: the default (2+1D: variant 7 -- 8 x 31, unit-strided lanes, rows against the unit threshold)
         got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=variant), fq=fq)
         assert st["code"] == 0 and st["n_cells_breakdown"] == nb
+        assert st["kernel_variant"] == (variant if variant else (3 if dim == 3 else 7))
         assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
 
 
@@ -198,6 +199,17 @@ def test_feqmod_row_culling_changes_no_bit_2d(fx):
     exact, st1 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=1), fq=fq)
     assert np.array_equal(rel, full) and np.array_equal(exact, full)
     assert st0["n_wave_rows_culled"] > st1["n_wave_rows_culled"] >= 0 == st2["n_wave_rows_culled"]
+    assert st0["kernel_variant"] == 7
+    # the round-1 row walk on the 8 x 61 tile (a threshold and a minimum per row): the same spectrum to rounding, and no fewer rows culled than a
+    # tenth below it (the unit threshold is the looser one)
+    old, so = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0, kernel_variant=2), fq=fq)
+    assert relerr(rel, old) < 1e-12
+    assert st0["n_wave_rows_culled"] / st0["n_wave_rows"] > 0.9 * so["n_wave_rows_culled"] / so["n_wave_rows"]
+    # few momentum bins (pi, K, p: 96 bins, four lane slots per bin, each on its own unit): culling on / off, same bits
+    a4, s4 = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=0), fq=fq)
+    b4, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=2), fq=fq)
+    c4, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=2, kernel_variant=2), fq=fq)
+    assert np.array_equal(a4, b4) and relerr(a4, c4) < 1e-12 and s4["kernel_variant"] == 7
 
 
 @pytest.mark.parametrize("df_mode", [4, 3])
