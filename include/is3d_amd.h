@@ -257,7 +257,8 @@ int is3d_probe_shader_clock(int32_t device, double seconds, double *ghz);
 /* Diagnostic (no reference counterpart): the elementary functions the kernels are built from (is3d_amd/csrc/cf_math.h), evaluated on the
  * device, y[i] = f(x[i]) for HOST arrays of n doubles -- so that their accuracy is a tested number, not a comment.  which: 0 exp_full
  * (Cody-Waite, degree 10) | 1 exp_p9 (one-fma reduction, degree 9; |x| < 1.4e9) | 2 exp_p9_sat | 3 exp_full_sat (|x| up to ~1e45) | 4 sqrt_g1 (v_rsq_f64 +
- * one Goldschmidt step) | 5 sqrt_nr | 6 rcp_nr1 (v_rcp_f64 + one Newton step) | 7 rcp_nr (two steps). */
+ * one Goldschmidt step) | 5 sqrt_nr | 6 rcp_nr1 (v_rcp_f64 + one Newton step) | 7 rcp_nr (two steps) | 8 exp_p9_scaled with e = 5 (32 e^x: the
+ * power-of-two factor cf_main_feqmod takes out of p.dsigma comes back through the exponential's shift constant). */
 int is3d_math_probe(int32_t which, int64_t n, const double *x, double *y, int32_t device);
 /* Diagnostic (no reference counterpart): process-wide counts of the plans this library has created (is3d_plan_create*, the per-shard plans of
  * is3d_multi_plan_create and of the one-shot entries) and of the device allocations (hipMalloc) it has made, since the library was loaded.  What a

@@ -640,7 +640,7 @@ class Comm:
             pass
 
 
-MATH_FUNCS = dict(exp_full=0, exp_p9=1, exp_p9_sat=2, exp_full_sat=3, sqrt_g1=4, sqrt_nr=5, rcp_nr1=6, rcp_nr=7)
+MATH_FUNCS = dict(exp_full=0, exp_p9=1, exp_p9_sat=2, exp_full_sat=3, sqrt_g1=4, sqrt_nr=5, rcp_nr1=6, rcp_nr=7, exp_p9_x32=8)
 
 
 def resource_counters():

@@ -11,7 +11,7 @@
 //   alphaf_k = (1 + |A^-1 a_k|^2)/T_mod^2,  betaf_jk = 2 (A^-1 a_k).(A^-1 b_j)/T_mod^2,  gammaf_j = (|A^-1 b_j|^2 - 1)/T_mod^2
 // (m^2 = mT^2 - pT^2 folded in), and f = |renorm| / (exp(E_mod/T_mod) + sign).  cf_prep_feqmod writes these coefficients
 // into the same tiled unit-record stream the delta-f kernel uses (cf_device.h) with the slots reused:
-//   header jj : {B_j, gammaf_j, 0, 0}          row r, 2+1D : {A_k, alphaf_k, W_k, min_j betaf_jk, betaf_{j0..j0+JT-1,k}}
+//   header jj : {B_j, gammaf_j, 0, 0} (free slots: the unit bounds of the cull, slot 15 the cell's scale exponent, cf_prep_feqmod)          row r, 2+1D : {A_k, alphaf_k, W_k, min_j betaf_jk, betaf_{j0..j0+JT-1,k}}
 //                                              row r, 3+1D : {alphaf_k, min_j betaf_jk, A_k, W_k, betaf_{j0..j0+JT-1,k}} -- the two operands of a row's
 //                                              liveness test in ONE 16-byte LDS read (fq_row_slots)
 //   (include_baryon: header slot 2 of jj = 0 carries alpha_B,mod = alpha_B + Pi G / beta_Pi, :637; the lane's baryon number
@@ -58,6 +58,8 @@ struct FqPrepParams {
     int32_t *flag;                      // [n_cells] 0 feqmod | 1 breakdown (all rows linear) | 2 detA < 0.01 (narrow rows linear)
     unsigned long long *status;         // [0] min bad cell, [1] skipped, [7] min cell whose E_mod/T_mod can exceed 1e9
     double mTmax, kmin, kmax;           // largest lane mT; range of the k grid: bound of E_mod/T_mod for the exponential's domain (exp_p9: < 1.4e9)
+    double pTmax;                       // largest lane pT (with mTmax: the bound of |p.dsigma| behind scale_rows)
+    int32_t scale_rows;                 // df_mode 4 with outflow: A_k, W_k of a cell times 2^-e_c, header slot 15 = kExpShift + e_c (cf_prep_feqmod phase 2e)
 };
 
 struct FqMainArgs {

@@ -41,6 +41,7 @@ struct FqScal {
     double detA;
     double narrow;                 // 1: 3+1D cell with detA < 0.01: rows with |y - eta| < detA go to the linear kernel
     double alphaB_mod;             // include_baryon: alpha_B + Pi G / beta_Pi (:637), else 0
+    double shiftc;                 // kExpShift + e_c: the cell's rows carry A_k, W_k times 2^-e_c (df_mode 4 with the outflow clamp, see cf_main_feqmod)
 };
 
 enum FbIdx { FB_DAT = 0, FB_DAX, FB_DAY, FB_DAN, FB_UT, FB_UX, FB_UY, FB_UN, FB_TAU, FB_ETA, FB_T,
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
     {
         const int JT = p.JT, R = p.R, HDR = 4 * JT, RWD = 4 + JT, REC = HDR + R * RWD;
         const int o_A = (int)(l_A - lds), o_al = (int)(l_al - lds), o_W = (int)(l_W - lds), o_B = (int)(l_B - lds), o_ga = (int)(l_ga - lds);
-        const int o_bm = (int)(l_bm - lds), o_ub = (int)(l_ub - lds), o_aB = (int)(&cs[0].alphaB_mod - lds);
+        const int o_bm = (int)(l_bm - lds), o_ub = (int)(l_ub - lds), o_aB = (int)(&cs[0].alphaB_mod - lds), o_sh = (int)(&cs[0].shiftc - lds);
         constexpr int ZERO = 1 << 22, PADZ = 1 << 21, BETA = 1 << 20;
         for (int e = tid; e < REC; e += kFqThreads) {
             int x = ZERO, y = 0;
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                     else if (e == 6) x = (o_ub + 3 * p.rblocks) | (3 << 16);
                     else if (e == 7) x = (o_ub + 3 * p.rblocks + p.rblocks * p.jtiles) | (4 << 16);
                     else if (e == 14) x = (o_ub + 3 * p.rblocks + p.rblocks * p.jtiles + 1) | (4 << 16);
+                    else if (e == 15) x = o_sh | (5 << 16);   // kExpShift + e_c: the exponent of the cell's power-of-two scale (phase 2e)
                 }
             } else {
                 const int q = e - HDR, r = q / RWD, f = q - r * RWD;
@@ -443,6 +445,31 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                 o[0] = gmin; o[1] = Bmax;
             }
             __syncthreads();
+            // ---- phase 2e: the cell's power-of-two scale.  |p.dsigma| <= mTmax max_k |A_k| + pTmax max_j |B_j| max_k |W_k| < 2^e_c for every lane, so
+            // with A_k, W_k stored times 2^-e_c the main kernel's outflow clamp max(p.dsigma, 0) is the VOP3 clamp of the fma that forms
+            // p.dsigma (one instruction fewer per evaluation); 2^e_c comes back inside the exponential, whose shift constant the header
+            // carries as kExpShift + e_c.  Exact: powers of two.  df_mode 4 with outflow only (df_mode 3 multiplies |renorm| in the lanes);
+            // the unit bounds of the header (max |A_k|, max |W_k|: the cull threshold) stay unscaled. ----
+            if (tid < ncb) {
+                int ec = 0;
+                if (p.scale_rows) {
+                    const double *ub = l_ub + tid * ubs;
+                    double Amax = 0.0, Wmax = 0.0, Bmax = 0.0;
+                    for (int rb = 0; rb < p.rblocks; rb++) { Amax = fmax(Amax, ub[3 * rb + 1]); Wmax = fmax(Wmax, ub[3 * rb + 2]); }
+                    for (int jt = 0; jt < p.jtiles; jt++) Bmax = fmax(Bmax, ub[3 * p.rblocks + p.rblocks * p.jtiles + 2 * jt + 1]);
+                    const double bound = (p.mTmax * Amax + p.pTmax * Bmax * Wmax) * 1.0000001;
+                    if (bound >= 1.0 && bound < 1.0e300) ec = __builtin_amdgcn_frexp_exp(bound);   // bound < 2^ec
+                }
+                cs[tid].shiftc = kExpShift + (double)ec;
+            }
+            __syncthreads();
+            if (p.scale_rows) {
+                for (int idx = tid; idx < ncb * K; idx += kFqThreads) {
+                    const double sc = ldexp_fast(1.0, -(int)(cs[idx / K].shiftc - kExpShift));
+                    l_A[idx] *= sc; l_W[idx] *= sc;
+                }
+                __syncthreads();
+            }
         }
         // ---- phase 3: unit records (layout of cf_device.h, slots as in cf_feqmod.h): one unit per wave at a time, lanes <-> elements,
         // one descriptor read and one batch of source reads per 64 elements ----
@@ -689,6 +716,11 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     // z = e^(cm - X) <= e^(cm - sqrt(x2lb)); the accumulators only grow and fma(pds, w, acc) == acc when pds w < ulp(acc)/2.
     // With pmax < 2^ep and min(acc) >= 2^(acc_e - 1): X > cm + (ep - acc_e + 58) ln 2 leaves every accumulator unchanged.
     constexpr bool RELCULL = OUTFLOW;
+    // Outflow clamp by the VOP3 clamp modifier (df_mode 4): cf_prep_feqmod stores a cell's A_k, W_k times 2^-e_c with 2^e_c above every lane's
+    // |p.dsigma| (phase 2e), so max(p.dsigma, 0) 2^-e_c is the clamp to [0, 1] of the fma that forms it -- one instruction fewer per
+    // evaluation than fma + v_max_f64; the factor 2^e_c comes back in z' = 2^e_c exp(-X) (exp_p9_scaled: the header carries the shift
+    // constant), with sign 2^-e_c in 1 + sign z.  All exact: the spectrum's bits are those of the unscaled form.
+    constexpr bool CLAMP = OUTFLOW && !MODE3;
     int acc_e = -100000;   // frexp exponent of a (stale) minimum over the lane's accumulators; refreshed once per batch
     auto process_unit = [&](const double *U, double rn) -> bool {
         double pTB[JT], pT2g[JT];
@@ -698,8 +730,8 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
         const double xcut = BARYON ? 745.25 + __builtin_fmax(cm, 0.0) : 745.25;
         const double x2cut = BARYON ? xcut * xcut : 555400.0;
         // threshold on X^2 from an upper bound pmax of the row's (or the unit's) p.dsigma: see RELCULL above
-        auto x2_threshold = [&](double pmax) {
-            const int de = __builtin_amdgcn_frexp_exp(pmax) - acc_e + 58;
+        auto x2_threshold = [&](double pmax, int eadd = 0) {   // eadd: e_c when pmax is formed from the cell's scaled rows
+            const int de = __builtin_amdgcn_frexp_exp(pmax) + eadd - acc_e + 58;
             const double xc = cm + (double)(de > 1 ? de : 1) * 0.6931471805599453;
             const double xcp = __builtin_fmax(xc, 0.0);
             return __builtin_fmin(x2cut, xcp * xcp);
@@ -737,6 +769,13 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             gmin_u = pT2 * u_ga;
             if (RELCULL && g.zskip == 2) x2c_u = x2_threshold(__builtin_fma(__builtin_fabs(rpT * u_B), u_W, __builtin_fabs(rmT * u_A)));
         }
+        double shiftc = kExpShift, signc = sign;
+        int eu = 0;
+        if constexpr (CLAMP) {
+            shiftc = U[15];
+            eu = (int)(shiftc - kExpShift);
+            signc = ldexp_fast(sign, -eu);
+        }
         unsigned live = (1u << (MASK ? R : 1)) - 1u;
         if constexpr (MASK) {
             if (g.zskip) {
@@ -772,7 +811,7 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
             if (!MASK) n_rows += 1;
             double X2[JT];
             double x2c = x2cut;                                                     // X > 745.25 (+ cm): exp(cm - X) == +0
-            if (RELCULL && ROWS < 2 && g.zskip == 2) x2c = x2_threshold(__builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA)));
+            if (RELCULL && ROWS < 2 && g.zskip == 2) x2c = x2_threshold(__builtin_fma(pb_max, __builtin_fabs(W), __builtin_fabs(mTA)), eu);
             if constexpr (DIM3) {
                 // X^2_j >= mT^2 alphaf_k + mT pT min_j betaf_jk + pT^2 min_j gammaf_j (mT pT >= 0; the row carries min_j betaf_jk):
                 // two instructions per row instead of a minimum per evaluation, and a culled row forms no X^2 at all
@@ -806,15 +845,20 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const double X = sqrt_g1(X2[j0 + i]);   // 3e-15 relative: e^-X moves by X * 3e-15
-                    zz[i] = exp_p9(BARYON ? cm - X : -X);   // degree 9 + one-fma reduction (cf_math.h): 7e-14; cf_prep_feqmod keeps X = |A^-1 p|/T_mod below 1e9 (status[7])
-                    d[i] = __builtin_fma(sign, zz[i], 1.0);
+                    // degree 9 + one-fma reduction (cf_math.h): 7e-14; cf_prep_feqmod keeps X = |A^-1 p|/T_mod below 1e9 (status[7])
+                    zz[i] = CLAMP ? exp_p9_scaled(-X, shiftc) : exp_p9(BARYON ? cm - X : -X);
+                    d[i] = __builtin_fma(signc, zz[i], 1.0);
                 }
                 rcp_batch<RB>(d, inv);
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const int jj = j0 + i;
-                    double pds = __builtin_fma(pTB[jj], W, mTA);
-                    if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
+                    double pds;
+                    if constexpr (CLAMP) pds = fma_clamp01(pTB[jj], W, mTA);
+                    else {
+                        pds = __builtin_fma(pTB[jj], W, mTA);
+                        if (OUTFLOW) pds = __builtin_fmax(pds, 0.0);
+                    }
                     const double w = zz[i] * inv[i];
                     if (DIM3) acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
                     else acc[jj] = __builtin_fma(pds, w, acc[jj]);

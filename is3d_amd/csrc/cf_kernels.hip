@@ -1982,6 +1982,7 @@ __global__ void __launch_bounds__(256) cf_math_probe(int which, int64_t n, const
     case 4: r = sqrt_g1(v); break;
     case 5: r = sqrt_nr(v); break;
     case 6: r = rcp_nr1(v); break;
+    case 8: r = exp_p9_scaled(v, kExpShift + 5.0); break;   // 32 exp_p9(v), bit for bit
     default: r = rcp_nr(v); break;
     }
     y[i] = r;

@@ -148,6 +148,16 @@ __device__ __forceinline__ double exp_p9(double v)   // |v| < 1.4e9 (shift trick
     const double r = __builtin_fma(-dn, IS3D_LN2, v);
     return ldexp_fast(exp_p9_poly(r), __double2loint(t));
 }
+// exp_p9(v) * 2^e with shiftc = kExpShift + e (e a small integer): the shift constant places n + e in the low word, the reduced argument is
+// v - n ln2 as before -- a power-of-two factor for free (cf_main_feqmod: the cell's p.dsigma scale comes back here)
+constexpr double kExpShift = 6755399441055744.0;   // 0x1.8p52
+__device__ __forceinline__ double exp_p9_scaled(double v, double shiftc)
+{
+    const double t = __builtin_fma(v, IS3D_LOG2E, shiftc);
+    const double dn = t - shiftc;
+    const double r = __builtin_fma(-dn, IS3D_LN2, v);
+    return ldexp_fast(exp_p9_poly(r), __double2loint(t));
+}
 __device__ __forceinline__ double exp_p9_sat(double v)   // |v| up to ~1e45: v_cvt_i32_f64 saturates, e^-huge = +0 (beyond that the reduced argument's polynomial overflows)
 {
     const double dn = __builtin_rint(v * IS3D_LOG2E);

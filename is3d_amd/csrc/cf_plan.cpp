@@ -604,7 +604,7 @@ extern "C" int is3d_probe_shader_clock(int32_t device, double seconds, double *g
 
 extern "C" int is3d_math_probe(int32_t which, int64_t n, const double *x, double *y, int32_t device)
 {
-    if (which < 0 || which > 7 || n < 0 || (n > 0 && (!x || !y))) return fail(IS3D_EINVAL, "is3d_math_probe: which in 0..7, n >= 0, non-null arrays");
+    if (which < 0 || which > 8 || n < 0 || (n > 0 && (!x || !y))) return fail(IS3D_EINVAL, "is3d_math_probe: which in 0..8, n >= 0, non-null arrays");
     if (is3d_device_count() < 1) return fail(IS3D_ENODEVICE, "no HIP device visible; this library has no CPU path");
     if (n == 0) return IS3D_OK;
     if (device >= 0) HIP_TRY(hipSetDevice(device));
@@ -720,6 +720,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 fp.jx = P->d_jonah.p; fp.jl2 = fp.jx + P->nj; fp.jz = fp.jx + 2 * P->nj; fp.jcl = fp.jx + 3 * P->nj; fp.jcz = fp.jx + 4 * P->nj;
                 fp.bp_max = P->bp_max;
                 fp.mTmax = P->mTmax; fp.kmin = P->kmin; fp.kmax = P->kmax;
+                fp.pTmax = P->pTmax; fp.scale_rows = (o.df_mode == 4 && o.outflow != 0) ? 1 : 0;   // cf_main_feqmod's CLAMP instantiations
                 fp.ngl = P->ngl; fp.gl = P->d_gl.p;
                 fp.detA_min = P->detA_min; fp.mass_pion0 = P->mass_pion0;
                 fp.JT = P->JT; fp.R = P->KT; fp.jtiles = P->jtiles; fp.rblocks = P->rblocks;

@@ -24,6 +24,9 @@ def test_exponentials():
     assert e9 < 7e-14, e9                                              # one-fma reduction (|n| 2.3e-17) + degree 9 (4.5e-14)
     assert _rel(api.math_probe("exp_p9_sat", x), ref) < 7e-14
     assert np.array_equal(api.math_probe("exp_p9", x), api.math_probe("exp_p9_sat", x))   # the two conversions agree wherever both are defined
+    # a power-of-two factor through the shift constant (cf_main_feqmod: the cell's p.dsigma scale): 2^5 e^x, the bits of 32 * exp_p9(x)
+    norm = x[x > -700.0]
+    assert np.array_equal(api.math_probe("exp_p9_x32", norm), 32.0 * api.math_probe("exp_p9", norm))
     # the exact-zero rule of the row culls: e^v is exactly +0 for v < -745.2 in every variant, and the saturating forms take any argument
     far = np.array([-745.25, -746.0, -1000.0, -1.0e6, -1.3e9])
     for f in ("exp_full", "exp_p9", "exp_full_sat", "exp_p9_sat"):
@@ -49,4 +52,4 @@ def test_square_roots_and_reciprocals():
     assert _rel(api.math_probe("rcp_nr1", d), 1 / d.astype(LD)) < 4e-15           # v_rcp_f64 + one Newton step
     assert _rel(api.math_probe("rcp_nr", d), 1 / d.astype(LD)) < 3e-16
     api.math_probe("rcp_nr", d[:1])                                                 # sets the argument types
-    assert api.load().is3d_math_probe(9, 0, None, None, -1) == api.IS3D_EINVAL      # an unknown function is refused
+    assert api.load().is3d_math_probe(10, 0, None, None, -1) == api.IS3D_EINVAL      # an unknown function is refused
