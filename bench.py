@@ -338,8 +338,10 @@ def main():
             # RCCL builds its rings / connections lazily at the first collective: pay that here, not in a timed step (--warmup 0 included)
             try:
                 prime = torch.zeros(1024, dtype=torch.float64, device=dev)
+                comm.set_timeout(120.0)   # a communicator that cannot complete its first collective is given up within two minutes (deadline wait, not torch.cuda.synchronize)
                 comm.allreduce(prime.data_ptr(), prime.numel(), torch.cuda.current_stream().cuda_stream)
-                torch.cuda.synchronize()
+                comm.synchronize(torch.cuda.current_stream().cuda_stream)
+                comm.set_timeout(300.0)
             except Exception as e:
                 print("bench.py rank %d: priming all-reduce failed (%s); falling back to torch.distributed.all_reduce" % (rank, e), file=sys.stderr, flush=True)
                 comm.close()

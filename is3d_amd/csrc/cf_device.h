@@ -117,7 +117,21 @@ struct MainGeom {
     int32_t ub;        // variant 5: units per LDS batch (from the LDS budget of the workgroup)
     int32_t split;     // 2+1D: lane slots per momentum bin (unit-strided lanes, cf_main_tile); 1 = off
     int32_t ch0, nch_run;  // cf_main_tile3e: this launch runs chunks [ch0, ch0 + nch_run) of the nch (nch_run 0 = all of them)
+    int32_t nch_small;     // the LAST nch_small of the nch chunks hold a quarter of the cells of the others (chunk_cells)
 };
+
+// Cells [c0, c1) of a chunk.  The chunks are equal but for a tapered tail: the last g.nch_small chunks are a quarter of the size of the others,
+// so that the grid drains in quarter-length tasks (the fixed ~2.7 ms a launch of the main kernel cost beyond its per-cell time was the tail of
+// full-length tasks: 6 % of a 125 000-cell shard's step).  nch_small = 0: c0 = chunk n_cells / nch, the partition of rounds 1-3.
+__host__ __device__ inline void chunk_cells(const MainGeom &g, int chunk, int &c0, int &c1)
+{
+    const int nbig = g.nch - g.nch_small;
+    const long long Q = 4LL * nbig + g.nch_small;                                  // the surface in quarter-chunks
+    const long long q0 = chunk < nbig ? 4LL * chunk : 4LL * nbig + (chunk - nbig);
+    const long long q1 = chunk + 1 <= nbig ? 4LL * (chunk + 1) : 4LL * nbig + (chunk + 1 - nbig);
+    c0 = (int)((q0 * g.n_cells) / Q);
+    c1 = (int)((q1 * g.n_cells) / Q);
+}
 
 struct MainArgs {
     const double *S1, *S2, *S3, *TS, *lane_mT, *lane_pT, *lane_sign, *lane_b;

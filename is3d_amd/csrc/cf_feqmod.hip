@@ -694,8 +694,8 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     // dead for every one of them.
     const int S = (!DIM3 && g.split > 1) ? g.split : 1;
     const int sub_off = (!DIM3 && g.split > 1 && lane_sub) ? lane_sub[l] * REC : 0;
-    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
-    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    int c0, c1;
+    chunk_cells(g, chunk, c0, c1);
     const int n_units = (c1 - c0) * g.upc;
     const int s_tile = DIM3 ? (jt * g.ktiles + kt) : jt;
     const double2 *src = (const double2 *)(TS + (((int64_t)s_tile * g.n_cells + c0) * g.upc) * REC);

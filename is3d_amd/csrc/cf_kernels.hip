@@ -828,8 +828,8 @@ cf_main_direct(const double *__restrict__ S1, const double *__restrict__ S2, con
     const int j = t.jt;
     const double mT = lane_mT[t.l], pT = lane_pT[t.l], sign = lane_sign[t.l];
     const double mT2 = mT * mT, mTpT = mT * pT, pT2 = pT * pT;
-    const int c0 = (int)(((int64_t)t.chunk * g.n_cells) / g.nch);
-    const int c1 = (int)(((int64_t)(t.chunk + 1) * g.n_cells) / g.nch);
+    int c0, c1;
+    chunk_cells(g, t.chunk, c0, c1);
     const int k0 = DIM3 ? t.kt * KT : 0;
 
     double acc[KT];
@@ -983,8 +983,8 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
     const double bq = BARYON ? lane_b[l] : 0.0;              // baryon number of the lane's species class
     const double hbmT = hs * bq * mT, hbpT = hs * bq * pT;
-    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
-    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    int c0, c1;
+    chunk_cells(g, chunk, c0, c1);
     const int n_units = (c1 - c0) * g.upc;
     const int s_tile = DIM3 ? (jt * g.ktiles + kt) : jt;
     const double2 *src = (const double2 *)(TS + (((int64_t)s_tile * g.n_cells + c0) * g.upc) * REC);
@@ -1335,8 +1335,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
     const double bq = BARYON ? lane_b[l] : 0.0;
     const double hbmT = hs * bq * mT, hbpT = hs * bq * pT;
-    const int c0 = (int)(((int64_t)chunk * g.n_cells) / g.nch);
-    const int c1 = (int)(((int64_t)(chunk + 1) * g.n_cells) / g.nch);
+    int c0, c1;
+    chunk_cells(g, chunk, c0, c1);
     const int n_units = c1 - c0;                  // one unit per cell in 3+1D
     const int s_tile = jt * g.ktiles + kt;
     const double2 *src_ts = (const double2 *)(TS + ((int64_t)s_tile * g.n_cells + c0) * REC);

@@ -62,6 +62,8 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int kTaperBig = 6;   // chunk_plan: full-size chunks whose cells go to 4 kTaperBig quarter-size chunks at the end of the partition
+
 struct is3d_plan {
     is3d_options opts{};
     int device = 0;
@@ -539,7 +541,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
         HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
     }
-    BIG_ALLOC(P->d_partial, (size_t)P->nch_max * P->J * P->Kacc * P->Lpad, "the per-chunk partial spectra");
+    BIG_ALLOC(P->d_partial, (size_t)(P->nch_max + 3 * kTaperBig /* the tapered tail: chunk_plan */) * P->J * P->Kacc * P->Lpad, "the per-chunk partial spectra");
 #undef BIG_ALLOC
     if (P->e2tab) HIP_TRY(P->d_cull_floor.alloc((size_t)P->jtiles * P->ktiles * P->Lpad));
     HIP_TRY(P->d_status.alloc(8));
@@ -654,6 +656,20 @@ static int chunks_for(const is3d_plan *P, int64_t n)
     return (int)std::max<int64_t>(1, std::min<int64_t>(P->nch_max, by_cells));
 }
 
+// Tapered tail of the cell partition (cf_device.h::chunk_cells): the last kTaperBig full-size chunks become 4 kTaperBig quarter-size ones, four
+// rounds of the chip in quarter-length tasks, so that the grid of the main kernel drains in a quarter of the time -- the fixed ~2.7 ms a launch cost
+// beyond its per-cell time (profiles/r04_shard_sizes.json: 329.0 / 166.2 / 85.5 / 43.5 ms main at 1e6 / 5e5 / 2.5e5 / 1.25e5 cells).  Not with an
+// explicit opts.cell_chunks (the caller's count is kept as it is) and not for chunks of fewer than 256 cells.
+static void chunk_plan(const is3d_plan *P, int64_t n, int &nch, int &nsmall)
+{
+    nch = chunks_for(P, n);
+    nsmall = 0;
+    if (P->opts.cell_chunks <= 0 && nch >= 4 * kTaperBig && n / nch >= 256) {
+        nsmall = 4 * kTaperBig;
+        nch += 3 * kTaperBig;
+    }
+}
+
 extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *dN_out, void *hip_stream, is3d_status *status)
 {
     if (!P || !cells || !dN_out) return fail(IS3D_EINVAL, "null argument");
@@ -688,7 +704,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
     unsigned long long init[8] = {~0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL, ~0ULL};
     HIP_TRY(hipMemcpyAsync(P->d_status.p, init, sizeof init, hipMemcpyHostToDevice, st));
 
-    int nch_used = 1;
+    int nch_used = 1, nch_small = 0;
     // tiled delta-f stream: p.dsigma travels times 2^-e (status[6] = bits of the bound, cf_device.h)
     const bool use_scale = !P->feqmod && P->variant != 1;
     if (n == 0) {
@@ -696,7 +712,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
         if (!o.accumulate) HIP_TRY(hipMemsetAsync(dN_out, 0, (size_t)P->nout * sizeof(double), st));
     } else {
         // all passes use the chunk count of the first (largest) pass so that partial slots line up
-        nch_used = chunks_for(P, std::min<int64_t>(n, P->pass_cells));
+        chunk_plan(P, std::min<int64_t>(n, P->pass_cells), nch_used, nch_small);
         if (use_scale) {
             is3d::CellPtrs cp{};
             cp.tau = cells->tau; cp.eta = cells->eta; cp.dat = cells->dat; cp.dax = cells->dax; cp.day = cells->day; cp.dan = cells->dan;
@@ -742,7 +758,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
                 a.g.upc = P->upc; a.g.zskip = (o.zero_skip == 2) ? 0 : (o.zero_skip == 1 ? 1 : 2); a.g.baryon = 0;
                 a.g.n_cells = nc; a.g.J = P->J; a.g.K = P->K; a.g.Lpad = P->Lpad; a.g.wpb = P->wpb;
                 a.g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
-                a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles; a.g.nch = nch_used;
+                a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles; a.g.nch = nch_used; a.g.nch_small = nch_small;
                 a.g.NT = P->jtiles * P->ktiles * nch_used; a.g.Kacc = P->Kacc; a.g.first_pass = (pass == 0);
                 HIP_TRY(is3d::launch_main_feqmod(P->variant, P->dim3, o.outflow != 0, o.df_mode == 3, P->baryon ? 1 : 0, a, st));
                 // flagged cells (breakdown, narrow rows): ordered list, then the linearised delta-f on top of chunk 0
@@ -801,7 +817,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.g.wpb = P->wpb;
             a.g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
             a.g.jtiles = P->jtiles; a.g.ktiles = P->ktiles;
-            a.g.nch = nch_used;
+            a.g.nch = nch_used; a.g.nch_small = nch_small;
             a.g.NT = P->jtiles * P->ktiles * nch_used;
             a.g.Kacc = P->Kacc;
             a.g.first_pass = (pass == 0);
