@@ -34,6 +34,15 @@ elif [ "$PART" = "d" ]; then   # only the sampler leg (after a change to its ker
   run_pmc smppmc_write WRITE_SIZE --workload config5-sampler
   run_pmc smppmc_sq "$SQ1" --workload config5-sampler
   run_pmc smppmc_misc "$SQ2" --workload config5-sampler
+elif [ "$PART" = "e" ]; then   # the 2+1D kernels on the config-2 surface: delta-f (BASELINE config 2) and modified equilibrium (df_mode 4)
+  run_stats trace_c2 --workload config2
+  run_pmc c2pmc_fetch FETCH_SIZE --workload config2
+  run_pmc c2pmc_write WRITE_SIZE --workload config2
+  run_pmc c2pmc_sq "$SQ1" --workload config2
+  run_pmc c2pmc_misc "$SQ2" --workload config2
+  run_stats trace_c2fq --workload config2 --df-mode 4
+  run_pmc c2fqpmc_sq "$SQ1" --workload config2 --df-mode 4
+  run_pmc c2fqpmc_misc "$SQ2" --workload config2 --df-mode 4
 elif [ "$PART" = "c" ]; then   # only the kernel-trace stats of the anisotropic-hydro workloads (after a change to cf_prep_vah)
   run_stats trace_c5 --workload config5
   run_stats trace_v2 --workload config5 --dimension 2
