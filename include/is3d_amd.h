@@ -137,9 +137,13 @@ typedef struct {
                                            in 2+1D | 5: variant 3 with the phi-side exponentials read from a table stream written by the
                                            prep kernel | 6: variant 5 with the rows of a unit tested for liveness before their exponentials |
                                            7: 2+1D, 8x31 tile with unit-strided lanes | 8: variant 7 with the register-staged LDS copy of
-                                           round 1 (A/B only).  A variant that does not exist for the requested mode falls back to the
+                                           round 1 (A/B only).  Modified equilibrium (df_mode 3, 4): 3+1D default 3 (8x7, rows masked
+                                           against the unit threshold; 5, 6: the other row walks, A/B), 2+1D default 7 (8x31, unit-strided
+                                           lanes, rows tested against the unit threshold; 2-4: the round-1 walk on the 61-row tiles).
+                                           A variant that does not exist for the requested mode falls back to the
                                            default; status.kernel_variant says which one ran */
-    int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into */
+    int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into; 0 (default): the library's count, with
+                                           a tapered tail (the last chunks a quarter of the size of the others); > 0: that many equal chunks */
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass; 0: max(16 GiB, 45 % of the device's TOTAL memory) --
                                            the total, not what is free at the moment, so that the pass / chunk count (and with it the
                                            summation order) of a large surface does not depend on the GPU's other tenants.  An
