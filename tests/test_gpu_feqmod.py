@@ -38,6 +38,35 @@ def test_feqmod_parity_matrix(fx, dim, df_mode, flags):
         assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
 
 
+def test_feqmod_odd_grids(fx):
+    """Grid lengths that are not multiples of the kernel tiles: phi 5, pT 3; 2+1D eta tables of 41, 7, 48 and 100 nodes (one to four row blocks of
+    the 8 x 31 tile: the lane slots per bin follow the row blocks), 3+1D rapidity tables of 5 and 29 -- every row walk."""
+    rng = np.random.default_rng(5)
+    g = dict(pT=np.array([0.1, 0.7, 2.5]), phi=np.sort(rng.random(5) * 2 * np.pi), y=np.linspace(-2, 2, 5), eta=fx["grid"]["eta"], eta_w=fx["grid"]["eta_w"])
+    c2 = synth.synth_surface(7, 2, seed=19)
+    fq2 = fq_for(c2)
+    for neta in (41, 7, 48, 100):
+        eta = np.linspace(-2.5, 2.5, neta)
+        w = np.full(neta, eta[1] - eta[0])
+        w[[0, -1]] *= 0.5
+        gg = dict(g, eta=eta, eta_w=w)
+        for dfm in (4, 3):
+            o = dict(dimension=2, df_mode=dfm)
+            ref, nb = oracle.dN_pTdpTdphidy_feqmod(c2, fx["pikp"], gg, fx["df"], fq2, o)
+            for variant in (0, 2, 3, 4):
+                got, st = api.smooth_spectra(c2, fx["pikp"], gg, fx["df"], dict(o, kernel_variant=variant), fq=fq2)
+                assert st["n_cells_breakdown"] == nb and relerr(got, ref) < TOL, (neta, dfm, variant, relerr(got, ref))
+    c3 = synth.synth_surface(15, 3, seed=20)
+    fq3 = fq_for(c3)
+    for ygrid in (np.linspace(-2, 2, 5), np.linspace(-3.5, 3.5, 29)):
+        gg = dict(g, y=ygrid)
+        o = dict(dimension=3, df_mode=4)
+        ref, nb = oracle.dN_pTdpTdphidy_feqmod(c3, fx["pikp"], gg, fx["df"], fq3, o)
+        for variant in (0, 2, 4, 5, 6):
+            got, st = api.smooth_spectra(c3, fx["pikp"], gg, fx["df"], dict(o, kernel_variant=variant), fq=fq3)
+            assert st["n_cells_breakdown"] == nb and relerr(got, ref) < TOL, (len(ygrid), variant, relerr(got, ref))
+
+
 def test_feqmod_golden_vectors(fx, pins):
     """The committed long-double restatement (tests/golden/make_golden.py::highprec_feqmod)."""
     hp = np.load(os.path.join(ROOT, "tests", "golden", "golden_highprec.npz"))
