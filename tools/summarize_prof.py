@@ -99,8 +99,19 @@ if c2:
                 agg2[r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt2[r["Counter_Name"]] += 1
     old = json.load(open(tp))
+    fw2 = {}
+    for ctr, sub in (("FETCH_SIZE", "c2pmc_fetch"), ("WRITE_SIZE", "c2pmc_write")):   # separate passes, one launch of the main kernel each
+        fs = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        if fs:
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(max(fs, key=os.path.getmtime))) if "cf_main" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if v:
+                fw2[ctr] = sum(v) / len(v)
+    traffic2 = {}
+    if len(fw2) == 2:
+        traffic2 = dict(FETCH_SIZE_KiB=fw2["FETCH_SIZE"], WRITE_SIZE_KiB=fw2["WRITE_SIZE"], fetch_correction=2.0,
+                        hbm_bytes_per_launch=(2.0 * fw2["FETCH_SIZE"] + fw2["WRITE_SIZE"]) * 1024.0)
     old["config2"] = dict(cells=b2["config"]["cells_per_gpu"], kernel=b2["config"]["kernel"], kernel_variant=b2["config"]["kernel_variant"],
-                          bench_hip_event_kernel_ms=b2["kernel_ms"]["main"],
+                          bench_hip_event_kernel_ms=b2["kernel_ms"]["main"], **traffic2,
                           rocprof_avg_kernel_ms=[float(r[3]) / 1e6 for r in rows[1:] if "cf_main" in r[0]][:1],
                           sq_counters_per_launch={k: agg2[k] / cnt2[k] for k in sorted(agg2)})
     json.dump(old, open(tp, "w"), indent=1)
