@@ -965,7 +965,7 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     P->nch = (int)nch;
     for (int which = 0; which < 2; which++) {
         const size_t bytes = which == 0 ? (size_t)P->pass_cells * bytes_per_cell + 64 * 1024   // + slack: the staging pieces of the last batch over-read the stream
-                                        : (size_t)nch * J * Kacc * Lpad * sizeof(double);
+                                        : (size_t)(nch + 18 /* the tapered tail of the partition, below */) * J * Kacc * Lpad * sizeof(double);
         const hipError_t e = (which == 0 ? P->d_TS : P->d_partial).alloc(bytes);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
@@ -1033,7 +1033,10 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
     if (n == 0) {
         if (!o.accumulate) VAH_TRY(hipMemsetAsync(dN_out, 0, (size_t)P->nout * sizeof(double), st));
     }
-    const int nch = (int)std::max<int64_t>(1, std::min<int64_t>(P->nch, std::min<int64_t>(n, P->pass_cells) / 64));
+    int nch = (int)std::max<int64_t>(1, std::min<int64_t>(P->nch, std::min<int64_t>(n, P->pass_cells) / 64));
+    // tapered tail of the cell partition as in cf_plan.cpp (chunk_plan; cf_device.h::chunk_cells): the last 6 chunks as 24 quarter-size ones
+    int nch_small = 0;
+    if (o.cell_chunks <= 0 && nch >= 24 && std::min<int64_t>(n, P->pass_cells) / nch >= 256) { nch_small = 24; nch += 18; }
     for (int pass = 0; pass < npasses; pass++) {
         const int64_t c0 = (int64_t)pass * P->pass_cells;
         const int32_t nc = (int32_t)std::min<int64_t>(P->pass_cells, n - c0);
@@ -1066,7 +1069,7 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 1], st));
         is3d::MainGeom g{};
         g.n_cells = nc; g.J = P->J; g.K = P->K; g.Lpad = P->Lpad; g.wpb = P->wpb; g.G = (P->Lpad / 64 + P->wpb - 1) / P->wpb;
-        g.jtiles = P->jtiles; g.ktiles = P->ktiles; g.nch = nch; g.NT = P->jtiles * P->ktiles * nch; g.Kacc = P->Kacc;
+        g.jtiles = P->jtiles; g.ktiles = P->ktiles; g.nch = nch; g.nch_small = nch_small; g.NT = P->jtiles * P->ktiles * nch; g.Kacc = P->Kacc;
         g.first_pass = 1; g.upc = P->upc; g.zskip = (o.zero_skip != 2); g.baryon = 0; g.split = P->split;
         if (P->fact && P->three_d) launch_vah3<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, nullptr, st);
         else if (P->fact) launch_vah3<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, P->d_lane_sub.as<int32_t>(), st);

@@ -286,6 +286,23 @@ def test_passes_chunks_and_accumulate(fx, torch_mod):
         assert relerr(got, b2) < 1e-13
 
 
+def test_tapered_partition_passes_and_explicit_chunks(fx):
+    """The default cell partition has a tapered tail (is3d::chunk_cells: the last chunks a quarter of the size of the others) once its chunks
+    hold 256 cells or more: 80 000 cells x 305 species here.  Against the uniform partition of an explicit cell_chunks, and split into passes
+    that reuse the first pass's chunk count for fewer cells: the same spectrum to rounding (another summation order)."""
+    cells = synth.synth_surface(80000, 3, seed=23)
+    sp = inputs.species("urqmd")
+    o = dict(dimension=3, df_mode=2)
+    base, st0 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+    assert st0["n_passes"] == 1 and st0["code"] == 0
+    uni, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, cell_chunks=144))
+    assert relerr(uni, base) < 1e-12 and not np.array_equal(uni, base)      # (not the same partition: the taper is in use)
+    multi, st1 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, workspace_bytes=600 << 20))
+    assert st1["n_passes"] >= 2 and relerr(multi, base) < 1e-12
+    again, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], o)
+    assert np.array_equal(again, base)
+
+
 def test_workgroup_sizes_and_batch_tails_change_no_bit(fx):
     """waves_per_group (1, 2, 4, 8 lane-waves sharing one LDS-staged stream; 1 = no barrier partner, cf_main_tile3e only) and the
     cell count modulo the units per LDS batch are scheduling only: a lane sees the same units in the same order, so the spectrum
