@@ -123,6 +123,18 @@ struct MainGeom {
 // Cells [c0, c1) of a chunk.  The chunks are equal but for a tapered tail: the last g.nch_small chunks are a quarter of the size of the others,
 // so that the grid drains in quarter-length tasks (the fixed ~2.7 ms a launch of the main kernel cost beyond its per-cell time was the tail of
 // full-length tasks: 6 % of a 125 000-cell shard's step).  nch_small = 0: c0 = chunk n_cells / nch, the partition of rounds 1-3.
+// The host side of it (cf_plan.cpp, cf_vah.hip): given the base chunk count of `cells` cells, the last kTaperBig full-size chunks become
+// 4 kTaperBig quarter-size ones -- four rounds of the chip in quarter-length tasks.  Not with an explicit opts.cell_chunks (the caller's count is
+// kept as it is) and not for chunks of fewer than 256 cells.  Returns nch_small and raises nch by 3 kTaperBig; the partial buffer is allocated for
+// kTaperExtra slabs beyond the base count.
+constexpr int kTaperBig = 6, kTaperExtra = 3 * kTaperBig;
+inline int chunk_taper(long long cells, int explicit_chunks, int &nch)
+{
+    if (explicit_chunks > 0 || nch < 4 * kTaperBig || cells / nch < 256) return 0;
+    nch += kTaperExtra;
+    return 4 * kTaperBig;
+}
+
 __host__ __device__ inline void chunk_cells(const MainGeom &g, int chunk, int &c0, int &c1)
 {
     const int nbig = g.nch - g.nch_small;

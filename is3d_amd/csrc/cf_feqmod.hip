@@ -481,7 +481,6 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
             int n = 0;
             for (int c = 0; c < ncb; c++) {
                 const int64_t cell = cbase + c;
-                const double i2 = 2.0 * cs[c].invTm2;
                 for (int jt = 0; jt < p.jtiles; jt++) {
                     for (int rb = 0; rb < p.rblocks; rb++, n++) {
                         if ((n & (kFqThreads / 64 - 1)) != wave) continue;
@@ -508,7 +507,6 @@ __global__ void __launch_bounds__(kFqThreads) cf_prep_feqmod(FqPrepParams p)
                         }
                     }
                 }
-                (void)i2;
             }
         }
         __syncthreads();

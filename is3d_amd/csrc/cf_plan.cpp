@@ -62,8 +62,6 @@ struct DevBuf {
 
 }  // namespace
 
-constexpr int kTaperBig = 6;   // chunk_plan: full-size chunks whose cells go to 4 kTaperBig quarter-size chunks at the end of the partition
-
 struct is3d_plan {
     is3d_options opts{};
     int device = 0;
@@ -541,7 +539,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         HIP_TRY(P->d_S2.alloc((size_t)pc * P->J * is3d::kS2Rec));
         HIP_TRY(P->d_S3.alloc((size_t)pc * P->J * P->K));
     }
-    BIG_ALLOC(P->d_partial, (size_t)(P->nch_max + 3 * kTaperBig /* the tapered tail: chunk_plan */) * P->J * P->Kacc * P->Lpad, "the per-chunk partial spectra");
+    BIG_ALLOC(P->d_partial, (size_t)(P->nch_max + is3d::kTaperExtra /* the tapered tail: chunk_plan */) * P->J * P->Kacc * P->Lpad, "the per-chunk partial spectra");
 #undef BIG_ALLOC
     if (P->e2tab) HIP_TRY(P->d_cull_floor.alloc((size_t)P->jtiles * P->ktiles * P->Lpad));
     HIP_TRY(P->d_status.alloc(8));
@@ -656,18 +654,13 @@ static int chunks_for(const is3d_plan *P, int64_t n)
     return (int)std::max<int64_t>(1, std::min<int64_t>(P->nch_max, by_cells));
 }
 
-// Tapered tail of the cell partition (cf_device.h::chunk_cells): the last kTaperBig full-size chunks become 4 kTaperBig quarter-size ones, four
-// rounds of the chip in quarter-length tasks, so that the grid of the main kernel drains in a quarter of the time -- the fixed ~2.7 ms a launch cost
-// beyond its per-cell time (profiles/r04_shard_sizes.json: 329.0 / 166.2 / 85.5 / 43.5 ms main at 1e6 / 5e5 / 2.5e5 / 1.25e5 cells).  Not with an
-// explicit opts.cell_chunks (the caller's count is kept as it is) and not for chunks of fewer than 256 cells.
+// ... with the tapered tail of the cell partition (cf_device.h: chunk_cells, chunk_taper): the grid of the main kernel drains in quarter-length
+// tasks -- the fixed ~2.7 ms a launch cost beyond its per-cell time (profiles/r04_shard_sizes.json: 329.0 / 166.2 / 85.5 / 43.5 ms main at 1e6 /
+// 5e5 / 2.5e5 / 1.25e5 cells; profiles/r04_ab_chunk_taper.log)
 static void chunk_plan(const is3d_plan *P, int64_t n, int &nch, int &nsmall)
 {
     nch = chunks_for(P, n);
-    nsmall = 0;
-    if (P->opts.cell_chunks <= 0 && nch >= 4 * kTaperBig && n / nch >= 256) {
-        nsmall = 4 * kTaperBig;
-        nch += 3 * kTaperBig;
-    }
+    nsmall = is3d::chunk_taper(n, P->opts.cell_chunks, nch);
 }
 
 extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *dN_out, void *hip_stream, is3d_status *status)

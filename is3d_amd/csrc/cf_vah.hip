@@ -965,7 +965,7 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     P->nch = (int)nch;
     for (int which = 0; which < 2; which++) {
         const size_t bytes = which == 0 ? (size_t)P->pass_cells * bytes_per_cell + 64 * 1024   // + slack: the staging pieces of the last batch over-read the stream
-                                        : (size_t)(nch + 18 /* the tapered tail of the partition, below */) * J * Kacc * Lpad * sizeof(double);
+                                        : (size_t)(nch + is3d::kTaperExtra /* the tapered tail of the partition, below */) * J * Kacc * Lpad * sizeof(double);
         const hipError_t e = (which == 0 ? P->d_TS : P->d_partial).alloc(bytes);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
@@ -1034,9 +1034,8 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         if (!o.accumulate) VAH_TRY(hipMemsetAsync(dN_out, 0, (size_t)P->nout * sizeof(double), st));
     }
     int nch = (int)std::max<int64_t>(1, std::min<int64_t>(P->nch, std::min<int64_t>(n, P->pass_cells) / 64));
-    // tapered tail of the cell partition as in cf_plan.cpp (chunk_plan; cf_device.h::chunk_cells): the last 6 chunks as 24 quarter-size ones
-    int nch_small = 0;
-    if (o.cell_chunks <= 0 && nch >= 24 && std::min<int64_t>(n, P->pass_cells) / nch >= 256) { nch_small = 24; nch += 18; }
+    // tapered tail of the cell partition as in cf_plan.cpp (cf_device.h: chunk_cells, chunk_taper)
+    const int nch_small = is3d::chunk_taper(std::min<int64_t>(n, P->pass_cells), o.cell_chunks, nch);
     for (int pass = 0; pass < npasses; pass++) {
         const int64_t c0 = (int64_t)pass * P->pass_cells;
         const int32_t nc = (int32_t)std::min<int64_t>(P->pass_cells, n - c0);
