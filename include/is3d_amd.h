@@ -376,8 +376,8 @@ void is3d_multi_plan_destroy(is3d_multi_plan *mplan);
  * too (this kernel does not reconstruct them); T is accepted and unused.  No outflow cut, no skipped cells.  opts: dimension,
  * include_bulk_deltaf, include_shear_deltaf, regulate_deltaf, accumulate, device, workspace_bytes, cell_chunks, collapse_species,
  * zero_skip (exact zeros only on this path: 0 and 1 are the same), kernel_variant (0 default = 3 in 3+1D: factored exponent on the 8 x 7
- * tile, cf_main_vah3 | 2: the round-1 kernel on the 6 x 7 tile, kept for A/B; 2+1D always runs the 8 x 61 tile).  A cell whose
- * E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (the reference's exp overflows there).
+ * tile, cf_main_vah3, and the same kernel on 8 x 31 records with unit-strided lanes in 2+1D | 2: the round-1 kernel on the 6 x 7 / 8 x 61 tile,
+ * kept for A/B).  A cell whose E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (the reference's exp overflows there).
  * HOST pointers; dN_out as for is3d_smooth_spectra.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
