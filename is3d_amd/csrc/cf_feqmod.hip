@@ -657,7 +657,9 @@ cf_main_feqmod(const double *__restrict__ TS, const double *__restrict__ lane_mT
     constexpr int UB = (LDSD / REC) > 0 ? (LDSD / REC) : 1;
     constexpr int BUF2 = UB * REC / 2;
     constexpr int NLD = (BUF2 + 127) / 128;
-    constexpr int RB = DIM3 ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : 4);   // as in cf_main_tile
+    // evaluations per v_rcp_f64: 8 where the tile allows (3+1D since round 4: 466.6 -> 463.0 ms on the config-3 surface, culling off 1047.6 -> 1039.5,
+    // 224 VGPRs; the two A/B row walks keep 4 -- the pipelined one spills with 8, and kernel_variant 5 and 6 stay bitwise equal to each other)
+    constexpr int RB = (DIM3 && ROWS < 2) ? (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)) : (JT % 8 == 0 ? 8 : (JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2)));
     static_assert(REC % 2 == 0 && JT % RB == 0, "unit records must be 16-byte multiples (JT even)");
     static_assert(ROWS == 0 || (DIM3 && JT >= 4 && ROWS <= 2) || (!DIM3 && JT >= 4 && ROWS == 3), "the row tests against the unit threshold need the bounds in the header");
     constexpr bool MASK = ROWS == 1 || ROWS == 2;     // 3+1D: liveness of all rows of a unit first
