@@ -131,8 +131,7 @@ typedef struct {
     int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
     int32_t device;                     /* HIP device ordinal; -1 = current device */
     /* tuning; 0 = library default */
-    int32_t kernel_variant;             /* 0 default: 6 in 3+1D without baryon terms (pT grids of up to 32 values, else 3), 7 in 2+1D when
-                                           its lane slots fill the waves, else 2.  1: direct kernel (flat streams, one exp per evaluation) |
+    int32_t kernel_variant;             /* 0 default: 6 in 3+1D without baryon terms (pT grids of up to 32 values, else 3), 7 in 2+1D.  1: direct kernel (flat streams, one exp per evaluation) |
                                            2, 3, 4: LDS-staged tile kernel, (phi x rows) tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61
                                            in 2+1D | 5: variant 3 with the phi-side exponentials read from a table stream written by the
                                            prep kernel | 6: variant 5 with the rows of a unit tested for liveness before their exponentials |

@@ -247,7 +247,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // unit-strided lanes (variant 7, 2+1D): S lane slots per bin so that the slots fill whole waves (96 bins: 128 slots = 25 %
     // idle lanes with S = 1, 384 = 6 full waves with S = 4); S must divide the units per cell and the units per LDS batch (4)
     P->split = 1;
-    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8) && split_for(P->Lbins) > 1) P->variant = 7;   // default
+    // default in 2+1D: the 8 x 31 tile, with or without extra lane slots (305 species, one slot per bin: 96.0 against 101.0 ms for 8 x 61 per 2e4 cells)
+    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8)) P->variant = 7;
     if (P->variant == 7 || P->variant == 8) P->split = split_for(P->Lbins);
     if (fq && o->dimension == 2 && P->variant != 7) {
         // modified equilibrium, 2+1D, the 61-row tiles (A/B): the same lane slots on the kernel's own tile -- S = 2 when it divides the units per cell and

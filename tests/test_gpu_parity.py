@@ -376,8 +376,9 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
     if species == "pikp":
         assert relerr(rel, oracle.dN_pTdpTdphidy(cells, sp, fx["grid"], fx["df"], dict(dimension=dim, df_mode=df_mode))) < TOL
     if dim == 2:
-        # 96 momentum bins: the default is variant 7 (unit-strided lanes, four lane slots per bin); the plain 8 x 61 tile agrees to rounding
-        assert st0["kernel_variant"] == (7 if species == "pikp" else 2)
+        # the default in 2+1D is variant 7 (8 x 31; 96 momentum bins: unit-strided lanes, four lane slots per bin; 2 400 bins: one); the
+        # plain 8 x 61 tile agrees to rounding
+        assert st0["kernel_variant"] == 7
         v2, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=2))
         assert relerr(rel, v2) < 5e-11
     if dim == 3:
