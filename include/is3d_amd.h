@@ -645,6 +645,12 @@ void is3d_surface_close(is3d_surface *surface);
 int is3d_pdg_read(const char *path, int32_t *n, int64_t *mc_id, double *mass, double *gspin,
                   double *baryon, double *sign, int32_t capacity);
 
+/* PDG_Data::read_resonances_smash_box with read_mcid (src/cpp/readindata.cpp:1571-1685, :1201-1418): the line-oriented list of hrg_eos = 3
+ * (PDG/pdg_box.dat: "name mass width parity id [id...]", '#' comments) -- degeneracy, baryon number, statistics and the antiparticle
+ * entries follow from the digits of the Monte-Carlo ids.  Same outputs and two-call pattern as is3d_pdg_read. */
+int is3d_pdg_read_box(const char *path, int32_t *n, int64_t *mc_id, double *mass, double *gspin,
+                      double *baryon, double *sign, int32_t capacity);
+
 /* Deltaf_Data::load_df_coefficient_data (src/cpp/deltafReader.cpp:65-219) for one file, mu_B = 0 row.
  * Two-call pattern (T == NULL -> only *n_T). */
 int is3d_df_table_read(const char *path, int32_t *n_T, double *T, double *value, int32_t capacity);

@@ -98,7 +98,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_plan_create_feqmod",
            "is3d_probe_shader_clock", "is3d_plan_output_size", "is3d_plan_execute", "is3d_plan_set_timing", "is3d_plan_timings", "is3d_plan_observables",
            "is3d_plan_main_kernel_name", "is3d_plan_tile_shape", "is3d_plan_workspace_bytes", "is3d_plan_destroy", "is3d_param_get",
-           "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_df_table_read", "is3d_df_table_read_full",
+           "is3d_table_read", "is3d_surface_read_vh", "is3d_surface_read", "is3d_pdg_read", "is3d_pdg_read_box", "is3d_df_table_read", "is3d_df_table_read_full",
            "is3d_gla_read", "is3d_write_results", "is3d_sample_particles", "is3d_write_particle_list_osc",
            "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
@@ -825,14 +825,15 @@ def surface_open(path, mode=1, include_baryon=0, include_baryondiff_deltaf=0, di
     return arrs, (None if mode == 2 else avg), source
 
 
-def pdg_read(path):
+def pdg_read(path, box=False):
+    """is3d_pdg_read (hrg_eos 1, 2: the conventional token-stream files) | box = True: is3d_pdg_read_box (hrg_eos 3: PDG/pdg_box.dat)."""
     L = load()
+    f = L.is3d_pdg_read_box if box else L.is3d_pdg_read
     n = C.c_int32(0)
-    _check(L.is3d_pdg_read(path.encode(), C.byref(n), None, None, None, None, None, 0))
+    _check(f(path.encode(), C.byref(n), None, None, None, None, None, 0))
     ids = np.zeros(n.value, dtype=np.int64)
     mass, gspin, baryon, sign = (np.zeros(n.value) for _ in range(4))
-    _check(L.is3d_pdg_read(path.encode(), C.byref(n), ids.ctypes.data_as(C.POINTER(C.c_int64)), _p(mass), _p(gspin),
-                           _p(baryon), _p(sign), n.value))
+    _check(f(path.encode(), C.byref(n), ids.ctypes.data_as(C.POINTER(C.c_int64)), _p(mass), _p(gspin), _p(baryon), _p(sign), n.value))
     return dict(mc_id=ids, mass=mass, gspin=gspin, baryon=baryon, sign=sign)
 
 

@@ -953,6 +953,72 @@ extern "C" int is3d_pdg_read(const char *path, int32_t *n, int64_t *mc_id, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
+// PDG_Data::read_resonances_smash_box  (src/cpp/readindata.cpp:1571-1685; hrg_eos = 3, PDG/pdg_box.dat) with read_mcid (:1201-1418).
+//   Line oriented: "name mass width parity id [id [id [id]]]", '#' starts a comment line (and ends a data line: the extraction of the ids
+//   stops at the first token that is not a number), blank lines skipped.  Every non-zero id gives an entry, followed by its antiparticle when
+//   the particle has a distinct one.  Spin degeneracy, baryon number, statistics and "has an antiparticle" come from the digits of the
+//   Monte-Carlo id: n nR nL nq1 nq2 nq3 nJ (an eighth digit adds to nJ); hadron = nq2, nq3 != 0; meson = nq1 == 0; gspin = nJ;
+//   antiparticle iff baryon or nq2 != nq3.  The reference handles the deuteron (1000010020) and non-hadrons with an error print;
+//   here they are an error (IS3D_EIO): neither occurs in the shipped file.
+// ---------------------------------------------------------------------------------------------
+extern "C" int is3d_pdg_read_box(const char *path, int32_t *n, int64_t *mc_id, double *mass, double *gspin, double *baryon,
+                                 double *sign, int32_t capacity)
+{
+    if (!path || !n) return io_fail(IS3D_EINVAL, "null argument");
+    std::string text;
+    if (!slurp(path, text)) return io_fail(IS3D_EIO, "cannot open %s", path);
+    struct Ent { long id; double m; int g, b, s; };
+    std::vector<Ent> v;
+    std::istringstream all(text);
+    std::string line;
+    int lineno = 0;
+    while (std::getline(all, line)) {
+        lineno++;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        std::string name;
+        double m = 0.0, width = 0.0;
+        char parity = 0;
+        if (!(ls >> name >> m >> width >> parity)) {
+            // (a line of white space only: the reference's extraction fails and adds nothing)
+            bool blank = true;
+            for (char c : line) blank = blank && isspace((unsigned char)c);
+            if (blank) continue;
+            return io_fail(IS3D_EIO, "%s:%d: expected \"name mass width parity id...\"", path, lineno);
+        }
+        for (int k = 0; k < 4; k++) {   // mcid_entries = 4 (:1577)
+            long id = 0;
+            if (!(ls >> id)) break;
+            if (id == 0) continue;
+            if (id < 0) return io_fail(IS3D_EIO, "%s:%d: antiparticle id %ld (the file lists particles only)", path, lineno, id);
+            int d[10];
+            long x = id;
+            for (int i = 0; i < 10; i++) { d[i] = (int)(x % 10); x /= 10; }
+            if (x > 0) return io_fail(IS3D_EIO, "%s:%d: id %ld has more than 10 digits", path, lineno, id);
+            const int nJ = d[0] + d[7], nq3 = d[1], nq2 = d[2], nq1 = d[3];
+            const bool hadron = id != 1000010020L && nq3 != 0 && nq2 != 0;
+            if (!hadron || nJ <= 0) return io_fail(IS3D_EIO, "%s:%d: id %ld is not a hadron with a spin digit (the reference prints an error there)", path, lineno, id);
+            const bool is_baryon = nq1 != 0;
+            const Ent e{id, m, nJ, is_baryon ? 1 : 0, is_baryon ? 1 : -1};
+            v.push_back(e);
+            if (is_baryon || nq2 != nq3) v.push_back(Ent{-id, m, nJ, -e.b, e.s});
+        }
+    }
+    *n = (int32_t)v.size();
+    if (!mc_id) return IS3D_OK;
+    if ((int32_t)v.size() > capacity) return io_fail(IS3D_EINVAL, "%s: capacity %d < %zu particles", path, capacity, v.size());
+    for (size_t k = 0; k < v.size(); k++) {
+        mc_id[k] = v[k].id;
+        if (mass) mass[k] = v[k].m;
+        if (gspin) gspin[k] = v[k].g;
+        if (baryon) baryon[k] = v[k].b;
+        if (sign) sign[k] = v[k].s;
+    }
+    return IS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Deltaf_Data::load_df_coefficient_data, one file, include_baryon = 0  (src/cpp/deltafReader.cpp:120-197)
 //   line 1: points_T, line 2: points_muB, line 3: labels, then rows "T muB value" with T fastest;
 //   only the first points_T rows (muB = 0) are kept.

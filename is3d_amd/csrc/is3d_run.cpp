@@ -221,10 +221,11 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     }
     // ---- species (iS3D.cpp:138-140, 156; emissionfunction.cpp:336-351, 1293-1307) ----
     int32_t npdg = 0;
-    if (is3d_pdg_read(pdg_path, &npdg, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
+    const auto pdg_read = (hrg_eos == 3) ? is3d_pdg_read_box : is3d_pdg_read;   // read_resonances: conventional | smash box (readindata.cpp:1687-1713)
+    if (pdg_read(pdg_path, &npdg, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) DIE("%s", is3d_last_error());
     std::vector<int64_t> pid(npdg);
     std::vector<double> pmass(npdg), pg(npdg), pb(npdg), ps(npdg);
-    if (is3d_pdg_read(pdg_path, &npdg, pid.data(), pmass.data(), pg.data(), pb.data(), ps.data(), npdg)) DIE("%s", is3d_last_error());
+    if (pdg_read(pdg_path, &npdg, pid.data(), pmass.data(), pg.data(), pb.data(), ps.data(), npdg)) DIE("%s", is3d_last_error());
     std::vector<double> chosen, dummy;
     if (read_table("PDG/chosen_particles.dat", chosen, dummy)) DIE("%s", is3d_last_error());
     std::vector<int64_t> mcid;

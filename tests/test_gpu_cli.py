@@ -61,6 +61,32 @@ def test_cli_run_directory(tmp_path, fx, dim, df_mode):
     assert len(avg) == 5 and 0.14 < avg[0] < 0.16 and avg[3] == 0.0
 
 
+@pytest.mark.parametrize("hrg_eos", [2, 3])
+def test_cli_other_particle_lists(tmp_path, fx, hrg_eos):
+    """hrg_eos = 2 (the reference's shipped default: PDG/pdg_smash.dat, deltaf_coefficients/vh/smash/, the conventional reader) and hrg_eos = 3
+    (PDG/pdg_box.dat, the line-oriented list read by read_resonances_smash_box, deltaf_coefficients/vh/smash_box/; readindata.cpp:1687-1713,
+    deltafReader.h:27-29): the driver finds its files and the spectra are the oracle's for the species the list defines."""
+    ids = [211, -321, 2212, -2212, 3122]
+    cells = synth.synth_surface(19, 3, seed=47)
+    root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(dimension=3, df_mode=2, hrg_eos=hrg_eos))
+    assert not os.path.exists(os.path.join(root, "PDG", "pdg-urqmd_v3.3+.dat"))
+    r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Number of chosen particles: 5" in r.stdout
+    parsed = refformat.read_surface_like_reference(os.path.join(root, "input", "surface.dat"))
+    if hrg_eos == 3:
+        ent = {e[0]: e for e in refformat.box_entries(refformat.BOX_ROWS)}
+        sp = dict(mass=np.array([ent[i][1] for i in ids]), degeneracy=np.array([ent[i][2] for i in ids]),
+                  baryon=np.array([ent[i][3] for i in ids]), sign=np.array([ent[i][4] for i in ids]))
+    else:
+        sp = inputs.species(ids)
+    ref = oracle.dN_pTdpTdphidy(parsed, sp, fx["grid"], fx["df"], dict(dimension=3, df_mode=2))
+    ref4 = ref.reshape(21, 24, 32, 5)
+    for k, i in enumerate(ids):
+        one = read_spectra_file(os.path.join(root, "results", "dN_pTdpTdphidy_%d.dat" % i), header=True)
+        assert relerr(one[:, 3], ref4[:, :, :, k].reshape(-1), floor=1e-250) < 2e-8, i
+
+
 @pytest.mark.parametrize("df_mode", [1, 2])
 def test_cli_include_baryon(tmp_path, fx, df_mode):
     """25-column surface (muB, nB, Vx, Vy, Vn), full (T, mu_B) coefficient files, bilinear branch."""

@@ -388,6 +388,57 @@ def test_readers_on_the_reference_files():
     assert api.param_get(os.path.join(REFERENCE, "iS3D_parameters.dat"), "df_mode") == 4.0
 
 
+def test_pdg_box_reader(tmp_path):
+    """is3d_pdg_read_box (hrg_eos = 3): read_resonances_smash_box with read_mcid (readindata.cpp:1571-1685, :1201-1418) -- comment and blank lines,
+    a comment behind the ids, up to four ids per line, UTF-8 names; degeneracy / baryon number / statistics / antiparticles from the id's digits."""
+    path = str(tmp_path / "pdg_box.dat")
+    refformat.write_pdg_box(path, refformat.BOX_ROWS)
+    got = api.pdg_read(path, box=True)
+    want = refformat.box_entries(refformat.BOX_ROWS)
+    assert len(got["mc_id"]) == len(want) == 27
+    for k, (i, m, g, b, sg) in enumerate(want):
+        assert (got["mc_id"][k], got["mass"][k], got["gspin"][k], got["baryon"][k], got["sign"][k]) == (i, m, g, b, sg), k
+    assert 221 in got["mc_id"] and -221 not in got["mc_id"] and -311 in got["mc_id"] and got["gspin"][list(got["mc_id"]).index(225)] == 5.0
+    with open(path, "a", encoding="utf-8") as f:
+        f.write("d   1.876  0  +  1000010020\n")            # the deuteron: the reference prints an error and carries on with wrong numbers
+    with pytest.raises(api.Is3dError) as e:
+        api.pdg_read(path, box=True)
+    assert e.value.code == api.IS3D_EIO and "1000010020" in str(e.value)
+
+
+@pytest.mark.reference
+def test_smash_particle_lists_of_the_reference():
+    """hrg_eos = 2 (the reference's shipped default) reads PDG/pdg_smash.dat with the conventional reader: against an independent token parse here;
+    hrg_eos = 3 reads PDG/pdg_box.dat with the line reader: against refformat.box_entries on an independent line parse.  Both chosen lists are
+    subsets of what is read (the reference requires it, iS3D_parameters.dat:18)."""
+    tok = open(os.path.join(REFERENCE, "PDG/pdg_smash.dat"), encoding="utf-8").read().split()
+    want, i = [], 0
+    while i < len(tok):
+        mc, mass, g, b, nd = int(tok[i]), float(tok[i + 2]), int(tok[i + 4]), int(tok[i + 5]), int(tok[i + 11])
+        want.append((mc, mass, g, b))
+        if b > 0:
+            want.append((-mc, mass, g, -b))
+        i += 12 + 8 * nd
+    got = api.pdg_read(os.path.join(REFERENCE, "PDG/pdg_smash.dat"))
+    assert len(got["mc_id"]) == len(want) == 493
+    assert [(int(a), float(m), int(g), int(b)) for a, m, g, b in zip(got["mc_id"], got["mass"], got["gspin"], got["baryon"])] == want
+    chosen = api.table_read(os.path.join(REFERENCE, "PDG/chosen_particles_smash.dat"))[:, 0]
+    assert len(chosen) == 444 and set(chosen.astype(np.int64)) <= set(got["mc_id"])
+    rows = []
+    for line in open(os.path.join(REFERENCE, "PDG/pdg_box.dat"), encoding="utf-8"):
+        if not line.strip() or line.startswith("#"):
+            continue
+        f = line.split("#")[0].split()
+        rows.append((f[0], float(f[1]), [int(x) for x in f[4:8]]))
+    box = api.pdg_read(os.path.join(REFERENCE, "PDG/pdg_box.dat"), box=True)
+    wantb = refformat.box_entries(rows)
+    assert len(box["mc_id"]) == len(wantb) == 400
+    assert [(int(a), float(m), float(g), float(b), float(s)) for a, m, g, b, s in
+            zip(box["mc_id"], box["mass"], box["gspin"], box["baryon"], box["sign"])] == wantb
+    chosen = api.table_read(os.path.join(REFERENCE, "PDG/chosen_particles_box.dat"))[:, 0]
+    assert len(chosen) == 399 and set(chosen.astype(np.int64)) <= set(box["mc_id"])
+
+
 def test_vah_table_reader(tmp_path):
     """is3d_vah_df_read on files in the shipped layout (src/cuda/deltafReader.cu:104-127, :196-213): dimensions, one label line read by
     fgets(header, 100), rows with alpha_L outer and Lambda inner; the node arrays are what the LAST rows leave behind."""
