@@ -269,12 +269,12 @@ def test_embedding_class(tmp_path, fx, operation):
 
 
 def test_cli_shipped_default_shape(tmp_path, fx):
-    """The shape of the reference's shipped iS3D_parameters.dat: operation = 2, dimension = 2, df_mode = 4 (Jonah), fast = 1,
-    set_FO_temperature = 1, test_sampler = 1 -> binned test distributions instead of the particle list."""
+    """The shape of the reference's shipped iS3D_parameters.dat: operation = 2, hrg_eos = 2 (PDG/pdg_smash.dat, deltaf_coefficients/vh/smash/),
+    dimension = 2, df_mode = 4 (Jonah), fast = 1, set_FO_temperature = 1, test_sampler = 1 -> binned test distributions instead of the particle list."""
     ids = [211, 321, 2212]
     cells = synth.synth_surface(4000, 2, seed=97)
     root = refformat.make_run_dir(str(tmp_path), cells, ids, dict(operation=2, dimension=2, df_mode=4, fast=1, test_sampler=1, oversample=1,
-                                                                  min_num_hadrons=20000, sampler_seed=5))
+                                                                  min_num_hadrons=20000, sampler_seed=5, hrg_eos=2))
     r = subprocess.run([api.CLI_PATH], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Sampling particles with Jonah's modified distribution..." in r.stdout and "Using fast mode: (Tavg, muBavg) = (0.151000" in r.stdout
