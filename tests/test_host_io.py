@@ -437,6 +437,13 @@ def test_smash_particle_lists_of_the_reference():
             zip(box["mc_id"], box["mass"], box["gspin"], box["baryon"], box["sign"])] == wantb
     chosen = api.table_read(os.path.join(REFERENCE, "PDG/chosen_particles_box.dat"))[:, 0]
     assert len(chosen) == 399 and set(chosen.astype(np.int64)) <= set(box["mc_id"])
+    # ... and their coefficient tables (deltafReader.h:27-29): the mu_B = 0 rows against numpy's own parse
+    for d in ("smash", "smash_box"):
+        for name in ("c0", "c2", "F", "betabulk", "betapi"):
+            path = os.path.join(REFERENCE, "deltaf_coefficients/vh", d, name + ".dat")
+            T, v = api.df_table_read(path)
+            raw = np.loadtxt(path, skiprows=3)
+            assert len(T) == 101 and np.array_equal(T, raw[:101, 0]) and np.array_equal(v, raw[:101, 2]) and np.all(raw[:101, 1] == 0.0)
 
 
 def test_vah_table_reader(tmp_path):
