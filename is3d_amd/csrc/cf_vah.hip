@@ -224,6 +224,8 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
             __syncthreads();
             const int wave = tid >> 6, lane = tid & 63, nwaves = kVahThreads / 64;
             const int n_units = ncb * p.jtiles * p.rblocks;
+            const int NRAW = HDR + RS * R, NBETA = R * JT;
+            const int invRS = (1 << 20) / RS + 1, invJT = (1 << 20) / JT + 1;   // (t * inv) >> 20 == t / RS resp. t / JT for t < 4096
             for (int u = wave; u < n_units; u += nwaves) {
                 int c, jt, rb;
                 if (p.dim3) { c = u % ncb; const int t = u / ncb; rb = t % p.rblocks; jt = t / p.rblocks; }      // cells innermost: adjacent records of one stream
@@ -234,7 +236,12 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
                 double *o = p.TS + unit * REC;
                 const int cJ = c * J, cK = c * K;
                 const double c4 = s.c4, c3 = s.c3, pc2 = 2.0 * s.Pi * s.c2;
-                for (int e = lane; e < REC; e += 64) {
+                // two kinds of trip (as in cf_prep_feqmod): raw trips, lanes <-> the header and the RS scalars of every row (one descriptor read, one
+                // source read); beta trips, lanes <-> (row, phi column): no descriptor, nine reads and the bilinear form.  One loop over all
+                // elements evaluated the form on every lane.
+                for (int t = lane; t < NRAW; t += 64) {
+                    int e = t;
+                    if (t >= HDR) { const int q = t - HDR, r = (q * invRS) >> 20; e = HDR + r * RWD + (q - r * RS); }
                     const int2 d = desc[e];
                     const int jj = d.y & 0xff, r = d.y >> 8;
                     const int j = cJ + min(jt * JT + jj, J - 1);
@@ -243,10 +250,13 @@ __global__ void __launch_bounds__(kVahThreads) cf_prep_vah(VahPrepParams p)
                     const int add = rule == 0 ? j : rule == 1 ? kc : rule == 2 ? c * p.rblocks + rb : c * p.jtiles + jt;
                     const bool zero = ((d.x >> 26) & 1) | (((d.x >> 25) & 1) & (k >= K));   // padding rows: the forms of row K-1 with p.dsigma = 0
                     const double raw = lds[zero ? 0 : (d.x & 0xfffff) + add];
+                    o[e] = zero ? 0.0 : raw;
+                }
+                for (int t = lane; t < NBETA; t += 64) {
+                    const int r = (t * invJT) >> 20, jj = t - r * JT;
+                    const int j = cJ + min(jt * JT + jj, J - 1), kc = cK + min(rb * R + r, K - 1);
                     const double X = l_E[j] * l_ch[kc] + l_F[j] * l_sh[kc];
-                    const double bet = c4 * X - c3 * l_Z[kc] * l_V2[j] - pc2 * l_C[kc] * l_D[j];
-                    const double v = ((d.x >> 24) & 1) ? bet : raw;
-                    o[e] = zero ? 0.0 : v;
+                    o[HDR + r * RWD + RS + jj] = c4 * X - c3 * l_Z[kc] * l_V2[j] - pc2 * l_C[kc] * l_D[j];
                 }
             }
         } else {
