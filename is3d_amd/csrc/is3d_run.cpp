@@ -244,7 +244,16 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     // ---- grids (iS3D.cpp:161-167) ----
     std::vector<double> pT, pTw, phi, phiw, y, yw, eta, etaw;
     if (read_table("tables/pT_gauss_legendre_table.dat", pT, pTw) || read_table("tables/phi_gauss_legendre_table.dat", phi, phiw) ||
-        read_table("tables/y_trapezoid_table_21pt.dat", y, yw) || read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
+        read_table("tables/y_trapezoid_table_21pt.dat", y, yw))
+        DIE("%s", is3d_last_error());
+    // the eta table: 241 points for the smooth spectra; the reference opens the 41-point one when it samples (iS3D.cpp:164-167) and never uses it
+    // there (nor does the sampler here): a run directory made for either operation is accepted
+    if (operation == 2) {
+        if (read_table("tables/eta/eta_trapezoid_table_41pt.dat", eta, etaw) && read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw)) {
+            eta.assign(1, 0.0);
+            etaw.assign(1, 1.0);
+        }
+    } else if (read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
         DIE("%s", is3d_last_error());
     // ---- delta-f coefficient tables (iS3D.cpp:144-145) ----
     //      include_baryon = 0: the mu_B = 0 rows; include_baryon = 1: the full (mu_B, T) grids (deltafReader.cpp:134)
