@@ -1060,8 +1060,8 @@ static void launch_fq_t(const FqMainArgs &a, hipStream_t st)
         launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 4 * (4 * JT + R * (4 + JT))>(a, st);
     } else {
         if constexpr (DIM3 && JT == 8 && ROWS != 0) {
-            // one-wave workgroups (3+1D, 8 x 7, no baryon slots): 9-unit LDS batches so that eight workgroups fit a CU, no barrier partner
-            if (a.g.wpb == 1 && !a.lane_b) { launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1100>(a, st); return; }
+            // one-wave workgroups (3+1D, 8 x 7): 9-unit LDS batches so that eight workgroups fit a CU, no barrier partner
+            if (a.g.wpb == 1) { launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1100>(a, st); return; }
         }
         launch_fq_l<DIM3, OF, M3, JT, R, ROWS, 1536>(a, st);
     }

@@ -210,7 +210,8 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         return S_best;
     };
     const bool plain3 = o->dimension == 3 && !o->include_baryon;
-    int default_variant = plain3 ? 3 : 2;
+    // (modified equilibrium in 3+1D: 8 x 7 with or without the baryon slots -- its records do not grow with them; 247.1 against 260.5 ms for 6 x 7 per 3e5 cells)
+    int default_variant = (plain3 || (fq && o->dimension == 3)) ? 3 : 2;
     if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
     P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 8) ? o->kernel_variant : default_variant;
     // modified equilibrium in 2+1D: variant 7 (8 x 31 tile, unit-strided lanes, rows tested against the unit's threshold from the beta minimum
@@ -490,7 +491,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             if (o->waves_per_group == 1 && P->e2tab) P->wpb = 1;   // cf_main_tile3e: one-wave workgroups (no barrier partner)
             // cf_main_feqmod, 3+1D 8 x 7 without baryon slots: one-wave workgroups (cf_feqmod.hip, LDSD); the pipelined A/B form (variant 5) keeps two
             // -- the default there since round 4 (486 against 501 ms on the config-3 surface, profiles/r04_ab_feqmod.log); waves_per_group = 2 keeps the pair
-            if (P->feqmod && P->dim3 && !P->baryon && (P->variant == 3 || P->variant == 6) && (o->waves_per_group == 1 || o->waves_per_group == 0)) P->wpb = 1;
+            if (P->feqmod && P->dim3 && (P->variant == 3 || P->variant == 6) && (o->waves_per_group == 1 || o->waves_per_group == 0)) P->wpb = 1;
         }
         const int64_t tasks_per_chunk = (int64_t)lane_waves * P->jtiles * P->ktiles;
         const int64_t capacity = 256LL * 4 * 4;  // CUs x SIMDs x ~4 waves
