@@ -13,7 +13,12 @@
  *   (a) the reference source text cited line by line below,
  *   (b) closed-form known answers for the 1-cell toy surface (tests/test_oracle.py),
  *   (c) an independent extended-precision numpy restatement (tests/golden/make_golden.py),
- *   (d) scipy's independent natural cubic spline for the GSL replacement.
+ *   (d) scipy's independent natural cubic spline for the GSL replacement,
+ *   (e) round 5 -- the one set of numbers of its own arithmetic the reference DOES hold: the ten shipped coefficient tables
+ *       deltaf_coefficients/vh/urqmd/*.dat, recomputed digit for digit (all 81 810 printed values) by oracle_df_generator_row at the
+ *       end of this file from this repository's PDG / Gauss-Laguerre readers and the thermal integrands the sampler, yield and
+ *       feqmod restatements use (tests/test_oracle_dfcoef.py).  That pins the particle-list semantics and every J_nq / N_nq / M_nq
+ *       convention; it does not pin the Cooper-Frye integrand, for which the reference holds nothing: PARITY stays UNPINNED.
  *
  * What is restated (all paths relative to /root/reference):
  *   src/cpp/emissionfunction_smooth_kernels.cpp:28-393   EmissionFunctionArray::calculate_dN_pTdpTdphidy
@@ -1792,6 +1797,152 @@ int oracle_vah_coefficients(int nL, int naL, const double *L_array, const double
             if (found == 1) break;
         }
         if (found_out) found_out[icell] = found;
+    }
+    return 0;
+}
+
+/* ==========================================================================================
+ * The df-coefficient GENERATOR, restated: generate_delta_f_coefficients/urqmd/df_vh_dimensionless/src/
+ *   deltaf_table.cpp:137-248   14-moment c0..c4 (the "update 3/25" form, :215-225)
+ *   deltaf_table.cpp:296-395   Chapman-Enskog F, G, betabulk, betaV, betapi (the alpha_B form, :354-366)
+ *   thermal_integrands.cpp:13-116, :136-206   the integrands;   gauss_integration.cpp:18-23   Gauss1D
+ *   readindata.cpp:55-194      the particle list (the same loop as src/cpp/readindata.cpp:1440-1568: degeneracy = gspin,
+ *                              sign = -1 for even baryon number, antibaryons synthesised behind every baryon, count - 1)
+ * Why it is here: its OUTPUT ships with the reference (deltaf_coefficients/vh/urqmd/{c0..c4,F,G,betabulk,betaV,betapi}.dat,
+ * 101 T x 81 mu_B rows each, printed `fixed` with 6 decimals) -- the only numbers of the reference's own thermal-integral code
+ * that exist in the tree.  Recomputing them from the PDG list as THIS repository's reader returns it, the Gauss-Laguerre file as
+ * its reader returns it, and the integrand functions the sampler / yield / feqmod restatements above already use pins those
+ * pieces against reference-held values (tests/test_oracle_dfcoef.py).  Wherever the generator's integrand is textually one of
+ * the functions above it is that function that is called (with alpha_B = mu_B / T):
+ *   e_int = E_mod_int(lambda = 0),  p_int = P_mod_int(lambda = 0)           (deltafReader.cpp:222-297 uses them for Jonah's table)
+ *   nB_int = b neq_int,  N10_int = b J10_int,  M10_int = b^2 J10_int         (gaussThermal.cpp: the sampler's densities)
+ *   J20_int,  N20_int = b J20_int,  M20_int = b^2 J20_int                    (df_mode 3 renormalisation)
+ *   M11_int = b^2 J11_int,  J30_int,  N30_int = b J30_int,  N31_int = b J31_int   (calculate_total_yield's bulk / diffusion densities)
+ * new here: J21, J40, J41, J32 (thermal_integrands.cpp:29-56, :173-179).
+ * out[10] in the order of DF_NAMES_2D (oracle.py): c0 T^4, c1 T^3, c2 T^4, c3 T^4, c4 T^5, F / T, G, betabulk / T^4, betaV / T^3,
+ * betapi / T^4 -- the numbers the generator prints (:240-244, :387-391).  integrals[20] (may be NULL): J20, J21, J40, J41, N10, N30,
+ * N31, M20, M21, A20, A21, B10, nB, e, p, J30, J32, N20, M10, M11 in the generator's units.
+ * ========================================================================================== */
+static double J21_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return pbar * pbar / Ebar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);           /* thermal_integrands.cpp:29-36 */
+}
+static double J40_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return Ebar * Ebar * Ebar / pbar / pbar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);   /* :39-46 */
+}
+static double J41_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return Ebar * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);                           /* :49-56 */
+}
+static double J32_int(double pbar, double mbar, double alphaB, double baryon, double sign)
+{
+    double Ebar = sqrt(pbar * pbar + mbar * mbar);
+    double qstat = exp(Ebar - baryon * alphaB) + sign;
+    return pbar * pbar * pbar / (Ebar * Ebar) * exp(pbar + Ebar - baryon * alphaB) / (qstat * qstat);   /* :173-179 */
+}
+
+int oracle_df_generator_row(int n_pdg, const double *pdg_mass, const double *pdg_gspin, const double *pdg_baryon, const double *pdg_sign,
+                            int gla_pts, const double *root1, const double *weight1, const double *root2, const double *weight2,
+                            const double *root3, const double *weight3, const double *root4, const double *weight4,
+                            double T, double muB, double *out, double *integrals)
+{
+    if (n_pdg <= 0 || gla_pts <= 0 || !(T > 0.0)) return -1;
+    const double hbarC = 0.197327053;                                                            /* deltaf_table.cpp:18 */
+    const double two_pi2_hbarC3 = 2.0 * pow(M_PI, 2) * pow(hbarC, 3);                            /* :19 */
+    const double alphaB = muB / T;
+    /* ---- 14 moment, deltaf_table.cpp:144-206 ---- */
+    double J20_fact = pow(T, 4) / (two_pi2_hbarC3);
+    double J21_fact = pow(T, 4) / (3.0 * two_pi2_hbarC3);
+    double J40_fact = pow(T, 6) / (two_pi2_hbarC3);
+    double J41_fact = pow(T, 6) / (3.0 * two_pi2_hbarC3);
+    double N10_fact = pow(T, 3) / (two_pi2_hbarC3);
+    double N30_fact = pow(T, 5) / (two_pi2_hbarC3);
+    double N31_fact = pow(T, 5) / (3.0 * two_pi2_hbarC3);
+    double M20_fact = J20_fact, M21_fact = J21_fact, A20_fact = J20_fact, A21_fact = J21_fact, B10_fact = N10_fact;
+    double J20 = 0.0, J21 = 0.0, J40 = 0.0, J41 = 0.0, N10 = 0.0, N30 = 0.0, N31 = 0.0, M20 = 0.0, M21 = 0.0, A20 = 0.0, A21 = 0.0, B10 = 0.0;
+    for (int k = 0; k < n_pdg; k++) {
+        if (pdg_mass[k] == 0.0) continue;                                                        /* :176 */
+        double dof = pdg_gspin[k], mbar = pdg_mass[k] / T, b = pdg_baryon[k], Theta = pdg_sign[k];
+        double mass2 = pdg_mass[k] * pdg_mass[k];
+        double g20 = gauss_thermal(J20_int, root2, weight2, gla_pts, mbar, alphaB, b, Theta);
+        double g21 = gauss_thermal(J21_int, root2, weight2, gla_pts, mbar, alphaB, b, Theta);
+        A20 += mass2 * dof * A20_fact * g20;                                                     /* :187-193 */
+        A21 += mass2 * dof * A21_fact * g21;
+        J20 += dof * J20_fact * g20;
+        J21 += dof * J21_fact * g21;
+        J40 += dof * J40_fact * gauss_thermal(J40_int, root4, weight4, gla_pts, mbar, alphaB, b, Theta);
+        J41 += dof * J41_fact * gauss_thermal(J41_int, root4, weight4, gla_pts, mbar, alphaB, b, Theta);
+        if (b != 0.0) {                                                                          /* :196-204 */
+            double g10 = b * gauss_thermal(J10_int, root1, weight1, gla_pts, mbar, alphaB, b, Theta);
+            B10 += mass2 * dof * B10_fact * g10;
+            N10 += dof * N10_fact * g10;
+            N30 += dof * N30_fact * (b * gauss_thermal(J30_int, root3, weight3, gla_pts, mbar, alphaB, b, Theta));
+            N31 += dof * N31_fact * (b * gauss_thermal(J31_int, root3, weight3, gla_pts, mbar, alphaB, b, Theta));
+            M20 += dof * M20_fact * (b * b * g20);
+            M21 += dof * M21_fact * (b * b * g21);
+        }
+    }
+    double bulk0 = (4.0 * N30 - B10) * N30 - M20 * (4.0 * J40 - A20);                            /* :215-225 */
+    double bulk1 = (B10 - N30) * (4.0 * J40 - A20) - (4.0 * N30 - B10) * (A20 - J40);
+    double bulk2 = M20 * (A20 - J40) - (B10 - N30) * N30;
+    double denom = (A21 - J41) * bulk0 + N31 * bulk1 + (4.0 * J41 - A21) * bulk2;
+    double c0 = bulk0 / denom, c1 = bulk1 / denom, c2 = bulk2 / denom;
+    double c3 = J41 / (N31 * N31 - M21 * J41);
+    double c4 = -N31 / (N31 * N31 - M21 * J41);
+    out[0] = c0 * pow(T, 4); out[1] = c1 * pow(T, 3); out[2] = c2 * pow(T, 4); out[3] = c3 * pow(T, 4); out[4] = c4 * pow(T, 5);   /* :240-244 */
+    /* ---- Chapman-Enskog, deltaf_table.cpp:304-366 ---- */
+    double nB_fact = pow(T, 3) / (two_pi2_hbarC3);
+    double e_fact = pow(T, 4) / (two_pi2_hbarC3);
+    double p_fact = pow(T, 4) / (3.0 * two_pi2_hbarC3);
+    double J30_fact = pow(T, 5) / (two_pi2_hbarC3);
+    double J32_fact = pow(T, 5) / (15.0 * two_pi2_hbarC3);
+    double N20_fact = pow(T, 4) / (two_pi2_hbarC3);
+    double M10_fact = pow(T, 3) / (two_pi2_hbarC3);
+    double M11_fact = pow(T, 3) / (3.0 * two_pi2_hbarC3);
+    double nB = 0.0, e = 0.0, p = 0.0, J30 = 0.0, J32 = 0.0, N20 = 0.0, M10 = 0.0, M11 = 0.0;
+    for (int k = 0; k < n_pdg; k++) {
+        if (pdg_mass[k] == 0.0) continue;                                                        /* :327 */
+        double dof = pdg_gspin[k], mbar = pdg_mass[k] / T, b = pdg_baryon[k], Theta = pdg_sign[k];
+        if (b == 0.0) {
+            /* e_int / p_int carry b mu_B / T in the exponent (thermal_integrands.cpp:145-161); E_mod_int / P_mod_int are the b = 0 forms */
+            e += dof * e_fact * gauss1d_mod(E_mod_int, root2, weight2, gla_pts, mbar, 0.0, Theta);   /* :336-339 */
+            p += dof * p_fact * gauss1d_mod(P_mod_int, root2, weight2, gla_pts, mbar, 0.0, Theta);
+        } else {
+            double se = 0.0, sp = 0.0;
+            for (int i = 0; i < gla_pts; i++) {
+                double pbar = root2[i], Ebar = sqrt(pbar * pbar + mbar * mbar);
+                double f = exp(pbar) / (exp(Ebar - b * alphaB) + Theta);
+                se += weight2[i] * (Ebar * f);
+                sp += weight2[i] * (pbar * pbar / Ebar * f);
+            }
+            e += dof * e_fact * se;
+            p += dof * p_fact * sp;
+        }
+        J30 += dof * J30_fact * gauss_thermal(J30_int, root3, weight3, gla_pts, mbar, alphaB, b, Theta);
+        J32 += dof * J32_fact * gauss_thermal(J32_int, root3, weight3, gla_pts, mbar, alphaB, b, Theta);
+        if (b != 0.0) {                                                                          /* :343-349 */
+            nB += dof * nB_fact * (b * gauss_thermal(neq_int, root1, weight1, gla_pts, mbar, alphaB, b, Theta));
+            N20 += dof * N20_fact * (b * gauss_thermal(J20_int, root2, weight2, gla_pts, mbar, alphaB, b, Theta));
+            M10 += dof * M10_fact * (b * b * gauss_thermal(J10_int, root1, weight1, gla_pts, mbar, alphaB, b, Theta));
+            M11 += dof * M11_fact * (b * b * gauss_thermal(J11_int, root1, weight1, gla_pts, mbar, alphaB, b, Theta));
+        }
+    }
+    double G = ((e + p) * N20 - J30 * nB) / (J30 * M10 - N20 * N20);                             /* :354-356 */
+    double F = T * T * (N20 * nB - (e + p) * M10) / (J30 * M10 - N20 * N20);
+    double betabulk = G * nB * T + F * (e + p) / T + 5.0 * J32 / (3.0 * T);
+    double betaV = M11 - nB * nB * T / (e + p);                                                  /* :365-366 */
+    double betapi = J32 / T;
+    out[5] = F / T; out[6] = G; out[7] = betabulk / pow(T, 4); out[8] = betaV / pow(T, 3); out[9] = betapi / pow(T, 4);   /* :387-391 */
+    if (integrals) {
+        double v[20] = {J20, J21, J40, J41, N10, N30, N31, M20, M21, A20, A21, B10, nB, e, p, J30, J32, N20, M10, M11};
+        memcpy(integrals, v, sizeof v);
     }
     return 0;
 }

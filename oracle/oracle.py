@@ -452,3 +452,20 @@ def read_surf_VAH_PLMatch(path):
     s["aL"] = aL
     s["Lambda"] = (T / np.power(0.5 * aL * R200(aL), 0.25)) * h
     return s
+
+
+def df_generator_row(pdg, gla_root, gla_weight, T, muB, with_integrals=False):
+    """oracle_df_generator_row: the ten numbers the reference's coefficient generator prints for (T, muB) (deltaf_table.cpp:137-248, :296-395),
+    in the order of DF_NAMES_2D.  pdg: dict with mass, gspin, baryon, sign (every entry of the list, antibaryons included);
+    gla_root / gla_weight: [alpha][points] as Gauss_Laguerre::load_roots_and_weights returns them (alpha = 1..4 are used)."""
+    L = lib()
+    m, g, b, s_ = (_f64(pdg[k]) for k in ("mass", "gspin", "baryon", "sign"))
+    r = [_f64(gla_root[a]) for a in (1, 2, 3, 4)]
+    w = [_f64(gla_weight[a]) for a in (1, 2, 3, 4)]
+    out, integ = np.zeros(10), np.zeros(20)
+    L.oracle_df_generator_row.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_int] + [_dp] * 8 + [C.c_double, C.c_double, _dp, _dp]
+    rc = L.oracle_df_generator_row(len(m), _p(m), _p(g), _p(b), _p(s_), len(r[0]), _p(r[0]), _p(w[0]), _p(r[1]), _p(w[1]), _p(r[2]), _p(w[2]),
+                                   _p(r[3]), _p(w[3]), float(T), float(muB), _p(out), _p(integ))
+    if rc != 0:
+        raise ValueError("oracle_df_generator_row: %d" % rc)
+    return (out, integ) if with_integrals else out
