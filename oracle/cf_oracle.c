@@ -15,7 +15,7 @@
  *   (c) an independent extended-precision numpy restatement (tests/golden/make_golden.py),
  *   (d) scipy's independent natural cubic spline for the GSL replacement,
  *   (e) round 5 -- the one set of numbers of its own arithmetic the reference DOES hold: the ten shipped coefficient tables
- *       deltaf_coefficients/vh/urqmd/*.dat, recomputed digit for digit (all 81 810 printed values) by oracle_df_generator_row at the
+ *       deltaf_coefficients/vh/urqmd/c0.dat ... betapi.dat, recomputed digit for digit (all 81 810 printed values) by oracle_df_generator_row at the
  *       end of this file from this repository's PDG / Gauss-Laguerre readers and the thermal integrands the sampler, yield and
  *       feqmod restatements use (tests/test_oracle_dfcoef.py).  That pins the particle-list semantics and every J_nq / N_nq / M_nq
  *       convention; it does not pin the Cooper-Frye integrand, for which the reference holds nothing: PARITY stays UNPINNED.

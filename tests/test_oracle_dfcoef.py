@@ -161,6 +161,32 @@ def test_readers_and_oracle_on_the_references_own_files():
     assert not bad, bad[:5]
 
 
+@pytest.mark.reference
+@pytest.mark.parametrize("which", ["smash", "smash_box"])
+def test_smash_tables_of_the_reference_pin_the_other_two_particle_list_readers(which):
+    """hrg_eos = 2 (the reference's shipped default: PDG/pdg_smash.dat through read_resonances_conventional, 493 entries) and hrg_eos = 3
+    (PDG/pdg_box.dat through read_resonances_smash_box / read_mcid, 400 entries): deltaf_coefficients/vh/{smash, smash_box}/*.dat are the same
+    generator's output for those lists (generate_delta_f_coefficients/{smash, smash_box}/df_vh_dimensionless/src: deltaf_table.cpp differs from the
+    urqmd one in file names only).  The lists as is3d_pdg_read / is3d_pdg_read_box return them reproduce every sampled printed value."""
+    if which == "smash":
+        pdg = api.pdg_read(os.path.join(REFERENCE, "PDG/pdg_smash.dat"))
+        assert len(pdg["mass"]) == 493
+    else:
+        pdg = api.pdg_read(os.path.join(REFERENCE, "PDG/pdg_box.dat"), box=True)
+        assert len(pdg["mass"]) == 400
+    root, weight = api.gla_read(os.path.join(REFERENCE, "generate_delta_f_coefficients", which, "df_vh_dimensionless/gauss_laguerre/gla_roots_weights_64_points.txt"))
+    tabs = {n: api.df_table_read_full(os.path.join(REFERENCE, "deltaf_coefficients/vh", which, n + ".dat")) for n in oracle.DF_NAMES_2D}
+    T, B, _ = tabs["c0"]
+    bad = []
+    for iB in range(0, len(B), 8):
+        for iT in range(0, len(T), 10):
+            out = oracle.df_generator_row(pdg, root, weight, T[iT], B[iB])
+            for k, n in enumerate(oracle.DF_NAMES_2D):
+                if printed(out[k]) != printed(tabs[n][2][iB, iT]):
+                    bad.append((n, T[iT], B[iB], out[k], tabs[n][2][iB, iT]))
+    assert not bad, bad[:5]
+
+
 if __name__ == "__main__" and "--all" in sys.argv:
     # every row of every shipped table (container only, ~35 s)
     pdg = api.pdg_read(os.path.join(REFERENCE, "PDG/pdg-urqmd_v3.3+.dat"))
