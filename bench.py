@@ -75,7 +75,7 @@ def workload(name):
     raise SystemExit("unknown workload %s" % name)
 
 
-def isa_counts(kernel_name, wl, JT_R, variant=0):
+def isa_counts(kernel_name, wl, JT_R, variant=0, baryon=False):
     p = os.path.join(ROOT, "is3d_amd", "csrc", "isa_counts.json")
     if not os.path.exists(p):
         return None
@@ -89,9 +89,9 @@ def isa_counts(kernel_name, wl, JT_R, variant=0):
     elif kernel_name == "cf_main_vah3":
         key = "cf_main_vah3:DIM3=%d,REG=1,JT=%d,R=%d" % (d3, JT_R[0], JT_R[1])
     elif kernel_name == "cf_main_tile3e":
-        key = "cf_main_tile3e:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,MODE=%d" % (ce, JT_R[0], JT_R[1], 0 if variant == 5 else 1)
+        key = "cf_main_tile3e%s:CE=%d,OUTFLOW=1,REG=1,JT=%d,R=%d,MODE=%d" % ("_baryon" if baryon else "", ce, JT_R[0], JT_R[1], 0 if variant == 5 else 1)
     elif kernel_name == "cf_main_tile":
-        key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,BARYON=0,JT=%d,R=%d" % (ce, d3, JT_R[0], JT_R[1])
+        key = "cf_main_tile:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,BARYON=%d,JT=%d,R=%d" % (ce, d3, int(baryon), JT_R[0], JT_R[1])
     else:
         key = "cf_main_direct:CE=%d,DIM3=%d,OUTFLOW=1,REG=1,KT=%d" % (ce, d3, JT_R[1])
     return d.get(key)
@@ -141,18 +141,27 @@ def host_mem_available():
 
 def pmc_traffic(workload_name, n_cells):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE need their
-    own passes and cannot be collected inside this run): newest profiles/rNN_pmc_traffic.json that holds this workload at this shard
-    size -- `shards` maps a cell count (a rank's shard at N = 1, 2, 4, 8) to its counter set."""
-    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        tp = os.path.join(ROOT, "profiles", tname)
-        if not os.path.exists(tp):
+    own passes and cannot be collected inside this run): the NEWEST profiles/rNN_pmc_traffic.json (by round number, found by glob -- a new
+    round's profile is picked up without touching this file) that holds this workload at this shard size; `shards` maps a cell count
+    (a rank's shard at N = 1, 2, 4, 8) to its counter set.  The source file is named in the line (`traffic_source`): a kernel changed
+    since that round's passes is visible there."""
+    import glob
+    import re
+    found = []
+    for tp in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(tp))
+        if m:
+            found.append((int(m.group(1)), tp))
+    for _, tp in sorted(found, reverse=True):
+        try:
+            tj = json.load(open(tp)).get(workload_name)
+        except (OSError, ValueError):
             continue
-        tj = json.load(open(tp)).get(workload_name)
         if not tj:
             continue
         hit = tj if tj.get("cells") == n_cells else (tj.get("shards") or {}).get(str(n_cells))
         if hit and hit.get("hbm_bytes_per_launch"):
-            return hit["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc passes of this command at %d cells, not measured in this run)" % (tname, n_cells)
+            return hit["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc passes of this command at %d cells, not measured in this run)" % (os.path.basename(tp), n_cells)
     return None, None
 
 
@@ -164,13 +173,15 @@ def cpu_baseline(wl, sp, grid, df, seconds_budget=25.0, fq=None):
     nbins = len(grid["pT"]) * len(grid["phi"]) * (len(grid["y"]) if wl["dimension"] == 3 else 1)
     per_cell = nbins * len(sp["mass"])
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"])
+    if wl.get("baryon"):
+        opts.update(include_baryon=1, include_baryondiff_deltaf=1)
     vah_tab = df if wl["name"] == "config5" else None   # config5: `df` is the VAH (Lambda, alpha_L) table set
     # every host core this process may run on ("all host cores, count and model stated"); the oracle keeps one
     # partial spectrum per thread (39 MB for config 3), so the count is bounded by a quarter of the free host memory, nothing else
     avail = host_cores()
     per_thread = 8.0 * per_cell + 1e6
     tmax = max(1, min(avail, int(0.25 * host_mem_available() / per_thread)))
-    make = synth.synth_surface
+    make = (lambda n, d: synth.synth_surface(n, d, baryon=True)) if wl.get("baryon") else synth.synth_surface
     if vah_tab is not None:
         make = synth.synth_vah_surface
 
@@ -275,6 +286,9 @@ def main():
     ap.add_argument("--events", type=int, default=20, help="--workload config5-sampler: events sampled per step")
     ap.add_argument("--df-mode", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="override the workload's df_mode (3, 4: modified-equilibrium kernel; not the BASELINE metric's configuration)")
+    ap.add_argument("--include-baryon", action="store_true",
+                    help="config3 / config2 with df_mode 1, 2: include_baryon = 1 and include_baryondiff_deltaf = 1 -- mu_B, n_B, V^mu per cell, bilinear (T, mu_B) "
+                         "coefficients, 124 species classes (SURVEY.md 8f rank 1; smooth_kernels.cpp:186-197, :297, :303-321); not the BASELINE metric's configuration")
     ap.add_argument("--cells", type=int, default=0, help="override the surface size: total cells (strong scaling) / cells per GPU (weak)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--zero-skip", type=int, default=0, choices=[0, 1, 2, 3], help="dev: culling mode of the main kernel (2 = off; 3 = surface-relative floors, bounded instead of bitwise: include/is3d_amd.h)")
@@ -374,15 +388,22 @@ def main():
     if a.df_mode:
         wl["text"] += " -- df_mode overridden to %d" % a.df_mode
         wl["df_mode"] = a.df_mode
+    if a.include_baryon:
+        if a.workload not in ("config3", "config2") or wl["df_mode"] not in (1, 2):
+            raise SystemExit("--include-baryon applies to --workload config3 / config2 with df_mode 1 or 2")
+        wl["baryon"] = True
+        wl["text"] += " -- include_baryon = 1, include_baryondiff_deltaf = 1: + mu_B, n_B, V^x, V^y, V^eta per cell, bilinear (T, mu_B) coefficient tables"
     g = inputs.grid()
     grid = dict(pT=g["pT"], phi=g["phi"], y=g["y"], eta=g["eta"], eta_w=g["eta_w"])
-    df = inputs.df_tables()
+    df = inputs.df_tables_full() if wl.get("baryon") else inputs.df_tables()
     sp = inputs.species(wl["species"])
     n_total = (a.cells or wl["cells"]) * (world if a.scaling == "weak" else 1)
     lo, hi = idist.shard_bounds(n_total, rank, world)
     n_loc = hi - lo
     vah = wl["name"] == "config5"
     opts = dict(dimension=wl["dimension"], df_mode=wl["df_mode"], kernel_variant=a.variant, device=local, zero_skip=a.zero_skip, cell_chunks=a.cell_chunks)
+    if wl.get("baryon"):
+        opts.update(include_baryon=1, include_baryondiff_deltaf=1)
     fq = None
     if vah:
         # anisotropic hydro: 24 cell arrays (no T, no c0..c4: the coefficients are interpolated on the device from the tables)
@@ -395,8 +416,8 @@ def main():
         tens = {k: torch.from_numpy(cells[k]).to(dev) for k in cell_fields}   # resident in HBM before timing
         make_plan = lambda o: api.VahPlan(sp, grid, o, tab=df, max_cells=max(n_loc, 1))
     else:
-        cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo)
-        cell_fields = list(synth.CELL_FIELDS)
+        cells = synth.synth_surface(n_loc, wl["dimension"], first_cell=lo, baryon=bool(wl.get("baryon")))
+        cell_fields = list(synth.CELL_FIELDS) + (list(synth.BARYON_FIELDS) if wl.get("baryon") else [])
         tens = {k: torch.from_numpy(cells[k]).to(dev) for k in cell_fields}   # resident in HBM before timing
         if wl["df_mode"] in (3, 4):   # modified equilibrium: Gauss-Laguerre nodes, PDG list, the surface-average temperature (all ranks' cells)
             fq = inputs.feqmod_tables(idist.surface_average_T_global(cells))
@@ -465,7 +486,7 @@ def main():
     executed_evals = unique_evals * (1.0 - culled)   # rows the kernel proved unable to change a bit for a whole wave are not executed
     ms_main = float(np.mean(ms["main"]))
     # ---- the binding roofline, per rank: fp64 VALU (flops and instructions per integrand from the emitted ISA, this rank's own culled fraction and kernel time)
-    ic = isa_counts(plan.main_kernel_name, wl, plan.tile_shape, st["kernel_variant"])
+    ic = isa_counts(plan.main_kernel_name, wl, plan.tile_shape, st["kernel_variant"], baryon=bool(wl.get("baryon")))
 
     def valu_roofline(clock_ghz=None):
         if not ic:
@@ -585,10 +606,11 @@ def main():
         evals_step = float(n_total) * nbins * nsp
         value = evals_step * a.steps / elapsed
         # ---- roofline (contract form, HBM): algorithmic bytes of the launch = cell arrays read once + spectrum written once
-        ncell_arrays = len(cell_fields) - (0 if wl["dimension"] == 3 else 1)   # 18 (17 in 2+1D: no eta); VAH: 24
+        ncell_arrays = len(cell_fields) - (0 if wl["dimension"] == 3 else 1)   # 18 (17 in 2+1D: no eta; 23 / 22 with the baryon arrays); VAH: 24
         b_alg = 8.0 * (ncell_arrays * n_loc + nsp * nbins)
-        tkey = wl["name"] + ("_feqmod%d" % a.df_mode if a.df_mode in (3, 4) else "") + ("_dim2" if (vah and wl["dimension"] == 2) else "")
-        traffic, traffic_source = (None, None) if (a.variant or a.df_mode in (1, 2)) else pmc_traffic(tkey, n_loc)
+        tkey = wl["name"] + ("_feqmod%d" % a.df_mode if a.df_mode in (3, 4) else "_df%d" % a.df_mode if a.df_mode in (1, 2) and a.df_mode != workload(a.workload)["df_mode"] else "") \
+            + ("_baryon" if wl.get("baryon") else "") + ("_dim2" if (vah and wl["dimension"] == 2) else "")
+        traffic, traffic_source = (None, None) if a.variant else pmc_traffic(tkey, n_loc)
         roofline = dict(bound="hbm", achieved=b_alg / (ms_main * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=b_alg / (ms_main * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source, kernel=plan.main_kernel_name,
                         kernel_ms=ms_main, algorithmic_bytes=b_alg,
@@ -618,7 +640,8 @@ def main():
                                bins=nbins, evals_per_step=evals_step, kernel=plan.main_kernel_name, kernel_variant=st["kernel_variant"],
                                parallelism=("cell-axis shards x%d of %s, one all-reduce of the spectrum" % (
                                    world, "one surface (BASELINE config 4 at 8)" if a.scaling == "strong" else "a surface that grows with N")) if world > 1 else "1 GPU",
-                               workspace_GB=plan.workspace_bytes / 1e9, spectrum_finite=spectrum_ok,
+                               workspace_GB=plan.workspace_bytes / 1e9, workspace_bytes_per_cell=plan.workspace_bytes / float(max(n_loc, 1)),
+                               spectrum_finite=spectrum_ok,
                                culled_rows_change_no_bit=cull_identical),
                    kernel_ms=dict(prep=float(np.mean(ms["prep"])), main=ms_main, finalize=float(np.mean(ms["finalize"])), main_no_cull=ms_no_cull, surface_cull=surf_cull),
                    roofline=roofline, roofline_valu=rv)
@@ -628,8 +651,10 @@ def main():
             # every N: the CPU path on this node's own host cores in the same run (north_star); rank 0 computes it after the timed region while
             # the other ranks wait at the closing barrier
             res["cpu_baseline"] = cpu_baseline(wl, sp, grid, df, seconds_budget=a.cpu_baseline_seconds, fq=fq)
+            # like for like first: integrands the GPU executed against the evals the CPU port executed (it evaluates every species and every row);
+            # gpu_over_cpu divides reference-equivalent evals (305 species, every row) by the same CPU rate -- neither is a measure of kernel quality
+            res["gpu_over_cpu_executed"] = executed_per_s / inner / res["cpu_baseline"]["value"]
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
-            res["gpu_over_cpu_executed"] = executed_per_s / inner / res["cpu_baseline"]["value"]   # the CPU port executes every eval
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     plan.close()
@@ -758,9 +783,11 @@ def bench_sampler(a, rank, world, local, dev, multi, json_fd):
                   frac=tf / FP64_VALU_PEAK_TF, quadrature_nodes_per_launch=nodes, flop_per_node=ic["flop_per_node"],
                   fp64_valu_instr_per_node=ic["valu_f64_instr_per_node"])
     div = None
-    pp = os.path.join(ROOT, "profiles", "r04_pmc_sampler.json")
-    if os.path.exists(pp):
-        div = json.load(open(pp))
+    import glob
+    pps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_sampler.json")))   # newest round's counters
+    if pps:
+        div = json.load(open(pps[-1]))
+        div.setdefault("file", "profiles/" + os.path.basename(pps[-1]))
     res = dict(metric="FO-cell x event samples/sec (Monte Carlo particle sampler, the second leg of BASELINE config 5)", value=value, unit="cell-events/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3, higher_is_better=True, scaling=a.scaling, vs_baseline=None,
                dtype="f64", data="synthetic",

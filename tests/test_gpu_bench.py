@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("workload,kernel,extra", [("config3", "cf_main_tile3e", []), ("config2", "cf_main_tile", []), ("config5", "cf_main_vah3", []),
-                                                   ("config3", "cf_main_feqmod", ["--df-mode", "4"])])
+                                                   ("config3", "cf_main_feqmod", ["--df-mode", "4"]),
+                                                   ("config3", "cf_main_tile3e", ["--include-baryon"]),      # SURVEY.md 8f rank 1 at the bench
+                                                   ("config3", "cf_main_tile3e", ["--df-mode", "1"]),        # config 1's physics (14-moment) on config 3's surface
+                                                   ("config2", "cf_main_tile", ["--include-baryon"])])
 def test_bench_line(workload, kernel, extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--cells", "6000", "--steps", "2", "--warmup", "1",
@@ -38,6 +41,17 @@ def test_bench_line(workload, kernel, extra):
     assert d["transfers_included"] is False and 0 < d["value_incl_transfers"] <= d["value"] * 1.05 and d["ms_per_step_incl_transfers"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and 1 <= cb["cores"] <= cb["cores_available"] and cb["cpu_model"] and cb["unit"] == "evals/s"
+    keys = list(d)
+    assert keys.index("gpu_over_cpu_executed") < keys.index("gpu_over_cpu")       # the like-for-like ratio leads
+    assert d["config"]["workspace_bytes_per_cell"] > 0
+    if "--include-baryon" in extra:
+        # baryon number joins the class key (p / pbar, Lambda / Lambdabar ... are different classes), five more cell arrays in the algorithmic bytes
+        assert d["config"]["species_classes_evaluated"] == (124 if workload == "config3" else 5)
+        n_arr = 23 if workload == "config3" else 22
+        assert ro["algorithmic_bytes"] == 8.0 * (n_arr * 6000 + d["config"]["species"] * d["config"]["bins"])
+        assert "include_baryon = 1" in d["config"]["workload"]
+    if extra == ["--df-mode", "1"]:
+        assert "df_mode overridden to 1" in d["config"]["workload"] and rv["executed_flop_per_eval"] < 22
 
 
 def test_bench_line_sampler_leg():
