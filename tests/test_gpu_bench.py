@@ -46,7 +46,7 @@ def test_bench_line(workload, kernel, extra):
     assert d["config"]["workspace_bytes_per_cell"] > 0
     if "--include-baryon" in extra:
         # baryon number joins the class key (p / pbar, Lambda / Lambdabar ... are different classes), five more cell arrays in the algorithmic bytes
-        assert d["config"]["species_classes_evaluated"] == (124 if workload == "config3" else 5)
+        assert d["config"]["species_classes_evaluated"] == (124 if workload == "config3" else 3)
         n_arr = 23 if workload == "config3" else 22
         assert ro["algorithmic_bytes"] == 8.0 * (n_arr * 6000 + d["config"]["species"] * d["config"]["bins"])
         assert "include_baryon = 1" in d["config"]["workload"]
