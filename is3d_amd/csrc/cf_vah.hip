@@ -547,9 +547,17 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
     constexpr double X2CUT = 555400.0;   // E_a/Lambda > 745.25: exp(-E_a/Lambda) == +0
 
     auto process_unit = [&](const double *U) {
-        const double pTdmax = pT * U[11];
+        // max_j d_j is wave-uniform and lives through the unit's rows (every row test uses it): kept in an SGPR pair and fed to the row test's
+        // fma as its one scalar operand -- as the product pT * dmax it held a VGPR pair through the unit, and the 3+1D 8 x 7 tile then kept its
+        // 56th accumulator in a scratch slot (scratch_load / v_fmac / scratch_store in every unit: tools/count_isa.py `scratch_in_loop`)
+        double dmax_s;
+        {
+            const double dm = U[11];
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(dm)), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(dm));
+            dmax_s = __hiloint2double((int)hi, (int)lo);
+        }
         if (g.zskip) {   // unit-level cull: every row of the unit would fail its own test below
-            const double lbu = __builtin_fmax(__builtin_fma(mT, U[3], -pTdmax), 0.0);
+            const double lbu = __builtin_fmax(__builtin_fma(mT, U[3], -(pT * dmax_s)), 0.0);
             const double x2lb_u = __builtin_fma(lbu, lbu, mT2 * U[7]);
             if (__all(x2lb_u > X2CUT)) { n_rows += R; n_dead += R; return; }
         }
@@ -568,7 +576,7 @@ cf_main_vah3(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
         auto evals = [&](const Row &rw, int r) {
             const double mTc = mT * rw.v[1], mT2e = mT2 * rw.v[3];
             n_rows += 1;
-            const double lb = __builtin_fmax(mTc - pTdmax, 0.0);
+            const double lb = __builtin_fmax(__builtin_fma(-pT, dmax_s, mTc), 0.0);   // one rounding less than mTc - pT dmax: the bound moves by an ulp, the cut has 1.6e-4 of slack (745.25 against 745.14)
             const double x2lb = __builtin_fma(lb, lb, mT2e);
             if (g.zskip && __all(x2lb > X2CUT)) { n_dead += 1; return; }
             const double mTA = mT * rw.v[0], ad = mT2s * rw.v[2];

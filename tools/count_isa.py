@@ -139,8 +139,13 @@ def main():
                                    "-I", os.path.dirname(src), "-I", os.path.join(ROOT, "include"), src, "-o", s_path], stderr=subprocess.DEVNULL)
             flat[os.path.basename(src)] = len(re.findall(r"^\s+flat_(?:load|store|atomic)", open(s_path).read(), re.M))
     kernels = {}
-    cur, blocks = None, None
+    resources = collections.defaultdict(dict)   # symbol -> {NumVgprs, NumAgprs, ScratchSize, Occupancy, ...} from the compiler's resource comments
+    cur, blocks, meta_for = None, None, None
     for ln in text:
+        if cur is None and meta_for is not None:
+            m = re.match(r"^; (NumVgprs|NumAgprs|TotalNumSgprs|ScratchSize|Occupancy|LDSByteSize): (\d+)", ln)
+            if m:
+                resources[meta_for].setdefault(m.group(1), int(m.group(2)))
         m = re.match(r"^(_ZN4is3d\d+cf_main_\w+):", ln)
         if m:
             cur = m.group(1)
@@ -150,6 +155,7 @@ def main():
         if cur is None:
             continue
         if ln.startswith(".Lfunc_end"):   # (an early-exit s_endpgm can sit in the middle of the body)
+            meta_for = cur                # the resource comments ("; NumVgprs: 256", "; ScratchSize: 8") follow the function body
             cur = None
             continue
         m = re.match(r"^\.LBB\d+_\d+:(.*)", ln)
@@ -169,8 +175,10 @@ def main():
         name, params = p
         if params.pop("PROF", 0):   # the cycle-accounting instantiation (dev) is not a product kernel
             continue
-        if name == "cf_main_vah3" and params.pop("LDSD", 1536) != 1536:   # the one-wave-workgroup instantiation: same loop body
-            continue
+        ldsd = params.pop("LDSD", None) if name in ("cf_main_vah3", "cf_main_vah") else None
+        # cf_main_vah3 in 3+1D exists twice: LDSD = 1100 is the one-wave workgroup the plan launches by default (cf_vah.hip), 1536 the two-wave
+        # one of waves_per_group = 2 -- the plain key is the default's, the other carries its LDSD
+        vah3_alt = name == "cf_main_vah3" and params.get("DIM3") == 1 and ldsd == 1536
         if name == "cf_main_tile":
             params.pop("LAZY", None)
             if not params.pop("DMA", 1):   # the register-staged copy kept for A/B (variant 8)
@@ -218,7 +226,16 @@ def main():
         if name == "cf_main_tile3e" and params.pop("BARYON", 0):
             name = "cf_main_tile3e_baryon"
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
-        out[key] = dict(evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), m0_writes=m0_set, global_load_lds=glds, m0_other_users=m0_other, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
+        if vah3_alt:
+            key += ",LDSD=1536"
+        # spills: scratch instructions of the counted loop (per pass of the loop and per evaluation) and of the whole kernel.  One in the loop sits on
+        # the critical path of every unit; one outside (prologue / epilogue: lane constants parked while the accumulators are live) is paid once per wave
+        scr_loop = sum(v for k, v in hot.items() if k.startswith("scratch_"))
+        scr_all = sum(1 for op, _ in all_ins if op.startswith("scratch_"))
+        res = resources.get(sym, {})
+        out[key] = dict(scratch_in_loop=scr_loop, scratch_in_kernel=scr_all, scratch_bytes_per_lane=res.get("ScratchSize"), vgprs=res.get("NumVgprs"), sgprs=res.get("TotalNumSgprs"),
+                        occupancy_waves_per_simd=res.get("Occupancy"),
+                        evals_in_loop=n_eval, evals_per_rcp=rbatch, evals_per_rcp_template=rbatch_t, evals_counted_from_isa=bool(from_isa), m0_writes=m0_set, global_load_lds=glds, m0_other_users=m0_other, flop_per_eval=round(flops / n_eval, 3), valu_f64_instr_per_eval=round(sum(f64.values()) / n_eval, 3),
                         issue_cycles_per_eval=round(cycles / n_eval, 2), lds_instr_per_eval=round(sum(v for k, v in hot.items() if k.startswith("ds_")) / n_eval, 3),
                         histogram={k: v for k, v in sorted(hot.items()) if v and (k.startswith("v_") or k.startswith("ds_"))})
     # ---- the sampler's Gauss-Laguerre density kernel (cf_sampler.hip): fp64 instructions and flops per quadrature node, from its innermost loops
