@@ -344,7 +344,11 @@ int is3d_comm_check(is3d_comm *comm, void *hip_stream, int32_t *n_failed);
 /* ncclCommAbort on this rank's communicator: for a host that has to leave a job.  Local -- the other ranks find out through their own
  * deadline (see is3d_plan_execute_allreduce), not through this call. */
 int is3d_comm_abort(is3d_comm *comm);
-/* Deadline, in seconds, of the host-side waits behind this communicator's collectives (default 300). */
+/* Deadline, in seconds, of the host-side waits behind this communicator's collectives (default 300).  What it times (round 5): with ONE collective
+ * enqueued since the last completed wait -- the usual step: execute, all-reduce, wait -- the clock starts when the stream REACHES the collective
+ * (an event recorded just before it), so this rank's own kernels queued ahead of it do not count, however long they run.  With several collectives
+ * queued before one wait, and as a backstop while the collective has not been reached, the wait gives up 20 x `seconds` after it was entered: a caller
+ * that queues many steps before it waits must choose `seconds` above 1/20 of the compute it queues. */
 int is3d_comm_set_timeout(is3d_comm *comm, double seconds);
 /* hipStreamSynchronize(hip_stream) with that deadline and with ncclCommGetAsyncError polled beside it: IS3D_OK when everything enqueued on
  * the stream has finished, IS3D_ENODEVICE (communicator aborted) on an asynchronous RCCL error or when the deadline passes. */
@@ -631,12 +635,16 @@ int is3d_surface_read(const char *path, int32_t mode, int32_t include_baryon, in
  * is3d_surface_arrays: modes 0-7 except 2: n_arrays = 25 -- cell_arrays23 order (T P E tau eta ux uy un dat dax day dan pixx pixy pixn piyy
  * piyn bulkPi muB nB Vx Vy Vn; NULL for the ones the flags leave out) then the positions x, y (columns 2, 3: the sampler's) -- and avg5 as
  * is3d_surface_read; mode 2: n_arrays = 32, the arrays32 of is3d_surface_read_vah, avg5 untouched.  Pointers stay valid until is3d_surface_close.
- * is3d_surface_source: 0 the text was parsed, no sidecar written | 1 parsed, sidecar written (waits for the writer) | 2 loaded from the sidecar. */
+ *   The sidecar's key (round 5): the text's size, mtime, CHANGE time, inode and device, the sampled (or whole-file) content hash and the parse
+ *   parameters -- an edit that restores size and mtime (cp -p, rsync -t, utime) still changes the inode's ctime and is re-parsed.
+ * is3d_surface_source: 0 the text was parsed, no sidecar written | 1 parsed, sidecar written (waits for the writer) | 2 loaded from the sidecar.
+ * is3d_surface_from_sidecar: 1 when the arrays came from the sidecar, else 0; known when is3d_surface_open returns, never waits. */
 typedef struct is3d_surface is3d_surface;
 int is3d_surface_open(const char *path, int32_t mode, int32_t include_baryon, int32_t include_baryondiff_deltaf, int32_t dimension,
                       int32_t cache, is3d_surface **surface);
 int64_t is3d_surface_cells(const is3d_surface *surface);
 int32_t is3d_surface_source(is3d_surface *surface);
+int32_t is3d_surface_from_sidecar(const is3d_surface *surface);
 int is3d_surface_arrays(const is3d_surface *surface, const double **arrays, int32_t n_arrays, double avg5[5]);
 void is3d_surface_close(is3d_surface *surface);
 

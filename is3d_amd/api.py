@@ -103,7 +103,7 @@ EXPORTS = ["is3d_last_error", "is3d_version", "is3d_device_count", "is3d_smooth_
            "is3d_run_particlization", "is3d_run_result_free", "is3d_write_sampler_tests", "is3d_smooth_spectra_vah",
            "is3d_smooth_spectra_multi", "is3d_shard_bounds", "is3d_comm_unique_id", "is3d_comm_create", "is3d_comm_rank",
            "is3d_comm_allreduce", "is3d_comm_destroy", "is3d_plan_execute_allreduce", "is3d_run_particlization_on", "is3d_total_yield", "is3d_plan_check", "is3d_sample_particles_multi",
-           "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_comm_set_timeout", "is3d_comm_synchronize", "is3d_surface_open", "is3d_surface_cells", "is3d_surface_source",
+           "is3d_comm_check", "is3d_comm_abort", "is3d_comm_timings", "is3d_comm_set_timeout", "is3d_comm_synchronize", "is3d_surface_open", "is3d_surface_cells", "is3d_surface_source", "is3d_surface_from_sidecar",
            "is3d_surface_arrays", "is3d_surface_close", "is3d_sampler_plan_create", "is3d_sampler_plan_execute", "is3d_sampler_plan_destroy", "is3d_multi_plan_create", "is3d_multi_plan_execute",
            "is3d_multi_plan_shards", "is3d_multi_plan_output_size", "is3d_multi_plan_destroy",
            "is3d_vah_df_read", "is3d_vah_coefficients", "is3d_smooth_spectra_vah_df", "is3d_vah_plan_create", "is3d_vah_plan_output_size",
@@ -819,7 +819,10 @@ def surface_open(path, mode=1, include_baryon=0, include_baryondiff_deltaf=0, di
             arrs = {f: (np.ctypeslib.as_array(ptrs[i], shape=(n,)).copy() if ptrs[i] else None) for i, f in enumerate(names)}
         else:
             arrs = {f: np.zeros(0) for f in names}
+        L.is3d_surface_from_sidecar.argtypes = [C.c_void_p]
+        early = L.is3d_surface_from_sidecar(h)                 # known at open, never waits for the writer
         source = L.is3d_surface_source(h)
+        assert early == (1 if source == 2 else 0)
     finally:
         L.is3d_surface_close(h)
     return arrs, (None if mode == 2 else avg), source

@@ -2,8 +2,26 @@
 #pragma once
 #include "cf_device.h"
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <cstdint>
 namespace is3d {
 constexpr int kWavesPerBlock = 4;
+// Cap on the derived streams of one pass over the cell axis, shared by every plan (cf_plan.cpp, cf_vah.hip): the caller's opts.workspace_bytes, else
+// max(16 GiB, 45 % of the device's TOTAL memory) -- the total, not what happens to be free: the pass count, the chunk count and with them the summation
+// order of a surface that needs several passes must not depend on what else occupies the GPU at the moment -- and never more than the device can hold
+// beside the partial slab (<= kPartialCapBytes by default) and the fixed buffers: streams + slab <= 90 % of the total.
+constexpr int64_t kPartialCapBytes = (int64_t)12 << 30;
+inline int64_t default_stream_cap_bytes(int64_t requested)
+{
+    if (requested > 0) return requested;
+    int64_t ws = (int64_t)16 << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
+        ws = std::min<int64_t>(ws, std::max<int64_t>((int64_t)1 << 30, (int64_t)((double)total_b * 0.9) - kPartialCapBytes));
+    }
+    return ws;
+}
 size_t prep_lds_bytes(int nT, int nspl, int J, int K, int baryon, int rec, int dim3);
 hipError_t launch_prep(const PrepParams &p, hipStream_t stream);
 void main_tile_shape(int variant, int dim3, int *JT, int *KT);

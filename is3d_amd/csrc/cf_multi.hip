@@ -156,6 +156,7 @@ struct is3d_comm {
     bool flag_in_flight = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last collective (is3d_comm_timings)
     bool timed = false, aborted = false;
+    int pending = 0;                  // collectives enqueued since the last host-side wait that saw the stream (or ev1) complete
     double timeout_s = 300.0;         // deadline of every host-side wait behind a collective (is3d_comm_set_timeout; IS3D_COMM_TIMEOUT_S at creation)
 };
 
@@ -232,6 +233,7 @@ int comm_allreduce_flagged(is3d_comm *c, double *dN_dev, int64_t n, bool local_e
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     c->timed = true;
+    c->pending++;
     hipLaunchKernelGGL(cf_comm_flag, dim3(1), dim3(1), 0, st, c->d_flag, 1, 0.0);
     HIP_TRY(hipGetLastError());
     c->flag_in_flight = true;
@@ -246,11 +248,21 @@ int comm_allreduce_flagged(is3d_comm *c, double *dN_dev, int64_t n, bool local_e
 // expected to exit non-zero so that the launcher tears the job down.
 int comm_wait(is3d_comm *c, hipStream_t st, hipEvent_t ev, const char *what)
 {
-    const auto t0 = std::chrono::steady_clock::now();
+    // What the deadline times (round 5).  The wait sits behind everything queued on the stream -- this rank's own kernels first, then the
+    // collective.  With exactly ONE collective in flight since the last completed wait, ev0 (recorded just before it) is unambiguous: the clock
+    // starts when ev0 completes, so only time spent in or behind the collective counts and a long local execute (a large surface in several
+    // passes, culling off) cannot be taken for a dead peer.  With several collectives queued ev0 is the LAST one's and would never complete
+    // behind an earlier one that hangs: then, and as a backstop while ev0 has not completed, the clock runs from entry against
+    // kQueuedFactor x timeout_s -- the caller's timeout must exceed 1/kQueuedFactor of the longest compute it queues ahead of a wait
+    // (include/is3d_amd.h, is3d_comm_set_timeout).
+    constexpr double kQueuedFactor = 20.0;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto t0 = t_entry;
+    bool started = !(c->pending == 1 && c->timed && c->ev0);
     int spins = 0;
     for (;;) {
         const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(st);
-        if (q == hipSuccess) return IS3D_OK;
+        if (q == hipSuccess) { c->pending = 0; return IS3D_OK; }
         if (q != hipErrorNotReady) {
             (void)hipGetLastError();
             comm_abort(c);
@@ -258,6 +270,10 @@ int comm_wait(is3d_comm *c, hipStream_t st, hipEvent_t ev, const char *what)
                         c->rank, c->n_ranks);
         }
         (void)hipGetLastError();   // hipErrorNotReady is sticky in hipGetLastError otherwise
+        if (!started) {
+            if (hipEventQuery(c->ev0) != hipErrorNotReady) { started = true; t0 = std::chrono::steady_clock::now(); }   // the collective has been reached
+            (void)hipGetLastError();
+        }
         if (c->comm && rccl().CommGetAsyncError) {
             ncclResult_t ar = ncclSuccess;
             if (rccl().CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
@@ -267,11 +283,13 @@ int comm_wait(is3d_comm *c, hipStream_t st, hipEvent_t ev, const char *what)
                             c->n_ranks, w.c_str());
             }
         }
-        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (waited > c->timeout_s) {
+        const auto now = std::chrono::steady_clock::now();
+        const double waited = std::chrono::duration<double>(now - t0).count(), since_entry = std::chrono::duration<double>(now - t_entry).count();
+        if (started ? waited > c->timeout_s : since_entry > kQueuedFactor * c->timeout_s) {
             comm_abort(c);
-            return fail(IS3D_ENODEVICE, "%s: rank %d of %d waited %.0f s behind a collective (a peer that never joined?); the communicator was aborted -- "
-                        "this rank should exit so that the launcher ends the job", what, c->rank, c->n_ranks, waited);
+            return fail(IS3D_ENODEVICE, "%s: rank %d of %d waited %.3g s %s (a peer that never joined?); the communicator was aborted -- "
+                        "this rank should exit so that the launcher ends the job", what, c->rank, c->n_ranks, started ? waited : since_entry,
+                        started ? "in or behind a collective" : "for the work queued ahead of a collective (more than 20 x the communicator's timeout)");
         }
         if (++spins < 2000) std::this_thread::yield();                              // the usual case: a few hundred microseconds
         else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 50 : 500));
@@ -363,6 +381,7 @@ extern "C" int is3d_comm_allreduce(is3d_comm *c, double *dN_dev, int64_t n, void
     NCCL_TRY(rccl().AllReduce(dN_dev, dN_dev, (size_t)n, ncclDouble, ncclSum, c->comm, (hipStream_t)hip_stream));
     HIP_TRY(hipEventRecord(c->ev1, (hipStream_t)hip_stream));
     c->timed = true;
+    c->pending++;
     return IS3D_OK;
 }
 

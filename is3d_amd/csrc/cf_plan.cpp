@@ -457,16 +457,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // total, not what happens to be free: the pass count, the chunk count and with them the summation order of a surface that needs several
     // passes must not depend on what else occupies the GPU at the moment (the partial slab below adds up to 12 GiB on top; an allocation that
     // does not fit is reported as IS3D_ENOMEM with the sizes, and opts.workspace_bytes sets the cap explicitly)
-    int64_t ws = o->workspace_bytes;
-    if (ws <= 0) {
-        ws = (int64_t)16 << 30;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
-            // ... and never more than the device can hold beside the partial slab (<= 12 GiB) and the fixed buffers: streams + slab <= 90 % of the total
-            ws = std::min<int64_t>(ws, std::max<int64_t>((int64_t)1 << 30, (int64_t)((double)total_b * 0.9) - ((int64_t)12 << 30)));
-        }
-    }
+    const int64_t ws = is3d::default_stream_cap_bytes(o->workspace_bytes);   // cf_launch.h: one rule for every plan
     int64_t pc = ws / (int64_t)P->bytes_per_cell;
     if (pc < 1) pc = 1;
     if (pc > max_cells) pc = max_cells;

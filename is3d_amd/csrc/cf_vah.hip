@@ -961,12 +961,7 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     if (P->lds_prep > 160 * 1024) return set_error(IS3D_EINVAL, "grids too large for the prep kernel's LDS staging");
     // passes over the cell axis bounded by the workspace (default 16 GB), chunks as in cf_plan.cpp
     const size_t bytes_per_cell = sizeof(double) * (size_t)P->jtiles * P->rblocks * P->REC;
-    int64_t ws = o->workspace_bytes;
-    if (ws <= 0) {   // as cf_plan.cpp: 16 GiB or 45 % of the device's TOTAL memory (not of what is free now: the pass count must not depend on the GPU's other tenants)
-        ws = (int64_t)16 << 30;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws = std::max<int64_t>(ws, (int64_t)((double)total_b * 0.45));
-    }
+    const int64_t ws = is3d::default_stream_cap_bytes(o->workspace_bytes);   // cf_launch.h: the rule of cf_plan.cpp, its clamp beside the partial slab included
     P->pass_cells = std::max<int64_t>(1, std::min<int64_t>(max_cells, ws / (int64_t)bytes_per_cell));
     const int lane_waves = Lpad / 64;
     int best = 1 << 30;
@@ -987,8 +982,12 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
         const hipError_t e = (which == 0 ? P->d_TS : P->d_partial).alloc(bytes);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
-            return set_error(IS3D_ENOMEM, "out of device memory allocating %s (%.2f GB): lower opts.workspace_bytes (more passes) or opts.cell_chunks",
-                             which == 0 ? "the unit-record stream" : "the per-chunk partial spectra", bytes / 1e9);
+            size_t fr = 0, to = 0;
+            (void)hipMemGetInfo(&fr, &to);
+            return set_error(IS3D_ENOMEM, "out of device memory allocating %s (%.2f GB; %.2f GB free of %.2f GB): %lld cells per pass x %zu B of streams, "
+                             "%d partial slabs -- lower opts.workspace_bytes (more passes) or opts.cell_chunks",
+                             which == 0 ? "the unit-record stream" : "the per-chunk partial spectra", bytes / 1e9, fr / 1e9, to / 1e9, (long long)P->pass_cells,
+                             bytes_per_cell, (int)(nch + is3d::kTaperExtra));
         }
         if (e != hipSuccess) return set_error(IS3D_ENODEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
     }

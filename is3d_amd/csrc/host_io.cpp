@@ -5,6 +5,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <exception>
 #include <memory>
 #include <algorithm>
 #include <charconv>
@@ -630,7 +631,7 @@ struct CacheHeader {
     int64_t n_cells;
     uint64_t array_mask;
     double avg[5];
-    uint8_t pad[8];
+    uint64_t stat_key;                     // version 2: mix of the text's st_ctim (ns), st_ino, st_dev -- utime() can restore an mtime, nothing restores a ctime
 };
 static_assert(sizeof(CacheHeader) == 128, "cache header is 128 bytes");
 const char kCacheMagic[8] = {'I', 'S', '3', 'D', 'S', 'R', 'F', '1'};
@@ -731,6 +732,10 @@ extern "C" int is3d_surface_open(const char *path, int32_t mode, int32_t include
     if (fstat(fd, &stt) != 0) { close(fd); return io_fail(IS3D_EIO, "%s: cannot stat", path); }
     const uint64_t tsize = (uint64_t)stt.st_size;
     const int64_t tmtime = (int64_t)stt.st_mtim.tv_sec * 1000000000LL + (int64_t)stt.st_mtim.tv_nsec;
+    // an edit that keeps size and mtime (fixed-width hydro output restored by cp -p / rsync -t / utime) and misses every sampled block would
+    // otherwise be served from the sidecar: the inode's change time cannot be set from user space, so it joins the key (a copy of the text with
+    // its sidecar is re-parsed once: the safe direction)
+    const uint64_t tkey = mix64(mix64(mix64(0x1553D5ULL, (uint64_t)stt.st_ctim.tv_sec * 1000000000ULL + (uint64_t)stt.st_ctim.tv_nsec), (uint64_t)stt.st_ino), (uint64_t)stt.st_dev);
     std::unique_ptr<is3d_surface> S(new is3d_surface);
     S->mode = mode; S->include_baryon = include_baryon != 0; S->include_diff = include_baryondiff_deltaf != 0; S->dimension = dimension;
     const int narr = vah ? kSurfArraysVAH : kSurfArraysVH;
@@ -755,21 +760,28 @@ extern "C" int is3d_surface_open(const char *path, int32_t mode, int32_t include
         FILE *cf = fopen(cpath.c_str(), "rb");
         if (cf) {
             CacheHeader hd;
-            bool ok = fread(&hd, sizeof hd, 1, cf) == 1 && !memcmp(hd.magic, kCacheMagic, 8) && hd.version == 1 && hd.header_bytes == sizeof hd &&
-                      hd.text_size == tsize && hd.text_mtime_ns == tmtime && hd.sample_hash == shash && hd.mode == mode &&
+            bool ok = fread(&hd, sizeof hd, 1, cf) == 1 && !memcmp(hd.magic, kCacheMagic, 8) && hd.version == 2 && hd.header_bytes == sizeof hd &&
+                      hd.text_size == tsize && hd.text_mtime_ns == tmtime && hd.stat_key == tkey && hd.sample_hash == shash && hd.mode == mode &&
                       hd.include_baryon == S->include_baryon && hd.include_diff == S->include_diff && hd.dimension == dimension &&
                       hd.array_mask == mask && hd.n_cells >= 0 && (cache != 2 || hd.full_hash == fhash);
             if (ok) {
+                // n_cells is bounded by the sidecar's own size BEFORE it is multiplied: a corrupt or foreign header cannot wrap the product
                 struct stat cst;
-                const uint64_t want = sizeof hd + (uint64_t)__builtin_popcountll(mask) * (uint64_t)hd.n_cells * sizeof(double);
-                ok = fstat(fileno(cf), &cst) == 0 && (uint64_t)cst.st_size == want;
+                const uint64_t per_cell = (uint64_t)__builtin_popcountll(mask) * sizeof(double);
+                ok = fstat(fileno(cf), &cst) == 0 && (uint64_t)cst.st_size >= sizeof hd && per_cell > 0 &&
+                     (uint64_t)hd.n_cells <= ((uint64_t)cst.st_size - sizeof hd) / per_cell &&
+                     (uint64_t)cst.st_size == sizeof hd + per_cell * (uint64_t)hd.n_cells;
             }
             if (ok) {
-                for (int k = 0; ok && k < narr; k++)
-                    if ((mask >> k) & 1ULL) {
-                        S->a[(size_t)k].resize((size_t)hd.n_cells);
-                        ok = hd.n_cells == 0 || fread(S->a[(size_t)k].data(), sizeof(double), (size_t)hd.n_cells, cf) == (size_t)hd.n_cells;
-                    }
+                try {   // "a sidecar that cannot be used is ignored": that includes one whose arrays cannot be allocated
+                    for (int k = 0; ok && k < narr; k++)
+                        if ((mask >> k) & 1ULL) {
+                            S->a[(size_t)k].resize((size_t)hd.n_cells);
+                            ok = hd.n_cells == 0 || fread(S->a[(size_t)k].data(), sizeof(double), (size_t)hd.n_cells, cf) == (size_t)hd.n_cells;
+                        }
+                } catch (const std::exception &) {
+                    ok = false;
+                }
                 if (ok) {
                     S->n = hd.n_cells;
                     memcpy(S->avg, hd.avg, sizeof S->avg);
@@ -796,8 +808,12 @@ extern "C" int is3d_surface_open(const char *path, int32_t mode, int32_t include
         p = q + 1;
     }
     std::vector<double *> ptr((size_t)narr, nullptr);
-    for (int k = 0; k < narr; k++)
-        if ((mask >> k) & 1ULL) { S->a[(size_t)k].assign((size_t)std::max<int64_t>(rows, 1), 0.0); ptr[(size_t)k] = S->a[(size_t)k].data(); }
+    try {
+        for (int k = 0; k < narr; k++)
+            if ((mask >> k) & 1ULL) { S->a[(size_t)k].assign((size_t)std::max<int64_t>(rows, 1), 0.0); ptr[(size_t)k] = S->a[(size_t)k].data(); }
+    } catch (const std::exception &) {   // nothing may unwind through the C ABI
+        return io_fail(IS3D_ENOMEM, "%s: %lld rows x %d arrays do not fit the host memory", path, (long long)rows, __builtin_popcountll(mask));
+    }
     int64_t n = rows;
     int rc;
     if (vah) rc = surface_read_vah_text(text, path, dimension, &n, ptr.data());
@@ -811,8 +827,8 @@ extern "C" int is3d_surface_open(const char *path, int32_t mode, int32_t include
         CacheHeader hd;
         memset(&hd, 0, sizeof hd);
         memcpy(hd.magic, kCacheMagic, 8);
-        hd.version = 1; hd.header_bytes = sizeof hd;
-        hd.text_size = tsize; hd.text_mtime_ns = tmtime; hd.sample_hash = shash; hd.full_hash = fhash;
+        hd.version = 2; hd.header_bytes = sizeof hd;
+        hd.text_size = tsize; hd.text_mtime_ns = tmtime; hd.stat_key = tkey; hd.sample_hash = shash; hd.full_hash = fhash;
         hd.mode = mode; hd.include_baryon = S->include_baryon; hd.include_diff = S->include_diff; hd.dimension = dimension;
         hd.n_cells = n; hd.array_mask = mask;
         memcpy(hd.avg, S->avg, sizeof hd.avg);
@@ -833,6 +849,8 @@ extern "C" int32_t is3d_surface_source(is3d_surface *s)
     if (s->source == 1 && s->written.load() != 1) s->source = 0;   // the sidecar could not be written (read-only directory): not an error
     return s->source;
 }
+
+extern "C" int32_t is3d_surface_from_sidecar(const is3d_surface *s) { return (s && s->source == 2) ? 1 : 0; }
 
 extern "C" int is3d_surface_arrays(const is3d_surface *s, const double **arrays, int32_t n_arrays, double avg5[5])
 {

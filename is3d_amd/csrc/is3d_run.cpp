@@ -199,6 +199,8 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (is3d_surface_open("input/surface.dat", 2, 0, 0, dimension, 1, &surf)) DIE("%s", is3d_last_error());
         n_cells = is3d_surface_cells(surf);
         if (is3d_surface_arrays(surf, sa, 32, nullptr)) DIE("%s", is3d_last_error());
+        if (is3d_surface_from_sidecar(surf))
+            printf("surface: %lld cells from the binary sidecar input/surface.dat.is3dcache (IS3D_NO_CACHE=1 to re-parse the text)\n", (long long)n_cells);
     } else if (mem) {
         // iS3D.cpp:100-134: the surface comes from the caller's vectors, already in GeV / fm units (no hbar*c conversion)
         printf("Reading in freezeout surface from memory \n");
@@ -213,6 +215,10 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
         if (is3d_surface_open("input/surface.dat", mode, include_baryon, include_diff, dimension, 1, &surf)) DIE("%s", is3d_last_error());
         n_cells = is3d_surface_cells(surf);
         if (is3d_surface_arrays(surf, sa, 25, avg)) DIE("%s", is3d_last_error());
+        // said BEFORE the spectra are computed: a user who did not expect the cache sees it while the run can still be stopped
+        if (is3d_surface_from_sidecar(surf))
+            printf("surface: %lld cells from the binary sidecar input/surface.dat.is3dcache (its key -- size, mtime, ctime, inode, content hash -- matches "
+                   "input/surface.dat; IS3D_NO_CACHE=1 to re-parse the text)\n", (long long)n_cells);
         for (int a = 0; a < 23; a++) ptr[a] = const_cast<double *>(sa[a]);   // read-only from here on
     }
     if (!vah) {   // read_surf_VAH_PLMatch accumulates no averages (readindata.cpp:813-928)
@@ -249,10 +255,9 @@ static int run_impl(const is3d_cells *mem, const double *mem_x, const double *me
     // the eta table: 241 points for the smooth spectra; the reference opens the 41-point one when it samples (iS3D.cpp:164-167) and never uses it
     // there (nor does the sampler here): a run directory made for either operation is accepted
     if (operation == 2) {
-        if (read_table("tables/eta/eta_trapezoid_table_41pt.dat", eta, etaw) && read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw)) {
-            eta.assign(1, 0.0);
-            etaw.assign(1, 1.0);
-        }
+        // neither there: the reference fails on its missing table (readBlockData, arsenal.cpp:406-413) -- a mis-built run directory must not pass silently
+        if (read_table("tables/eta/eta_trapezoid_table_41pt.dat", eta, etaw) && read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
+            DIE("operation 2 opens tables/eta/eta_trapezoid_table_41pt.dat (or tables/eta/eta_trapezoid_table_241pt.dat): neither can be read (%s)", is3d_last_error());
     } else if (read_table("tables/eta/eta_trapezoid_table_241pt.dat", eta, etaw))
         DIE("%s", is3d_last_error());
     // ---- delta-f coefficient tables (iS3D.cpp:144-145) ----

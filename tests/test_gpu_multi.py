@@ -299,6 +299,13 @@ def test_waits_behind_a_collective_have_a_deadline(fx):
     plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
     comm.synchronize(stream)                                            # default deadline (300 s): finishes
     ref = out.cpu().numpy().copy()
+    # round 5: with one collective in flight the clock starts when the stream REACHES it -- a timeout below the run time of this rank's own
+    # kernels (~15 ms here) no longer poisons the communicator (round 4 aborted it after 2.5 ms of local compute) ...
+    comm.set_timeout(2.5e-3)
+    plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
+    comm.synchronize(stream)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    # ... and the backstop (20 x the timeout from entry while the collective has not been reached) still ends a wait behind work that never finishes
     comm.set_timeout(1e-4)
     plan.execute_allreduce(n, ptrs, out.data_ptr(), comm, stream, want_status=False)
     with pytest.raises(api.Is3dError) as e:
@@ -437,4 +444,32 @@ def test_bench_two_ranks_through_the_library_communicator(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["allreduce"].startswith("is3d_plan_execute_allreduce")
     assert d["ranks_seen"] == [0, 1] and [x["comm_rank_seen"] for x in d["ranks"]] == [[0, 2], [1, 2]]
     assert all(x["allreduce_ms"] is not None and x["allreduce_ms"] >= 0 for x in d["ranks"]) and d["config"]["spectrum_finite"]
+    _check_multi_rank_line(d)
+
+
+def test_bench_four_ranks_uneven_shards_through_the_library_communicator(tmp_path):
+    """The same path with FOUR self-started ranks and a cell count that does not divide (3 001 cells: shards of 751, 750, 750, 750), so that the first
+    real N > 2 line is not also the first line with more than two `ranks[]` entries.  Four, not eight: a GPU box of this pool lets at most six
+    processes use its card at once (this test process is one of them), so the N = 8 shape of BASELINE config 4 cannot be rehearsed on one GPU;
+    nothing in bench.py depends on N beyond is3d_shard_bounds and the length of `ranks`."""
+    import json
+    import sys
+    from conftest import ROOT
+    so = str(tmp_path / "libfakerccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "fake_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IS3D_RCCL_LIBRARY"] = so
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--cells", "3001", "--steps", "2",
+                        "--warmup", "1", "--cpu-baseline-seconds", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["allreduce"].startswith("is3d_plan_execute_allreduce")
+    assert d["config"]["cells_total"] == 3001 and [x["cells"] for x in d["ranks"]] == [751, 750, 750, 750]
+    assert [x["first_cell"] for x in d["ranks"]] == [0, 751, 1501, 2251] and [x["rank"] for x in d["ranks"]] == [0, 1, 2, 3]
+    assert d["ranks_seen"] == [0, 1, 2, 3] and [x["comm_rank_seen"] for x in d["ranks"]] == [[i, 4] for i in range(4)]
+    assert all(x["allreduce_ms"] is not None and x["allreduce_ms"] >= 0 for x in d["ranks"]) and d["config"]["spectrum_finite"]
+    assert d["value"] == pytest.approx(3001.0 * d["config"]["bins"] * d["config"]["species"] / (d["ms_per_step"] * 1e-3), rel=1e-9)
     _check_multi_rank_line(d)

@@ -620,13 +620,26 @@ def test_surface_sidecar_cache_and_its_invalidation_rules(tmp_path, monkeypatch)
     text[j - 1:j] = b"7" if text[j - 1:j] != b"7" else b"6"
     open(path, "wb").write(text)
     os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
-    _, _, s = api.surface_open(path, 1, 1, 0, 2, cache=1)
-    assert s == 2                                           # the documented limit of the sampled hash
-    got, _, s = api.surface_open(path, 1, 1, 0, 2, cache=2)
-    assert s == 1                                           # the whole-file hash is not fooled
+    # round 5: the key holds the inode's CHANGE time too -- utime() restored the mtime above, nothing in user space restores a ctime, so the
+    # default (cache = 1) re-parses this edit as well (round 4 served the stale sidecar here: the sampled hash alone misses it)
+    got, _, s = api.surface_open(path, 1, 1, 0, 2, cache=1)
+    assert s == 1
     ref, _ = api.surface_read(path, 1, 1, 0, 2)
     assert all(np.array_equal(got[k], ref[k]) for k in synth.CELL_FIELDS)
+    _, _, s = api.surface_open(path, 1, 1, 0, 2, cache=1)
+    assert s == 2
+    _, _, s = api.surface_open(path, 1, 1, 0, 2, cache=2)   # a sidecar written without the whole-file hash does not satisfy cache = 2
+    assert s == 1
     _, _, s = api.surface_open(path, 1, 1, 0, 2, cache=2)
+    assert s == 2
+    # a copy of the text WITH its sidecar (another inode): re-parsed once, the safe direction
+    import shutil
+    path2 = str(tmp_path / "copy.dat")
+    shutil.copy2(path, path2)
+    shutil.copy2(side, path2 + ".is3dcache")
+    _, _, s = api.surface_open(path2, 1, 1, 0, 2)
+    assert s == 1
+    _, _, s = api.surface_open(path2, 1, 1, 0, 2)
     assert s == 2
     # (d) a truncated or foreign sidecar is ignored and replaced
     blob = open(side, "rb").read()
@@ -636,6 +649,16 @@ def test_surface_sidecar_cache_and_its_invalidation_rules(tmp_path, monkeypatch)
     open(side, "wb").write(b"not a cache")
     _, _, s = api.surface_open(path, 1, 1, 0, 2)
     assert s == 1
+    # a header whose n_cells makes popcount(mask) * n_cells * 8 wrap around 2^64 to the file's own length: bounded before it is multiplied,
+    # ignored like any other unusable sidecar (round 4: the size check passed and vector::resize threw through the C ABI)
+    import struct
+    blob = bytearray(open(side, "rb").read())
+    n_here, = struct.unpack_from("<q", blob, 64)
+    assert n_here == 6000
+    struct.pack_into("<q", blob, 64, n_here + (1 << 61))
+    open(side, "wb").write(blob)
+    got, _, s = api.surface_open(path, 1, 1, 0, 2)
+    assert s == 1 and len(got["tau"]) == 6000
     # (e) size changed (a row appended)
     with open(path, "ab") as f:
         f.write(open(path, "rb").readline())
