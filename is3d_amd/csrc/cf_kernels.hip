@@ -1624,6 +1624,259 @@ int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon)
 int tile3e_stream_slack_doubles(int JT, int R) { return 16 * (unit_rec_doubles(JT, R, 1) + kE2Stride * JT) + 128; }
 
 // ------------------------------------------------------------------------------------------------
+// cf_main_tile3s (variant 9, round 5; DEVELOPER BUILD ONLY -- measured and dropped): cf_main_tile3e<MODE 1> with the unit records on the SCALAR path.
+// Every operand of a unit record is wave-uniform, yet in cf_main_tile3e it travels global -> LDS (direct-to-LDS pieces, ~200 cycles of issue each) ->
+// ds_read_b128 -> VGPRs behind a per-batch barrier: 5.2 % of the wave cycles go to issuing the staging loads and 8.3 % to the barrier that pairs two
+// waves of unequal work (profiles/r05_cycle_accounting_tile3e.log).  Here a workgroup is ONE wave that reads its record stream through the constant
+// address space (s_load_dwordx2 ... x16 into SGPRs, the scalar cache in front of the XCD's L2) and feeds the values to the fp64 instructions as their one
+// scalar source: no LDS image of the records, no staging instruction, no barrier, no readfirstlane.
+//   * unit bounds {Dmax, Cmin} are loaded two units ahead, a unit's liveness is decided one unit ahead, and only a live unit's C'_k (row tests) and
+//     E2 column (the lane's 8 table entries, plain global loads into VGPRs -- the table is the one lane-dependent stream) are fetched, one unit ahead;
+//   * a row's scalars are consumed into VGPR values at the head of the row (m_T A, m_T C', the 8 quadratic forms) and the NEXT live row's are
+//     requested right behind that: one 22-SGPR set, a whole row (~1100 cycles) of cover, one lgkmcnt(0) per row (scalar loads return out of order);
+//   * the header (B_j, D'_j, gamma_j) is requested at the head of a live unit, in front of the row tests that cover most of its latency.
+// tools/ubench_smem.hip (profiles/r05_ubench_smem.log) had measured the bare row loop fed this way against the same loop fed from LDS-resident rows:
+// + 1 % (L2-resident streams) to + 3-6 % (HBM-resident), against the 13.5 % above.  THE KERNEL: 120.4 against 100.2 ms per 3e5 cells x 305 species
+// (237.7 against 201.0 with culling off), spectrum equal to 1.1e-14 (profiles/r05_ab_tile3s.log).  Why, from the ISA:
+//   * the SGPR file (102) cannot hold the row in flight (22) + gamma_j of the unit (16) + the next live unit's C'_k (14) + two sets of bounds (8) +
+//     addresses and counters (~16) + the constants of the row exponential (26, which the register allocator keeps resident): gamma_j is spilled to the
+//     lanes of a VGPR and comes back through 16 v_readlane_b32 in EVERY row -- VALU slots, 12 % of a row's ~130;
+//   * a load from the constant address space is rematerialisable: left alone the compiler re-issues the gamma_j loads in every row with an
+//     lgkmcnt(0) behind them, which also waits for the next row's request (the asm pin below stops that, and produces the spill above);
+//   * 256 VGPRs are needed anyway (a second E2 column for the unit ahead replaces the row operands), two accumulators' worth spill to scratch.
+// Holding gamma_j as lane products costs the 16 VGPRs that are not there; building the exponential's constants per use costs 26 SALU instructions per
+// live row.  Each way out costs the few per cent the scheme could gain: dropped, kept in the developer build (kernel_variant = 9) for A/B.
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) double cdouble;
+
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R>
+__global__ void __launch_bounds__(512)   // launched with 64 threads; the bound keeps the register budget at two waves per SIMD (256 VGPRs)
+cf_main_tile3s(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
+               const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
+               double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
+               const double *__restrict__ cull_floor)
+{
+    constexpr int HDR = 4 * JT, RS = 4, RW = RS + JT, REC = HDR + R * RW;
+    constexpr int RB = JT % 4 == 0 ? 4 : (JT % 3 == 0 ? 3 : 2);
+    constexpr int TEREC = kE2Stride * JT;
+    static_assert(JT % RB == 0 && JT % 2 == 0, "phi tile: whole reciprocal batches");
+    // block -> task as cf_main_tile3e with one-wave workgroups: the workgroups of one (phi tile, cell chunk) pair on ONE XCD
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
+    const int grp = q % g.G;
+    const int m = q / g.G;
+    const int kt = m % g.ktiles;
+    const int pair = (m / g.ktiles) * 8 + xcd;
+    if (pair >= g.jtiles * g.nch_run) return;
+    const int jt = pair % g.jtiles;
+    const int chunk = g.ch0 + pair / g.jtiles;
+    if (grp * 64 >= g.Lpad) return;
+    const int l = grp * 64 + (int)threadIdx.x;
+
+    const int J = g.J, K = g.K;
+    const double mT = lane_mT[l], pT = lane_pT[l], sign = lane_sign[l];
+    const int tabrow = lane_ipT[l];
+    const double hs = REG ? 0.5 : 1.0;
+    const double mT2s = hs * mT * mT, mTpTs = hs * mT * pT, pT2s = hs * pT * pT;
+    int c0, c1;
+    chunk_cells(g, chunk, c0, c1);
+    const int n_units = c1 - c0;
+    const int s_tile = jt * g.ktiles + kt;
+    cdouble *S = (cdouble *)(TS + ((int64_t)s_tile * g.n_cells + c0) * REC);
+    const double *te = TE + ((int64_t)jt * g.n_cells + c0) * TEREC + tabrow;
+
+    constexpr int NACC = JT * R;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+    int n_rows = 0, n_dead = 0;
+    constexpr bool RELCULL = OUTFLOW && REG;
+    const double thr_floor = (RELCULL && cull_floor && g.zskip == 2) ? cull_floor[(int64_t)s_tile * g.Lpad + l] : -745.2;
+    double cull_thr = thr_floor;
+    const int pe = (RELCULL && lane_pe) ? lane_pe[l] : 0;
+    asm volatile("" :: "v"(mT), "v"(pT), "v"(sign), "v"(mT2s), "v"(mTpTs), "v"(pT2s), "v"(tabrow), "v"(cull_thr) : "memory");   // the lane constants have arrived
+
+    auto unit_live = [&](double dmaxv, double cminv) -> bool {
+        const double eu = __dsub_rn(__dmul_rn(pT, dmaxv), __dmul_rn(mT, cminv));       // the unit-level cull of cf_main_tile3e
+        // (readfirstlane: the vote is wave-uniform by construction, this tells the compiler -- branches on it are scalar, values set under them stay in SGPRs)
+        return !(g.zskip && __builtin_amdgcn_readfirstlane((int)__all(eu < cull_thr)));
+    };
+    struct RowS { double A, C, al, be[JT]; };
+    auto load_row = [&](cdouble *U, int r) -> RowS {
+        cdouble *p = U + HDR + r * RW;
+        RowS o;
+        o.A = p[0]; o.C = p[1]; o.al = p[2];
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) o.be[jj] = p[RS + jj];
+        return o;
+    };
+
+    // SGPR budget (102): gamma_j of the unit 16, the row in flight 22, the next live unit's C'_k 14, bounds 8, addresses and counters ~16; the
+    // exponential's constants are rematerialised where they do not fit.  VGPRs: 112 accumulators, 16 + 16 E2 columns (this unit, next live unit),
+    // pT B_j and pT D'_j 32, the row's 8 quadratic forms 16, lane constants 14, the reciprocal batch ~36.
+    double E2[JT], E2n[JT], cn[R];
+    double dmax_cur = 0.0, dmax_nxt = 0.0, cmin_nxt = 0.0;
+    bool live_cur = false, live_nxt = false;
+    auto fetch_cn = [&](int u) {
+        cdouble *U = S + (int64_t)u * REC;
+#pragma unroll
+        for (int r = 0; r < R; r++) cn[r] = U[HDR + r * RW + 1];
+    };
+    auto fetch_e2n = [&](int u) {
+        const double *t = te + (int64_t)u * TEREC;
+#pragma unroll
+        for (int jj = 0; jj < JT; jj++) E2n[jj] = t[jj * kE2Stride];
+    };
+    // what is requested one unit ahead, issued where the SGPRs for it are free: the bounds of unit u + 2 and, if unit u + 1 is live, its C'_k and E2 column
+    auto request_ahead = [&](int u) {
+        if (u + 2 < n_units) { cdouble *U2 = S + (int64_t)(u + 2) * REC; dmax_nxt = U2[3]; cmin_nxt = U2[7]; }
+        if (live_nxt) { fetch_cn(u + 1); fetch_e2n(u + 1); }
+    };
+    auto refresh_threshold = [&]() {
+        double mn = acc[0];
+#pragma unroll
+        for (int i = 1; i < NACC; i++) mn = __builtin_fmin(mn, acc[i]);
+        const int e = __builtin_amdgcn_frexp_exp(mn);
+        cull_thr = (mn > 1.0e-290) ? __builtin_fmax(thr_floor, (double)(e - 58 - pe) * 0.6931471805599453) : thr_floor;
+    };
+    if (n_units > 0) {
+        dmax_cur = S[3];
+        const double cmin_cur = S[7];
+        live_cur = unit_live(dmax_cur, cmin_cur);
+        if (live_cur) {
+            fetch_cn(0);
+            const double *t = te;
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) E2[jj] = t[jj * kE2Stride];
+        }
+        if (n_units > 1) { cdouble *U1 = S + REC; dmax_nxt = U1[3]; cmin_nxt = U1[7]; }
+    }
+    for (int u = 0; u < n_units; u++) {
+        cdouble *U = S + (int64_t)u * REC;
+        // liveness of unit u + 1: its bounds were requested during unit u - 1
+        const double dmax_u1 = dmax_nxt;
+        live_nxt = (u + 1 < n_units) && unit_live(dmax_nxt, cmin_nxt);
+        if (live_cur) {
+            // header: B_j, D'_j become lane values, gamma_j stays scalar for the unit's rows; requested in front of the row tests, which cover most of the latency
+            double hB[JT], hD[JT], hG[JT];
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) { hB[jj] = U[4 * jj + 0]; hD[jj] = U[4 * jj + 1]; hG[jj] = U[4 * jj + 2]; }
+            // gamma_j must STAY in its SGPR pair through the rows: a load from the constant address space is rematerialisable, and the compiler otherwise
+            // re-issues it in every row with an lgkmcnt(0) behind it -- which also waits for the next row's request
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) asm volatile("" : "+s"(hG[jj]));
+            __builtin_amdgcn_sched_barrier(0);
+            const double bmax = __dmul_rn(pT, dmax_cur);
+            unsigned live = (1u << R) - 1u;
+            if (g.zskip) {
+                live = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double earg = bmax - mT * cn[r];
+                    live |= __all(earg < cull_thr) ? 0u : (1u << r);
+                }
+            }
+            live = __builtin_amdgcn_readfirstlane(live);
+            n_rows += R;
+            n_dead += R - __builtin_popcount(live);
+            __builtin_amdgcn_sched_barrier(0);
+            RowS ro = load_row(U, live ? __builtin_ctz(live) : 0);      // cn is dead from here on
+            double pTB[JT], pTD[JT];
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) {
+                pTB[jj] = pT * hB[jj];
+                pTD[jj] = pT * hD[jj];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            request_ahead(u);                                            // into the SGPRs the header and cn have left
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (live & (1u << r)) {
+                    // the row's scalars become lane values at its head ...
+                    const double mTC = mT * ro.C;
+                    const double mTA = mT * ro.A;
+                    const double mT2a = mT2s * ro.al;
+                    double br[JT];
+#pragma unroll
+                    for (int jj = 0; jj < JT; jj++) br[jj] = __builtin_fma(mTpTs, ro.be[jj], __builtin_fma(pT2s, hG[jj], mT2a));
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ... and the next live row's are requested into the same SGPRs, a whole row ahead of their use
+                    const unsigned rest = live >> (r + 1);
+                    if (rest) ro = load_row(U, r + 1 + __builtin_ctz(rest));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double E1 = exp_p9(bmax - mTC);
+#pragma unroll
+                    for (int j0 = 0; j0 < JT; j0 += RB) {
+                        double zv[RB], qq[RB], inv[RB];
+#pragma unroll
+                        for (int i = 0; i < RB; i++) {
+                            const double z = E1 * E2[j0 + i];
+                            if (CE) {
+                                const double x = mTC - pTD[j0 + i];
+                                zv[i] = z * x;
+                                qq[i] = __builtin_fma(sign, zv[i], x);
+                            } else {
+                                zv[i] = z;
+                                qq[i] = __builtin_fma(sign, z, 1.0);
+                            }
+                        }
+                        rcp_batch<RB>(qq, inv);
+#pragma unroll
+                        for (int i = 0; i < RB; i++) {
+                            const int jj = j0 + i;
+                            const double pds = OUTFLOW ? add_clamp01(mTA, pTB[jj]) : (mTA + pTB[jj]);
+                            const double dfr = inv[i];
+                            const double uu = REG ? fma_clamp01_half(dfr, br[jj]) : __builtin_fma(dfr, br[jj], 1.0);
+                            const double w = (zv[i] * dfr) * uu;
+                            acc[jj * R + r] = __builtin_fma(pds, w, acc[jj * R + r]);
+                        }
+                    }
+                }
+            }
+        } else {
+            n_rows += R;
+            n_dead += R;
+            request_ahead(u);
+        }
+        // the threshold follows log2 of the accumulators: refreshed on cf_main_tile3e's schedule (its 6-unit batches 0, 1, 3, 7, 15, ... and every 64th)
+        if (RELCULL && g.zskip == 2 && (u % 6) == 5) {
+            const int ib = u / 6;
+            if (((ib + 1) & ib) == 0 || (ib & 63) == 63) refresh_threshold();
+        }
+        live_cur = live_nxt;
+        dmax_cur = dmax_u1;
+        if (live_nxt) {
+#pragma unroll
+            for (int jj = 0; jj < JT; jj++) E2[jj] = E2n[jj];
+        }
+    }
+
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2], (unsigned long long)n_rows);
+        atomicAdd(&stats[3], (unsigned long long)min(n_dead, n_rows));
+    }
+    const double unscale = REG ? 2.0 : 1.0;
+    const int64_t JKacc = (int64_t)J * g.Kacc;
+    double *pp = partial + (int64_t)chunk * JKacc * g.Lpad;
+#pragma unroll
+    for (int jj = 0; jj < JT; jj++) {
+        const int j = jt * JT + jj;
+        if (j < J) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int k = kt * R + r;
+                if (k < K) {
+                    double *o = pp + ((int64_t)j * g.Kacc + k) * g.Lpad + l;
+                    const double v = unscale * acc[jj * R + r];
+                    *o = g.first_pass ? v : (*o + v);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // cf_finalize: out[sp + npart*(ipT + npT*(j + J*k))] (smooth_kernels.cpp:363)
 //              (+)= prefactor * degeneracy[sp] * sum_chunks partial[chunk][j*Kacc + k][class(sp)*npT + ipT]
 // ------------------------------------------------------------------------------------------------
@@ -1758,7 +2011,7 @@ constexpr int kTile7JT = 8, kTile7R = 31;   // variant 7 (2+1D)
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
     if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
-    if (variant == 5 || variant == 6) variant = 3;   // same tile, E2 table stream
+    if (variant == 5 || variant == 6 || variant == 9) variant = 3;   // same tile, E2 table stream
     if (variant == 7 || variant == 8) {
         if (!dim3) { *JT = kTile7JT; *KT = kTile7R; return; }
         variant = 3;
@@ -1806,8 +2059,18 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
         if (variant == 5 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1]>(a, st); return; }
         if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1>(a, st); return; }
         if ((variant == 5 || variant == 6) && a.TE && a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, true>(a, st); return; }
+        if constexpr (kDevBuild)   // measured and dropped (profiles/r05_ab_tile3s.log: 120.4 against 100.2 ms): exists in the developer build only
+        if (variant == 9 && a.TE && !a.g.baryon && a.g.wpb == 1) {   // cf_main_tile3s: one-wave workgroups, no LDS
+            MainArgs b = a;
+            if (b.g.nch_run <= 0) { b.g.ch0 = 0; b.g.nch_run = b.g.nch; }
+            const int pairs = b.g.jtiles * b.g.nch_run;
+            const int grid = ((pairs + 7) / 8) * 8 * b.g.ktiles * b.g.G;
+            hipLaunchKernelGGL((cf_main_tile3s<CE, OF, RG, kTileJT3[1], kTileR3[1]>), dim3(grid), dim3(64), 0, st, b.TS, b.TE, b.lane_mT, b.lane_pT, b.lane_sign,
+                               b.lane_ipT, b.partial, b.stats, b.g, b.lane_pe, b.cull_floor);
+            return;
+        }
     }
-    if (variant == 5 || variant == 6) variant = 3;
+    if (variant == 5 || variant == 6 || variant == 9) variant = 3;
     if constexpr (!DIM3) {
         // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
         if (variant == 7) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
@@ -1884,7 +2147,10 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
     return hipGetLastError();
 }
 
-const char *main_kernel_name(int variant) { return variant == 1 ? "cf_main_direct" : ((variant == 5 || variant == 6) ? "cf_main_tile3e" : "cf_main_tile"); }
+const char *main_kernel_name(int variant)
+{
+    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6) ? "cf_main_tile3e" : "cf_main_tile");
+}
 
 // ------------------------------------------------------------------------------------------------
 // Derived observables from the device-resident spectrum: what the reference's writers

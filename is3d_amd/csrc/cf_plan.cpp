@@ -213,7 +213,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // (modified equilibrium in 3+1D: 8 x 7 with or without the baryon slots -- its records do not grow with them; 247.1 against 260.5 ms for 6 x 7 per 3e5 cells)
     int default_variant = (plain3 || (fq && o->dimension == 3)) ? 3 : 2;
     if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
-    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 8) ? o->kernel_variant : default_variant;
+    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 9) ? o->kernel_variant : default_variant;
     // modified equilibrium in 2+1D: variant 7 (8 x 31 tile, unit-strided lanes, rows tested against the unit's threshold from the beta minimum
     // they carry) is the default since round 4; variants 2-4 keep the round-1 row walk on the 61-row tiles for A/B
     if (fq && o->dimension == 2 && !(o->kernel_variant >= 2 && o->kernel_variant <= 4)) P->variant = 7;
@@ -224,8 +224,10 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // (modified equilibrium in 3+1D: variants 5 and 6 are A/B forms of its 8 x 7 kernel -- rows pipelined as in round 1 / row mask with the exact
     // per-row thresholds, cf_feqmod.hip -- without baryon slots)
     const bool fq56 = fq && plain3;
+    // variant 9 (round 5, developer build): cf_main_tile3s, the E2-table kernel with its unit records on the scalar path -- 3+1D delta-f without baryon slots only
+    if (P->variant == 9 && !(e2ok && plain3 && is3d::kDevBuild)) P->variant = default_variant;   // measured and dropped: the developer build keeps it for A/B
     if ((P->variant == 5 || P->variant == 6) && !e2ok && !fq56) P->variant = (fq || !plain3) ? default_variant : 3;
-    P->e2tab = (P->variant == 5 || P->variant == 6) && e2ok;
+    P->e2tab = (P->variant == 5 || P->variant == 6 || P->variant == 9) && e2ok;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
@@ -249,7 +251,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // idle lanes with S = 1, 384 = 6 full waves with S = 4); S must divide the units per cell and the units per LDS batch (4)
     P->split = 1;
     // default in 2+1D: the 8 x 31 tile, with or without extra lane slots (305 species, one slot per bin: 96.0 against 101.0 ms for 8 x 61 per 2e4 cells)
-    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8)) P->variant = 7;
+    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8)) P->variant = 7;   // (9 is 3+1D only)
     if (P->variant == 7 || P->variant == 8) P->split = split_for(P->Lbins);
     if (fq && o->dimension == 2 && P->variant != 7) {
         // modified equilibrium, 2+1D, the 61-row tiles (A/B): the same lane slots on the kernel's own tile -- S = 2 when it divides the units per cell and
@@ -480,6 +482,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             }
             if (o->waves_per_group == 2 || o->waves_per_group == 4 || o->waves_per_group == 8) P->wpb = o->waves_per_group;
             if (o->waves_per_group == 1 && P->e2tab) P->wpb = 1;   // cf_main_tile3e: one-wave workgroups (no barrier partner)
+            if (P->variant == 9) P->wpb = 1;                       // cf_main_tile3s: a workgroup IS one wave
             // cf_main_feqmod, 3+1D 8 x 7 without baryon slots: one-wave workgroups (cf_feqmod.hip, LDSD); the pipelined A/B form (variant 5) keeps two
             // -- the default there since round 4 (486 against 501 ms on the config-3 surface, profiles/r04_ab_feqmod.log); waves_per_group = 2 keeps the pair
             if (P->feqmod && P->dim3 && (P->variant == 3 || P->variant == 6) && (o->waves_per_group == 1 || o->waves_per_group == 0)) P->wpb = 1;

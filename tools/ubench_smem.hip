@@ -62,8 +62,9 @@ __global__ void __launch_bounds__(512) k(const double *streams, int rows, int re
 #pragma unroll
         for (int i = 0; i < ROWD; i++) op[i] = S[i];
         for (int r = 0; r < rows; r++) {
+#pragma unroll
+            for (int i = 0; i < ROWD; i++) asm volatile("" : "+s"(op[i]));   // opaque per row: the loop-invariant work must not be hoisted
             row_work<FPE>(acc, op, x, y);
-            asm volatile("" : "+v"(acc[0]));
         }
     } else if (MODE == 1) {
         for (int r = 0; r < rows; r++) {
