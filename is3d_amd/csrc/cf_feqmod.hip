@@ -1073,7 +1073,11 @@ static void launch_fq_variant(int variant, const FqMainArgs &a, hipStream_t st)
     // tile shapes of main_tile_shape (cf_kernels.hip): variants 2, 3, 4 (3+1D: rows walked by the row mask from the unit threshold, ROWS = 2:
     // 499 against 558 ms on the config-3 surface, profiles/r04_ab_feqmod.log); variants 5 and 6 are the 8 x 7 tile of variant 3 with ROWS = 0 (the
     // pipelined round-1 form) resp. ROWS = 1 (row mask + the exact per-row thresholds: the culled set of ROWS = 0, 541 ms) for A/B
-    if constexpr (DIM3) {
+    // The shipped library holds the defaults (3+1D: 3, 2+1D: 7; the plan maps every other request onto them); the other forms are developer-build A/B.
+    if constexpr (!kDevBuild) {
+        if constexpr (DIM3) launch_fq_t<DIM3, OF, M3, 8, 7, 2>(a, st);
+        else launch_fq_t<DIM3, OF, M3, 8, 31, 3>(a, st);
+    } else if constexpr (DIM3) {
         switch (variant) {
         case 3: launch_fq_t<DIM3, OF, M3, 8, 7, 2>(a, st); break;
         case 5: launch_fq_t<DIM3, OF, M3, 8, 7, 0>(a, st); break;

@@ -2054,12 +2054,19 @@ static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
 template <bool CE, bool DIM3, bool OF, bool RG>
 static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
 {
+    // The shipped library holds the kernels a default path of the plan reaches (cf_plan.cpp maps every other request onto them):
+    //   3+1D: 6 -- cf_main_tile3e<MODE 1>, with or without baryon slots (pT grids of up to 32 values); 3 -- the 8 x 7 tile without the E2 stream
+    //         (larger pT grids, no baryon slots); 2 -- the 6 x 7 tile (larger pT grids with baryon slots);   2+1D: 7 -- the 8 x 31 tile.
+    // The other variants (1 direct, 2 / 4 other tile shapes, 5 hand-pipelined rows, 8 register-staged copy, 9 scalar path) are A/B forms of rounds
+    // 1-5: developer build only (make DEV=1 -> is3d_amd/lib_dev), where their parity tests run (tests/test_gpu_devlib.py).
     if constexpr (DIM3) {
-        // variant 5: the 8 x 7 tile with the E2 table stream (the plan only sets TE up for 3+1D without baryon slots)
-        if (variant == 5 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1]>(a, st); return; }
+        if constexpr (kDevBuild) {
+            // variant 5: the 8 x 7 tile with the E2 table stream, rows hand-pipelined (the plan only sets TE up for 3+1D)
+            if (variant == 5 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1]>(a, st); return; }
+        }
         if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1>(a, st); return; }
         if ((variant == 5 || variant == 6) && a.TE && a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, true>(a, st); return; }
-        if constexpr (kDevBuild)   // measured and dropped (profiles/r05_ab_tile3s.log: 120.4 against 100.2 ms): exists in the developer build only
+        if constexpr (kDevBuild)   // measured and dropped (profiles/r05_ab_tile3s.log: 120.4 against 100.2 ms)
         if (variant == 9 && a.TE && !a.g.baryon && a.g.wpb == 1) {   // cf_main_tile3s: one-wave workgroups, no LDS
             MainArgs b = a;
             if (b.g.nch_run <= 0) { b.g.ch0 = 0; b.g.nch_run = b.g.nch; }
@@ -2073,17 +2080,24 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
     if (variant == 5 || variant == 6 || variant == 9) variant = 3;
     if constexpr (!DIM3) {
         // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
-        if (variant == 7) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
-        if (variant == 8) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R, false, false>(a, st); return; }
+        if (variant == 7 || !kDevBuild) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
+        if constexpr (kDevBuild) {
+            if (variant == 8) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R, false, false>(a, st); return; }
+        }
     }
     if (variant == 7 || variant == 8) variant = 3;
-    switch (variant) {
-    case 1: launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st); break;
-    // 8 x 7 in 3+1D: its 56 accumulators leave no room to prefetch whole rows (54 VGPRs spill, 180 GB of scratch traffic per
-    // config-3 launch): row operands are read when the row is evaluated (LAZY) -- 8 spills, and 0.7 % faster besides
-    case 3: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[1] : kTileJT2[1]), (DIM3 ? kTileR3[1] : kTileR2[1]), DIM3>(a, st); break;
-    case 4: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[2] : kTileJT2[2]), (DIM3 ? kTileR3[2] : kTileR2[2])>(a, st); break;
-    default: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[0] : kTileJT2[0]), (DIM3 ? kTileR3[0] : kTileR2[0])>(a, st); break;
+    if constexpr (kDevBuild) {
+        switch (variant) {
+        case 1: launch_direct_t<CE, DIM3, OF, RG, (DIM3 ? kV1KT3 : kV1KT2)>(a, st); break;
+        // 8 x 7 in 3+1D: its 56 accumulators leave no room to prefetch whole rows (54 VGPRs spill, 180 GB of scratch traffic per
+        // config-3 launch): row operands are read when the row is evaluated (LAZY) -- 8 spills, and 0.7 % faster besides
+        case 3: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[1] : kTileJT2[1]), (DIM3 ? kTileR3[1] : kTileR2[1]), DIM3>(a, st); break;
+        case 4: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[2] : kTileJT2[2]), (DIM3 ? kTileR3[2] : kTileR2[2])>(a, st); break;
+        default: launch_tile_t<CE, DIM3, OF, RG, (DIM3 ? kTileJT3[0] : kTileJT2[0]), (DIM3 ? kTileR3[0] : kTileR2[0])>(a, st); break;
+        }
+    } else if constexpr (DIM3) {
+        if (variant == 3) launch_tile_t<CE, true, OF, RG, kTileJT3[1], kTileR3[1], true>(a, st);   // 8 x 7, rows read when evaluated (LAZY)
+        else launch_tile_t<CE, true, OF, RG, kTileJT3[0], kTileR3[0]>(a, st);                      // 6 x 7 (baryon slots, pT grids of more than 32 values)
     }
 }
 

@@ -214,9 +214,15 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     int default_variant = (plain3 || (fq && o->dimension == 3)) ? 3 : 2;
     if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
     P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 9) ? o->kernel_variant : default_variant;
+    // The shipped library holds the kernels the defaults reach (cf_kernels.hip::launch_variant, cf_feqmod.hip): any other request runs the default --
+    // status.kernel_variant says which one ran.  One explicit choice is honoured: the 8 x 7 tile without the E2 table stream (3) for a 3+1D delta-f
+    // surface without baryon slots, which is also the default for pT grids of more than 32 values.  The A/B forms of rounds 1-5 (1, 2, 4, 5, 8, 9; the
+    // modified-equilibrium row walks 5, 6 and 61-row tiles) exist in the developer build (make DEV=1), where tests/test_gpu_devlib.py runs their parity tests.
+    const bool ab_variants = is3d::kDevBuild;
+    if (!ab_variants && !(!fq && plain3 && P->variant == 3)) P->variant = default_variant;
     // modified equilibrium in 2+1D: variant 7 (8 x 31 tile, unit-strided lanes, rows tested against the unit's threshold from the beta minimum
     // they carry) is the default since round 4; variants 2-4 keep the round-1 row walk on the 61-row tiles for A/B
-    if (fq && o->dimension == 2 && !(o->kernel_variant >= 2 && o->kernel_variant <= 4)) P->variant = 7;
+    if (fq && o->dimension == 2 && !(ab_variants && o->kernel_variant >= 2 && o->kernel_variant <= 4)) P->variant = 7;
     if ((P->variant == 7 || P->variant == 8) && o->dimension == 3) P->variant = default_variant;
     if (P->variant == 8 && fq) P->variant = 7;
     if (P->variant == 8 && o->include_baryon) P->variant = 7;   // variant 8 = variant 7 with the register-staged copy (A/B), without baryon slots only   // unit-strided lanes: the 2+1D delta-f tile kernel
@@ -251,7 +257,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // idle lanes with S = 1, 384 = 6 full waves with S = 4); S must divide the units per cell and the units per LDS batch (4)
     P->split = 1;
     // default in 2+1D: the 8 x 31 tile, with or without extra lane slots (305 species, one slot per bin: 96.0 against 101.0 ms for 8 x 61 per 2e4 cells)
-    if (!fq && o->dimension == 2 && !(o->kernel_variant >= 1 && o->kernel_variant <= 8)) P->variant = 7;   // (9 is 3+1D only)
+    if (!fq && o->dimension == 2 && !(ab_variants && o->kernel_variant >= 1 && o->kernel_variant <= 8)) P->variant = 7;   // (9 is 3+1D only)
     if (P->variant == 7 || P->variant == 8) P->split = split_for(P->Lbins);
     if (fq && o->dimension == 2 && P->variant != 7) {
         // modified equilibrium, 2+1D, the 61-row tiles (A/B): the same lane slots on the kernel's own tile -- S = 2 when it divides the units per cell and

@@ -905,7 +905,8 @@ extern "C" int is3d_vah_plan_create(is3d_vah_plan **out, const is3d_species *sp,
     if (o->kernel_variant != 0 && o->kernel_variant != 2 && o->kernel_variant != 3)
         return set_error(IS3D_EINVAL, "VAH kernel_variant %d: 0 (default), 2 (round-1 kernel: 6 x 7 tile in 3+1D, 8 x 61 in 2+1D) or 3 (factored exponent: "
                          "8 x 7 tile in 3+1D, 8 x 31 with unit-strided lanes in 2+1D)", o->kernel_variant);
-    P->fact = o->kernel_variant != 2;
+    // kernel_variant 2 (the round-1 kernel, expanded quadratic form) exists in the developer build for A/B; the shipped library runs cf_main_vah3
+    P->fact = !(is3d::kDevBuild && o->kernel_variant == 2);
     P->JT = three_d ? (P->fact ? kJT3F : kJT3) : (P->fact ? kJT2F : kJT2); P->R = three_d ? (P->fact ? kR3F : kR3) : (P->fact ? kR2F : kR2);
     P->jtiles = (J + P->JT - 1) / P->JT; P->rblocks = (K + P->R - 1) / P->R;
     const int ncls = (int)cmass.size(), Lbins = ncls * npT;
@@ -1089,8 +1090,10 @@ extern "C" int is3d_vah_plan_execute(is3d_vah_plan *P, const is3d_vah_cells *cel
         g.first_pass = 1; g.upc = P->upc; g.zskip = (o.zero_skip != 2); g.baryon = 0; g.split = P->split;
         if (P->fact && P->three_d) launch_vah3<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, nullptr, st);
         else if (P->fact) launch_vah3<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, P->d_lane_sub.as<int32_t>(), st);
+#ifdef IS3D_DEV   // the round-1 kernel (kernel_variant 2): developer build only
         else if (P->three_d) launch_vah<true>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
         else launch_vah<false>(o.regulate_deltaf != 0, P->d_TS.as<double>(), P->d_mT.as<double>(), P->d_pT.as<double>(), P->d_sg.as<double>(), P->d_partial.as<double>(), d_st, g, st);
+#endif
         VAH_TRY(hipGetLastError());
         if (P->timing) VAH_TRY(hipEventRecord(P->ev[pass * 3 + 2], st));
         // each pass finalises into the output (accumulating after the first): the partial slots are rewritten per pass

@@ -14,6 +14,7 @@ REFERENCE = "/root/reference"   # present only in the build container; never rea
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: reads data files under /root/reference (container only)")
+    config.addinivalue_line("markers", "devlib: has work for the developer build of the library too (A/B kernel variants): tests/test_gpu_devlib.py re-runs it there")
     # a fresh checkout has no built library (build products are git-ignored): build it once, as __graft_entry__.build() does
     lib = os.path.join(ROOT, "is3d_amd", "lib", "libis3d_amd.so")
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
@@ -26,6 +27,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "reference" in item.keywords and not os.path.isdir(REFERENCE):
             item.add_marker(skip_ref)
+
+
+def honoured(kind, dim, variants, baryon=False):
+    """The kernel variants of `variants` that the library loaded in THIS process runs as requested.  The shipped library (is3d_amd/lib) holds the
+    kernels the plan's defaults reach -- delta-f: 6 (E2 table stream) and 3 (8 x 7 without it, no baryon slots) in 3+1D, 7 in 2+1D; modified
+    equilibrium ("fq"): 3 in 3+1D, 7 in 2+1D; anisotropic hydro ("vah"): 3 -- and maps every other request onto them; the A/B forms of rounds 1-5
+    exist in the developer build (is3d_amd/lib_dev, IS3D_USE_DEV_LIB=1), where tests/test_gpu_devlib.py re-runs the tests marked `devlib`."""
+    from is3d_amd import api
+    if api.DEV_LIB:
+        return list(variants)
+    if kind == "vah":
+        ok = {0, 3}
+    elif kind == "fq":
+        ok = {0, 3} if dim == 3 else {0, 7}
+    else:
+        ok = ({0, 6} | (set() if baryon else {3})) if dim == 3 else {0, 7}
+    return [v for v in variants if v in ok]
 
 
 def relerr(a, b, floor=1e-280):

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ROOT, relerr
+from conftest import honoured, ROOT, relerr
 from is3d_amd import api, inputs, synth
 from oracle import oracle  # the checker
 
@@ -25,19 +25,21 @@ def fq_for(cells, **kw):
 @pytest.mark.parametrize("dim", [3, 2])
 @pytest.mark.parametrize("df_mode", [3, 4])
 @pytest.mark.parametrize("flags", [dict(), dict(outflow=0, regulate_deltaf=0), dict(include_bulk_deltaf=0), dict(include_shear_deltaf=0)])
+@pytest.mark.devlib
 def test_feqmod_parity_matrix(fx, dim, df_mode, flags):
     cells = synth.synth_surface(70 if dim == 3 else 9, dim, seed=300 + dim)
     sp = inputs.species(SP6) if dim == 3 else fx["pikp"]
     fq = fq_for(cells)
     o = dict(dimension=dim, df_mode=df_mode, **flags)
     ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], fx["df"], fq, o)
-    for variant in (0, 2, 3, 4):   # 0: the default (2+1D: variant 7 -- 8 x 31, unit-strided lanes, rows against the unit threshold)
+    for variant in honoured("fq", dim, (0, 2, 3, 4)):   # 0: the default (2+1D: variant 7 -- 8 x 31, unit-strided lanes, rows against the unit threshold)
         got, st = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=variant), fq=fq)
         assert st["code"] == 0 and st["n_cells_breakdown"] == nb
         assert st["kernel_variant"] == (variant if variant else (3 if dim == 3 else 7))
         assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
 
 
+@pytest.mark.devlib
 def test_feqmod_odd_grids(fx):
     """Grid lengths that are not multiples of the kernel tiles: phi 5, pT 3; 2+1D eta tables of 41, 7, 48 and 100 nodes (one to four row blocks of
     the 8 x 31 tile: the lane slots per bin follow the row blocks), 3+1D rapidity tables of 5 and 29 -- every row walk."""
@@ -53,7 +55,7 @@ def test_feqmod_odd_grids(fx):
         for dfm in (4, 3):
             o = dict(dimension=2, df_mode=dfm)
             ref, nb = oracle.dN_pTdpTdphidy_feqmod(c2, fx["pikp"], gg, fx["df"], fq2, o)
-            for variant in (0, 2, 3, 4):
+            for variant in honoured("fq", 2, (0, 2, 3, 4)):
                 got, st = api.smooth_spectra(c2, fx["pikp"], gg, fx["df"], dict(o, kernel_variant=variant), fq=fq2)
                 assert st["n_cells_breakdown"] == nb and relerr(got, ref) < TOL, (neta, dfm, variant, relerr(got, ref))
     c3 = synth.synth_surface(15, 3, seed=20)
@@ -62,7 +64,7 @@ def test_feqmod_odd_grids(fx):
         gg = dict(g, y=ygrid)
         o = dict(dimension=3, df_mode=4)
         ref, nb = oracle.dN_pTdpTdphidy_feqmod(c3, fx["pikp"], gg, fx["df"], fq3, o)
-        for variant in (0, 2, 4, 5, 6):
+        for variant in honoured("fq", 3, (0, 2, 4, 5, 6)):
             got, st = api.smooth_spectra(c3, fx["pikp"], gg, fx["df"], dict(o, kernel_variant=variant), fq=fq3)
             assert st["n_cells_breakdown"] == nb and relerr(got, ref) < TOL, (len(ygrid), variant, relerr(got, ref))
 
@@ -204,7 +206,7 @@ def test_feqmod_with_baryon_parity(fx, dim, flags):
     o = dict(dimension=dim, df_mode=3, include_baryon=1, **flags)
     ref, nb = oracle.dN_pTdpTdphidy_feqmod(cells, sp, fx["grid"], dff, fq, o)
     assert (nb > 0) == bool(flags.get("include_bulk_deltaf", 1))
-    for variant in (2, 3):
+    for variant in (honoured("fq", dim, (2, 3)) or [0]):
         got, st = api.smooth_spectra(cells, sp, fx["grid"], dff, dict(o, kernel_variant=variant), fq=fq)
         assert st["code"] == 0 and st["n_cells_breakdown"] == nb
         assert relerr(got, ref) < TOL, (variant, relerr(got, ref))
@@ -218,6 +220,7 @@ def test_feqmod_with_baryon_parity(fx, dim, flags):
         assert e.value.code == -3 and "cell 3" in str(e.value)
 
 
+@pytest.mark.devlib
 def test_feqmod_row_culling_changes_no_bit_2d(fx):
     cells = synth.synth_surface(120, 2, seed=89)
     sp = inputs.species("urqmd")
@@ -231,14 +234,17 @@ def test_feqmod_row_culling_changes_no_bit_2d(fx):
     assert st0["kernel_variant"] == 7
     # the round-1 row walk on the 8 x 61 tile (a threshold and a minimum per row): the same spectrum to rounding, and no fewer rows culled than a
     # tenth below it (the unit threshold is the looser one)
-    old, so = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0, kernel_variant=2), fq=fq)
-    assert relerr(rel, old) < 1e-12
-    assert st0["n_wave_rows_culled"] / st0["n_wave_rows"] > 0.9 * so["n_wave_rows_culled"] / so["n_wave_rows"]
+    if api.DEV_LIB:
+        old, so = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, zero_skip=0, kernel_variant=2), fq=fq)
+        assert relerr(rel, old) < 1e-12
+        assert st0["n_wave_rows_culled"] / st0["n_wave_rows"] > 0.9 * so["n_wave_rows_culled"] / so["n_wave_rows"]
     # few momentum bins (pi, K, p: 96 bins, four lane slots per bin, each on its own unit): culling on / off, same bits
     a4, s4 = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=0), fq=fq)
     b4, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=2), fq=fq)
-    c4, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=2, kernel_variant=2), fq=fq)
-    assert np.array_equal(a4, b4) and relerr(a4, c4) < 1e-12 and s4["kernel_variant"] == 7
+    assert np.array_equal(a4, b4) and s4["kernel_variant"] == 7
+    if api.DEV_LIB:
+        c4, _ = api.smooth_spectra(cells, fx["pikp"], fx["grid"], fx["df"], dict(o, zero_skip=2, kernel_variant=2), fq=fq)
+        assert relerr(a4, c4) < 1e-12
 
 
 @pytest.mark.parametrize("df_mode", [4, 3])
@@ -280,6 +286,7 @@ def test_feqmod_argument_errors(fx):
 
 
 @pytest.mark.parametrize("df_mode", [4, 3])
+@pytest.mark.devlib
 def test_feqmod_config3_size_stratified_oracle_sample_and_row_walks(fx, df_mode):
     """The modified-equilibrium kernel at BASELINE config-3 size (df_mode 4 is the reference's shipped default): a 60 000-cell slice of the 1e6-cell
     surface x 305 species through the default kernel (3+1D: row mask against the unit threshold, one-wave workgroups) against the oracle on a
@@ -313,8 +320,11 @@ def test_feqmod_config3_size_stratified_oracle_sample_and_row_walks(fx, df_mode)
     assert np.array_equal(off, got) and st_off["n_wave_rows_culled"] == 0
     pair, st_pair = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, waves_per_group=2), fq=fq)
     assert np.array_equal(pair, got)                                     # the batch size moves the threshold refresh, not a bit of the result
+    if not api.DEV_LIB:
+        return                                                           # the other two row walks exist in the developer build
     v5, st5 = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5), fq=fq)
     v6, st6 = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=6, waves_per_group=2), fq=fq)
+    assert st5["kernel_variant"] == 5 and st6["kernel_variant"] == 6
     assert np.array_equal(v5, v6) and st5["n_wave_rows_culled"] == st6["n_wave_rows_culled"] >= st_pair["n_wave_rows_culled"]
     assert relerr(v5, got) < 1e-12
     off5, _ = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, kernel_variant=5, zero_skip=2), fq=fq)

@@ -5,7 +5,7 @@ the tiles, more than 32 rows or pT values, one-element grids, passes over the ce
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import honoured, relerr
 from is3d_amd import api, inputs, synth
 from oracle import oracle  # the checker
 
@@ -33,6 +33,7 @@ def _species(rng, fx):
 
 
 @pytest.mark.parametrize("case", range(60))
+@pytest.mark.devlib
 def test_random_configuration_matches_the_oracle(fx, case):
     rng = np.random.default_rng(7000 + case)
     dim = int(rng.choice([3, 3, 2]))
@@ -70,6 +71,7 @@ def test_random_configuration_matches_the_oracle(fx, case):
                                         dict(o, outflow=1, regulate_deltaf=1))
             scale = np.maximum(scale, 1e-4 * (pos + neg))
         variants = [0] + list(rng.choice([2, 3, 4, 5, 6, 7] if baryon else [1, 2, 3, 4, 5, 6, 7], size=2, replace=False))   # variant 1 has no baryon slots
+        variants = [0] + honoured("df", dim, [int(v) for v in variants[1:]], baryon=bool(baryon))   # the shipped library: the ones it holds; all of them in the developer build
         # and the cell-axis split: a random number of shards on the one device sums to the same spectrum
         shards = int(rng.integers(2, 6))
         multi, _, _ = api.smooth_spectra_multi(cells, sp, g, fx["df"], o, devices=[0] * shards)
@@ -83,7 +85,7 @@ def test_random_configuration_matches_the_oracle(fx, case):
         o.update(df_mode=int(rng.choice([3, 4])), outflow=int(rng.random() < 0.75))
         fq = inputs.feqmod_tables(inputs.surface_average_T(cells))
         ref, _ = oracle.dN_pTdpTdphidy_feqmod(cells, sp, g, fx["df"], fq, o)
-        for v in (0, int(rng.choice([2, 3, 4]))):
+        for v in [0] + honoured("fq", dim, [int(rng.choice([2, 3, 4]))]):
             got, st = api.smooth_spectra(cells, sp, g, fx["df"], dict(o, kernel_variant=v, **extra), fq=fq)
             assert relerr(got, ref) < TOL, (case, v, relerr(got, ref), {k: len(x) for k, x in g.items()}, n)
     else:
@@ -92,7 +94,7 @@ def test_random_configuration_matches_the_oracle(fx, case):
         coef, found = oracle.vah_coefficients(tab, cells["Lambda"], cells["aL"])
         assert found.all()
         ref = oracle.dN_pTdpTdphidy_vah(dict(cells, **coef), sp, g, o)
-        for v in (0, 2):
+        for v in honoured("vah", dim, (0, 2)):
             got, st = api.smooth_spectra_vah(cells, sp, g, dict(o, kernel_variant=v, **extra), tab=tab)
             assert relerr(got, ref, floor=1e-270) < TOL, (case, v, relerr(got, ref, floor=1e-270), {k: len(x) for k, x in g.items()}, n)
 

@@ -49,3 +49,17 @@ def test_isa_counts_are_read_from_the_isa_and_sane():
     # BASELINE config 3's kernel
     k3 = d["cf_main_tile3e:CE=1,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1"]
     assert k3["evals_in_loop"] == 56 and k3["evals_per_rcp"] == 4
+    # round 5: spills are accounted for -- no scratch instruction inside the counted loop of any kernel a default path launches (one there sits on the
+    # critical path of every unit; the ones outside the loop park lane constants in the prologue / epilogue, once per wave)
+    defaults = ["cf_main_tile3e:CE=1,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1", "cf_main_tile3e:CE=0,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1",
+                "cf_main_tile3e_baryon:CE=1,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1", "cf_main_tile3e_baryon:CE=0,OUTFLOW=1,REG=1,JT=8,R=7,MODE=1",
+                "cf_main_tile:CE=0,DIM3=0,OUTFLOW=1,REG=1,BARYON=0,JT=8,R=31", "cf_main_tile:CE=1,DIM3=0,OUTFLOW=1,REG=1,BARYON=0,JT=8,R=31",
+                "cf_main_feqmod:DIM3=1,OUTFLOW=1,MODE3=0,JT=8,R=7,ROWS=2", "cf_main_feqmod:DIM3=1,OUTFLOW=1,MODE3=1,JT=8,R=7,ROWS=2",
+                "cf_main_feqmod:DIM3=0,OUTFLOW=1,MODE3=0,JT=8,R=31,ROWS=3", "cf_main_vah3:DIM3=1,REG=1,JT=8,R=7", "cf_main_vah3:DIM3=0,REG=1,JT=8,R=31"]
+    for k in defaults:
+        assert d[k]["scratch_in_loop"] == 0, (k, d[k]["scratch_in_loop"])
+        assert d[k]["vgprs"] <= 256 and d[k]["occupancy_waves_per_simd"] >= 2, k
+    # cf_main_vah3 in 3+1D kept its 56th accumulator in a scratch slot until round 5 (max_j d_j now rides in an SGPR pair)
+    assert d["cf_main_vah3:DIM3=1,REG=1,JT=8,R=7"]["scratch_in_kernel"] <= 4
+    # the scalar-path experiment of round 5 (developer build): more instructions per evaluation than the kernel it was to replace -- the spilled gamma_j
+    assert d["cf_main_tile3s:CE=1,OUTFLOW=1,REG=1,JT=8,R=7"]["valu_f64_instr_per_eval"] >= k3["valu_f64_instr_per_eval"]

@@ -46,6 +46,8 @@ def demangle_params(sym):
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R", "LAZY", "DMA"]
     elif name == "cf_main_tile3e":
         keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON"]
+    elif name == "cf_main_tile3s":
+        keys = ["CE", "OUTFLOW", "REG", "JT", "R"]
     elif name == "cf_main_feqmod":
         keys = ["DIM3", "OUTFLOW", "MODE3", "JT", "R", "BARYON", "ROWS", "PROF"]
     elif name == "cf_main_vah":
@@ -125,7 +127,9 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         for src in SRCS:
             s_path = os.path.join(td, "k.s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+            # -DIS3D_DEV: the developer build holds every kernel instantiation -- the ones the shipped library launches (identical code: the switch only
+            # gates launchers) and the A/B variants of rounds 1-5 that tools/gpu_ab.py and `IS3D_USE_DEV_LIB=1 bench.py --variant N` still price
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DIS3D_DEV", "-S", "--cuda-device-only",
                                    "-I", os.path.dirname(src), src, "-o", s_path], stderr=subprocess.DEVNULL)
             asm = open(s_path).read()
             text += asm.split("\n")
