@@ -625,3 +625,64 @@ def test_shader_clock_probe():
     assert ghz == 0.0 or 1.0 < ghz < 2.6, ghz
     with pytest.raises(api.Is3dError):
         api.probe_shader_clock(0.0)
+
+
+@pytest.mark.parametrize("df_mode", [2, 1])
+def test_config3_size_include_baryon_stratified_oracle_sample(fx, df_mode):
+    """SURVEY.md 8f rank 1 at BASELINE config-3 size, as `bench.py --include-baryon` runs it: include_baryon = 1 with baryon diffusion on a 60 000-cell
+    slice of the 1e6-cell surface x 305 species (124 classes: the baryon number joins the class key) through cf_main_tile3e<.., BARYON> against the
+    oracle on a stratified sample -- one species of every fourth (mass, sign, baryon) class x 4 pT x 4 phi x all 21 rapidities -- with the bilinear
+    (T, mu_B) coefficients and the b mu_B / T exponent (smooth_kernels.cpp:186-197, :254, :297, :303-321); culling on / off: the same bits."""
+    n = 60000
+    cells = synth.synth_surface(1000000, 3, baryon=True)
+    sl = {k: v[500000:500000 + n] for k, v in cells.items()}
+    sp = fx["urqmd"]
+    dff = inputs.df_tables_full()
+    o = dict(dimension=3, df_mode=df_mode, include_baryon=1, include_baryondiff_deltaf=1)
+    got, st = api.smooth_spectra(sl, sp, fx["grid"], dff, o)
+    assert st["n_classes"] == 124 and st["kernel_variant"] == DEFAULT3 and st["n_wave_rows_culled"] > 0.3 * st["n_wave_rows"]
+    seen, reps = set(), []
+    for s, key in enumerate(zip(sp["mass"], sp["sign"], sp["baryon"])):
+        if key not in seen:
+            seen.add(key)
+            reps.append(s)
+    assert len(reps) == 124
+    reps = reps[::4]
+    assert any(sp["baryon"][s] > 0 for s in reps) and any(sp["baryon"][s] < 0 for s in reps)
+    ipT, iphi = [0, 9, 20, 31], [2, 7, 13, 22]
+    g = fx["grid"]
+    sub_grid = dict(g, pT=g["pT"][ipT], phi=g["phi"][iphi])
+    ref = oracle.dN_pTdpTdphidy(sl, inputs.species([int(sp["mc_id"][s]) for s in reps]), sub_grid, dff, o)
+    g5 = got.reshape(21, 24, 32, 305)
+    sub = g5[:, iphi][:, :, ipT][:, :, :, reps]
+    assert sub.size == 21 * 16 * len(reps) and relerr(sub, ref.reshape(21, 4, 4, len(reps))) < TOL
+    off, st_off = api.smooth_spectra(sl, sp, fx["grid"], dff, dict(o, zero_skip=2))
+    assert np.array_equal(off, got) and st_off["n_wave_rows_culled"] == 0
+    # a proton and an antiproton bin differ (mu_B > 0 on this surface), a pi+ and a pi- bin do not
+    ids = list(sp["mc_id"])
+    p, pbar, pip, pim = (ids.index(i) for i in (2212, -2212, 211, -211))
+    assert g5[..., p].sum() > 5.0 * g5[..., pbar].sum() and np.array_equal(g5[..., pip], g5[..., pim])   # e^(2 mu_B / T) with mu_B 0.05 .. 0.4 GeV
+
+
+def test_config3_size_14_moment_stratified_oracle_sample(fx):
+    """BASELINE config 1's physics (14-moment delta-f) at config-3 size, as `bench.py --df-mode 1` runs it: cf_main_tile3e<CE = false> on a 60 000-cell
+    slice x 305 species against the oracle on the stratified sample of the Chapman-Enskog test above (every fifth class)."""
+    n = 60000
+    cells = synth.synth_surface(1000000, 3)
+    sl = {k: v[700000:700000 + n] for k, v in cells.items()}
+    sp = fx["urqmd"]
+    o = dict(dimension=3, df_mode=1)
+    got, st = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], o)
+    assert st["n_classes"] == 75 and st["kernel_variant"] == DEFAULT3
+    seen, reps = set(), []
+    for s, key in enumerate(zip(sp["mass"], sp["sign"])):
+        if key not in seen:
+            seen.add(key)
+            reps.append(s)
+    reps = reps[::5]
+    ipT, iphi = [0, 9, 20, 31], [2, 7, 13, 22]
+    ref = _subset_oracle(fx, sl, [int(sp["mc_id"][s]) for s in reps], ipT, iphi, o).reshape(21, 4, 4, len(reps))
+    g5 = got.reshape(21, 24, 32, 305)
+    assert relerr(g5[:, iphi][:, :, ipT][:, :, :, reps], ref) < TOL
+    off, _ = api.smooth_spectra(sl, sp, fx["grid"], fx["df"], dict(o, zero_skip=2))
+    assert np.array_equal(off, got)
