@@ -1273,7 +1273,9 @@ cf_main_tile(const double *__restrict__ TS, const double *__restrict__ lane_mT, 
 //   [7] dead units (count)  [8] live units (count)  [9] first-wave share of [3]  [10] threshold refresh  [11] vmcnt part of [3]  [12] prologue
 __device__ unsigned long long g_prof3e[16];
 
-template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false>
+// E2G (variant 10, round 5, developer build): the E2 tables do NOT go through LDS -- a lane fetches its own column (8 doubles per unit, plain global
+// loads from the table stream through L2) one unit ahead into registers; the LDS batches hold records only (3.2 x as many units per batch).
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false, bool E2G = false>
 __global__ void __launch_bounds__(512)
 cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
                const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
@@ -1357,6 +1359,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
 
     unsigned long long pf_stage = 0, pf_wait = 0, pf_dead = 0, pf_live = 0, pf_hdr = 0, pf_nd = 0, pf_nl = 0, pf_thr = 0, pf_t0 = 0, pf_u0 = 0, pf_vm = 0, pf_pro = 0, pf_mid = 0, pf_ts = 0;
     if constexpr (PROF) pf_t0 = clock64();
+    double e2cur[E2G ? JT : 1], e2nxt[E2G ? JT : 1];              // E2G: the lane's table column of this unit / of the next one (in flight)
+    const double *te_lane = TE + ((int64_t)jt * g.n_cells + c0) * TEREC + tabrow;
     auto process_unit = [&](const double *U, const double *tab) -> bool {
         // (both bounds in ONE LDS round trip: read before the test is formed, not under its g.zskip short-circuit)
         const double dmaxv = BARYON ? U[4 * JT + 1] : U[3], cminv = BARYON ? U[HDR + 5] : U[7];
@@ -1392,7 +1396,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
             pTD[jj] = pT * U[4 * jj + 1];
             pT2g[jj] = pT2s * U[4 * jj + 2];
             if (BARYON) pT2g[jj] = __builtin_fma(hbpT, U[4 * jj + 3], pT2g[jj]);       // + hs b pT L2_j
-            E2[jj] = tab[jj * kE2Stride];
+            E2[jj] = E2G ? e2cur[jj] : tab[jj * kE2Stride];
         }
         struct Row { const double *v; double mTC, E1; bool live; };
         auto fetch = [&](Row &rw, const double *row) {
@@ -1487,7 +1491,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // scalar): the last record piece and the pieces of a short last batch over-read the run -- the next units of the stream, or
     // the slack the plan allocates behind TS and TE -- into the pad / the unused units of the buffer.
     const int TSP = (UB * REC * (int)sizeof(double) + 1023) & ~1023;          // bytes of the padded record part
-    const int TEP = (UB * TEREC * (int)sizeof(double) + 1023) & ~1023;        // bytes of the padded table part
+    const int TEP = E2G ? 0 : ((UB * TEREC * (int)sizeof(double) + 1023) & ~1023);   // bytes of the padded table part
     const int BUFB = TSP + TEP;                                               // bytes per buffer
     const unsigned lane16 = (unsigned)(tid & 63) * 16u;
     // every wave of the workgroup takes a contiguous range of the pieces, four per address: the instruction's immediate offset
@@ -1523,6 +1527,15 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
         const double *tabs = (const double *)((const char *)base + TSP) + tabrow;
         for (int u = 0; u < nu; u++) {
             if constexpr (PROF) pf_u0 = clock64();
+            if constexpr (E2G) {
+                // take over the column requested during the previous unit, request the next unit's (clamped at the chunk's end)
+#pragma unroll
+                for (int jj = 0; jj < JT; jj++) e2cur[jj] = e2nxt[jj];
+                const int un = min(ib * UB + u + 1, n_units - 1);
+                const double *t = te_lane + (int64_t)un * TEREC;
+#pragma unroll
+                for (int jj = 0; jj < JT; jj++) e2nxt[jj] = t[jj * kE2Stride];
+            }
             const bool lv = process_unit(base + u * REC, tabs + u * TEREC);
             if constexpr (PROF) {
                 const unsigned long long d = clock64() - pf_u0;
@@ -1545,6 +1558,10 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     {
         if (nb > 0) {
             stage(0, 0);
+            if constexpr (E2G) {
+#pragma unroll
+                for (int jj = 0; jj < JT; jj++) e2nxt[jj] = te_lane[jj * kE2Stride];
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if constexpr (PROF) pf_pro = clock64() - pf_t0;
@@ -1605,18 +1622,18 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
 
 // LDS bytes per workgroup of cf_main_tile3e: the CU's 160 KB shared by its 8 waves (two per SIMD), 20 KB per wave of the workgroup
 constexpr int kTile3eLdsPerWave = 20 * 1024;
-static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2, int baryon = 0)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
+static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2, int baryon = 0, int e2g = 0)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
 {
     const size_t tsp = ((size_t)ub * unit_rec_doubles(JT, R, baryon) * sizeof(double) + 1023) & ~(size_t)1023;
-    const size_t tep = ((size_t)ub * kE2Stride * JT * sizeof(double) + 1023) & ~(size_t)1023;
+    const size_t tep = e2g ? 0 : (((size_t)ub * kE2Stride * JT * sizeof(double) + 1023) & ~(size_t)1023);   // E2G: the tables do not go through LDS
     return nbuf * (tsp + tep);
 }
-int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon)
+int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon, int e2g)
 {
     if (npT > kE2Stride) return 0;
     const size_t budget = (size_t)kTile3eLdsPerWave * (wpb > 0 ? wpb : 1);
-    int ub = 16;
-    while (ub > 0 && tile3e_lds_bytes(JT, R, ub, 2, baryon) > budget) ub--;
+    int ub = e2g ? 48 : 16;
+    while (ub > 0 && tile3e_lds_bytes(JT, R, ub, 2, baryon, e2g) > budget) ub--;
     return ub;
 }
 // doubles of slack the plan allocates behind TS and TE: the unpredicated staging pieces of the last batch over-read up to one
@@ -2011,7 +2028,7 @@ constexpr int kTile7JT = 8, kTile7R = 31;   // variant 7 (2+1D)
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
     if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
-    if (variant == 5 || variant == 6 || variant == 9) variant = 3;   // same tile, E2 table stream
+    if (variant == 5 || variant == 6 || variant == 9 || variant == 10) variant = 3;   // same tile, E2 table stream
     if (variant == 7 || variant == 8) {
         if (!dim3) { *JT = kTile7JT; *KT = kTile7R; return; }
         variant = 3;
@@ -2021,14 +2038,19 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
     *KT = dim3 ? kTileR3[i] : kTileR2[i];
 }
 
-template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false>
+template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false, bool E2G = false>
 static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
 {
     MainArgs a = a_in;
     if (a.g.nch_run <= 0) { a.g.ch0 = 0; a.g.nch_run = a.g.nch; }
     const int pairs = a.g.jtiles * a.g.nch_run;                               // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
     const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
-    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0);
+    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0, E2G ? 1 : 0);
+    if constexpr (E2G) {
+        hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON, true>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
+                           a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b, a.cull_floor);
+        return;
+    }
     if constexpr (CE && OF && RG && MODE >= 1 && !BARYON) {
         // dev: the cycle-accounting instantiation, synchronous, counters to stderr
         static const bool prof = dev_env("IS3D_DEV_PROF") != nullptr;
@@ -2066,6 +2088,10 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
         }
         if (variant == 6 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1>(a, st); return; }
         if ((variant == 5 || variant == 6) && a.TE && a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, true>(a, st); return; }
+        if constexpr (kDevBuild) {
+            // variant 10 (round 5): the E2 column straight from global memory into registers, records-only LDS batches
+            if (variant == 10 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, false, true>(a, st); return; }
+        }
         if constexpr (kDevBuild)   // measured and dropped (profiles/r05_ab_tile3s.log: 120.4 against 100.2 ms)
         if (variant == 9 && a.TE && !a.g.baryon && a.g.wpb == 1) {   // cf_main_tile3s: one-wave workgroups, no LDS
             MainArgs b = a;
@@ -2077,7 +2103,7 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
             return;
         }
     }
-    if (variant == 5 || variant == 6 || variant == 9) variant = 3;
+    if (variant == 5 || variant == 6 || variant == 9 || variant == 10) variant = 3;
     if constexpr (!DIM3) {
         // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
         if (variant == 7 || !kDevBuild) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
@@ -2163,7 +2189,7 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
 
 const char *main_kernel_name(int variant)
 {
-    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6) ? "cf_main_tile3e" : "cf_main_tile");
+    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6 || variant == 10) ? "cf_main_tile3e" : "cf_main_tile");
 }
 
 // ------------------------------------------------------------------------------------------------

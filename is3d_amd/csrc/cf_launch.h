@@ -35,7 +35,7 @@ hipError_t launch_finalize(double *partial /* chunk 0 receives the sum over chun
 hipError_t launch_pds_bound(const CellPtrs &cells, int64_t n_cells, int is_dim3, double kmin, double kmax, double gw2d, double mTmax,
                             double pTmax, unsigned long long *out, hipStream_t st);
 const char *main_kernel_name(int variant);
-int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon);   // variant 5: units per LDS batch
+int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon, int e2g = 0);   // variants 5, 6 (10: e2g = 1, records only): units per LDS batch
 int tile3e_stream_slack_doubles(int JT, int R);                  // variant 5: over-read slack behind TS and TE
 hipError_t launch_observables(const double *dN, const double *phi_w, const double *pT_w, const double *coskphi,
                               const double *sinkphi, double *dndy, double *spec2pi, double *vn, int npart, int npT, int J,
