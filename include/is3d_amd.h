@@ -131,16 +131,15 @@ typedef struct {
     int32_t accumulate;                 /* 0: dN_out = result; 1: dN_out += result (reference) */
     int32_t device;                     /* HIP device ordinal; -1 = current device */
     /* tuning; 0 = library default */
-    int32_t kernel_variant;             /* 0 default: 6 in 3+1D without baryon terms (pT grids of up to 32 values, else 3), 7 in 2+1D.  1: direct kernel (flat streams, one exp per evaluation) |
-                                           2, 3, 4: LDS-staged tile kernel, (phi x rows) tiles 6x7 / 8x7 / 4x7 in 3+1D, 8x61 / 12x61 / 4x61
-                                           in 2+1D | 5: variant 3 with the phi-side exponentials read from a table stream written by the
-                                           prep kernel | 6: variant 5 with the rows of a unit tested for liveness before their exponentials |
-                                           7: 2+1D, 8x31 tile with unit-strided lanes | 8: variant 7 with the register-staged LDS copy of
-                                           round 1 (A/B only).  Modified equilibrium (df_mode 3, 4): 3+1D default 3 (8x7, rows masked
-                                           against the unit threshold; 5, 6: the other row walks, A/B), 2+1D default 7 (8x31, unit-strided
-                                           lanes, rows tested against the unit threshold; 2-4: the round-1 walk on the 61-row tiles).
-                                           A variant that does not exist for the requested mode falls back to the
-                                           default; status.kernel_variant says which one ran */
+    int32_t kernel_variant;             /* 0 default: 6 in 3+1D (pT grids of up to 32 values: the 8x7 tile with the phi-side exponentials read
+                                           from a table stream and the rows of a unit tested for liveness before their exponentials; larger pT
+                                           grids: 3, the 8x7 tile without the table -- 2, 6x7, with baryon slots), 7 in 2+1D (8x31 tile, unit-strided
+                                           lanes); modified equilibrium (df_mode 3, 4): 3 in 3+1D, 7 in 2+1D.  The shipped library holds these
+                                           kernels and honours one explicit choice -- 3 for a 3+1D delta-f surface without baryon slots; ANY other
+                                           request runs the default, and status.kernel_variant says which kernel ran.  The A/B forms of rounds 1-5
+                                           (1 direct kernel | 2, 4 other tile shapes | 5 hand-pipelined rows | 8 register-staged LDS copy | 9 unit
+                                           records on the scalar path | 10 E2 column from global memory | modified equilibrium: 5, 6 other row
+                                           walks, 2-4 the 61-row tiles) exist only in the developer build of the library (make DEV=1) */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into; 0 (default): the library's count, with
                                            a tapered tail (the last chunks a quarter of the size of the others); > 0: that many equal chunks */
     int64_t workspace_bytes;            /* cap on the derived-coefficient workspace per pass; 0: max(16 GiB, 45 % of the device's TOTAL memory) --
@@ -380,7 +379,7 @@ void is3d_multi_plan_destroy(is3d_multi_plan *mplan);
  * include_bulk_deltaf, include_shear_deltaf, regulate_deltaf, accumulate, device, workspace_bytes, cell_chunks, collapse_species,
  * zero_skip (exact zeros only on this path: 0 and 1 are the same), kernel_variant (0 default = 3 in 3+1D: factored exponent on the 8 x 7
  * tile, cf_main_vah3, and the same kernel on 8 x 31 records with unit-strided lanes in 2+1D | 2: the round-1 kernel on the 6 x 7 / 8 x 61 tile,
- * kept for A/B).  A cell whose E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (the reference's exp overflows there).
+ * kept for A/B in the developer build of the library -- the shipped one runs the default for it).  A cell whose E_a/Lambda could exceed 1e9 for the momentum grid returns IS3D_EDOMAIN (the reference's exp overflows there).
  * HOST pointers; dN_out as for is3d_smooth_spectra.
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
