@@ -45,7 +45,7 @@ def demangle_params(sym):
     if name == "cf_main_tile":
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R", "LAZY", "DMA"]
     elif name == "cf_main_tile3e":
-        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON"]
+        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON", "E2G"]
     elif name == "cf_main_tile3s":
         keys = ["CE", "OUTFLOW", "REG", "JT", "R"]
     elif name == "cf_main_feqmod":
@@ -227,8 +227,10 @@ def main():
         cycles = 4 * full_rate + 16 * trans + 2 * int_ops
         if name == "cf_main_feqmod" and params.pop("BARYON", 0):
             name = "cf_main_feqmod_baryon"
-        if name == "cf_main_tile3e" and params.pop("BARYON", 0):
-            name = "cf_main_tile3e_baryon"
+        if name == "cf_main_tile3e" and params.pop("E2G", 0):   # the developer build's variant 10 (E2 column from global memory): its own key
+            name = "cf_main_tile3e_e2g"
+        if name in ("cf_main_tile3e", "cf_main_tile3e_e2g") and params.pop("BARYON", 0):
+            name += "_baryon"
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
         if vah3_alt:
             key += ",LDSD=1536"
