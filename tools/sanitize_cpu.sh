@@ -15,7 +15,7 @@ echo "== oracle: gcc -fsanitize=address,undefined"
 gcc -O1 -g -fopenmp -fPIC -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o "$R/oracle/libcf_oracle.so" oracle/cf_oracle.c -lm
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 OMP_NUM_THREADS=4 \
   LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
-  python -m pytest tests/test_oracle.py tests/test_oracle_sampler.py tests/test_oracle_vah.py tests/test_oracle_yield.py -x -q
+  python -m pytest tests/test_oracle.py tests/test_oracle_sampler.py tests/test_oracle_vah.py tests/test_oracle_yield.py tests/test_oracle_dfcoef.py -x -q
 cp "$T/oracle_good.so" "$R/oracle/libcf_oracle.so"
 echo "== library host code: hipcc -x c++ -fsanitize=address (device objects unchanged)"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
