@@ -410,6 +410,11 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
             v9, s9 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=9))
             v9f, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=9, zero_skip=2))
             assert s9["kernel_variant"] == 9 and np.array_equal(v9, v9f) and relerr(v9, rel) < 5e-11
+            # variant 10 (developer build; measured and dropped in round 5): the E2 column from global memory, records-only LDS batches -- the default's
+            # arithmetic on the default's operands: bitwise the default's spectrum, with one- and two-wave workgroups, culling on or off
+            for extra in (dict(), dict(waves_per_group=1), dict(zero_skip=2)):
+                v10, s10 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=10, **extra))
+                assert s10["kernel_variant"] == 10 and np.array_equal(v10, rel), extra
 
 
 @pytest.mark.parametrize("dim", [3, 2])
