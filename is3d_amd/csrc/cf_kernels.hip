@@ -1275,7 +1275,10 @@ __device__ unsigned long long g_prof3e[16];
 
 // E2G (variant 10, round 5, developer build): the E2 tables do NOT go through LDS -- a lane fetches its own column (8 doubles per unit, plain global
 // loads from the table stream through L2) one unit ahead into registers; the LDS batches hold records only (3.2 x as many units per batch).
-template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false, bool E2G = false>
+// RAWH (round 5): the header values B_j, D'_j, gamma_j stay RAW in their registers and enter the evaluations as FMA operands -- p.dsigma = fma(pT, B_j, mT A)
+// with the clamp, x = fma(-pT, D'_j, mT C'), the quadratic form's constant part fma(pT^2, gamma_j, mT^2 alpha) -- instead of being multiplied by the
+// lane's pT / pT^2 once per live unit (24 multiplications per unit, two more per row in exchange: the per-evaluation count is the same, an FMA each).
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false, bool E2G = false, bool RAWH = false>
 __global__ void __launch_bounds__(512)
 cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
                const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
@@ -1392,9 +1395,15 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
         double pTB[JT], pTD[JT], pT2g[JT], E2[JT];
 #pragma unroll
         for (int jj = 0; jj < JT; jj++) {
-            pTB[jj] = pT * U[4 * jj + 0];
-            pTD[jj] = pT * U[4 * jj + 1];
-            pT2g[jj] = pT2s * U[4 * jj + 2];
+            if constexpr (RAWH) {   // raw header values (the names keep the products' roles)
+                pTB[jj] = U[4 * jj + 0];
+                pTD[jj] = U[4 * jj + 1];
+                pT2g[jj] = U[4 * jj + 2];
+            } else {
+                pTB[jj] = pT * U[4 * jj + 0];
+                pTD[jj] = pT * U[4 * jj + 1];
+                pT2g[jj] = pT2s * U[4 * jj + 2];
+            }
             if (BARYON) pT2g[jj] = __builtin_fma(hbpT, U[4 * jj + 3], pT2g[jj]);       // + hs b pT L2_j
             E2[jj] = E2G ? e2cur[jj] : tab[jj * kE2Stride];
         }
@@ -1421,7 +1430,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 for (int i = 0; i < RB; i++) {
                     const double z = E1 * E2[j0 + i];
                     if (CE) {
-                        const double x = mTC - pTD[j0 + i];
+                        const double x = RAWH ? __builtin_fma(-pT, pTD[j0 + i], mTC) : mTC - pTD[j0 + i];
                         zv[i] = z * x;
                         qq[i] = __builtin_fma(sign, zv[i], x);
                     } else {
@@ -1434,8 +1443,9 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 for (int i = 0; i < RB; i++) {
                     const int jj = j0 + i;
                     const double beta = rw.v[RS + jj];
-                    const double pds = OUTFLOW ? add_clamp01(mTA, pTB[jj]) : (mTA + pTB[jj]);
-                    const double br = __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
+                    const double pds = RAWH ? (OUTFLOW ? fma_clamp01(pT, pTB[jj], mTA) : __builtin_fma(pT, pTB[jj], mTA))
+                                            : (OUTFLOW ? add_clamp01(mTA, pTB[jj]) : (mTA + pTB[jj]));
+                    const double br = RAWH ? __builtin_fma(mTpTs, beta, __builtin_fma(pT2s, pT2g[jj], mT2a)) : __builtin_fma(mTpTs, beta, mT2a + pT2g[jj]);
                     const double dfr = inv[i];
                     const double u = REG ? fma_clamp01_half(dfr, br) : __builtin_fma(dfr, br, 1.0);
                     const double w = (zv[i] * dfr) * u;
@@ -2028,7 +2038,7 @@ constexpr int kTile7JT = 8, kTile7R = 31;   // variant 7 (2+1D)
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
     if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
-    if (variant == 5 || variant == 6 || variant == 9 || variant == 10) variant = 3;   // same tile, E2 table stream
+    if (variant == 5 || variant == 6 || (variant >= 9 && variant <= 11)) variant = 3;   // same tile, E2 table stream
     if (variant == 7 || variant == 8) {
         if (!dim3) { *JT = kTile7JT; *KT = kTile7R; return; }
         variant = 3;
@@ -2038,7 +2048,7 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
     *KT = dim3 ? kTileR3[i] : kTileR2[i];
 }
 
-template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false, bool E2G = false>
+template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false, bool E2G = false, bool RAWH = false>
 static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
 {
     MainArgs a = a_in;
@@ -2046,8 +2056,8 @@ static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
     const int pairs = a.g.jtiles * a.g.nch_run;                               // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
     const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
     const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0, E2G ? 1 : 0);
-    if constexpr (E2G) {
-        hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON, true>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
+    if constexpr (E2G || RAWH) {
+        hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON, E2G, RAWH>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
                            a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b, a.cull_floor);
         return;
     }
@@ -2091,6 +2101,8 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
         if constexpr (kDevBuild) {
             // variant 10 (round 5): the E2 column straight from global memory into registers, records-only LDS batches
             if (variant == 10 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, false, true>(a, st); return; }
+            // variant 11 (round 5): raw header values as FMA operands
+            if (variant == 11 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, false, false, true>(a, st); return; }
         }
         if constexpr (kDevBuild)   // measured and dropped (profiles/r05_ab_tile3s.log: 120.4 against 100.2 ms)
         if (variant == 9 && a.TE && !a.g.baryon && a.g.wpb == 1) {   // cf_main_tile3s: one-wave workgroups, no LDS
@@ -2103,7 +2115,7 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
             return;
         }
     }
-    if (variant == 5 || variant == 6 || variant == 9 || variant == 10) variant = 3;
+    if (variant == 5 || variant == 6 || (variant >= 9 && variant <= 11)) variant = 3;
     if constexpr (!DIM3) {
         // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
         if (variant == 7 || !kDevBuild) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
@@ -2189,7 +2201,7 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
 
 const char *main_kernel_name(int variant)
 {
-    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6 || variant == 10) ? "cf_main_tile3e" : "cf_main_tile");
+    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6 || variant == 10 || variant == 11) ? "cf_main_tile3e" : "cf_main_tile");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -213,7 +213,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // (modified equilibrium in 3+1D: 8 x 7 with or without the baryon slots -- its records do not grow with them; 247.1 against 260.5 ms for 6 x 7 per 3e5 cells)
     int default_variant = (plain3 || (fq && o->dimension == 3)) ? 3 : 2;
     if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
-    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 10) ? o->kernel_variant : default_variant;
+    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 11) ? o->kernel_variant : default_variant;
     // The shipped library holds the kernels the defaults reach (cf_kernels.hip::launch_variant, cf_feqmod.hip): any other request runs the default --
     // status.kernel_variant says which one ran.  One explicit choice is honoured: the 8 x 7 tile without the E2 table stream (3) for a 3+1D delta-f
     // surface without baryon slots, which is also the default for pT grids of more than 32 values.  The A/B forms of rounds 1-5 (1, 2, 4, 5, 8, 9; the
@@ -231,9 +231,9 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // per-row thresholds, cf_feqmod.hip -- without baryon slots)
     const bool fq56 = fq && plain3;
     // variant 9 (round 5, developer build): cf_main_tile3s, the E2-table kernel with its unit records on the scalar path -- 3+1D delta-f without baryon slots only
-    if ((P->variant == 9 || P->variant == 10) && !(e2ok && plain3 && is3d::kDevBuild)) P->variant = default_variant;   // measured and dropped: the developer build keeps them for A/B
+    if (P->variant >= 9 && P->variant <= 11 && !(e2ok && plain3 && is3d::kDevBuild)) P->variant = default_variant;   // measured and dropped: the developer build keeps them for A/B
     if ((P->variant == 5 || P->variant == 6) && !e2ok && !fq56) P->variant = (fq || !plain3) ? default_variant : 3;
-    P->e2tab = (P->variant == 5 || P->variant == 6 || P->variant == 9 || P->variant == 10) && e2ok;
+    P->e2tab = (P->variant == 5 || P->variant == 6 || (P->variant >= 9 && P->variant <= 11)) && e2ok;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
