@@ -285,6 +285,18 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
             order[c * P->npT + i] = c * P->npT + i;
         }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mT_nat[a] < mT_nat[b]; });
+    {
+        // dev A/B (IS3D_LANE_INTERLEAVE=1, developer build): the two waves of a workgroup take the even and the odd slots of their 128-slot span of
+        // the mT order instead of its lower and upper half -- both then cover the same mT range, cull the same units and rows, and meet at the
+        // per-batch barrier with (nearly) the same work done
+        static const bool inter = is3d::dev_env("IS3D_LANE_INTERLEAVE") != nullptr;
+        if (inter && o->dimension == 3 && !fq) {
+            std::vector<int> o2(order);
+            for (int b = 0; b + 128 <= P->Lbins; b += 128)
+                for (int i = 0; i < 64; i++) { o2[b + i] = order[b + 2 * i]; o2[b + 64 + i] = order[b + 2 * i + 1]; }
+            order.swap(o2);
+        }
+    }
     for (int s = 0; s < P->Lbins; s++) {
         const int nat = order[s], c = nat / P->npT, i = nat % P->npT;
         slot_of[nat] = s;
