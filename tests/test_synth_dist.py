@@ -91,6 +91,57 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, q):
+    """BASELINE config 4's shape on the host side: eight ranks, eight contiguous shards of ONE surface, one sum of the spectrum, the line's
+    `ranks[]` gathered as bench.py gathers it (all_gather_object) -- the oracle stands in for the kernel, gloo for RCCL."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    oracle.set_num_threads(1)
+    r, w, _ = idist.init_process_group("gloo")
+    g = inputs.grid()
+    grid = dict(pT=g["pT"][::8], phi=g["phi"][::6], y=g["y"][::5], eta=g["eta"], eta_w=g["eta_w"])
+    n = 83                                                       # 83 = 8 x 10 + 3: shards of 11, 11, 11, 10, 10, 10, 10, 10
+    lo, hi = idist.shard_bounds(n, r, w)
+    cells = synth.synth_surface(hi - lo, 3, seed=77, first_cell=lo)
+    part = oracle.dN_pTdpTdphidy(cells, inputs.species("pikp"), grid, inputs.df_tables(), dict(dimension=3, df_mode=2))
+    t = torch.from_numpy(part.copy())
+    idist.allreduce_spectrum(t)
+    ranks = [None] * w
+    dist.all_gather_object(ranks, dict(rank=r, cells=hi - lo, first_cell=lo))
+    tt = torch.tensor([float(r)], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # bench.py's MAX over ranks of the step time
+    dist.barrier()
+    if r == 0:
+        whole = oracle.dN_pTdpTdphidy(synth.synth_surface(n, 3, seed=77), inputs.species("pikp"), grid, inputs.df_tables(), dict(dimension=3, df_mode=2))
+        q.put((t.numpy().copy(), whole, ranks, float(tt.item())))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_shards_allreduce_to_the_whole_spectrum():
+    """world_size 8 on gloo (CPU): what can be rehearsed of BASELINE config 4 without eight GPUs -- a GPU box lets at most six processes use its
+    card, so the eight-rank shape runs here, on the host side (tests/test_gpu_multi.py has two and four ranks through the library's communicator)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got, whole, ranks, tmax = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert relerr(got, whole) < 1e-13
+    assert [x["rank"] for x in ranks] == list(range(8)) and [x["cells"] for x in ranks] == [11, 11, 11, 10, 10, 10, 10, 10]
+    assert [x["first_cell"] for x in ranks] == [0, 11, 22, 33, 43, 53, 63, 73] and tmax == 7.0
+
+
 def test_two_rank_shards_allreduce_to_the_whole_spectrum():
     import torch.multiprocessing as mp
     s = socket.socket()
