@@ -138,7 +138,7 @@ typedef struct {
                                            kernels and honours one explicit choice -- 3 for a 3+1D delta-f surface without baryon slots; ANY other
                                            request runs the default, and status.kernel_variant says which kernel ran.  The A/B forms of rounds 1-5
                                            (1 direct kernel | 2, 4 other tile shapes | 5 hand-pipelined rows | 8 register-staged LDS copy | 9 unit
-                                           records on the scalar path | 10 E2 column from global memory | 11 raw header values as FMA operands | modified equilibrium: 5, 6 other row
+                                           records on the scalar path | 10 E2 column from global memory | 11 raw header values as FMA operands | 12 E2 tables built per workgroup in LDS | modified equilibrium: 5, 6 other row
                                            walks, 2-4 the 61-row tiles) exist only in the developer build of the library (make DEV=1) */
     int32_t cell_chunks;                /* number of cell chunks the main kernel grid is split into; 0 (default): the library's count, with
                                            a tapered tail (the last chunks a quarter of the size of the others); > 0: that many equal chunks */

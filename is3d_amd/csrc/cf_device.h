@@ -156,6 +156,7 @@ struct MainArgs {
     const int32_t *lane_sub = nullptr;  // unit-strided lanes: per lane slot, which units (u = sub mod split) it takes
     const double *cull_floor = nullptr; // cf_main_tile3e, surface-relative cull: [jtiles * ktiles][Lpad] lower bounds of the row-cull threshold
                                         // (cf_cull_floor, from the partial spectrum of the chunks that ran first)
+    const double *pTgrid = nullptr;     // cf_main_tile3e<E2L> (developer build): the pT grid, for tables built in LDS
 };
 
 }  // namespace is3d

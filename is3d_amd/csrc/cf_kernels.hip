@@ -1278,12 +1278,15 @@ __device__ unsigned long long g_prof3e[16];
 // RAWH (round 5): the header values B_j, D'_j, gamma_j stay RAW in their registers and enter the evaluations as FMA operands -- p.dsigma = fma(pT, B_j, mT A)
 // with the clamp, x = fma(-pT, D'_j, mT C'), the quadratic form's constant part fma(pT^2, gamma_j, mT^2 alpha) -- instead of being multiplied by the
 // lane's pT / pT^2 once per live unit (24 multiplications per unit, two more per row in exchange: the per-evaluation count is the same, an FMA each).
-template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false, bool E2G = false, bool RAWH = false>
+// E2L (variant 12, round 5, developer build): the E2 tables are neither streamed nor staged -- the workgroup BUILDS the tables of a batch in LDS from the
+// staged records' D'_j and Dmax (the expression of cf_prep's table writer, rounding for rounding: bitwise the same tables), one table region beside
+// the two record buffers, one more barrier per batch.
+template <bool CE, bool OUTFLOW, bool REG, int JT, int R, int MODE = 0, bool PROF = false, bool BARYON = false, bool E2G = false, bool RAWH = false, bool E2L = false>
 __global__ void __launch_bounds__(512)
 cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, const double *__restrict__ lane_mT,
                const double *__restrict__ lane_pT, const double *__restrict__ lane_sign, const int32_t *__restrict__ lane_ipT,
                double *__restrict__ partial, unsigned long long *__restrict__ stats, MainGeom g, const int32_t *__restrict__ lane_pe,
-               const double *__restrict__ lane_b, const double *__restrict__ cull_floor)
+               const double *__restrict__ lane_b, const double *__restrict__ cull_floor, const double *__restrict__ pTgrid = nullptr)
 {
     // "B" records (include_baryon, cf_device.h): alpha_B and Dmax behind the header, {L_k, Cmin (row 0)} behind W in every row, L2_j in
     // the header's x; the lane's baryon number b enters the exponent (b alpha_B) and the b-linear part of df (cf_main_tile)
@@ -1501,7 +1504,7 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     // scalar): the last record piece and the pieces of a short last batch over-read the run -- the next units of the stream, or
     // the slack the plan allocates behind TS and TE -- into the pad / the unused units of the buffer.
     const int TSP = (UB * REC * (int)sizeof(double) + 1023) & ~1023;          // bytes of the padded record part
-    const int TEP = E2G ? 0 : ((UB * TEREC * (int)sizeof(double) + 1023) & ~1023);   // bytes of the padded table part
+    const int TEP = (E2G || E2L) ? 0 : ((UB * TEREC * (int)sizeof(double) + 1023) & ~1023);   // bytes of the padded table part
     const int BUFB = TSP + TEP;                                               // bytes per buffer
     const unsigned lane16 = (unsigned)(tid & 63) * 16u;
     // every wave of the workgroup takes a contiguous range of the pieces, four per address: the instruction's immediate offset
@@ -1534,7 +1537,8 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
     auto consume = [&](int ib, int buf) {
         const int nu = min(UB, n_units - ib * UB);
         const double *base = (const double *)((const char *)lds2 + (size_t)buf * BUFB);
-        const double *tabs = (const double *)((const char *)base + TSP) + tabrow;
+        const double *tabs = E2L ? (const double *)((const char *)lds2 + 2 * (size_t)BUFB) + tabrow     // the one table region behind the two record buffers
+                                 : (const double *)((const char *)base + TSP) + tabrow;
         for (int u = 0; u < nu; u++) {
             if constexpr (PROF) pf_u0 = clock64();
             if constexpr (E2G) {
@@ -1580,6 +1584,19 @@ cf_main_tile3e(const double *__restrict__ TS, const double *__restrict__ TE, con
                 if constexpr (PROF) pa = clock64();
                 if (ib + 1 < nb) stage(ib + 1, (ib + 1) & 1);
                 if constexpr (PROF) { pf_stage += clock64() - pa; if (ib + 1 < nb) pf_ts += pf_mid - pa; }
+                if constexpr (E2L) {
+                    // the batch's tables from its records (landed at the previous barrier): lanes <-> (unit, jj, ipT), ipT = tid & 31 fixed per lane
+                    const int nu = min(UB, n_units - ib * UB);
+                    const double *recs = (const double *)((const char *)lds2 + (size_t)(ib & 1) * BUFB);
+                    double *tb = (double *)((char *)lds2 + 2 * (size_t)BUFB);
+                    const double pTl = pTgrid[min(tid & 31, g.npT - 1)];
+                    for (int idx = tid; idx < nu * TEREC; idx += nthr) {
+                        const int u = idx / TEREC, e = idx - u * TEREC, jj = e >> 5;
+                        const double *Uh = recs + u * REC;
+                        tb[idx] = exp_full(__dsub_rn(__dmul_rn(pTl, Uh[4 * jj + 1]), __dmul_rn(pTl, Uh[3])));
+                    }
+                    __syncthreads();
+                }
                 if (wave_active) consume(ib, ib & 1);
                 if constexpr (PROF) pa = clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads of batch ib+1 have landed
@@ -1635,8 +1652,8 @@ constexpr int kTile3eLdsPerWave = 20 * 1024;
 static size_t tile3e_lds_bytes(int JT, int R, int ub, int nbuf = 2, int baryon = 0, int e2g = 0)   // nbuf buffers of [ub records, padded to whole KiB][ub tables]
 {
     const size_t tsp = ((size_t)ub * unit_rec_doubles(JT, R, baryon) * sizeof(double) + 1023) & ~(size_t)1023;
-    const size_t tep = e2g ? 0 : (((size_t)ub * kE2Stride * JT * sizeof(double) + 1023) & ~(size_t)1023);   // E2G: the tables do not go through LDS
-    return nbuf * (tsp + tep);
+    const size_t tep = e2g ? 0 : (((size_t)ub * kE2Stride * JT * sizeof(double) + 1023) & ~(size_t)1023);   // E2G / E2L: no staged tables
+    return nbuf * (tsp + tep) + (e2g == 2 ? (size_t)ub * kE2Stride * JT * sizeof(double) : 0);                // E2L: one table region, built in place
 }
 int tile3e_units_per_batch(int JT, int R, int npT, int wpb, int baryon, int e2g)
 {
@@ -2038,7 +2055,7 @@ constexpr int kTile7JT = 8, kTile7R = 31;   // variant 7 (2+1D)
 void main_tile_shape(int variant, int dim3, int *JT, int *KT)
 {
     if (variant == 1) { *JT = 1; *KT = dim3 ? kV1KT3 : kV1KT2; return; }
-    if (variant == 5 || variant == 6 || (variant >= 9 && variant <= 11)) variant = 3;   // same tile, E2 table stream
+    if (variant == 5 || variant == 6 || (variant >= 9 && variant <= 12)) variant = 3;   // same tile, E2 table stream
     if (variant == 7 || variant == 8) {
         if (!dim3) { *JT = kTile7JT; *KT = kTile7R; return; }
         variant = 3;
@@ -2048,17 +2065,17 @@ void main_tile_shape(int variant, int dim3, int *JT, int *KT)
     *KT = dim3 ? kTileR3[i] : kTileR2[i];
 }
 
-template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false, bool E2G = false, bool RAWH = false>
+template <bool CE, bool OF, bool RG, int JT, int R, int MODE = 0, bool BARYON = false, bool E2G = false, bool RAWH = false, bool E2L = false>
 static void launch_tile3e_t(const MainArgs &a_in, hipStream_t st)
 {
     MainArgs a = a_in;
     if (a.g.nch_run <= 0) { a.g.ch0 = 0; a.g.nch_run = a.g.nch; }
     const int pairs = a.g.jtiles * a.g.nch_run;                               // (phi tile, cell chunk) pairs, dealt round-robin to the 8 XCDs
     const int grid = ((pairs + 7) / 8) * 8 * a.g.ktiles * a.g.G;
-    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0, E2G ? 1 : 0);
-    if constexpr (E2G || RAWH) {
-        hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON, E2G, RAWH>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
-                           a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b, a.cull_floor);
+    const size_t lds = tile3e_lds_bytes(JT, R, a.g.ub, 2, BARYON ? 1 : 0, E2L ? 2 : E2G ? 1 : 0);
+    if constexpr (E2G || RAWH || E2L) {
+        hipLaunchKernelGGL((cf_main_tile3e<CE, OF, RG, JT, R, MODE, false, BARYON, E2G, RAWH, E2L>), dim3(grid), dim3(a.g.wpb * 64), lds, st, a.TS, a.TE, a.lane_mT,
+                           a.lane_pT, a.lane_sign, a.lane_ipT, a.partial, a.stats, a.g, a.lane_pe, a.lane_b, a.cull_floor, a.pTgrid);
         return;
     }
     if constexpr (CE && OF && RG && MODE >= 1 && !BARYON) {
@@ -2103,6 +2120,8 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
             if (variant == 10 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, false, true>(a, st); return; }
             // variant 11 (round 5): raw header values as FMA operands
             if (variant == 11 && a.TE && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, false, false, true>(a, st); return; }
+            // variant 12 (round 5): the E2 tables built per workgroup in LDS from the staged records
+            if (variant == 12 && a.TE && a.pTgrid && !a.g.baryon) { launch_tile3e_t<CE, OF, RG, kTileJT3[1], kTileR3[1], 1, false, false, false, true>(a, st); return; }
         }
         if constexpr (kDevBuild)   // measured and dropped (profiles/r05_ab_tile3s.log: 120.4 against 100.2 ms)
         if (variant == 9 && a.TE && !a.g.baryon && a.g.wpb == 1) {   // cf_main_tile3s: one-wave workgroups, no LDS
@@ -2115,7 +2134,7 @@ static void launch_variant(int variant, const MainArgs &a, hipStream_t st)
             return;
         }
     }
-    if (variant == 5 || variant == 6 || (variant >= 9 && variant <= 11)) variant = 3;
+    if (variant == 5 || variant == 6 || (variant >= 9 && variant <= 12)) variant = 3;
     if constexpr (!DIM3) {
         // variant 7: 2+1D, 8 x 31 tile: units short enough for four of them per LDS buffer, i.e. for unit-strided lanes with S = 4
         if (variant == 7 || !kDevBuild) { launch_tile_t<CE, false, OF, RG, kTile7JT, kTile7R>(a, st); return; }
@@ -2201,7 +2220,7 @@ hipError_t launch_main(int variant, int ce, int dim3, int outflow, int reg, cons
 
 const char *main_kernel_name(int variant)
 {
-    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6 || variant == 10 || variant == 11) ? "cf_main_tile3e" : "cf_main_tile");
+    return variant == 1 ? "cf_main_direct" : variant == 9 ? "cf_main_tile3s" : ((variant == 5 || variant == 6 || variant == 10 || variant == 11 || variant == 12) ? "cf_main_tile3e" : "cf_main_tile");
 }
 
 // ------------------------------------------------------------------------------------------------

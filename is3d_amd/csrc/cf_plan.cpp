@@ -213,7 +213,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // (modified equilibrium in 3+1D: 8 x 7 with or without the baryon slots -- its records do not grow with them; 247.1 against 260.5 ms for 6 x 7 per 3e5 cells)
     int default_variant = (plain3 || (fq && o->dimension == 3)) ? 3 : 2;
     if (!fq && o->dimension == 3 && g->n_pT <= is3d::kE2Stride) default_variant = 6;   // with or without baryon slots
-    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 11) ? o->kernel_variant : default_variant;
+    P->variant = (o->kernel_variant >= 1 && o->kernel_variant <= 12) ? o->kernel_variant : default_variant;
     // The shipped library holds the kernels the defaults reach (cf_kernels.hip::launch_variant, cf_feqmod.hip): any other request runs the default --
     // status.kernel_variant says which one ran.  One explicit choice is honoured: the 8 x 7 tile without the E2 table stream (3) for a 3+1D delta-f
     // surface without baryon slots, which is also the default for pT grids of more than 32 values.  The A/B forms of rounds 1-5 (1, 2, 4, 5, 8, 9; the
@@ -231,9 +231,9 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
     // per-row thresholds, cf_feqmod.hip -- without baryon slots)
     const bool fq56 = fq && plain3;
     // variant 9 (round 5, developer build): cf_main_tile3s, the E2-table kernel with its unit records on the scalar path -- 3+1D delta-f without baryon slots only
-    if (P->variant >= 9 && P->variant <= 11 && !(e2ok && plain3 && is3d::kDevBuild)) P->variant = default_variant;   // measured and dropped: the developer build keeps them for A/B
+    if (P->variant >= 9 && P->variant <= 12 && !(e2ok && plain3 && is3d::kDevBuild)) P->variant = default_variant;   // measured and dropped: the developer build keeps them for A/B
     if ((P->variant == 5 || P->variant == 6) && !e2ok && !fq56) P->variant = (fq || !plain3) ? default_variant : 3;
-    P->e2tab = (P->variant == 5 || P->variant == 6 || (P->variant >= 9 && P->variant <= 11)) && e2ok;
+    P->e2tab = (P->variant == 5 || P->variant == 6 || (P->variant >= 9 && P->variant <= 12)) && e2ok;
 
     // ---- species classes: identical (mass, sign) => identical integrand up to the degeneracy ----
     std::vector<int> cls(P->npart);
@@ -545,7 +545,7 @@ static int plan_create_impl(is3d_plan **out, const is3d_species *sp, const is3d_
         BIG_ALLOC(P->d_TS, (size_t)pc * P->jtiles * P->rblocks * is3d::unit_rec_doubles(P->JT, P->KT, (P->baryon && !P->feqmod) ? 1 : 0) + slack, "the unit-record stream");
         if (P->e2tab) {
             BIG_ALLOC(P->d_TE, (size_t)pc * P->jtiles * is3d::kE2Stride * P->JT + slack, "the E2 table stream");
-            P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb, P->baryon ? 1 : 0, P->variant == 10 ? 1 : 0);
+            P->ub3e = is3d::tile3e_units_per_batch(P->JT, P->KT, P->npT, P->wpb, P->baryon ? 1 : 0, P->variant == 10 ? 1 : P->variant == 12 ? 2 : 0);
             if (P->ub3e < 1) return fail(IS3D_EINVAL, "kernel_variant 5: a unit record plus its %d x %d E2 table does not fit the LDS budget", P->npT, P->JT);
         }
     } else {
@@ -828,7 +828,7 @@ extern "C" int is3d_plan_execute(is3d_plan *P, const is3d_cells *cells, double *
             a.g.NT = P->jtiles * P->ktiles * nch_used;
             a.g.Kacc = P->Kacc;
             a.g.first_pass = (pass == 0);
-            a.TE = P->e2tab ? P->d_TE.p : nullptr; a.lane_ipT = P->d_lane_ipT.p; a.g.npT = P->npT; a.g.ub = P->ub3e;
+            a.TE = P->e2tab ? P->d_TE.p : nullptr; a.lane_ipT = P->d_lane_ipT.p; a.g.npT = P->npT; a.g.ub = P->ub3e; a.pTgrid = P->e2tab ? P->d_pTgrid.p : nullptr;
             a.g.split = P->split; a.lane_sub = P->d_lane_sub.p;
             // zero_skip 3, surface-relative cull (cf_main_tile3e with outflow && regulate_deltaf; include/is3d_amd.h): an eighth of the chunks
             // runs first with the accumulator-relative rule; their partial spectrum is a lower bound of the final one (all terms >= 0) and

@@ -415,6 +415,14 @@ def test_row_culling_changes_no_bit(fx, dim, df_mode, species):
             for extra in (dict(), dict(waves_per_group=1), dict(zero_skip=2)):
                 v10, s10 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=10, **extra))
                 assert s10["kernel_variant"] == 10 and np.array_equal(v10, rel), extra
+            # variant 12 (developer build; measured and dropped in round 5): the E2 tables built per workgroup in LDS with cf_prep's own expression --
+            # bitwise the default's spectrum at two and four waves per workgroup, culling on or off; variant 11 (raw header values as FMA operands): to rounding
+            for extra in (dict(), dict(waves_per_group=4), dict(zero_skip=2)):
+                v12, s12 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=12, **extra))
+                assert s12["kernel_variant"] == 12 and np.array_equal(v12, rel), extra
+            v11, s11 = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=11))
+            v11f, _ = api.smooth_spectra(cells, sp, fx["grid"], fx["df"], dict(o, kernel_variant=11, zero_skip=2))
+            assert s11["kernel_variant"] == 11 and np.array_equal(v11, v11f) and relerr(v11, rel) < 5e-11
 
 
 @pytest.mark.parametrize("dim", [3, 2])

@@ -45,7 +45,7 @@ def demangle_params(sym):
     if name == "cf_main_tile":
         keys = ["CE", "DIM3", "OUTFLOW", "REG", "BARYON", "JT", "R", "LAZY", "DMA"]
     elif name == "cf_main_tile3e":
-        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON", "E2G", "RAWH"]
+        keys = ["CE", "OUTFLOW", "REG", "JT", "R", "MODE", "PROF", "BARYON", "E2G", "RAWH", "E2L"]
     elif name == "cf_main_tile3s":
         keys = ["CE", "OUTFLOW", "REG", "JT", "R"]
     elif name == "cf_main_feqmod":
@@ -232,7 +232,10 @@ def main():
         if name == "cf_main_tile3e" and params.pop("RAWH", 0):   # variant 11 (raw header values as FMA operands)
             name = "cf_main_tile3e_rawh"
         params.pop("RAWH", None)
-        if name in ("cf_main_tile3e", "cf_main_tile3e_e2g", "cf_main_tile3e_rawh") and params.pop("BARYON", 0):
+        if name == "cf_main_tile3e" and params.pop("E2L", 0):    # variant 12 (tables built per workgroup in LDS)
+            name = "cf_main_tile3e_e2l"
+        params.pop("E2L", None)
+        if name in ("cf_main_tile3e", "cf_main_tile3e_e2g", "cf_main_tile3e_rawh", "cf_main_tile3e_e2l") and params.pop("BARYON", 0):
             name += "_baryon"
         key = "%s:%s" % (name, ",".join("%s=%d" % kv for kv in params.items()))
         if vah3_alt:
