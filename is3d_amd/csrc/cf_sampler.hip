@@ -85,7 +85,8 @@ struct SamplerParams {
     double y_max;
     uint64_t seed;
     unsigned long long *status; // [0] min bad cell, [1] skipped, [2] momentum samples, [3] acceptances, [4] hadrons drawn, [5] breakdown cells
-    double *cdf;                // [npart][n_cells] running sums of the species weights of a cell, as cf_sampler_cells adds them (NULL: df_mode 3)
+    double *cdf;                // [ceil(npart / kCdfBlock)][n_cells]: the running sum of a cell's species weights after every kCdfBlock-th species, as
+                                // cf_sampler_cells adds them (NULL: df_mode 3)
 };
 
 // ---- Philox4x32-10 streams ----
@@ -213,6 +214,11 @@ cf_sampler_density(const double *__restrict__ T_fo, const double *__restrict__ m
 
 // mean-number weight of species ip in a cell: fast_max_particle_number (:239-280) / max_particle_number (:282-359)
 // gt, gt2, gt3: the cell's column of the class-major integral tables (GT + cell), element of class k at [k * p.n_cells]
+// The running sums are kept for every kCdfBlock-th species only (round 5: 39 planes instead of 305 -- cf_sampler_cells was bound by these stores, 2.4 GB
+// per 1e6 cells): a hadron's species is the bisection of the block sums followed by the producer's own additions inside one block, continued from the stored
+// sum in front of it -- the same doubles in the same order, so the same species as the bisection of all 305 sums.
+constexpr int kCdfBlock = 8;
+
 __device__ __forceinline__ double species_dn(const SamplerParams &p, const SamplerSpecies &sp, const SamplerCell &c, const double *gt,
                                              const double *gt2, const double *gt3, int ip)
 {
@@ -377,7 +383,7 @@ cf_sampler_cells(SamplerParams p, SamplerSpecies sp, const double *__restrict__ 
 #pragma unroll 4
         for (int ip = 0; ip < sp.npart; ip++) {
             dn += species_dn(p, sp, c, gtr, gt2, gt3, ip);
-            cdf[(int64_t)ip * p.n_cells] = dn;
+            if ((ip & (kCdfBlock - 1)) == kCdfBlock - 1 || ip == sp.npart - 1) cdf[(int64_t)(ip / kCdfBlock) * p.n_cells] = dn;
         }
     } else {
         for (int ip = 0; ip < sp.npart; ip++) dn += species_dn(p, sp, c, gt, gt2, gt3, ip);
@@ -507,13 +513,21 @@ __device__ __forceinline__ void sampler_thread(const SamplerParams &p, const Sam
         if (p.cdf) {
             // first species whose running sum exceeds ut_ (the last one if none does): bisection of the sums cf_sampler_cells stored -- the
             // weights are >= 0 for df_mode 1, 2, 4, so the sums are non-decreasing and this IS the linear inversion below, in 9 reads
-            int lo = 0, hi = sp.npart - 1;
+            // (round 5) ... of the sums at the block ends: the first block whose end sum exceeds ut_ (the last block if none does), then the producer's
+            // additions inside it, continued from the sum stored in front of it
+            int lo = 0, hi = (sp.npart + kCdfBlock - 1) / kCdfBlock - 1;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (ut_ < p.cdf[(int64_t)mid * p.n_cells + ic]) hi = mid;
                 else lo = mid + 1;
             }
-            chosen = lo;
+            double cum = lo ? p.cdf[(int64_t)(lo - 1) * p.n_cells + ic] : 0.0;
+            const int ip1 = min((lo + 1) * kCdfBlock, sp.npart);
+            chosen = ip1 - 1;
+            for (int ip = lo * kCdfBlock; ip < ip1; ip++) {
+                cum += species_dn(p, sp, c, gt, gt2, gt3, ip);
+                if (ut_ < cum) { chosen = ip; break; }
+            }
         } else {
             double cum = 0.0;
             for (int ip = 0; ip < sp.npart; ip++) {
@@ -971,9 +985,9 @@ extern "C" int is3d_sampler_plan_execute(is3d_sampler_plan *P, const is3d_cells 
         if (P->o.df_mode == 3 && !p.fast) SMP_TRY(P->d_GT2.alloc((size_t)n * ncls * sizeof(double)));
         if (P->o.df_mode == 3 && p.baryon) SMP_TRY(P->d_GT3.alloc((size_t)n * ncls * sizeof(double)));
         SMP_TRY(P->d_rec.alloc((size_t)n * sizeof(is3d::SamplerCell)));
-        // running sums of the species weights per cell (2.4 KB per cell for 305 species): df_mode 3's weights may be negative (n_eq + Pi dn_bulk),
+        // running sums of the species weights per cell, one per block of 8 species (312 B per cell for 305 species): df_mode 3's weights may be negative (n_eq + Pi dn_bulk),
         // its sums are not monotone and the species is found by the linear inversion there
-        if (P->o.df_mode != 3) SMP_TRY(P->d_cdf.alloc((size_t)n * sp.npart * sizeof(double)));
+        if (P->o.df_mode != 3) SMP_TRY(P->d_cdf.alloc((size_t)n * ((sp.npart + is3d::kCdfBlock - 1) / is3d::kCdfBlock) * sizeof(double)));
         P->cap_cells = n;
     }
     if (bt > P->cap_bt) {
